@@ -1,0 +1,1069 @@
+/*
+ * lpp_oracle.c -- CPU restatement of the LanczosPlusPlus stored-CSR Lanczos path.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may load it.  The product (lanczosplusplus_amd/) never
+ * links, imports or calls anything in oracle/.
+ *
+ * PARITY STATUS: "parity unpinned" for the arithmetic the reference delegates to
+ * PsimagLite (CrsMatrix::matrixVectorProduct, SparseRow::finalize, LanczosSolver,
+ * fillRandom): PsimagLite is un-vendored, un-pinned (referenced as ../../PsimagLite,
+ * reference src/Engine/LanczosDriver.h:3-6) and absent, and the reference tree holds no
+ * expected outputs (TestSuite/ = inputs only).  Those parts restate the published
+ * algorithm (Dagotto-style three-term recurrence, x += H y).  What IS pinned by in-tree
+ * reference code and followed line by line here: basis enumeration order, perfectIndex,
+ * fermion signs and every matrix-element formula (citations at each function), plus the
+ * one reference file that compiles stand-alone (src/HeisenbergInfiniteTemperatureEnergy.cpp,
+ * built by oracle/Makefile into oracle/_ref/) which pins sector enumeration and the
+ * Heisenberg diagonal.  Energies are additionally pinned by closed forms and by an
+ * independent dense ED (tests/).
+ *
+ * All citations are relative to /root/reference/src/.
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include <stdio.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+typedef uint64_t word_t; /* ProgramGlobals::WordType = unsigned long, Engine/ProgramGlobals.h:101 */
+
+#define BIT(i) (((word_t)1) << (i))
+
+/* ------------------------------------------------------------------ */
+/* small helpers                                                        */
+/* ------------------------------------------------------------------ */
+
+static int popcnt(word_t a) { return __builtin_popcountll(a); }
+
+/* ProgramGlobals::doSign(a,i): parity of set bits strictly below i.
+ * Engine/ProgramGlobals.h:109-114 */
+static int do_sign_below(word_t a, int i)
+{
+	word_t mask = BIT(i) - 1;
+	return (popcnt(a & mask) & 1) ? -1 : 1;
+}
+
+/* binomial table, BasisOneSpin::doCombinatorial, Models/HubbardOneOrbital/BasisOneSpin.h:178-191 */
+#define COMB_MAX 132
+static uint64_t comb_[COMB_MAX][COMB_MAX];
+static int comb_ready_ = 0;
+static void do_combinatorial(void)
+{
+	if (comb_ready_) return;
+	memset(comb_, 0, sizeof(comb_));
+	for (int n = 0; n < COMB_MAX; n++) {
+		uint64_t m = 0;
+		int j = n;
+		uint64_t i = 1;
+		unsigned __int128 cnm = 1;
+		for (; m <= (uint64_t)n / 2; m++, cnm = cnm * j / i, i++, j--) {
+			uint64_t v = (cnm > (unsigned __int128)UINT64_MAX) ? UINT64_MAX : (uint64_t)cnm;
+			comb_[n][m] = comb_[n][n - m] = v;
+		}
+	}
+	comb_ready_ = 1;
+}
+
+uint64_t lppo_comb(int n, int m)
+{
+	do_combinatorial();
+	if (n < 0 || m < 0 || n >= COMB_MAX || m >= COMB_MAX) return 0;
+	return comb_[n][m];
+}
+
+/* ------------------------------------------------------------------ */
+/* CSR container (64-bit row pointers; reference uses int)  */
+/* ------------------------------------------------------------------ */
+
+typedef struct {
+	int64_t nrows;
+	int64_t nnz;
+	int64_t cap;
+	int is_complex;
+	int64_t* rowptr; /* nrows+1 */
+	int32_t* colind; /* nnz */
+	double* values; /* nnz * (1|2) */
+} lppo_csr;
+
+static lppo_csr* csr_new(int64_t nrows, int is_complex, int64_t cap_guess)
+{
+	lppo_csr* m = (lppo_csr*)calloc(1, sizeof(lppo_csr));
+	m->nrows = nrows;
+	m->is_complex = is_complex;
+	m->cap = cap_guess > 16 ? cap_guess : 16;
+	m->rowptr = (int64_t*)calloc((size_t)nrows + 1, sizeof(int64_t));
+	m->colind = (int32_t*)malloc((size_t)m->cap * sizeof(int32_t));
+	m->values = (double*)malloc((size_t)m->cap * sizeof(double) * (is_complex ? 2 : 1));
+	return m;
+}
+
+static void csr_reserve(lppo_csr* m, int64_t need)
+{
+	if (need <= m->cap) return;
+	int64_t cap = m->cap;
+	while (cap < need) cap = cap + cap / 2 + 64;
+	m->colind = (int32_t*)realloc(m->colind, (size_t)cap * sizeof(int32_t));
+	m->values = (double*)realloc(m->values, (size_t)cap * sizeof(double) * (m->is_complex ? 2 : 1));
+	m->cap = cap;
+}
+
+void lppo_csr_free(lppo_csr* m)
+{
+	if (!m) return;
+	free(m->rowptr);
+	free(m->colind);
+	free(m->values);
+	free(m);
+}
+int64_t lppo_csr_nrows(const lppo_csr* m) { return m->nrows; }
+int64_t lppo_csr_nnz(const lppo_csr* m) { return m->nnz; }
+int lppo_csr_is_complex(const lppo_csr* m) { return m->is_complex; }
+const int64_t* lppo_csr_rowptr(const lppo_csr* m) { return m->rowptr; }
+const int32_t* lppo_csr_colind(const lppo_csr* m) { return m->colind; }
+const double* lppo_csr_values(const lppo_csr* m) { return m->values; }
+
+/* SparseRow restatement ([PsimagLite], call sites HubbardHelper.h:88-99): add(col,val)
+ * collects; finalize sorts by column (stable), sums duplicates in insertion order and
+ * appends; explicit zeros are kept (the diagonal is always stored, HubbardHelper.h:93). */
+typedef struct {
+	int n, cap;
+	int64_t* col;
+	double* re;
+	double* im;
+} sparse_row;
+
+static void srow_init(sparse_row* r)
+{
+	r->n = 0;
+	r->cap = 128;
+	r->col = (int64_t*)malloc(sizeof(int64_t) * r->cap);
+	r->re = (double*)malloc(sizeof(double) * r->cap);
+	r->im = (double*)malloc(sizeof(double) * r->cap);
+}
+static void srow_free(sparse_row* r)
+{
+	free(r->col);
+	free(r->re);
+	free(r->im);
+}
+static void srow_add(sparse_row* r, int64_t col, double re, double im)
+{
+	if (r->n == r->cap) {
+		r->cap *= 2;
+		r->col = (int64_t*)realloc(r->col, sizeof(int64_t) * r->cap);
+		r->re = (double*)realloc(r->re, sizeof(double) * r->cap);
+		r->im = (double*)realloc(r->im, sizeof(double) * r->cap);
+	}
+	r->col[r->n] = col;
+	r->re[r->n] = re;
+	r->im[r->n] = im;
+	r->n++;
+}
+/* stable insertion sort by column (rows are short) then merge duplicates */
+static int srow_sort_merge(sparse_row* r)
+{
+	for (int a = 1; a < r->n; a++) {
+		int64_t c = r->col[a];
+		double re = r->re[a], im = r->im[a];
+		int b = a - 1;
+		while (b >= 0 && r->col[b] > c) {
+			r->col[b + 1] = r->col[b];
+			r->re[b + 1] = r->re[b];
+			r->im[b + 1] = r->im[b];
+			b--;
+		}
+		r->col[b + 1] = c;
+		r->re[b + 1] = re;
+		r->im[b + 1] = im;
+	}
+	int m = 0;
+	for (int a = 0; a < r->n; a++) {
+		if (m > 0 && r->col[m - 1] == r->col[a]) {
+			r->re[m - 1] += r->re[a];
+			r->im[m - 1] += r->im[a];
+		} else {
+			r->col[m] = r->col[a];
+			r->re[m] = r->re[a];
+			r->im[m] = r->im[a];
+			m++;
+		}
+	}
+	r->n = m;
+	return m;
+}
+static int64_t srow_finalize(sparse_row* r, lppo_csr* m)
+{
+	int k = srow_sort_merge(r);
+	csr_reserve(m, m->nnz + k);
+	for (int a = 0; a < k; a++) {
+		m->colind[m->nnz + a] = (int32_t)r->col[a];
+		if (m->is_complex) {
+			m->values[2 * (m->nnz + a)] = r->re[a];
+			m->values[2 * (m->nnz + a) + 1] = r->im[a];
+		} else {
+			m->values[m->nnz + a] = r->re[a];
+		}
+	}
+	m->nnz += k;
+	r->n = 0;
+	return k;
+}
+
+/* ------------------------------------------------------------------ */
+/* BasisOneSpin  (Models/HubbardOneOrbital/BasisOneSpin.h)              */
+/* ------------------------------------------------------------------ */
+
+/* size: BasisOneSpin.h:34-39 */
+int64_t lppo_onespin_size(int nsite, int npart)
+{
+	uint64_t hilbert = 1;
+	int n = nsite;
+	uint64_t m = 1;
+	for (; m <= (uint64_t)npart; n--, m++) hilbert = hilbert * n / m;
+	return (int64_t)hilbert;
+}
+
+/* enumeration in ascending integer order via the next-permutation loop,
+ * BasisOneSpin.h:46-61 */
+void lppo_onespin_fill(int nsite, int npart, word_t* data)
+{
+	int64_t hilbert = lppo_onespin_size(nsite, npart);
+	if (npart == 0) {
+		data[0] = 0;
+		return;
+	}
+	word_t ket = (BIT(npart)) - 1;
+	for (int64_t i = 0; i < hilbert; i++) {
+		data[i] = ket;
+		int n = 0, m = 0;
+		for (; (ket & 3) != 1; n++, ket >>= 1) m += (int)(ket & 1);
+		ket = ((ket + 1) << n) ^ (BIT(m) - 1);
+	}
+}
+
+/* perfectIndex: sum_{set bits b, c=1,2,..} C(b,c),  BasisOneSpin.h:73-81 */
+int64_t lppo_onespin_rank(word_t state)
+{
+	do_combinatorial();
+	uint64_t n = 0;
+	for (int b = 0, c = 1; state > 0; b++, state >>= 1)
+		if (state & 1) n += comb_[b][c++];
+	return (int64_t)n;
+}
+
+/* ------------------------------------------------------------------ */
+/* Hubbard: BasisHubbardLanczos.h + HubbardHelper.h                     */
+/* ------------------------------------------------------------------ */
+
+typedef struct {
+	int L, nup, ndown;
+	int64_t n1, n2;
+	word_t *b1, *b2;
+} hub_basis;
+
+static void hub_basis_init(hub_basis* B, int L, int nup, int ndown)
+{
+	B->L = L;
+	B->nup = nup;
+	B->ndown = ndown;
+	B->n1 = lppo_onespin_size(L, nup);
+	B->n2 = lppo_onespin_size(L, ndown);
+	B->b1 = (word_t*)malloc(sizeof(word_t) * (size_t)B->n1);
+	B->b2 = (word_t*)malloc(sizeof(word_t) * (size_t)B->n2);
+	lppo_onespin_fill(L, nup, B->b1);
+	lppo_onespin_fill(L, ndown, B->b2);
+}
+static void hub_basis_free(hub_basis* B)
+{
+	free(B->b1);
+	free(B->b2);
+}
+
+/* BasisHubbardLanczos::perfectIndex(ket1,ket2), BasisHubbardLanczos.h:59-63 */
+static int64_t hub_perfect_index(const hub_basis* B, word_t k1, word_t k2)
+{
+	return lppo_onespin_rank(k1) + lppo_onespin_rank(k2) * B->n1;
+}
+
+int64_t lppo_hubbard_size(int L, int nup, int ndown)
+{
+	return lppo_onespin_size(L, nup) * lppo_onespin_size(L, ndown);
+}
+
+/* basis(i,spin): x = i % N_up, y = i / N_up.  BasisHubbardLanczos.h:77-84 */
+void lppo_hubbard_basis_words(int L, int nup, int ndown, word_t* up_words, word_t* down_words)
+{
+	hub_basis B;
+	hub_basis_init(&B, L, nup, ndown);
+	int64_t n = B.n1 * B.n2;
+	for (int64_t i = 0; i < n; i++) {
+		up_words[i] = B.b1[i % B.n1];
+		down_words[i] = B.b2[i / B.n1];
+	}
+	hub_basis_free(&B);
+}
+
+int64_t lppo_hubbard_perfect_index(int L, int nup, int ndown, word_t k1, word_t k2)
+{
+	int64_t n1 = lppo_onespin_size(L, nup);
+	(void)ndown;
+	return lppo_onespin_rank(k1) + lppo_onespin_rank(k2) * n1;
+}
+
+typedef struct {
+	int L;
+	int is_complex;
+	const double* hop_re; /* L*L, hop(i,j) at [i + j*L]?  we use row-major [i*L+j] */
+	const double* hop_im; /* or NULL */
+	const double* U; /* L */
+	const double* V; /* L: potentialV[i], i<L, used for both spins (HubbardHelper.h:180-183) */
+	const double* ninj; /* L*L Coulomb coupling (HubbardOneBandExtended) or NULL */
+} hub_params;
+
+/* calcDiagonalElements for one state, HubbardHelper.h:138-189
+ * (jCoupling / potentialT branches are for SuperHubbardExtended / time-dependent runs: not restated) */
+static double hub_diag_one(const hub_params* P, word_t ket1, word_t ket2)
+{
+	int L = P->L;
+	double s = 0;
+	for (int i = 0; i < L; i++) {
+		int nu = (ket1 & BIT(i)) ? 1 : 0;
+		int nd = (ket2 & BIT(i)) ? 1 : 0;
+		s += P->U[i] * nu * nd; /* :154-156 */
+		double ne = nu + nd; /* :168-169 */
+		if (P->ninj) {
+			for (int j = 0; j < L; j++) { /* :171-177 */
+				double value = 0.5 * P->ninj[i * L + j];
+				if (value == 0) continue;
+				double tmp2 = ((ket1 & BIT(j)) ? 1 : 0) + ((ket2 & BIT(j)) ? 1 : 0);
+				s += value * ne * tmp2;
+			}
+		}
+		double tmp = P->V[i]; /* :180 */
+		if (tmp != 0) s += tmp * ne; /* :183 */
+	}
+	return s;
+}
+
+/* setHoppingTerm for site i, HubbardHelper.h:191-243 (Rashba branch :245-278 not restated) */
+static void hub_set_hopping(const hub_params* P, const hub_basis* B, sparse_row* row, word_t ket1, word_t ket2, int i)
+{
+	int L = P->L;
+	int s1i = (ket1 & BIT(i)) ? 1 : 0;
+	int s2i = (ket2 & BIT(i)) ? 1 : 0;
+	for (int j = 0; j < L; j++) {
+		double hr = P->hop_re[i * L + j];
+		double hi = P->hop_im ? P->hop_im[i * L + j] : 0.0;
+		int has_hop = (hr != 0 || hi != 0);
+		int s1j = (ket1 & BIT(j)) ? 1 : 0;
+		int s2j = (ket2 & BIT(j)) ? 1 : 0;
+		if (has_hop && s1i == 1 && s1j == 0) { /* :214-228 */
+			word_t bra1 = ket1 ^ BIT(i);
+			double tmp2 = do_sign_below(ket1, i) * do_sign_below(bra1, j);
+			bra1 = bra1 ^ BIT(j);
+			int64_t temp = hub_perfect_index(B, bra1, ket2);
+			srow_add(row, temp, hr * tmp2, hi * tmp2);
+		}
+		if (has_hop && s2i == 1 && s2j == 0) { /* :231-243 */
+			word_t bra2 = ket2 ^ BIT(i);
+			double tmp2 = do_sign_below(ket2, i) * do_sign_below(bra2, j);
+			bra2 = bra2 ^ BIT(j);
+			int64_t temp = hub_perfect_index(B, ket1, bra2);
+			srow_add(row, temp, hr * tmp2, hi * tmp2);
+		}
+	}
+}
+
+/* HubbardHelper::setupHamiltonian, HubbardHelper.h:75-103 */
+lppo_csr* lppo_hubbard_setup(int L, int nup, int ndown, const double* hop_re, const double* hop_im,
+                             const double* U, const double* V, const double* ninj, int is_complex)
+{
+	hub_basis B;
+	hub_basis_init(&B, L, nup, ndown);
+	hub_params P = { L, is_complex, hop_re, hop_im, U, V, ninj };
+	int64_t hilbert = B.n1 * B.n2;
+	lppo_csr* m = csr_new(hilbert, is_complex, hilbert * 8);
+	sparse_row row;
+	srow_init(&row);
+	for (int64_t ispace = 0; ispace < hilbert; ispace++) {
+		m->rowptr[ispace] = m->nnz; /* matrix.setRow(ispace,nCounter) :89 */
+		word_t ket1 = B.b1[ispace % B.n1];
+		word_t ket2 = B.b2[ispace / B.n1];
+		srow_add(&row, ispace, hub_diag_one(&P, ket1, ket2), 0.0); /* :93 */
+		for (int i = 0; i < L; i++) hub_set_hopping(&P, &B, &row, ket1, ket2, i); /* :94-97 */
+		srow_finalize(&row, m); /* :99 */
+	}
+	m->rowptr[hilbert] = m->nnz; /* :102 */
+	srow_free(&row);
+	hub_basis_free(&B);
+	return m;
+}
+
+/* HubbardHelper::matrixVectorProduct (on-the-fly, threaded over rows), HubbardHelper.h:105-134.
+ * x += H y.  Rows [row0,row1) only (row1<=0 means all) so bench.py can time a bounded sample.
+ * Real hoppings only (the reference's threaded CPU path; used as the CPU timing baseline). */
+void lppo_hubbard_otf_mvp(int L, int nup, int ndown, const double* hop_re, const double* U, const double* V,
+                          double* x, const double* y, int64_t row0, int64_t row1, int nthreads)
+{
+	hub_basis B;
+	hub_basis_init(&B, L, nup, ndown);
+	hub_params P = { L, 0, hop_re, NULL, U, V, NULL };
+	int64_t hilbert = B.n1 * B.n2;
+	if (row1 <= 0 || row1 > hilbert) row1 = hilbert;
+	/* :110-114 serial diagonal pass */
+	for (int64_t ispace = row0; ispace < row1; ispace++)
+		x[ispace] += hub_diag_one(&P, B.b1[ispace % B.n1], B.b2[ispace / B.n1]) * y[ispace];
+#ifdef _OPENMP
+	if (nthreads > 0) omp_set_num_threads(nthreads);
+#pragma omp parallel
+#endif
+	{
+		sparse_row row;
+		srow_init(&row);
+#ifdef _OPENMP
+#pragma omp for schedule(static)
+#endif
+		for (int64_t ispace = row0; ispace < row1; ispace++) { /* lambda :119-129 */
+			word_t ket1 = B.b1[ispace % B.n1];
+			word_t ket2 = B.b2[ispace / B.n1];
+			row.n = 0;
+			for (int i = 0; i < L; i++) hub_set_hopping(&P, &B, &row, ket1, ket2, i);
+			int k = srow_sort_merge(&row); /* sparseRow.finalize(y) :128 */
+			double acc = 0;
+			for (int a = 0; a < k; a++) acc += row.re[a] * y[row.col[a]];
+			x[ispace] += acc;
+		}
+		srow_free(&row);
+	}
+	hub_basis_free(&B);
+}
+
+/* ------------------------------------------------------------------ */
+/* Heisenberg: BasisHeisenberg.h + Heisenberg.h                         */
+/* ------------------------------------------------------------------ */
+
+/* bits per site, BasisHeisenberg.h:35-37 */
+int lppo_heis_bits(int twiceS)
+{
+	int bits = 1 + (int)floor(log2((double)(twiceS + 1)));
+	if (twiceS & 1) bits--;
+	return bits;
+}
+
+static word_t heis_mask(int bits)
+{ /* getMask, BasisHeisenberg.h:196-202 */
+	word_t mask = 1;
+	for (int i = 0; i < bits; i++) mask |= BIT(i);
+	return mask;
+}
+
+/* mOf, BasisHeisenberg.h:204-227 */
+static int heis_m_of(word_t lui, word_t mask, int bits, int twiceS)
+{
+	unsigned m = 0;
+	while (lui != 0) {
+		word_t tmp = lui & mask;
+		if (!(twiceS & 1) && tmp > (word_t)twiceS) return -1;
+		m += (unsigned)tmp;
+		lui >>= bits;
+	}
+	return (int)m;
+}
+
+/* basis enumeration: all words < 2^(bits*L) with sum == szPlusConst, ascending,
+ * BasisHeisenberg.h:38-46.  Two-call protocol: data==NULL returns the count. */
+int64_t lppo_heis_basis(int L, int twiceS, int szPlusConst, word_t* data)
+{
+	int bits = lppo_heis_bits(twiceS);
+	word_t total = BIT(bits * L);
+	word_t mask = heis_mask(bits);
+	int64_t n = 0;
+	for (word_t lui = 0; lui < total; ++lui) {
+		int tmp = heis_m_of(lui, mask, bits, twiceS);
+		if (tmp < 0 || tmp != szPlusConst) continue;
+		if (data) data[n] = lui;
+		n++;
+	}
+	return n;
+}
+
+/* literal perfectIndex (O(N) scan), BasisHeisenberg.h:73-80 */
+int64_t lppo_find_linear(const word_t* data, int64_t n, word_t ket)
+{
+	for (int64_t i = 0; i < n; i++)
+		if (ket == data[i]) return i;
+	return -1;
+}
+
+/* exact binary search over the ascending array: returns the same index as the scan */
+int64_t lppo_find_bisect(const word_t* data, int64_t n, word_t ket)
+{
+	int64_t lo = 0, hi = n - 1;
+	while (lo <= hi) {
+		int64_t mid = lo + (hi - lo) / 2;
+		if (data[mid] == ket) return mid;
+		if (data[mid] < ket)
+			lo = mid + 1;
+		else
+			hi = mid - 1;
+	}
+	return -1;
+}
+
+static int heis_get_n(word_t ket, int site, int bits, word_t mask)
+{ /* getN, BasisHeisenberg.h:96-105 */
+	return (int)((ket >> (bits * site)) & mask);
+}
+
+/* Heisenberg::setupHamiltonian, Heisenberg.h:80-114 with calcDiagonalElements :242-276
+ * and setSplusSminus :278-307.  jpm = geometry term 0, jzz = term 1 (:49-58). */
+lppo_csr* lppo_heis_setup(int L, int twiceS, int szPlusConst, const double* jpm, const double* jzz,
+                          const double* magneticField, int nField, const double* anisotropy, int nAniso,
+                          int literal_index)
+{
+	int bits = lppo_heis_bits(twiceS);
+	word_t mask = heis_mask(bits);
+	int64_t hilbert = lppo_heis_basis(L, twiceS, szPlusConst, NULL);
+	word_t* data = (word_t*)malloc(sizeof(word_t) * (size_t)(hilbert > 0 ? hilbert : 1));
+	lppo_heis_basis(L, twiceS, szPlusConst, data);
+	double spin = twiceS * 0.5;
+	lppo_csr* m = csr_new(hilbert, 0, hilbert * 8);
+	sparse_row row;
+	srow_init(&row);
+	for (int64_t ispace = 0; ispace < hilbert; ispace++) {
+		m->rowptr[ispace] = m->nnz;
+		word_t ket = data[ispace];
+		/* diagonal :251-275 */
+		double s = 0;
+		for (int i = 0; i < L; i++) {
+			int val1 = heis_get_n(ket, i, bits, mask);
+			double tmp1 = val1 - twiceS * 0.5;
+			double tmp1d = tmp1 * tmp1;
+			if (i < nField) s += magneticField[i] * tmp1;
+			if (i < nAniso) s += anisotropy[i] * tmp1d;
+			for (int j = i + 1; j < L; j++) {
+				int val2 = heis_get_n(ket, j, bits, mask);
+				double tmp2 = val2 - twiceS * 0.5;
+				s += tmp1 * tmp2 * jzz[i * L + j];
+			}
+		}
+		srow_add(&row, ispace, s, 0.0); /* :100 */
+		for (int i = 0; i < L; i++) { /* :101-106 */
+			int val1 = heis_get_n(ket, i, bits, mask);
+			if (val1 == twiceS) continue;
+			val1++;
+			for (int j = 0; j < L; j++) { /* setSplusSminus :290-306 */
+				if (i == j) continue;
+				if (jpm[i * L + j] == 0) continue;
+				int val2 = heis_get_n(ket, j, bits, mask);
+				if (val2 == 0) continue;
+				double m2 = val2 - spin;
+				val2--;
+				double m1 = val2 - spin;
+				/* getBra, BasisHeisenberg.h:169-193 */
+				word_t bra = ket;
+				bra &= ~(mask << (i * bits));
+				bra &= ~(mask << (j * bits));
+				bra |= ((word_t)val1) << (i * bits);
+				bra |= ((word_t)val2) << (j * bits);
+				int64_t temp = literal_index ? lppo_find_linear(data, hilbert, bra) : lppo_find_bisect(data, hilbert, bra);
+				double tmp = sqrt(spin * (spin + 1.0) - m1 * (m1 + 1.0));
+				tmp *= sqrt(spin * (spin + 1.0) - m2 * (m2 - 1.0));
+				srow_add(&row, temp, 0.5 * tmp * jpm[i * L + j], 0.0);
+			}
+		}
+		srow_finalize(&row, m);
+	}
+	m->rowptr[hilbert] = m->nnz;
+	srow_free(&row);
+	free(data);
+	return m;
+}
+
+/* ------------------------------------------------------------------ */
+/* t-J (orbitals == 1): BasisTjMultiOrbLanczos.h + TjMultiOrb.h          */
+/* ------------------------------------------------------------------ */
+
+/* basis: { (down<<n)|up : up&down==0 } sorted ascending,
+ * BasisTjMultiOrbLanczos.h:29-42,354-369.  data==NULL returns the count. */
+static int cmp_word(const void* a, const void* b)
+{
+	word_t x = *(const word_t*)a, y = *(const word_t*)b;
+	return (x > y) - (x < y);
+}
+int64_t lppo_tj_basis(int L, int nup, int ndown, word_t* data)
+{
+	int64_t n1 = lppo_onespin_size(L, nup), n2 = lppo_onespin_size(L, ndown);
+	word_t* d1 = (word_t*)malloc(sizeof(word_t) * (size_t)n1);
+	word_t* d2 = (word_t*)malloc(sizeof(word_t) * (size_t)n2);
+	lppo_onespin_fill(L, nup, d1); /* fillOneSector :323-352, same loop as BasisOneSpin */
+	lppo_onespin_fill(L, ndown, d2);
+	int64_t n = 0;
+	for (int64_t i = 0; i < n1; i++) { /* combineAndFilter :354-369 */
+		for (int64_t j = 0; j < n2; j++) {
+			if (d1[i] & d2[j]) continue;
+			if (data) data[n] = (d2[j] << L) | d1[i];
+			n++;
+		}
+	}
+	if (data) qsort(data, (size_t)n, sizeof(word_t), cmp_word); /* std::sort :41 */
+	free(d1);
+	free(d2);
+	return n;
+}
+
+/* literal perfectIndex: bounded bisection then linear scan, BasisTjMultiOrbLanczos.h:70-107 */
+int64_t lppo_tj_perfect_index_literal(const word_t* data, int64_t elements, int L, word_t ket1, word_t ket2)
+{
+	word_t w = (ket2 << L) | ket1;
+	int64_t i = elements / 2, start = 0, end = elements, counter = 0;
+	int64_t max = (int64_t)(0.1 * elements);
+	if (max > 100) max = 100;
+	if (max < 1) max = 1;
+	while (counter < max) {
+		if (data[i] == w) return i;
+		if (data[i] > w) {
+			if (i < end) end = i;
+			i = i / 2;
+		} else {
+			if (i > start) start = i;
+			i = (i + elements) / 2;
+		}
+		counter++;
+	}
+	for (int64_t j = start; j < end; ++j)
+		if (data[j] == w) return j;
+	return -1;
+}
+
+/* parityFrom(i,j,ket) inclusive both ends, TjMultiOrb.h:788-800 */
+static int tj_parity_from(int i, int j, word_t ket)
+{
+	if (i == j) return (BIT(j) & ket) ? -1 : 1;
+	word_t mask = ket & ((BIT(i + 1) - 1) ^ (BIT(j) - 1));
+	int s = (popcnt(mask) & 1) ? -1 : 1;
+	if (BIT(i) & ket) s = -s;
+	if (BIT(j) & ket) s = -s;
+	return s;
+}
+
+/* signSplusSminus, TjMultiOrb.h:772-783 */
+static int tj_sign_spsm(int i, int j, word_t bra1, word_t bra2)
+{
+	int s = 1;
+	if (j > 0) s *= tj_parity_from(0, j - 1, bra2);
+	if (i > 0) s *= tj_parity_from(0, i - 1, bra2);
+	if (i > 0) s *= tj_parity_from(0, i - 1, bra1);
+	if (j > 0) s *= tj_parity_from(0, j - 1, bra1);
+	return s;
+}
+
+/* BasisTjMultiOrbLanczos::doSign(ket,i,j): parity of bits in [i,j), :381-400 */
+static int tj_do_sign(word_t ket, int i, int j)
+{
+	int sum = 0;
+	for (int c = i + 1; c < j; c++)
+		if (ket & BIT(c)) sum++;
+	for (int c = i; c < i + 1; c++)
+		if (ket & BIT(c)) sum++;
+	/* x0=j, x1=j: empty range */
+	return (sum & 1) ? -1 : 1;
+}
+
+/* TjMultiOrb::setupHamiltonian (orbitals==1), TjMultiOrb.h:100-131; diag :586-647;
+ * hopping :649-695; S+S- :697-770.  Terms: 0 hop, 1 J+-, 2 Jzz, 3 W (:63-79).
+ * potentialV has 2L entries (up then down, :612-615) guarded by i < size (:612). */
+lppo_csr* lppo_tj_setup(int L, int nup, int ndown, const double* hop_re, const double* hop_im, const double* jpm,
+                        const double* jzz, const double* w, const double* potentialV, int nPotentialV, int is_complex,
+                        int literal_index)
+{
+	int64_t hilbert = lppo_tj_basis(L, nup, ndown, NULL);
+	word_t* data = (word_t*)malloc(sizeof(word_t) * (size_t)(hilbert > 0 ? hilbert : 1));
+	lppo_tj_basis(L, nup, ndown, data);
+	word_t lowmask = BIT(L) - 1;
+	lppo_csr* m = csr_new(hilbert, is_complex, hilbert * 8);
+	sparse_row row;
+	srow_init(&row);
+#define TJ_INDEX(k1, k2)                                                                                             \
+	(literal_index ? lppo_tj_perfect_index_literal(data, hilbert, L, (k1), (k2))                                     \
+	               : lppo_find_bisect(data, hilbert, (((word_t)(k2)) << L) | (k1)))
+	for (int64_t ispace = 0; ispace < hilbert; ispace++) {
+		m->rowptr[ispace] = m->nnz;
+		word_t ket1 = data[ispace] & lowmask; /* operator()(i,spin) :127-141 */
+		word_t ket2 = (data[ispace] >> L) & lowmask;
+		/* diagonal :597-645, orbitals==1 so proij==1 */
+		double s = 0;
+		for (int i = 0; i < L; i++) {
+			int niup = (ket1 & BIT(i)) ? 1 : 0;
+			int nidown = (ket2 & BIT(i)) ? 1 : 0;
+			if (i < nPotentialV) {
+				s += potentialV[i] * niup;
+				s += potentialV[i + L] * nidown;
+			}
+			for (int j = i + 1; j < L; j++) {
+				int njup = (ket1 & BIT(j)) ? 1 : 0;
+				int njdown = (ket2 & BIT(j)) ? 1 : 0;
+				s += (niup - nidown) * (njup - njdown) * jzz[i * L + j] * 0.25;
+				s += (niup + nidown) * (njup + njdown) * w[i * L + j];
+			}
+		}
+		srow_add(&row, ispace, s, 0.0); /* :118 */
+		for (int i = 0; i < L; i++) { /* :119-124 */
+			int s1i = (ket1 & BIT(i)) ? 1 : 0;
+			int s2i = (ket2 & BIT(i)) ? 1 : 0;
+			/* setHoppingTerm :649-695 */
+			for (int j = 0; j < L; j++) {
+				if (j < i) continue;
+				double hr = hop_re[i * L + j];
+				double hi = hop_im ? hop_im[i * L + j] : 0.0;
+				if (hr == 0 && hi == 0) continue;
+				int s1j = (ket1 & BIT(j)) ? 1 : 0;
+				int s2j = (ket2 & BIT(j)) ? 1 : 0;
+				if (s1i + s1j == 1 && !(s1j == 0 && s2j > 0) && !(s1j > 0 && s2i > 0)) {
+					word_t bra1 = ket1 ^ (BIT(i) | BIT(j));
+					int64_t temp = TJ_INDEX(bra1, ket2);
+					double extraSign = (s1i == 1) ? -1 : 1;
+					double tmp2 = tj_do_sign(ket1, i, j);
+					srow_add(&row, temp, hr * extraSign * tmp2, hi * extraSign * tmp2);
+				}
+				if (s2i + s2j == 1 && !(s2j == 0 && s1j > 0) && !(s2j > 0 && s1i > 0)) {
+					word_t bra2 = ket2 ^ (BIT(i) | BIT(j));
+					int64_t temp = TJ_INDEX(ket1, bra2);
+					double extraSign = (s2i == 1) ? -1 : 1;
+					double tmp2 = tj_do_sign(ket2, i, j);
+					srow_add(&row, temp, hr * extraSign * tmp2, hi * extraSign * tmp2);
+				}
+			}
+			/* setSplusSminus :697-770 */
+			for (int j = 0; j < L; j++) {
+				if (j < i) continue;
+				double h = jpm[i * L + j] * 0.5;
+				if (h == 0) continue;
+				int s1j = (ket1 & BIT(j)) ? 1 : 0;
+				int s2j = (ket2 & BIT(j)) ? 1 : 0;
+				if (s1i == 1 && s1j == 0 && s2i == 0 && s2j == 1) {
+					word_t bra1 = (ket1 ^ BIT(i)) | BIT(j);
+					word_t bra2 = (ket2 | BIT(i)) ^ BIT(j);
+					int64_t temp = TJ_INDEX(bra1, bra2);
+					srow_add(&row, temp, h * tj_sign_spsm(i, j, bra1, bra2), 0.0);
+				}
+				if (s1i == 0 && s1j == 1 && s2i == 1 && s2j == 0) {
+					word_t bra1 = (ket1 | BIT(i)) ^ BIT(j);
+					word_t bra2 = (ket2 ^ BIT(i)) | BIT(j);
+					int64_t temp = TJ_INDEX(bra1, bra2);
+					srow_add(&row, temp, h * tj_sign_spsm(i, j, bra1, bra2), 0.0);
+				}
+			}
+		}
+		srow_finalize(&row, m);
+	}
+#undef TJ_INDEX
+	m->rowptr[hilbert] = m->nnz;
+	srow_free(&row);
+	free(data);
+	return m;
+}
+
+/* ------------------------------------------------------------------ */
+/* A1: accumulating SpMV  x += A y                                      */
+/* (InternalProductStored.h:121-124 -> DefaultSymmetry.h:112-116 ->     */
+/*  CrsMatrix::matrixVectorProduct [PsimagLite], serial double loop)    */
+/* ------------------------------------------------------------------ */
+
+void lppo_spmv_acc(int64_t nrows, const int64_t* rowptr, const int32_t* colind, const double* values, int is_complex,
+                   double* x, const double* y, int nthreads)
+{
+#ifdef _OPENMP
+	if (nthreads > 0) omp_set_num_threads(nthreads);
+#pragma omp parallel for schedule(static) if (nthreads != 1)
+#endif
+	for (int64_t i = 0; i < nrows; i++) {
+		if (!is_complex) {
+			double acc = x[i];
+			for (int64_t k = rowptr[i]; k < rowptr[i + 1]; k++) acc += values[k] * y[colind[k]];
+			x[i] = acc;
+		} else {
+			double ar = x[2 * i], ai = x[2 * i + 1];
+			for (int64_t k = rowptr[i]; k < rowptr[i + 1]; k++) {
+				double vr = values[2 * k], vi = values[2 * k + 1];
+				double yr = y[2 * (int64_t)colind[k]], yi = y[2 * (int64_t)colind[k] + 1];
+				ar += vr * yr - vi * yi;
+				ai += vr * yi + vi * yr;
+			}
+			x[2 * i] = ar;
+			x[2 * i + 1] = ai;
+		}
+	}
+}
+
+/* ------------------------------------------------------------------ */
+/* deterministic initial vector shared by oracle and GPU engine           */
+/* (replaces PsimagLite::fillRandom, Engine/Engine.h:621, whose stream    */
+/*  is unknowable; SURVEY 8(d): splitmix64 -> uniform(-0.5,0.5))          */
+/* ------------------------------------------------------------------ */
+
+static uint64_t splitmix64(uint64_t z)
+{
+	z += 0x9E3779B97F4A7C15ULL;
+	z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+	z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+	return z ^ (z >> 31);
+}
+/* element k (k counts doubles, so complex element i uses k=2i,2i+1) */
+void lppo_fill_random(double* v, int64_t ndoubles, uint64_t seed)
+{
+	for (int64_t k = 0; k < ndoubles; k++) {
+		uint64_t r = splitmix64(seed * 0x2545F4914F6CDD1DULL + (uint64_t)k);
+		v[k] = (double)(r >> 11) * (1.0 / 9007199254740992.0) - 0.5;
+	}
+}
+
+/* ------------------------------------------------------------------ */
+/* symmetric tridiagonal eigen-solver (implicit QL), replaces the        */
+/* LAPACK/`ground` call inside LanczosSolver [PsimagLite]                */
+/* d[n] diagonal, e[n-1] off-diagonal; eigenvalues ascending in w[n];    */
+/* eigenvectors column k in z[j*n+k] when z != NULL                       */
+/* ------------------------------------------------------------------ */
+
+int lppo_tridiag_eig(int n, const double* d_in, const double* e_in, double* w, double* z)
+{
+	double* d = w;
+	double* e = (double*)calloc((size_t)n + 1, sizeof(double));
+	for (int i = 0; i < n; i++) d[i] = d_in[i];
+	for (int i = 0; i + 1 < n; i++) e[i] = e_in[i];
+	e[n - 1 >= 0 ? n - 1 : 0] = 0;
+	if (z) {
+		for (int i = 0; i < n * n; i++) z[i] = 0;
+		for (int i = 0; i < n; i++) z[i * n + i] = 1;
+	}
+	for (int l = 0; l < n; l++) {
+		int iter = 0, mm;
+		do {
+			for (mm = l; mm < n - 1; mm++) {
+				double dd = fabs(d[mm]) + fabs(d[mm + 1]);
+				if (fabs(e[mm]) <= 2.3e-16 * dd) break;
+			}
+			if (mm != l) {
+				if (iter++ == 200) {
+					free(e);
+					return -1;
+				}
+				double g = (d[l + 1] - d[l]) / (2.0 * e[l]);
+				double r = hypot(g, 1.0);
+				g = d[mm] - d[l] + e[l] / (g + (g >= 0 ? fabs(r) : -fabs(r)));
+				double s = 1.0, c = 1.0, p = 0.0;
+				int i;
+				for (i = mm - 1; i >= l; i--) {
+					double f = s * e[i], b = c * e[i];
+					e[i + 1] = (r = hypot(f, g));
+					if (r == 0.0) {
+						d[i + 1] -= p;
+						e[mm] = 0.0;
+						break;
+					}
+					s = f / r;
+					c = g / r;
+					g = d[i + 1] - p;
+					r = (d[i] - g) * s + 2.0 * c * b;
+					d[i + 1] = g + (p = s * r);
+					g = c * r - b;
+					if (z) {
+						for (int k = 0; k < n; k++) {
+							f = z[k * n + i + 1];
+							z[k * n + i + 1] = s * z[k * n + i] + c * f;
+							z[k * n + i] = c * z[k * n + i] - s * f;
+						}
+					}
+				}
+				if (r == 0.0 && i >= l) continue;
+				d[l] -= p;
+				e[l] = g;
+				e[mm] = 0.0;
+			}
+		} while (mm != l);
+	}
+	/* selection sort ascending, carrying vectors */
+	for (int i = 0; i < n - 1; i++) {
+		int k = i;
+		double p = d[i];
+		for (int j = i + 1; j < n; j++)
+			if (d[j] < p) {
+				k = j;
+				p = d[j];
+			}
+		if (k != i) {
+			d[k] = d[i];
+			d[i] = p;
+			if (z)
+				for (int j = 0; j < n; j++) {
+					double t = z[j * n + i];
+					z[j * n + i] = z[j * n + k];
+					z[j * n + k] = t;
+				}
+		}
+	}
+	free(e);
+	return 0;
+}
+
+/* ------------------------------------------------------------------ */
+/* A2: the Lanczos loop (restating LanczosSolver::decomposition /        */
+/* computeAllStatesBelow [PsimagLite]; call sites Engine/Engine.h:626,478)*/
+/*                                                                      */
+/* per step j:  x += H y; a_j = Re<y|x>; x -= a_j y; (reortho);          */
+/*              b_j = ||x||; (y,x) <- (x/b_j, -b_j y);                    */
+/*              E_j = lowest eig of T_{j+1}; stop when |E_j-E_{j-1}|<eps  */
+/*              and j >= minSteps (or rows<=4), or j+1 == maxSteps.       */
+/* Ritz vectors  z_k = sum_j S(j,k) v_j  from the stored Lanczos vectors. */
+/* ------------------------------------------------------------------ */
+
+typedef struct {
+	int max_steps;
+	int min_steps;
+	double eps;
+	int reortho;
+} lppo_lanczos_params;
+
+static double dot_re(const double* y, const double* x, int64_t n, int is_complex)
+{ /* Re sum y_i conj(x_i) */
+	double s = 0;
+	int64_t nd = is_complex ? 2 * n : n;
+	for (int64_t i = 0; i < nd; i++) s += y[i] * x[i];
+	return s;
+}
+
+/* returns number of steps performed; a[steps], b[steps] filled.
+ * If V != NULL it must hold max_steps vectors; V[j] = Lanczos vector y_j. */
+int lppo_lanczos_decomposition(int64_t n, const int64_t* rowptr, const int32_t* colind, const double* values,
+                               int is_complex, const double* init, const lppo_lanczos_params* prm, double* a,
+                               double* b, double* V, double* e0_history, int nthreads)
+{
+	int64_t nd = is_complex ? 2 * n : n;
+	int max_steps = prm->max_steps;
+	if ((int64_t)max_steps > n) max_steps = (int)n;
+	double* x = (double*)calloc((size_t)nd, sizeof(double));
+	double* y = (double*)malloc(sizeof(double) * (size_t)nd);
+	double* wtmp = (double*)malloc(sizeof(double) * (size_t)(max_steps + 1));
+	double* coef = (double*)malloc(sizeof(double) * 2 * (size_t)(max_steps + 1));
+	double nrm = sqrt(dot_re(init, init, n, is_complex));
+	for (int64_t i = 0; i < nd; i++) y[i] = init[i] / nrm;
+	double eold = 100.0, enew = 0;
+	int j = 0, steps = 0;
+	for (; j < max_steps; j++) {
+		if (V) memcpy(V + (size_t)j * nd, y, sizeof(double) * (size_t)nd);
+		lppo_spmv_acc(n, rowptr, colind, values, is_complex, x, y, nthreads);
+		double atmp = dot_re(y, x, n, is_complex);
+		for (int64_t i = 0; i < nd; i++) x[i] -= atmp * y[i];
+		if (prm->reortho && V) {
+			/* classical Gram-Schmidt, two passes, against v_0..v_j */
+			for (int pass = 0; pass < 2; pass++) {
+				for (int k = 0; k <= j; k++) {
+					const double* vk = V + (size_t)k * nd;
+					double cr = 0, ci = 0;
+					if (!is_complex) {
+						for (int64_t i = 0; i < n; i++) cr += vk[i] * x[i];
+					} else {
+						for (int64_t i = 0; i < n; i++) { /* <vk|x> = sum conj(vk) x */
+							cr += vk[2 * i] * x[2 * i] + vk[2 * i + 1] * x[2 * i + 1];
+							ci += vk[2 * i] * x[2 * i + 1] - vk[2 * i + 1] * x[2 * i];
+						}
+					}
+					coef[2 * k] = cr;
+					coef[2 * k + 1] = ci;
+				}
+				for (int k = 0; k <= j; k++) {
+					const double* vk = V + (size_t)k * nd;
+					double cr = coef[2 * k], ci = coef[2 * k + 1];
+					if (!is_complex) {
+						for (int64_t i = 0; i < n; i++) x[i] -= cr * vk[i];
+					} else {
+						for (int64_t i = 0; i < n; i++) {
+							x[2 * i] -= cr * vk[2 * i] - ci * vk[2 * i + 1];
+							x[2 * i + 1] -= cr * vk[2 * i + 1] + ci * vk[2 * i];
+						}
+					}
+				}
+			}
+		}
+		double btmp = sqrt(dot_re(x, x, n, is_complex));
+		a[j] = atmp;
+		b[j] = btmp;
+		if (fabs(btmp) < 1e-10) {
+			for (int64_t i = 0; i < nd; i++) {
+				double t = y[i];
+				y[i] = x[i];
+				x[i] = -btmp * t;
+			}
+		} else {
+			double inv = 1.0 / btmp;
+			for (int64_t i = 0; i < nd; i++) {
+				double t = y[i];
+				y[i] = x[i] * inv;
+				x[i] = -btmp * t;
+			}
+		}
+		steps = j + 1;
+		lppo_tridiag_eig(steps, a, b, wtmp, NULL);
+		enew = wtmp[0];
+		if (e0_history) e0_history[j] = enew;
+		if (prm->eps > 0) {
+			int exitFlag = (fabs(enew - eold) < prm->eps);
+			if (exitFlag && n <= 4) break;
+			if (exitFlag && j >= prm->min_steps) break;
+		}
+		if (fabs(btmp) < 1e-10) break; /* invariant subspace exhausted */
+		eold = enew;
+	}
+	free(x);
+	free(y);
+	free(wtmp);
+	free(coef);
+	return steps;
+}
+
+/* computeAllStatesBelow: lowest nstates Ritz values (+ vectors when zs != NULL).
+ * zs holds nstates vectors of n elements. Returns steps, or <0 on failure. */
+int lppo_lanczos_solve(int64_t n, const int64_t* rowptr, const int32_t* colind, const double* values, int is_complex,
+                       const double* init, const lppo_lanczos_params* prm, int nstates, double* eigs, double* zs,
+                       int nthreads)
+{
+	int64_t nd = is_complex ? 2 * n : n;
+	int max_steps = prm->max_steps;
+	if ((int64_t)max_steps > n) max_steps = (int)n;
+	double* a = (double*)calloc((size_t)max_steps + 1, sizeof(double));
+	double* b = (double*)calloc((size_t)max_steps + 1, sizeof(double));
+	double* V = NULL;
+	if (zs || prm->reortho) V = (double*)malloc(sizeof(double) * (size_t)nd * (size_t)max_steps);
+	int steps = lppo_lanczos_decomposition(n, rowptr, colind, values, is_complex, init, prm, a, b, V, NULL, nthreads);
+	if (steps < nstates) {
+		free(a);
+		free(b);
+		free(V);
+		return -1;
+	}
+	double* w = (double*)malloc(sizeof(double) * (size_t)steps);
+	double* S = (double*)malloc(sizeof(double) * (size_t)steps * (size_t)steps);
+	lppo_tridiag_eig(steps, a, b, w, S);
+	for (int k = 0; k < nstates; k++) eigs[k] = w[k];
+	if (zs) {
+		for (int k = 0; k < nstates; k++) {
+			double* z = zs + (size_t)k * nd;
+			memset(z, 0, sizeof(double) * (size_t)nd);
+			for (int j = 0; j < steps; j++) {
+				double s = S[j * steps + k];
+				const double* vj = V + (size_t)j * nd;
+				for (int64_t i = 0; i < nd; i++) z[i] += s * vj[i];
+			}
+		}
+	}
+	free(a);
+	free(b);
+	free(V);
+	free(w);
+	free(S);
+	return steps;
+}
