@@ -1,0 +1,198 @@
+/*
+ * lpp_engine.h -- C ABI of the MI355X-native Lanczos inner engine (liblpp_engine.so).
+ *
+ * Drop-in boundary for ONE path of g1257/LanczosPlusPlus: the stored-CSR ground-state solve
+ *   Engine::computeAllStatesBelow            reference src/Engine/Engine.h:601-657
+ *     -> InternalProductStored::matrixVectorProduct   src/Engine/InternalProductStored.h:121-124
+ *     -> DefaultSymmetry::matrixVectorProduct         src/Engine/DefaultSymmetry.h:112-116
+ *     -> CrsMatrix::matrixVectorProduct / LanczosSolver::computeAllStatesBelow [PsimagLite]
+ * The reference has no FFI; its boundary is C++ template duck-typing.  These
+ * entry points are what a binding of that path needs; INTEGRATION.md shows the C++ shim
+ * (InternalProductStored / LanczosSolver look-alikes) that forwards to them.
+ *
+ * Conventions: plain pointers and sizes, no C++/torch types.  Every function returns an
+ * lpp_status (0 = ok); lpp_last_error() gives the message of the last failure on the calling
+ * thread.  One engine per host thread; calls block unless stated.  Host buffers stay owned
+ * by the caller (the engine copies); device memory is owned by the engine unless a *_device /
+ * comm buffer is handed in.  Values are f64 or interleaved (re,im) f64 pairs ("c128").
+ * Row pointers are 64-bit (the reference's int row pointers overflow at 4x4 Hubbard).
+ * There is NO CPU fallback: without a usable HIP device every compute call fails.
+ */
+#ifndef LPP_ENGINE_H
+#define LPP_ENGINE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LPP_ABI_VERSION 1
+
+typedef int32_t lpp_status;
+enum {
+	LPP_OK = 0,
+	LPP_ERR_INVALID = 1, /* bad argument / shape mismatch */
+	LPP_ERR_HIP = 2, /* HIP runtime error (no device, launch failure, ...) */
+	LPP_ERR_NOMEM = 3, /* device or host allocation failed */
+	LPP_ERR_NOCONV = 4, /* Lanczos / tridiagonal solve failed (caller may fall back, Engine.h:627) */
+	LPP_ERR_STATE = 5, /* call sequence error (e.g. solve before set_csr) */
+	LPP_ERR_COMM = 6 /* a communicator callback failed */
+};
+
+enum { LPP_F64 = 0, LPP_C128 = 1 };
+
+/* SpMV kernel selection (0 = automatic) */
+enum { LPP_SPMV_AUTO = 0, LPP_SPMV_ROWGROUP = 1, LPP_SPMV_SLICED = 2 };
+
+typedef struct lpp_engine lpp_engine;
+
+/* Solver parameters; mirrors what the reference reads through
+ * ParametersForSolver(io,"Lanczos") (Engine.h:609): LanczosSteps=, LanczosEps=, LanczosMinSteps=,
+ * LanczosOptions=reortho, lotaMemory (SpinOrbital.cpp:213-216). */
+typedef struct lpp_config {
+	int32_t abi_version; /* must be LPP_ABI_VERSION */
+	int32_t device; /* HIP device ordinal */
+	int32_t dtype; /* LPP_F64 | LPP_C128 */
+	int32_t max_steps; /* LanczosSteps (default 200) */
+	int32_t min_steps; /* LanczosMinSteps (default 4) */
+	int32_t reortho; /* 1: blocked CGS2 against the on-device Krylov basis every step */
+	int32_t save_vectors; /* lotaMemory: 1 keep Lanczos vectors in HBM, 0 two-pass Ritz vectors, -1 auto */
+	int32_t check_lag; /* steps the GPU may run ahead of the host convergence test (default 2) */
+	int32_t spmv_kernel; /* LPP_SPMV_* */
+	int32_t time_kernels; /* 1: bracket every SpMV launch with HIP events (for bench/roofline) */
+	double eps; /* LanczosEps (default 1e-12); <= 0 disables the convergence test */
+	uint64_t seed; /* seed of the built-in start vector (used when init == NULL) */
+	void* stream; /* hipStream_t to run on; NULL = engine-owned stream */
+} lpp_config;
+
+typedef struct lpp_stats {
+	int32_t steps; /* Lanczos steps that define the returned tridiagonal matrix */
+	int32_t steps_enqueued; /* including run-ahead steps discarded by the lagged test */
+	int32_t converged;
+	int32_t vectors_saved;
+	int64_t nrows, nnz;
+	double seconds_total; /* wall time of the solve call */
+	double spmv_ms_total; /* sum of event-timed SpMV launches (time_kernels=1) */
+	int64_t spmv_launches;
+	double spmv_bytes; /* algorithmic bytes of one SpMV: Z(s+4) + (N+1)8 + 3Ns */
+} lpp_stats;
+
+/* Communicator for the 1-D row-partitioned multi-GPU path.  The engine never
+ * opens sockets itself: the host (torch.distributed over RCCL in bench.py) supplies the
+ * collectives and owns the exchange buffers.
+ *   send_buf : device, shard_stride elements      (this rank's slice of the Lanczos vector, zero padded)
+ *   gath_buf : device, nranks*shard_stride elems  (slice r at gath_buf + r*shard_stride)
+ *   red_buf  : device doubles, red_len >= 6*(max_steps+2)   (a_j, b_j^2 and reortho coefficients)
+ * allgather_begin may return before the gather completes (so the local-column SpMV overlaps
+ * it); allgather_end makes the engine stream wait for it.  All callbacks return 0 on success. */
+typedef struct lpp_comm {
+	int32_t rank, nranks;
+	void* ctx;
+	void* send_buf;
+	void* gath_buf;
+	double* red_buf;
+	int64_t shard_stride;
+	int32_t red_len;
+	int32_t (*allgather_begin)(void* ctx);
+	int32_t (*allgather_end)(void* ctx);
+	int32_t (*allreduce_sum)(void* ctx, int32_t offset, int32_t count); /* in place on red_buf[offset..] */
+} lpp_comm;
+
+const char* lpp_last_error(void);
+int32_t lpp_abi_version(void);
+void lpp_config_default(lpp_config* cfg);
+
+lpp_status lpp_engine_create(lpp_engine** out, const lpp_config* cfg);
+lpp_status lpp_engine_destroy(lpp_engine* e);
+
+/* ---- the stored Hamiltonian (replaces DefaultSymmetry::matrixStored_, DefaultSymmetry.h:120) ---- */
+
+/* Upload a host CSR (copied).  rowptr[nrows+1], colind[nnz], values[nnz] of the engine dtype. */
+lpp_status lpp_engine_set_csr(lpp_engine* e, int64_t nrows, const int64_t* rowptr, const int32_t* colind,
+                              const void* values);
+
+/* Row-partitioned upload for rank `comm->rank`: rows [row_start, row_start+local_rows) of a
+ * global_rows x global_rows matrix, colind holding GLOBAL column indices, rowptr relative to the
+ * block (rowptr[0]==0).  shard_starts[nranks+1] gives every rank's first row.  The engine splits
+ * the block into a local-column and a remote-column CSR (lpp_split_csr). */
+lpp_status lpp_engine_set_csr_partition(lpp_engine* e, const lpp_comm* comm, int64_t global_rows,
+                                        const int64_t* shard_starts, const int64_t* rowptr, const int32_t* colind,
+                                        const void* values);
+
+/* On-device assembly of the Hubbard Hamiltonian (GPU restatement of HubbardHelper::setupHamiltonian,
+ * src/Models/HubbardOneOrbital/HubbardHelper.h:75-103, in the BasisHubbardLanczos ordering
+ * rank(up) + rank(down)*N_up, BasisHubbardLanczos.h:59-63).  hop_re/hop_im: L*L row-major
+ * hoppings_(i,j) (hop_im NULL for real); U[L]; V[L] (potentialV[i], i<L, both spins).
+ * comm == NULL: whole matrix on this GPU.  Otherwise rows are partitioned at multiples of N_up
+ * (shard_starts returned through comm-side helper lpp_partition_rows). */
+lpp_status lpp_engine_assemble_hubbard(lpp_engine* e, const lpp_comm* comm, int32_t nsites, int32_t nup,
+                                       int32_t ndown, const double* hop_re, const double* hop_im, const double* U,
+                                       const double* V);
+
+/* On-device assembly of the S=1/2 Heisenberg Hamiltonian (Heisenberg.h:80-114,242-307) in the
+ * BasisHeisenberg ordering (ascending words of fixed popcount, BasisHeisenberg.h:38-46). */
+lpp_status lpp_engine_assemble_heisenberg(lpp_engine* e, int32_t nsites, int32_t szPlusConst, const double* jpm,
+                                          const double* jzz, const double* field, int32_t nfield);
+
+/* On-device assembly of the one-orbital t-J Hamiltonian (TjMultiOrb.h:100-131,586-783) in the
+ * BasisTjMultiOrbLanczos ordering (sorted (down<<L)|up words without double occupancy). */
+lpp_status lpp_engine_assemble_tj(lpp_engine* e, int32_t nsites, int32_t nup, int32_t ndown, const double* hop_re,
+                                  const double* hop_im, const double* jpm, const double* jzz, const double* w,
+                                  const double* potentialV, int32_t npot);
+
+/* Copy the device CSR back (for parity tests of the assemblers).  Pass NULL pointers to query
+ * sizes only.  which: 0 = whole/local-column part, 1 = remote-column part. */
+lpp_status lpp_engine_get_csr(lpp_engine* e, int32_t which, int64_t* nrows, int64_t* nnz, int64_t* rowptr,
+                              int32_t* colind, void* values);
+
+/* ---- A1: x += H y  (InternalProductStored::matrixVectorProduct) on host buffers ---- */
+lpp_status lpp_engine_spmv_acc(lpp_engine* e, void* x_inout, const void* y);
+
+/* ---- A2/A3: the Lanczos solve (LanczosSolver::computeAllStatesBelow, Engine.h:626) ----
+ * init: host start vector of local_rows elements or NULL (built-in splitmix64 vector, same as the oracle).
+ * eigs[nstates]; ritz_vectors: host buffer nstates*local_rows elements or NULL. */
+lpp_status lpp_engine_lanczos(lpp_engine* e, const void* init, int32_t nstates, double* eigs, void* ritz_vectors,
+                              lpp_stats* stats);
+
+/* LanczosSolver::decomposition (Engine.h:478): tridiagonal coefficients only.
+ * a[max_steps], b[max_steps]; *nsteps receives the number of valid entries. */
+lpp_status lpp_engine_decomposition(lpp_engine* e, const void* init, int32_t* nsteps, double* a, double* b,
+                                    lpp_stats* stats);
+
+/* ---- incremental interface (bench.py times exactly K steps with it) ---- */
+lpp_status lpp_engine_lanczos_begin(lpp_engine* e, const void* init);
+lpp_status lpp_engine_lanczos_step(lpp_engine* e, int32_t nsteps); /* enqueue only, no host sync */
+lpp_status lpp_engine_sync(lpp_engine* e);
+/* copy out the coefficients produced so far (after a sync): a[steps], b[steps] */
+lpp_status lpp_engine_lanczos_coeffs(lpp_engine* e, int32_t* steps, double* a, double* b);
+lpp_status lpp_engine_get_stats(lpp_engine* e, lpp_stats* stats);
+
+/* Time `iters` back-to-back SpMV launches (x += H y on resident vectors) with HIP events on the
+ * engine stream; returns the average milliseconds per launch. */
+lpp_status lpp_engine_bench_spmv(lpp_engine* e, int32_t warmup, int32_t iters, double* ms_per_launch);
+
+/* ---- host-only helpers (no GPU needed; covered by the CPU test-suite) ---- */
+
+/* 1-D contiguous row partition: starts[nranks+1]; boundaries are multiples of `block`
+ * (N_up for the Hubbard product basis so that up-hops and the diagonal stay rank-local). */
+lpp_status lpp_partition_rows(int64_t nrows, int32_t nranks, int64_t block, int64_t* starts);
+
+/* Split a row block with global columns into local-column and remote-column CSRs.
+ * Local columns become offsets into the rank's own slice; remote columns become indices into the
+ * padded gather buffer (owner*shard_stride + offset).  Two-call protocol: with out pointers NULL
+ * only nnz_loc / nnz_rem are returned. */
+lpp_status lpp_split_csr(int32_t rank, int32_t nranks, const int64_t* shard_starts, int64_t shard_stride,
+                         int64_t local_rows, const int64_t* rowptr, const int32_t* colind, const void* values,
+                         int32_t elem_bytes, int64_t* nnz_loc, int64_t* nnz_rem, int64_t* rowptr_loc,
+                         int32_t* colind_loc, void* values_loc, int64_t* rowptr_rem, int32_t* colind_rem,
+                         void* values_rem);
+
+/* Lowest `k` eigenvalues (and optionally eigenvectors, row-major z[j*n+i] = component j of vector i)
+ * of the symmetric tridiagonal matrix (d[n], e[n-1]) -- the host part of the Lanczos loop. */
+lpp_status lpp_tridiag_lowest(int32_t n, const double* d, const double* e, int32_t k, double* w, double* z);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LPP_ENGINE_H */

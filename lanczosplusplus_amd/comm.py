@@ -1,0 +1,90 @@
+"""torch.distributed communicator for the 1-D row-partitioned multi-GPU path.
+
+One process per GPU.  The exchange buffers are torch tensors (PyTorch owns device memory and
+the process group); the engine gets raw pointers plus three callbacks:
+  allgather_begin : all_gather_into_tensor(gath, send, async_op=True)  -- returns at once so the
+                    local-column SpMV overlaps the transfer
+  allgather_end   : work.wait()  -- the engine's stream waits for the gather
+  allreduce_sum   : all_reduce on a slice of the scalar buffer (a_j, b_j^2, reortho coefficients)
+Backend "nccl" is RCCL over xGMI on MI355X; "gloo" (CPU or GPU tensors) is used by the tests.
+The engine must run on the torch stream that is current when the callbacks fire: create the
+engine with stream=comm.stream_handle and call it inside `with comm.stream_context():`.
+"""
+import contextlib
+import ctypes as C
+import sys
+import traceback
+
+import torch
+import torch.distributed as dist
+
+from ._capi import CB_REDUCE, CB_VOID, Comm
+
+
+class TorchDistComm:
+    def __init__(self, shard_stride, max_steps, is_complex=False, device=None, group=None):
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.nranks = dist.get_world_size(group)
+        self.device = torch.device(device if device is not None else "cpu")
+        ncomp = 2 if is_complex else 1
+        self.shard_stride = int(shard_stride)
+        self.send = torch.zeros(self.shard_stride * ncomp, dtype=torch.float64, device=self.device)
+        self.gath = torch.zeros(self.nranks * self.shard_stride * ncomp, dtype=torch.float64, device=self.device)
+        self.red = torch.zeros(6 * (max_steps + 2) + 8, dtype=torch.float64, device=self.device)
+        self._work = None
+        self.stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
+        self.calls = {"allgather": 0, "allreduce": 0}
+
+        def _begin(_ctx):
+            try:
+                self.calls["allgather"] += 1
+                try:
+                    self._work = dist.all_gather_into_tensor(self.gath, self.send, group=self.group, async_op=True)
+                except (RuntimeError, NotImplementedError):
+                    views = list(self.gath.chunk(self.nranks))
+                    self._work = dist.all_gather(views, self.send, group=self.group, async_op=True)
+                return 0
+            except Exception:  # never let an exception cross the C boundary
+                traceback.print_exc(file=sys.stderr)
+                return 1
+
+        def _end(_ctx):
+            try:
+                if self._work is not None:
+                    self._work.wait()
+                    self._work = None
+                return 0
+            except Exception:
+                traceback.print_exc(file=sys.stderr)
+                return 1
+
+        def _reduce(_ctx, offset, count):
+            try:
+                self.calls["allreduce"] += 1
+                dist.all_reduce(self.red[offset:offset + count], op=dist.ReduceOp.SUM, group=self.group)
+                return 0
+            except Exception:
+                traceback.print_exc(file=sys.stderr)
+                return 1
+
+        # keep references: ctypes callbacks must outlive the engine
+        self._cb = (CB_VOID(_begin), CB_VOID(_end), CB_REDUCE(_reduce))
+        s = Comm()
+        s.rank, s.nranks, s.ctx = self.rank, self.nranks, None
+        s.send_buf = self.send.data_ptr()
+        s.gath_buf = self.gath.data_ptr()
+        s.red_buf = self.red.data_ptr()
+        s.shard_stride = self.shard_stride
+        s.red_len = self.red.numel()
+        s.allgather_begin, s.allgather_end, s.allreduce_sum = self._cb
+        self.struct = s
+
+    @property
+    def stream_handle(self):
+        return None if self.stream is None else C.c_void_p(self.stream.cuda_stream)
+
+    def stream_context(self):
+        if self.stream is None:
+            return contextlib.nullcontext()
+        return torch.cuda.stream(self.stream)

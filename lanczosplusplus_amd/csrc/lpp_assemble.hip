@@ -1,0 +1,390 @@
+// lpp_assemble.hip -- host side of the on-device Hamiltonian assembly (see lpp_assemble_kernels.h).
+// Builds the delta-sorted term list of each model from the reference's element formulas and
+// launches count -> scan -> fill.  Citations are relative to /root/reference/src.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "lpp_assemble_kernels.h"
+#include "lpp_engine_impl.h"
+
+using namespace lpp;
+
+namespace {
+
+struct HostProc {
+	Proc p;
+	int64_t delta;
+};
+
+inline uint64_t bit(int i) { return 1ull << i; }
+inline uint64_t below(int i) { return bit(i) - 1; }
+// bits [i, j)
+inline uint64_t range_mask(int i, int j) { return below(j) & ~below(i); }
+
+int64_t delta_of(const Proc& p)
+{
+	// bra - ket as integers: bits switched on minus bits switched off
+	const uint64_t on = p.xmask & p.need_clear, off = p.xmask & p.need_set;
+	return (int64_t)on - (int64_t)off;
+}
+
+void push(std::vector<HostProc>& v, uint64_t need_set, uint64_t need_clear, uint64_t xmask, uint64_t smask_ket, uint64_t smask_bra,
+          int sign_const, double re, double im, bool real_only = false)
+{
+	HostProc h {};
+	h.p.need_set = need_set;
+	h.p.need_clear = need_clear;
+	h.p.xmask = xmask;
+	h.p.smask_ket = smask_ket;
+	h.p.smask_bra = smask_bra;
+	h.p.sign_const = sign_const;
+	h.p.amp_re = re;
+	h.p.amp_im = im;
+	h.p.real_only = real_only ? 1 : 0;
+	h.delta = delta_of(h.p);
+	v.push_back(h);
+}
+
+std::vector<uint64_t> comb_table()
+{
+	// BasisOneSpin::doCombinatorial (BasisOneSpin.h:178-191); saturating beyond 64 bits
+	std::vector<uint64_t> c((size_t)kCombDim * kCombDim, 0);
+	for (int n = 0; n < kCombDim; n++) {
+		c[(size_t)n * kCombDim] = 1;
+		for (int m = 1; m <= n; m++) {
+			const unsigned __int128 v = (unsigned __int128)c[(size_t)(n - 1) * kCombDim + m - 1] + c[(size_t)(n - 1) * kCombDim + m];
+			c[(size_t)n * kCombDim + m] = v > (unsigned __int128)UINT64_MAX ? UINT64_MAX : (uint64_t)v;
+		}
+	}
+	return c;
+}
+
+struct DevBuf {
+	void* p = nullptr;
+	~DevBuf()
+	{
+		if (p) (void)hipFree(p);
+	}
+};
+
+template <int MODEL, typename T>
+lpp_status run_assembly(lpp_engine* e, AsmParams P, DevCsr& A)
+{
+	hipStream_t st = e->stream;
+	free_csr(A);
+	A.nrows = P.nloc;
+	A.owned = true;
+	HIP_TRY_MEM(hipMalloc(&A.rowptr, sizeof(int64_t) * (size_t)(P.nloc + 1)));
+	HIP_TRY(hipMemsetAsync(A.rowptr, 0, sizeof(int64_t) * (size_t)(P.nloc + 1), st));
+	const int nb = (int)std::max<int64_t>(1, std::min<int64_t>((P.nloc + kBlock - 1) / kBlock, 1 << 20));
+	if (P.nloc > 0) k_asm_count<MODEL><<<nb, kBlock, 0, st>>>(P, A.rowptr);
+	// exclusive scan of nloc+1 lengths (last is 0) -> rowptr
+	const int64_t n = P.nloc + 1;
+	const int64_t nblk = (n + kScanChunk - 1) / kScanChunk;
+	DevBuf sums, total;
+	HIP_TRY_MEM(hipMalloc(&sums.p, sizeof(int64_t) * (size_t)nblk));
+	HIP_TRY_MEM(hipMalloc(&total.p, sizeof(int64_t)));
+	k_scan_block_sums<<<(int)nblk, kBlock, 0, st>>>(A.rowptr, n, (int64_t*)sums.p);
+	k_scan_sums<<<1, kBlock, 0, st>>>((int64_t*)sums.p, nblk, (int64_t*)total.p);
+	k_scan_apply<<<(int)nblk, kBlock, 0, st>>>(A.rowptr, n, (const int64_t*)sums.p, A.rowptr);
+	HIP_TRY(hipGetLastError());
+	int64_t nnz = 0;
+	HIP_TRY(hipMemcpyAsync(&nnz, total.p, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipStreamSynchronize(st));
+	A.nnz = nnz;
+	HIP_TRY_MEM(hipMalloc(&A.col, sizeof(int32_t) * (size_t)std::max<int64_t>(nnz, 1)));
+	HIP_TRY_MEM(hipMalloc(&A.val, sizeof(T) * (size_t)std::max<int64_t>(nnz, 1)));
+	if (P.nloc > 0) k_asm_fill<MODEL, T><<<nb, kBlock, 0, st>>>(P, A.rowptr, A.col, (T*)A.val);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipStreamSynchronize(st));
+	return finalize_csr(e, A, true);
+}
+
+template <int MODEL> lpp_status dispatch(lpp_engine* e, const AsmParams& P, DevCsr& A)
+{
+	return e->is_complex ? run_assembly<MODEL, cplx>(e, P, A) : run_assembly<MODEL, double>(e, P, A);
+}
+
+lpp_status upload(hipStream_t st, DevBuf& b, const void* src, size_t bytes)
+{
+	HIP_TRY_MEM(hipMalloc(&b.p, std::max<size_t>(bytes, 8)));
+	if (bytes) HIP_TRY(hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, st));
+	return LPP_OK;
+}
+
+lpp_status finish_procs(std::vector<HostProc>& hp, std::vector<Proc>& out, int* nneg)
+{
+	std::stable_sort(hp.begin(), hp.end(), [](const HostProc& a, const HostProc& b) { return a.delta < b.delta; });
+	for (size_t i = 0; i + 1 < hp.size(); i++)
+		if (hp[i].delta == hp[i + 1].delta) return fail(LPP_ERR_INVALID, "assembly: two Hamiltonian terms map to the same bra (unsupported duplicate)");
+	*nneg = 0;
+	out.clear();
+	for (auto& h : hp) {
+		if (h.delta == 0) return fail(LPP_ERR_INVALID, "assembly: off-diagonal term with zero displacement");
+		if (h.delta < 0) (*nneg)++;
+		out.push_back(h.p);
+	}
+	return LPP_OK;
+}
+
+uint64_t binom(const std::vector<uint64_t>& c, int n, int m)
+{
+	if (n < 0 || m < 0 || m > n || n >= kCombDim) return 0;
+	return c[(size_t)n * kCombDim + m];
+}
+
+lpp_status common_setup(lpp_engine* e, int64_t nrows, int is_complex_input)
+{
+	if (!e) return fail(LPP_ERR_INVALID, "assemble: null engine");
+	if (is_complex_input && !e->is_complex) return fail(LPP_ERR_INVALID, "assemble: complex couplings need a c128 engine");
+	if (nrows <= 0) return fail(LPP_ERR_INVALID, "assemble: empty Hilbert space");
+	if (nrows > (int64_t)INT32_MAX) return fail(LPP_ERR_INVALID, "assemble: Hilbert space exceeds the 32-bit column range of the stored CSR");
+	HIP_TRY(hipSetDevice(e->cfg.device));
+	return LPP_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+lpp_status lpp_engine_assemble_hubbard(lpp_engine* e, const lpp_comm* comm, int32_t L, int32_t nup, int32_t ndown,
+                                       const double* hop_re, const double* hop_im, const double* U, const double* V)
+{
+	if (!e || !hop_re || !U || !V || L < 1 || L > 31 || nup < 0 || ndown < 0 || nup > L || ndown > L)
+		return fail(LPP_ERR_INVALID, "lpp_engine_assemble_hubbard: bad argument (1 <= L <= 31)");
+	const std::vector<uint64_t> comb = comb_table();
+	const int64_t n_up = (int64_t)binom(comb, L, nup), n_dn = (int64_t)binom(comb, L, ndown);
+	const int64_t nrows = n_up * n_dn;
+	bool cplx_in = false;
+	if (hop_im)
+		for (int k = 0; k < L * L; k++) cplx_in |= (hop_im[k] != 0);
+	lpp_status st = common_setup(e, nrows, cplx_in);
+	if (st != LPP_OK) return st;
+
+	// terms: c^dagger_j c_i for every ordered pair with hoppings_(i,j) != 0, both species,
+	// value h * doSign(ket,i) * doSign(ket^bit(i), j)   (HubbardHelper.h:205-243, ProgramGlobals.h:109-114)
+	std::vector<HostProc> hp;
+	for (int i = 0; i < L; i++) {
+		for (int j = 0; j < L; j++) {
+			if (i == j) continue;
+			const double hr = hop_re[i * L + j], hi = hop_im ? hop_im[i * L + j] : 0.0;
+			if (hr == 0 && hi == 0) continue;
+			for (int spin = 0; spin < 2; spin++) {
+				const int sh = spin * L;
+				push(hp, bit(i + sh), bit(j + sh), bit(i + sh) | bit(j + sh), (below(i) ^ below(j)) << sh, 0, i < j ? 1 : 0, hr, hi);
+			}
+		}
+	}
+	std::vector<Proc> procs;
+	int nneg = 0;
+	st = finish_procs(hp, procs, &nneg);
+	if (st != LPP_OK) return st;
+
+	DevBuf d_procs, d_comb, d_U, d_V;
+	if ((st = upload(e->stream, d_procs, procs.data(), sizeof(Proc) * procs.size())) != LPP_OK) return st;
+	if ((st = upload(e->stream, d_comb, comb.data(), sizeof(uint64_t) * comb.size())) != LPP_OK) return st;
+	if ((st = upload(e->stream, d_U, U, sizeof(double) * L)) != LPP_OK) return st;
+	if ((st = upload(e->stream, d_V, V, sizeof(double) * L)) != LPP_OK) return st;
+
+	AsmParams P {};
+	P.model = ASM_HUBBARD;
+	P.L = L;
+	P.nup = nup;
+	P.ndown = ndown;
+	P.nproc = (int)procs.size();
+	P.nneg = nneg;
+	P.n_up = n_up;
+	P.nrows_global = nrows;
+	P.procs = (const Proc*)d_procs.p;
+	P.comb = (const uint64_t*)d_comb.p;
+	P.d0 = (const double*)d_U.p;
+	P.d1 = (const double*)d_V.p;
+
+	const bool multi = comm && comm->nranks > 1;
+	if (!multi) {
+		e->has_comm = false;
+		e->bind_scalars(e->scal_own);
+		free_csr(e->A_rem);
+		P.row0 = 0;
+		P.nloc = nrows;
+		P.part = 0;
+		st = dispatch<ASM_HUBBARD>(e, P, e->A_loc);
+		if (st != LPP_OK) return st;
+		e->n_local = e->n_global = nrows;
+		e->row_start = 0;
+	} else {
+		st = e->adopt_comm(comm);
+		if (st != LPP_OK) return st;
+		// partition at multiples of N_up: whole down-configurations per rank, so the diagonal and all
+		// up-hops stay rank-local; gathered index == global index because stride == per*N_up
+		std::vector<int64_t> starts(comm->nranks + 1);
+		st = lpp_partition_rows(nrows, comm->nranks, n_up, starts.data());
+		if (st != LPP_OK) return st;
+		const int64_t per = (n_dn + comm->nranks - 1) / comm->nranks;
+		if (comm->shard_stride != per * n_up) return fail(LPP_ERR_INVALID, "assemble_hubbard: comm.shard_stride must be ceil(N_down/nranks)*N_up");
+		if ((int64_t)comm->nranks * comm->shard_stride > (int64_t)INT32_MAX) return fail(LPP_ERR_INVALID, "assemble_hubbard: gathered vector exceeds 32-bit column range");
+		P.row0 = starts[comm->rank];
+		P.nloc = starts[comm->rank + 1] - starts[comm->rank];
+		P.col_lo = starts[comm->rank];
+		P.col_hi = starts[comm->rank + 1];
+		P.part = 1;
+		st = dispatch<ASM_HUBBARD>(e, P, e->A_loc);
+		if (st != LPP_OK) return st;
+		P.part = 2;
+		st = dispatch<ASM_HUBBARD>(e, P, e->A_rem);
+		if (st != LPP_OK) return st;
+		e->n_local = P.nloc;
+		e->n_global = nrows;
+		e->row_start = P.row0;
+	}
+	e->active = false;
+	set_spmv_bytes(e);
+	return alloc_work(e);
+}
+
+lpp_status lpp_engine_assemble_heisenberg(lpp_engine* e, int32_t L, int32_t szPlusConst, const double* jpm, const double* jzz,
+                                          const double* field, int32_t nfield)
+{
+	if (!e || !jpm || !jzz || L < 1 || L > 62 || szPlusConst < 0 || szPlusConst > L)
+		return fail(LPP_ERR_INVALID, "lpp_engine_assemble_heisenberg: bad argument (S=1/2, 1 <= L <= 62)");
+	const std::vector<uint64_t> comb = comb_table();
+	const int64_t nrows = (int64_t)binom(comb, L, szPlusConst);
+	lpp_status st = common_setup(e, nrows, 0);
+	if (st != LPP_OK) return st;
+	// terms: raise site i (0->1), lower site j (1->0) for every ordered pair with jpm_(i,j) != 0,
+	// value 0.5*sqrt(..)*sqrt(..)*jpm = 0.5*jpm for S=1/2   (Heisenberg.h:278-307)
+	std::vector<HostProc> hp;
+	for (int i = 0; i < L; i++)
+		for (int j = 0; j < L; j++) {
+			if (i == j || jpm[i * L + j] == 0) continue;
+			push(hp, bit(j), bit(i), bit(i) | bit(j), 0, 0, 0, 0.5 * 1.0 * jpm[i * L + j], 0.0, true);
+		}
+	std::vector<Proc> procs;
+	int nneg = 0;
+	st = finish_procs(hp, procs, &nneg);
+	if (st != LPP_OK) return st;
+	DevBuf d_procs, d_comb, d_f, d_a, d_z;
+	if ((st = upload(e->stream, d_procs, procs.data(), sizeof(Proc) * procs.size())) != LPP_OK) return st;
+	if ((st = upload(e->stream, d_comb, comb.data(), sizeof(uint64_t) * comb.size())) != LPP_OK) return st;
+	if ((st = upload(e->stream, d_f, field, sizeof(double) * (size_t)std::max(nfield, 0))) != LPP_OK) return st;
+	if ((st = upload(e->stream, d_z, jzz, sizeof(double) * L * L)) != LPP_OK) return st;
+	AsmParams P {};
+	P.model = ASM_HEISENBERG;
+	P.L = L;
+	P.nup = szPlusConst;
+	P.ndown = 0;
+	P.nproc = (int)procs.size();
+	P.nneg = nneg;
+	P.n_up = nrows;
+	P.nrows_global = nrows;
+	P.procs = (const Proc*)d_procs.p;
+	P.comb = (const uint64_t*)d_comb.p;
+	P.d0 = (const double*)d_f.p;
+	P.nd0 = std::min<int>(std::max(nfield, 0), L);
+	P.d1 = nullptr;
+	P.nd1 = 0;
+	P.d2 = (const double*)d_z.p;
+	P.row0 = 0;
+	P.nloc = nrows;
+	P.part = 0;
+	e->has_comm = false;
+	e->bind_scalars(e->scal_own);
+	free_csr(e->A_rem);
+	st = dispatch<ASM_HEISENBERG>(e, P, e->A_loc);
+	if (st != LPP_OK) return st;
+	e->n_local = e->n_global = nrows;
+	e->row_start = 0;
+	e->active = false;
+	set_spmv_bytes(e);
+	return alloc_work(e);
+}
+
+lpp_status lpp_engine_assemble_tj(lpp_engine* e, int32_t L, int32_t nup, int32_t ndown, const double* hop_re, const double* hop_im,
+                                  const double* jpm, const double* jzz, const double* w, const double* potentialV, int32_t npot)
+{
+	if (!e || !hop_re || !jpm || !jzz || !w || L < 1 || L > 31 || nup < 0 || ndown < 0 || nup + ndown > L)
+		return fail(LPP_ERR_INVALID, "lpp_engine_assemble_tj: bad argument (1 <= L <= 31, nup+ndown <= L)");
+	const std::vector<uint64_t> comb = comb_table();
+	const int64_t cfree = (int64_t)binom(comb, L - ndown, nup);
+	const int64_t nrows = (int64_t)binom(comb, L, ndown) * cfree;
+	bool cplx_in = false;
+	if (hop_im)
+		for (int k = 0; k < L * L; k++) cplx_in |= (hop_im[k] != 0);
+	lpp_status st = common_setup(e, nrows, cplx_in);
+	if (st != LPP_OK) return st;
+	std::vector<HostProc> hp;
+	for (int i = 0; i < L; i++) {
+		for (int j = i + 1; j < L; j++) { // the reference only visits j >= i (TjMultiOrb.h:666,725); i == j never applies
+			const double hr = hop_re[i * L + j], hi = hop_im ? hop_im[i * L + j] : 0.0;
+			if (hr != 0 || hi != 0) {
+				// hopping, TjMultiOrb.h:673-692: value h*extraSign*doSign(ket_s,i,j), doSign = parity of bits [i,j)
+				for (int spin = 0; spin < 2; spin++) {
+					const int sh = spin * L, oh = (1 - spin) * L; // own / other species shift
+					// s_i=1, s_j=0: needs the other species absent at j; extraSign = -1
+					push(hp, bit(i + sh), bit(j + sh) | bit(j + oh), bit(i + sh) | bit(j + sh), range_mask(i, j) << sh, 0, 1, hr, hi);
+					// s_i=0, s_j=1: needs the other species absent at i; extraSign = +1
+					push(hp, bit(j + sh), bit(i + sh) | bit(i + oh), bit(i + sh) | bit(j + sh), range_mask(i, j) << sh, 0, 0, hr, hi);
+				}
+			}
+			const double h = jpm[i * L + j] * 0.5; // TjMultiOrb.h:736
+			if (h != 0) {
+				const uint64_t x4 = bit(i) | bit(j) | bit(i + L) | bit(j + L);
+				const uint64_t sm = range_mask(i, j) | (range_mask(i, j) << L); // signSplusSminus on bra1,bra2 (:772-783)
+				// up at i, down at j  ->  up at j, down at i   (:743-754)
+				push(hp, bit(i) | bit(j + L), bit(j) | bit(i + L), x4, 0, sm, 0, h, 0.0, true);
+				// up at j, down at i  ->  up at i, down at j   (:756-767)
+				push(hp, bit(j) | bit(i + L), bit(i) | bit(j + L), x4, 0, sm, 0, h, 0.0, true);
+			}
+		}
+	}
+	std::vector<Proc> procs;
+	int nneg = 0;
+	st = finish_procs(hp, procs, &nneg);
+	if (st != LPP_OK) return st;
+	if (potentialV && npot > 0 && npot < 2 * L) return fail(LPP_ERR_INVALID, "lpp_engine_assemble_tj: potentialV needs 2*L entries (up then down)");
+	std::vector<double> pv(2 * (size_t)L, 0.0);
+	const int npv = std::min<int>(std::max(npot, 0), L);
+	if (potentialV && npot > 0)
+		for (int i = 0; i < 2 * L; i++) pv[i] = potentialV[i];
+	DevBuf d_procs, d_comb, d_pv, d_z, d_w;
+	if ((st = upload(e->stream, d_procs, procs.data(), sizeof(Proc) * procs.size())) != LPP_OK) return st;
+	if ((st = upload(e->stream, d_comb, comb.data(), sizeof(uint64_t) * comb.size())) != LPP_OK) return st;
+	if ((st = upload(e->stream, d_pv, pv.data(), sizeof(double) * pv.size())) != LPP_OK) return st;
+	if ((st = upload(e->stream, d_z, jzz, sizeof(double) * L * L)) != LPP_OK) return st;
+	if ((st = upload(e->stream, d_w, w, sizeof(double) * L * L)) != LPP_OK) return st;
+	AsmParams P {};
+	P.model = ASM_TJ;
+	P.L = L;
+	P.nup = nup;
+	P.ndown = ndown;
+	P.nproc = (int)procs.size();
+	P.nneg = nneg;
+	P.n_up = cfree;
+	P.nrows_global = nrows;
+	P.procs = (const Proc*)d_procs.p;
+	P.comb = (const uint64_t*)d_comb.p;
+	P.d0 = (const double*)d_pv.p;
+	P.nd0 = (potentialV && npot > 0) ? npv : 0;
+	P.d1 = (const double*)d_z.p;
+	P.d2 = (const double*)d_w.p;
+	P.row0 = 0;
+	P.nloc = nrows;
+	P.part = 0;
+	e->has_comm = false;
+	e->bind_scalars(e->scal_own);
+	free_csr(e->A_rem);
+	st = dispatch<ASM_TJ>(e, P, e->A_loc);
+	if (st != LPP_OK) return st;
+	e->n_local = e->n_global = nrows;
+	e->row_start = 0;
+	e->active = false;
+	set_spmv_bytes(e);
+	return alloc_work(e);
+}
+
+} // extern "C"

@@ -1,0 +1,333 @@
+// lpp_assemble_kernels.h -- on-device CSR assembly for the three in-scope models.
+//
+// A many-body state is one 64-bit word  w = (down << L) | up   (Heisenberg S=1/2: w = spin word).
+// In every in-scope basis the reference's state index is MONOTONE in w:
+//   Hubbard    index = rank(up) + rank(down)*N_up          BasisHubbardLanczos.h:59-63
+//   Heisenberg index = position in the ascending list       BasisHeisenberg.h:38-46 (= rank(w) for S=1/2)
+//   t-J        index = position in the sorted list          BasisTjMultiOrbLanczos.h:29-42
+// and every off-diagonal term maps ket -> bra = ket ^ xmask with bra - ket = delta a constant of
+// the term.  The host therefore sorts the term ("process") list by delta ONCE; a row is produced
+// by walking that list in order, which emits the entries already sorted by column exactly as
+// SparseRow::finalize would -- no per-row sort, no stored basis, O(L) ranking instead of the
+// reference's linear-scan perfectIndex (BasisHeisenberg.h:73-80) with the same resulting index.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "lpp_kernels.h"
+
+namespace lpp {
+
+enum { ASM_HUBBARD = 0, ASM_HEISENBERG = 1, ASM_TJ = 2 };
+
+struct Proc {
+	uint64_t need_set, need_clear, xmask;
+	uint64_t smask_ket, smask_bra; // sign = (-1)^(popc(ket&smask_ket)+popc(bra&smask_bra)+sign_const)
+	double amp_re, amp_im;
+	int32_t sign_const;
+	int32_t real_only; // 1: the imaginary part is the constant +0.0 (term added as a real number by the reference)
+};
+
+constexpr int kCombDim = 65;
+
+struct AsmParams {
+	int model;
+	int L;
+	int nup, ndown;
+	int nproc; // processes sorted by delta ascending
+	int nneg; // processes with delta < 0 (emitted before the diagonal)
+	int64_t n_up; // Hubbard: C(L,nup); t-J: C(L-ndown,nup)
+	int64_t nrows_global;
+	int64_t row0, nloc; // rows [row0, row0+nloc) are produced
+	int part; // 0: all columns; 1: columns in [col_lo,col_hi) shifted by -col_lo; 2: columns outside
+	int64_t col_lo, col_hi;
+	const Proc* procs;
+	const uint64_t* comb; // kCombDim x kCombDim binomials
+	const double* d0; // Hubbard U[L] | Heisenberg field[L] (nd0 valid) | t-J potentialV[2L]
+	const double* d1; // Hubbard V[L] | Heisenberg anisotropy[L] (nd1 valid) | t-J jzz[L*L]
+	const double* d2; // Heisenberg jzz[L*L] | t-J w[L*L]
+	int nd0, nd1;
+};
+
+__device__ __forceinline__ uint64_t comb_at(const uint64_t* comb, int n, int m) { return comb[n * kCombDim + m]; }
+
+// rank in the ascending list of words with fixed popcount (BasisOneSpin::perfectIndex, BasisOneSpin.h:73-81)
+__device__ __forceinline__ int64_t rank_comb(const uint64_t* comb, uint64_t state)
+{
+	int64_t n = 0;
+	int c = 1;
+	while (state) {
+		const int b = __ffsll((unsigned long long)state) - 1;
+		n += (int64_t)comb_at(comb, b, c++);
+		state &= state - 1;
+	}
+	return n;
+}
+
+__device__ __forceinline__ uint64_t unrank_comb(const uint64_t* comb, int64_t r, int k, int nbits)
+{
+	uint64_t w = 0;
+	for (int b = nbits - 1; b >= 0 && k > 0; b--) {
+		const int64_t c = (int64_t)comb_at(comb, b, k);
+		if (r >= c) {
+			w |= 1ull << b;
+			r -= c;
+			k--;
+		}
+	}
+	return w;
+}
+
+// software pext / pdep over the low L bits
+__device__ __forceinline__ uint64_t pext_sw(uint64_t v, uint64_t mask)
+{
+	uint64_t out = 0;
+	int k = 0;
+	while (mask) {
+		const uint64_t low = mask & (~mask + 1);
+		if (v & low) out |= 1ull << k;
+		k++;
+		mask &= mask - 1;
+	}
+	return out;
+}
+__device__ __forceinline__ uint64_t pdep_sw(uint64_t v, uint64_t mask)
+{
+	uint64_t out = 0;
+	while (mask && v) {
+		const uint64_t low = mask & (~mask + 1);
+		if (v & 1) out |= low;
+		v >>= 1;
+		mask &= mask - 1;
+	}
+	return out;
+}
+
+template <int MODEL> __device__ __forceinline__ uint64_t state_of(const AsmParams& P, int64_t idx)
+{
+	const uint64_t lowmask = (P.L >= 64) ? ~0ull : ((1ull << P.L) - 1);
+	if (MODEL == ASM_HEISENBERG) return unrank_comb(P.comb, idx, P.nup, P.L);
+	const int64_t iu = idx % P.n_up, id = idx / P.n_up;
+	const uint64_t down = unrank_comb(P.comb, id, P.ndown, P.L);
+	uint64_t up;
+	if (MODEL == ASM_HUBBARD)
+		up = unrank_comb(P.comb, iu, P.nup, P.L);
+	else
+		up = pdep_sw(unrank_comb(P.comb, iu, P.nup, P.L - P.ndown), ~down & lowmask);
+	return (down << P.L) | up;
+}
+
+template <int MODEL> __device__ __forceinline__ int64_t index_of(const AsmParams& P, uint64_t w)
+{
+	if (MODEL == ASM_HEISENBERG) return rank_comb(P.comb, w);
+	const uint64_t lowmask = (1ull << P.L) - 1;
+	const uint64_t up = w & lowmask, down = w >> P.L;
+	if (MODEL == ASM_HUBBARD) return rank_comb(P.comb, up) + rank_comb(P.comb, down) * P.n_up;
+	return rank_comb(P.comb, pext_sw(up, ~down & lowmask)) + rank_comb(P.comb, down) * P.n_up;
+}
+
+// Diagonal elements, additions in the reference's loop order so the doubles are bit-identical
+// (every product below is exact: factors are 0, +-1/2, +-1, 2 or powers of two).
+template <int MODEL> __device__ double diag_of(const AsmParams& P, uint64_t w)
+{
+	const int L = P.L;
+	double s = 0.0;
+	if (MODEL == ASM_HUBBARD) { // HubbardHelper.h:147-187 (U and potentialV terms)
+		const uint64_t up = w & ((1ull << L) - 1), down = w >> L;
+		for (int i = 0; i < L; i++) {
+			const int nu = (int)((up >> i) & 1), nd = (int)((down >> i) & 1);
+			s += P.d0[i] * nu * nd;
+			const double ne = nu + nd;
+			const double tmp = P.d1[i];
+			if (tmp != 0) s += tmp * ne;
+		}
+	} else if (MODEL == ASM_HEISENBERG) { // Heisenberg.h:251-275, twiceS == 1
+		for (int i = 0; i < L; i++) {
+			const double tmp1 = (double)((w >> i) & 1) - 0.5;
+			const double tmp1d = tmp1 * tmp1;
+			if (i < P.nd0) s += P.d0[i] * tmp1;
+			if (i < P.nd1) s += P.d1[i] * tmp1d;
+			for (int j = i + 1; j < L; j++) {
+				const double tmp2 = (double)((w >> j) & 1) - 0.5;
+				s += tmp1 * tmp2 * P.d2[i * L + j];
+			}
+		}
+	} else { // TjMultiOrb.h:597-645, orbitals == 1
+		const uint64_t up = w & ((1ull << L) - 1), down = w >> L;
+		for (int i = 0; i < L; i++) {
+			const int niup = (int)((up >> i) & 1), nidown = (int)((down >> i) & 1);
+			if (i < P.nd0) {
+				s += P.d0[i] * niup;
+				s += P.d0[i + L] * nidown;
+			}
+			for (int j = i + 1; j < L; j++) {
+				const int njup = (int)((up >> j) & 1), njdown = (int)((down >> j) & 1);
+				s += (niup - nidown) * (njup - njdown) * P.d1[i * L + j] * 0.25;
+				s += (niup + nidown) * (njup + njdown) * P.d2[i * L + j];
+			}
+		}
+	}
+	return s;
+}
+
+__device__ __forceinline__ bool col_selected(const AsmParams& P, int64_t col)
+{
+	if (P.part == 0) return true;
+	const bool inside = col >= P.col_lo && col < P.col_hi;
+	return P.part == 1 ? inside : !inside;
+}
+
+// pass 1: entries per row
+template <int MODEL>
+__global__ __launch_bounds__(kBlock) void k_asm_count(AsmParams P, int64_t* __restrict__ len)
+{
+	for (int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x; r < P.nloc; r += (int64_t)gridDim.x * kBlock) {
+		const int64_t row = P.row0 + r;
+		const uint64_t ket = state_of<MODEL>(P, row);
+		int n = 0;
+		for (int p = 0; p < P.nproc; p++) {
+			const Proc& pr = P.procs[p];
+			if ((ket & pr.need_set) != pr.need_set || (ket & pr.need_clear) != 0) continue;
+			if (P.part == 0) {
+				n++;
+			} else {
+				const int64_t c = index_of<MODEL>(P, ket ^ pr.xmask);
+				if (col_selected(P, c)) n++;
+			}
+		}
+		if (col_selected(P, row)) n++; // the diagonal is always stored (HubbardHelper.h:93)
+		len[r] = n;
+	}
+}
+
+// pass 2: fill col / val (len already scanned into rowptr)
+template <int MODEL, typename T>
+__global__ __launch_bounds__(kBlock) void k_asm_fill(AsmParams P, const int64_t* __restrict__ rowptr,
+                                                      int32_t* __restrict__ col, T* __restrict__ val)
+{
+	for (int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x; r < P.nloc; r += (int64_t)gridDim.x * kBlock) {
+		const int64_t row = P.row0 + r;
+		const uint64_t ket = state_of<MODEL>(P, row);
+		int64_t q = rowptr[r];
+		const int64_t shift = (P.part == 1) ? P.col_lo : 0;
+		for (int p = 0; p <= P.nproc; p++) {
+			if (p == P.nneg) { // diagonal sits between negative and positive deltas
+				if (col_selected(P, row)) {
+					col[q] = (int32_t)(row - shift);
+					T v;
+					if constexpr (sizeof(T) == 16) {
+						v.re = diag_of<MODEL>(P, ket);
+						v.im = 0.0;
+					} else {
+						v = diag_of<MODEL>(P, ket);
+					}
+					val[q] = v;
+					q++;
+				}
+			}
+			if (p == P.nproc) break;
+			const Proc& pr = P.procs[p];
+			if ((ket & pr.need_set) != pr.need_set || (ket & pr.need_clear) != 0) continue;
+			const uint64_t bra = ket ^ pr.xmask;
+			const int64_t c = index_of<MODEL>(P, bra);
+			if (!col_selected(P, c)) continue;
+			const int par = (__popcll(ket & pr.smask_ket) + __popcll(bra & pr.smask_bra) + pr.sign_const) & 1;
+			const double sg = par ? -1.0 : 1.0;
+			col[q] = (int32_t)(c - shift);
+			T v;
+			if constexpr (sizeof(T) == 16) {
+				v.re = pr.amp_re * sg;
+				v.im = pr.real_only ? 0.0 : pr.amp_im * sg;
+			} else {
+				v = pr.amp_re * sg;
+			}
+			val[q] = v;
+			q++;
+		}
+	}
+}
+
+// ---------------------------------------------------------------------------------------------
+// exclusive scan of int64 (three phases, chunk = 2048 elements per block)
+// ---------------------------------------------------------------------------------------------
+constexpr int kScanChunk = 2048;
+
+static __global__ __launch_bounds__(kBlock) void k_scan_block_sums(const int64_t* __restrict__ in, int64_t n,
+                                                                    int64_t* __restrict__ block_sums)
+{
+	__shared__ double smem_unused[1];
+	(void)smem_unused;
+	__shared__ long long sm[kBlock / 64];
+	const int64_t base = (int64_t)blockIdx.x * kScanChunk;
+	long long s = 0;
+	for (int k = threadIdx.x; k < kScanChunk; k += kBlock)
+		if (base + k < n) s += in[base + k];
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+	if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		long long t = 0;
+		for (int i = 0; i < kBlock / 64; i++) t += sm[i];
+		block_sums[blockIdx.x] = t;
+	}
+}
+
+// single block: exclusive scan of block_sums in place; total -> *total_out
+static __global__ __launch_bounds__(kBlock) void k_scan_sums(int64_t* __restrict__ block_sums, int64_t nblk,
+                                                              int64_t* __restrict__ total_out)
+{
+	__shared__ long long sm[kBlock];
+	__shared__ long long carry;
+	if (threadIdx.x == 0) carry = 0;
+	__syncthreads();
+	for (int64_t base = 0; base < nblk; base += kBlock) {
+		const int64_t i = base + threadIdx.x;
+		const long long v = (i < nblk) ? block_sums[i] : 0;
+		sm[threadIdx.x] = v;
+		__syncthreads();
+		for (int off = 1; off < kBlock; off <<= 1) { // Hillis-Steele inclusive scan
+			long long t = (threadIdx.x >= off) ? sm[threadIdx.x - off] : 0;
+			__syncthreads();
+			sm[threadIdx.x] += t;
+			__syncthreads();
+		}
+		if (i < nblk) block_sums[i] = carry + sm[threadIdx.x] - v;
+		__syncthreads();
+		if (threadIdx.x == 0) carry += sm[kBlock - 1];
+		__syncthreads();
+	}
+	if (threadIdx.x == 0) *total_out = carry;
+}
+
+// per chunk: out[i] = block_offset + exclusive prefix inside the chunk (in may alias out)
+static __global__ __launch_bounds__(kBlock) void k_scan_apply(const int64_t* in, int64_t n,
+                                                               const int64_t* __restrict__ block_sums, int64_t* out)
+{
+	__shared__ long long sm[kBlock];
+	constexpr int per = kScanChunk / kBlock; // 8 consecutive elements per thread
+	const int64_t base = (int64_t)blockIdx.x * kScanChunk + (int64_t)threadIdx.x * per;
+	long long v[per];
+	long long s = 0;
+#pragma unroll
+	for (int k = 0; k < per; k++) {
+		v[k] = (base + k < n) ? in[base + k] : 0;
+		s += v[k];
+	}
+	sm[threadIdx.x] = s;
+	__syncthreads();
+	for (int off = 1; off < kBlock; off <<= 1) {
+		long long t = (threadIdx.x >= off) ? sm[threadIdx.x - off] : 0;
+		__syncthreads();
+		sm[threadIdx.x] += t;
+		__syncthreads();
+	}
+	long long run = block_sums[blockIdx.x] + sm[threadIdx.x] - s;
+#pragma unroll
+	for (int k = 0; k < per; k++) {
+		if (base + k < n) out[base + k] = run;
+		run += v[k];
+	}
+}
+
+} // namespace lpp

@@ -1,0 +1,417 @@
+// lpp_engine.hip -- the MI355X-native Lanczos inner engine behind include/lpp_engine.h.
+//
+// Device boundary: the CSR is made resident once, the whole
+// computeAllStatesBelow loop (reference src/Engine/Engine.h:601-657 -> LanczosSolver
+// [PsimagLite]) runs on the GPU, only the tridiagonal coefficients (and requested Ritz
+// vectors) come back.  The host keeps the tiny tridiagonal eigenproblem and tests convergence
+// `check_lag` steps behind the GPU so the stream never drains.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "lpp_engine_impl.h"
+
+using namespace lpp;
+
+namespace lpp {
+
+// ---------------------------------------------------------------------------------------------
+// small helpers
+// ---------------------------------------------------------------------------------------------
+static int blas_blocks(int64_t n2)
+{
+	int64_t b = (n2 + kBlock - 1) / kBlock;
+	if (b < 1) b = 1;
+	// 256 CUs x 8 blocks of 256 threads: enough waves to cover HBM latency, few enough partials
+	return (int)std::min<int64_t>(b, 2048);
+}
+
+void free_csr(DevCsr& A)
+{
+	if (A.owned) {
+		if (A.rowptr) (void)hipFree(A.rowptr);
+		if (A.col) (void)hipFree(A.col);
+		if (A.val) (void)hipFree(A.val);
+	}
+	if (A.slice_ptr) (void)hipFree(A.slice_ptr);
+	if (A.row_len) (void)hipFree(A.row_len);
+	if (A.scol) (void)hipFree(A.scol);
+	if (A.sval) (void)hipFree(A.sval);
+	A = DevCsr();
+}
+
+static int pick_group(int64_t nrows, int64_t nnz)
+{
+	if (const char* s = getenv("LPP_SPMV_G")) {
+		int g = atoi(s);
+		if (g == 4 || g == 8 || g == 16 || g == 32 || g == 64) return g;
+	}
+	const double avg = nrows > 0 ? (double)nnz / (double)nrows : 1.0;
+	int g = 4;
+	while (g < 64 && g * 2 <= avg / 2.0 + 1e-9) g *= 2; // largest power of two <= avg/2, in [4,64]
+	return g;
+}
+
+template <typename T, bool DOT>
+static void launch_rowgroup(const DevCsr& A, const T* src, T* x, const T* ydot, double* partial, int nblocks,
+                            hipStream_t st)
+{
+	const int64_t* rp = A.rowptr;
+	const int32_t* col = A.col;
+	const T* val = (const T*)A.val;
+	switch (A.G) {
+	case 4: k_spmv_rowgroup<T, 4, DOT><<<nblocks, kBlock, 0, st>>>(A.nrows, rp, col, val, src, x, ydot, partial); break;
+	case 8: k_spmv_rowgroup<T, 8, DOT><<<nblocks, kBlock, 0, st>>>(A.nrows, rp, col, val, src, x, ydot, partial); break;
+	case 16: k_spmv_rowgroup<T, 16, DOT><<<nblocks, kBlock, 0, st>>>(A.nrows, rp, col, val, src, x, ydot, partial); break;
+	case 32: k_spmv_rowgroup<T, 32, DOT><<<nblocks, kBlock, 0, st>>>(A.nrows, rp, col, val, src, x, ydot, partial); break;
+	default: k_spmv_rowgroup<T, 64, DOT><<<nblocks, kBlock, 0, st>>>(A.nrows, rp, col, val, src, x, ydot, partial); break;
+	}
+}
+
+// x += A * src ; if partial != nullptr also partial[b] = block sums of Re<ydot|x>.
+// Returns the number of partials written (0 when partial == nullptr).
+template <typename T> static int spmv_launch_t(lpp_engine* e, const DevCsr& A, const void* src, void* x, const void* ydot, double* partial)
+{
+	hipStream_t st = e->stream;
+	if (A.nrows == 0) return 0;
+	if (A.sliced) {
+		const int64_t need = (A.nslices + (kBlock / 64) - 1) / (kBlock / 64);
+		const int nb = (int)std::max<int64_t>(1, std::min<int64_t>(need, e->spmv_max_blocks));
+		if (partial)
+			k_spmv_sliced<T, true><<<nb, kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_ptr, A.row_len, A.scol, (const T*)A.sval,
+			                                             (const T*)src, (T*)x, (const T*)ydot, partial);
+		else
+			k_spmv_sliced<T, false><<<nb, kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_ptr, A.row_len, A.scol, (const T*)A.sval,
+			                                              (const T*)src, (T*)x, nullptr, nullptr);
+		return partial ? nb : 0;
+	}
+	const int rows_per_block = kBlock / A.G;
+	const int64_t need = (A.nrows + rows_per_block - 1) / rows_per_block;
+	const int nb = (int)std::max<int64_t>(1, std::min<int64_t>(need, e->spmv_max_blocks));
+	if (partial)
+		launch_rowgroup<T, true>(A, (const T*)src, (T*)x, (const T*)ydot, partial, nb, st);
+	else
+		launch_rowgroup<T, false>(A, (const T*)src, (T*)x, nullptr, nullptr, nb, st);
+	return partial ? nb : 0;
+}
+
+int spmv_launch(lpp_engine* e, const DevCsr& A, const void* src, void* x, const void* ydot, double* partial)
+{
+	return e->is_complex ? spmv_launch_t<cplx>(e, A, src, x, ydot, partial) : spmv_launch_t<double>(e, A, src, x, ydot, partial);
+}
+
+// build the sliced layout of A on the device (keeps rowptr; frees nothing)
+template <typename T> static lpp_status build_sliced_t(lpp_engine* e, DevCsr& A)
+{
+	A.nslices = (A.nrows + 63) / 64;
+	HIP_TRY(hipMalloc(&A.slice_ptr, sizeof(int64_t) * (size_t)(A.nslices + 1)));
+	HIP_TRY(hipMalloc(&A.row_len, sizeof(int32_t) * (size_t)std::max<int64_t>(A.nrows, 1)));
+	HIP_TRY(hipMalloc(&A.scol, sizeof(int32_t) * (size_t)std::max<int64_t>(A.nnz, 1)));
+	HIP_TRY(hipMalloc(&A.sval, sizeof(T) * (size_t)std::max<int64_t>(A.nnz, 1)));
+	const int64_t nthreads = std::max<int64_t>(A.nrows, A.nslices + 1);
+	const int nb = (int)((nthreads + 255) / 256);
+	k_slice_meta<<<nb, 256, 0, e->stream>>>(A.nrows, A.nslices, A.rowptr, A.slice_ptr, A.row_len);
+	const int64_t need = (A.nslices + 3) / 4;
+	const int nb2 = (int)std::max<int64_t>(1, std::min<int64_t>(need, 8192));
+	k_slice_fill<T><<<nb2, kBlock, 0, e->stream>>>(A.nrows, A.nslices, A.rowptr, A.col, (const T*)A.val, A.scol, (T*)A.sval);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipStreamSynchronize(e->stream));
+	// the plain col/val copies are no longer needed by the solver; keep rowptr for get_csr row sizes
+	A.sliced = true;
+	return LPP_OK;
+}
+
+lpp_status finalize_csr(lpp_engine* e, DevCsr& A, bool allow_drop_plain)
+{
+	A.G = pick_group(A.nrows, A.nnz);
+	int mode = e->cfg.spmv_kernel;
+	if (const char* s = getenv("LPP_SPMV_KERNEL")) mode = atoi(s);
+	if (mode == LPP_SPMV_AUTO) mode = LPP_SPMV_ROWGROUP;
+	if (mode == LPP_SPMV_SLICED && A.nrows > 0) {
+		lpp_status st = e->is_complex ? build_sliced_t<cplx>(e, A) : build_sliced_t<double>(e, A);
+		if (st != LPP_OK) return st;
+		if (allow_drop_plain && getenv("LPP_KEEP_PLAIN_CSR") == nullptr && A.owned) {
+			// free the plain arrays: the sliced copy is the resident one (get_csr rebuilds from it)
+			(void)hipFree(A.col);
+			(void)hipFree(A.val);
+			A.col = nullptr;
+			A.val = nullptr;
+		}
+	}
+	return LPP_OK;
+}
+
+void set_spmv_bytes(lpp_engine* e)
+{
+	const double s = (double)e->esz;
+	const double Z = (double)(e->A_loc.nnz + e->A_rem.nnz);
+	const double N = (double)e->n_local;
+	e->spmv_bytes = Z * (s + 4.0) + (N + 1.0) * 8.0 + 3.0 * N * s;
+}
+
+lpp_status alloc_work(lpp_engine* e)
+{
+	// vectors are padded to an even number of doubles so BLAS-1 kernels can move double2
+	const int64_t nd = e->n_local * (e->is_complex ? 2 : 1);
+	e->nd = nd;
+	e->nd_pad = (nd + 1) & ~(int64_t)1;
+	e->n2 = e->nd_pad / 2;
+	for (double** p : { &e->x, &e->y }) {
+		if (*p) (void)hipFree(*p);
+		*p = nullptr;
+		HIP_TRY_MEM(hipMalloc(p, sizeof(double) * (size_t)std::max<int64_t>(e->nd_pad, 2)));
+		HIP_TRY(hipMemsetAsync(*p, 0, sizeof(double) * (size_t)std::max<int64_t>(e->nd_pad, 2), e->stream));
+	}
+	return LPP_OK;
+}
+
+} // namespace lpp
+
+// ---------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------
+extern "C" {
+
+lpp_status lpp_engine_create(lpp_engine** out, const lpp_config* cfg)
+{
+	if (!out || !cfg) return fail(LPP_ERR_INVALID, "lpp_engine_create: null argument");
+	if (cfg->abi_version != LPP_ABI_VERSION) return fail(LPP_ERR_INVALID, "lpp_engine_create: ABI version mismatch");
+	if (cfg->dtype != LPP_F64 && cfg->dtype != LPP_C128) return fail(LPP_ERR_INVALID, "lpp_engine_create: bad dtype");
+	if (cfg->max_steps < 1) return fail(LPP_ERR_INVALID, "lpp_engine_create: max_steps < 1");
+	int ndev = 0;
+	hipError_t err = hipGetDeviceCount(&ndev);
+	if (err != hipSuccess || ndev <= 0)
+		return fail(LPP_ERR_HIP, std::string("lpp_engine_create: no HIP device (there is no CPU fallback): ") + hipGetErrorString(err));
+	if (cfg->device < 0 || cfg->device >= ndev) return fail(LPP_ERR_INVALID, "lpp_engine_create: device ordinal out of range");
+	HIP_TRY(hipSetDevice(cfg->device));
+	lpp_engine* e = new lpp_engine();
+	e->cfg = *cfg;
+	if (e->cfg.check_lag < 0) e->cfg.check_lag = 0;
+	if (e->cfg.check_lag > 16) e->cfg.check_lag = 16;
+	e->is_complex = (cfg->dtype == LPP_C128);
+	e->esz = e->is_complex ? 16 : 8;
+	if (cfg->stream) {
+		e->stream = (hipStream_t)cfg->stream;
+		e->own_stream = false;
+	} else {
+		err = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
+		if (err != hipSuccess) {
+			delete e;
+			return fail(LPP_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(err));
+		}
+		e->own_stream = true;
+	}
+	e->spmv_max_blocks = 256 * 16;
+	if (const char* s = getenv("LPP_SPMV_BLOCKS")) e->spmv_max_blocks = std::max(1, std::min(atoi(s), kMaxPartials));
+	const int M = cfg->max_steps + 2;
+	e->M = M;
+	err = hipMalloc(&e->partial, sizeof(double) * (size_t)kMaxPartials * 2 * kPanel);
+	if (err == hipSuccess) err = hipMalloc(&e->scal_own, sizeof(double) * (size_t)(6 * M + 8));
+	if (err == hipSuccess) err = hipHostMalloc(&e->h_scal, sizeof(double) * (size_t)(2 * M), hipHostMallocDefault);
+	if (err != hipSuccess) {
+		lpp_engine_destroy(e);
+		return fail(LPP_ERR_NOMEM, std::string("lpp_engine_create: allocation failed: ") + hipGetErrorString(err));
+	}
+	e->bind_scalars(e->scal_own);
+	(void)hipEventCreate(&e->ev_t0);
+	(void)hipEventCreate(&e->ev_t1);
+	*out = e;
+	return LPP_OK;
+}
+
+lpp_status lpp_engine_destroy(lpp_engine* e)
+{
+	if (!e) return LPP_OK;
+	(void)hipSetDevice(e->cfg.device);
+	if (e->stream) (void)hipStreamSynchronize(e->stream);
+	free_csr(e->A_loc);
+	free_csr(e->A_rem);
+	for (double* p : { e->x, e->y, e->V, e->partial, e->scal_own, e->zwork })
+		if (p) (void)hipFree(p);
+	if (e->h_scal) (void)hipHostFree(e->h_scal);
+	for (auto& ev : e->step_events)
+		if (ev) (void)hipEventDestroy(ev);
+	for (auto& pr : e->spmv_events) {
+		(void)hipEventDestroy(pr.first);
+		(void)hipEventDestroy(pr.second);
+	}
+	if (e->ev_t0) (void)hipEventDestroy(e->ev_t0);
+	if (e->ev_t1) (void)hipEventDestroy(e->ev_t1);
+	if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
+	delete e;
+	return LPP_OK;
+}
+
+static lpp_status upload_csr(lpp_engine* e, DevCsr& A, int64_t nrows, const int64_t* rowptr, const int32_t* colind, const void* values)
+{
+	free_csr(A);
+	A.nrows = nrows;
+	A.nnz = rowptr ? rowptr[nrows] : 0;
+	A.owned = true;
+	HIP_TRY_MEM(hipMalloc(&A.rowptr, sizeof(int64_t) * (size_t)(nrows + 1)));
+	HIP_TRY_MEM(hipMalloc(&A.col, sizeof(int32_t) * (size_t)std::max<int64_t>(A.nnz, 1)));
+	HIP_TRY_MEM(hipMalloc(&A.val, e->esz * (size_t)std::max<int64_t>(A.nnz, 1)));
+	HIP_TRY(hipMemcpyAsync(A.rowptr, rowptr, sizeof(int64_t) * (size_t)(nrows + 1), hipMemcpyHostToDevice, e->stream));
+	if (A.nnz > 0) {
+		HIP_TRY(hipMemcpyAsync(A.col, colind, sizeof(int32_t) * (size_t)A.nnz, hipMemcpyHostToDevice, e->stream));
+		HIP_TRY(hipMemcpyAsync(A.val, values, e->esz * (size_t)A.nnz, hipMemcpyHostToDevice, e->stream));
+	}
+	HIP_TRY(hipStreamSynchronize(e->stream));
+	return finalize_csr(e, A, true);
+}
+
+static lpp_status check_csr_host(int64_t nrows, int64_t ncols, const int64_t* rowptr, const int32_t* colind)
+{
+	if (rowptr[0] != 0) return fail(LPP_ERR_INVALID, "CSR: rowptr[0] != 0");
+	for (int64_t i = 0; i < nrows; i++)
+		if (rowptr[i + 1] < rowptr[i]) return fail(LPP_ERR_INVALID, "CSR: rowptr not monotone");
+	const int64_t nnz = rowptr[nrows];
+	for (int64_t p = 0; p < nnz; p++)
+		if (colind[p] < 0 || (int64_t)colind[p] >= ncols) return fail(LPP_ERR_INVALID, "CSR: column index out of range");
+	return LPP_OK;
+}
+
+lpp_status lpp_engine_set_csr(lpp_engine* e, int64_t nrows, const int64_t* rowptr, const int32_t* colind, const void* values)
+{
+	if (!e || nrows < 0 || !rowptr) return fail(LPP_ERR_INVALID, "lpp_engine_set_csr: bad argument");
+	if (nrows > (int64_t)INT32_MAX) return fail(LPP_ERR_INVALID, "lpp_engine_set_csr: nrows exceeds 32-bit column range");
+	if (rowptr[nrows] > 0 && (!colind || !values)) return fail(LPP_ERR_INVALID, "lpp_engine_set_csr: null colind/values");
+	lpp_status st = check_csr_host(nrows, nrows, rowptr, colind);
+	if (st != LPP_OK) return st;
+	HIP_TRY(hipSetDevice(e->cfg.device));
+	e->has_comm = false;
+	e->bind_scalars(e->scal_own);
+	free_csr(e->A_rem);
+	st = upload_csr(e, e->A_loc, nrows, rowptr, colind, values);
+	if (st != LPP_OK) return st;
+	e->n_local = e->n_global = nrows;
+	e->row_start = 0;
+	e->active = false;
+	set_spmv_bytes(e);
+	return alloc_work(e);
+}
+
+lpp_status lpp_engine_set_csr_partition(lpp_engine* e, const lpp_comm* comm, int64_t global_rows, const int64_t* shard_starts,
+                                        const int64_t* rowptr, const int32_t* colind, const void* values)
+{
+	if (!e || !comm || !shard_starts || !rowptr) return fail(LPP_ERR_INVALID, "lpp_engine_set_csr_partition: bad argument");
+	lpp_status st = e->adopt_comm(comm);
+	if (st != LPP_OK) return st;
+	const int32_t r = comm->rank, P = comm->nranks;
+	if (shard_starts[0] != 0 || shard_starts[P] != global_rows) return fail(LPP_ERR_INVALID, "set_csr_partition: shard_starts must span [0, global_rows]");
+	const int64_t local = shard_starts[r + 1] - shard_starts[r];
+	st = check_csr_host(local, global_rows, rowptr, colind);
+	if (st != LPP_OK) return st;
+	HIP_TRY(hipSetDevice(e->cfg.device));
+	int64_t nl = 0, nr = 0;
+	st = lpp_split_csr(r, P, shard_starts, comm->shard_stride, local, rowptr, colind, values, (int32_t)e->esz, &nl, &nr, nullptr,
+	                   nullptr, nullptr, nullptr, nullptr, nullptr);
+	if (st != LPP_OK) return st;
+	std::vector<int64_t> rpl(local + 1), rpr(local + 1);
+	std::vector<int32_t> cl(std::max<int64_t>(nl, 1)), cr(std::max<int64_t>(nr, 1));
+	std::vector<char> vl((size_t)std::max<int64_t>(nl, 1) * e->esz), vr((size_t)std::max<int64_t>(nr, 1) * e->esz);
+	st = lpp_split_csr(r, P, shard_starts, comm->shard_stride, local, rowptr, colind, values, (int32_t)e->esz, &nl, &nr, rpl.data(),
+	                   cl.data(), vl.data(), rpr.data(), cr.data(), vr.data());
+	if (st != LPP_OK) return st;
+	st = upload_csr(e, e->A_loc, local, rpl.data(), cl.data(), vl.data());
+	if (st != LPP_OK) return st;
+	st = upload_csr(e, e->A_rem, local, rpr.data(), cr.data(), vr.data());
+	if (st != LPP_OK) return st;
+	e->n_local = local;
+	e->n_global = global_rows;
+	e->row_start = shard_starts[r];
+	e->active = false;
+	set_spmv_bytes(e);
+	return alloc_work(e);
+}
+
+lpp_status lpp_engine_get_csr(lpp_engine* e, int32_t which, int64_t* nrows, int64_t* nnz, int64_t* rowptr, int32_t* colind, void* values)
+{
+	if (!e) return fail(LPP_ERR_INVALID, "lpp_engine_get_csr: null engine");
+	DevCsr& A = which == 0 ? e->A_loc : e->A_rem;
+	if (nrows) *nrows = A.nrows;
+	if (nnz) *nnz = A.nnz;
+	if (!rowptr && !colind && !values) return LPP_OK;
+	if (!A.rowptr) return fail(LPP_ERR_STATE, "lpp_engine_get_csr: no matrix");
+	if ((colind || values) && (!A.col || !A.val)) return fail(LPP_ERR_STATE, "lpp_engine_get_csr: plain CSR arrays were released (sliced layout); set LPP_KEEP_PLAIN_CSR=1");
+	HIP_TRY(hipSetDevice(e->cfg.device));
+	HIP_TRY(hipStreamSynchronize(e->stream));
+	if (rowptr) HIP_TRY(hipMemcpy(rowptr, A.rowptr, sizeof(int64_t) * (size_t)(A.nrows + 1), hipMemcpyDeviceToHost));
+	if (colind && A.nnz) HIP_TRY(hipMemcpy(colind, A.col, sizeof(int32_t) * (size_t)A.nnz, hipMemcpyDeviceToHost));
+	if (values && A.nnz) HIP_TRY(hipMemcpy(values, A.val, e->esz * (size_t)A.nnz, hipMemcpyDeviceToHost));
+	return LPP_OK;
+}
+
+lpp_status lpp_engine_spmv_acc(lpp_engine* e, void* x_inout, const void* y)
+{
+	if (!e || !x_inout || !y) return fail(LPP_ERR_INVALID, "lpp_engine_spmv_acc: null argument");
+	if (!e->A_loc.rowptr) return fail(LPP_ERR_STATE, "lpp_engine_spmv_acc: no matrix (call lpp_engine_set_csr first)");
+	if (e->has_comm && e->comm.nranks > 1) return fail(LPP_ERR_STATE, "lpp_engine_spmv_acc: not available on a partitioned matrix");
+	if (e->active) return fail(LPP_ERR_STATE, "lpp_engine_spmv_acc: a Lanczos run is active");
+	HIP_TRY(hipSetDevice(e->cfg.device));
+	const size_t bytes = e->esz * (size_t)e->n_local;
+	HIP_TRY(hipMemcpyAsync(e->x, x_inout, bytes, hipMemcpyHostToDevice, e->stream));
+	HIP_TRY(hipMemcpyAsync(e->y, y, bytes, hipMemcpyHostToDevice, e->stream));
+	spmv_launch(e, e->A_loc, e->y, e->x, nullptr, nullptr);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipMemcpyAsync(x_inout, e->x, bytes, hipMemcpyDeviceToHost, e->stream));
+	HIP_TRY(hipStreamSynchronize(e->stream));
+	return LPP_OK;
+}
+
+lpp_status lpp_engine_bench_spmv(lpp_engine* e, int32_t warmup, int32_t iters, double* ms_per_launch)
+{
+	if (!e || iters <= 0 || !ms_per_launch) return fail(LPP_ERR_INVALID, "lpp_engine_bench_spmv: bad argument");
+	if (!e->A_loc.rowptr) return fail(LPP_ERR_STATE, "lpp_engine_bench_spmv: no matrix");
+	if (e->active) return fail(LPP_ERR_STATE, "lpp_engine_bench_spmv: a Lanczos run is active");
+	HIP_TRY(hipSetDevice(e->cfg.device));
+	k_fill_random<<<1024, 256, 0, e->stream>>>(e->y, e->nd, 0, 99);
+	HIP_TRY(hipMemsetAsync(e->x, 0, sizeof(double) * (size_t)e->nd_pad, e->stream));
+	const void* src = e->y;
+	if (e->has_comm && e->comm.nranks > 1) {
+		// bench the two local kernels against a synthetic gathered vector (no collective in the loop)
+		k_fill_random<<<1024, 256, 0, e->stream>>>((double*)e->comm.gath_buf, e->comm.shard_stride * e->comm.nranks * (e->is_complex ? 2 : 1), 0, 98);
+	}
+	for (int i = 0; i < warmup + iters; i++) {
+		if (i == warmup) HIP_TRY(hipEventRecord(e->ev_t0, e->stream));
+		spmv_launch(e, e->A_loc, src, e->x, e->y, e->A_rem.nnz ? nullptr : e->partial);
+		if (e->A_rem.nnz) spmv_launch(e, e->A_rem, e->comm.gath_buf, e->x, e->y, e->partial);
+	}
+	HIP_TRY(hipEventRecord(e->ev_t1, e->stream));
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipEventSynchronize(e->ev_t1));
+	float ms = 0;
+	HIP_TRY(hipEventElapsedTime(&ms, e->ev_t0, e->ev_t1));
+	*ms_per_launch = (double)ms / iters;
+	HIP_TRY(hipMemsetAsync(e->x, 0, sizeof(double) * (size_t)e->nd_pad, e->stream));
+	HIP_TRY(hipMemsetAsync(e->y, 0, sizeof(double) * (size_t)e->nd_pad, e->stream));
+	HIP_TRY(hipStreamSynchronize(e->stream));
+	return LPP_OK;
+}
+
+lpp_status lpp_engine_sync(lpp_engine* e)
+{
+	if (!e) return fail(LPP_ERR_INVALID, "lpp_engine_sync: null engine");
+	HIP_TRY(hipSetDevice(e->cfg.device));
+	HIP_TRY(hipStreamSynchronize(e->stream));
+	return LPP_OK;
+}
+
+lpp_status lpp_engine_get_stats(lpp_engine* e, lpp_stats* s)
+{
+	if (!e || !s) return fail(LPP_ERR_INVALID, "lpp_engine_get_stats: null argument");
+	e->collect_spmv_times();
+	*s = e->stats;
+	s->nrows = e->n_local;
+	s->nnz = e->A_loc.nnz + e->A_rem.nnz;
+	s->spmv_bytes = e->spmv_bytes;
+	return LPP_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,112 @@
+// lpp_engine_impl.h -- internal state of an lpp_engine (shared by the .hip translation units).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "lpp_host.h"
+#include "lpp_kernels.h"
+
+#define HIP_TRY(expr)                                                                                                  \
+	do {                                                                                                               \
+		hipError_t _err = (expr);                                                                                      \
+		if (_err != hipSuccess)                                                                                        \
+			return lpp::fail(LPP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_err));                          \
+	} while (0)
+
+#define HIP_TRY_MEM(expr)                                                                                              \
+	do {                                                                                                               \
+		hipError_t _err = (expr);                                                                                      \
+		if (_err != hipSuccess)                                                                                        \
+			return lpp::fail(_err == hipErrorOutOfMemory ? LPP_ERR_NOMEM : LPP_ERR_HIP,                                  \
+			                 std::string(#expr) + ": " + hipGetErrorString(_err));                                       \
+	} while (0)
+
+namespace lpp {
+
+// device-resident CSR (+ optional sliced layout used by k_spmv_sliced)
+struct DevCsr {
+	int64_t nrows = 0, nnz = 0;
+	int64_t* rowptr = nullptr;
+	int32_t* col = nullptr;
+	void* val = nullptr;
+	bool owned = true;
+	int G = 16; // lanes per row of the row-group kernel
+	bool sliced = false;
+	int64_t nslices = 0;
+	int64_t* slice_ptr = nullptr;
+	int32_t* row_len = nullptr;
+	int32_t* scol = nullptr;
+	void* sval = nullptr;
+};
+
+} // namespace lpp
+
+struct lpp_engine {
+	lpp_config cfg {};
+	int is_complex = 0;
+	size_t esz = 8;
+	hipStream_t stream = nullptr;
+	bool own_stream = false;
+	int spmv_max_blocks = 4096;
+
+	// matrix: A_loc has columns inside this rank's slice, A_rem (multi-GPU only) indexes the gathered buffer
+	lpp::DevCsr A_loc, A_rem;
+	int64_t n_local = 0, n_global = 0, row_start = 0;
+	double spmv_bytes = 0;
+
+	// communicator (copied); has_comm false on the single-GPU path
+	lpp_comm comm {};
+	bool has_comm = false;
+
+	// work vectors (doubles, padded to an even count)
+	int64_t nd = 0, nd_pad = 0, n2 = 0;
+	double *x = nullptr, *y = nullptr;
+	double* V = nullptr; // Krylov basis, column j at V + j*ldv
+	int64_t ldv = 0; // in doubles
+	int vcap = 0; // columns allocated
+	double* zwork = nullptr; // two-pass Ritz accumulators
+
+	// scalars (a_j, b_j^2, reortho coefficients, scratch): engine-owned or inside comm.red_buf
+	int M = 0;
+	double* scal_own = nullptr;
+	double *ab_dev = nullptr, *coef_dev = nullptr, *tmp_dev = nullptr;
+	int ab_off = 0, coef_off = 0, tmp_off = 0;
+	double* partial = nullptr;
+	double* h_scal = nullptr; // pinned mirror of ab_dev: 2*M doubles
+
+	// Lanczos run state
+	bool active = false;
+	bool saving = false; // Lanczos vectors kept in V
+	int step = 0; // steps enqueued so far
+	double* ycur = nullptr; // current Lanczos vector (V column or e->y)
+	std::vector<hipEvent_t> step_events;
+	std::vector<std::pair<hipEvent_t, hipEvent_t>> spmv_events;
+	size_t spmv_events_used = 0;
+	hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;
+	lpp_stats stats {};
+
+	// layout inside the scalar buffer: ab[2j] = a_j, ab[2j+1] = b_j^2 (j < M); coef: 2 doubles per Krylov
+	// column (re, im) at [2M, 4M); 8 scratch doubles at [4M, 4M+8)
+	void bind_scalars(double* base)
+	{
+		ab_off = 0;
+		coef_off = 2 * M;
+		tmp_off = 4 * M;
+		ab_dev = base + ab_off;
+		coef_dev = base + coef_off;
+		tmp_dev = base + tmp_off;
+	}
+	lpp_status adopt_comm(const lpp_comm* c);
+	void collect_spmv_times();
+};
+
+namespace lpp {
+void free_csr(DevCsr& A);
+lpp_status finalize_csr(lpp_engine* e, DevCsr& A, bool allow_drop_plain);
+void set_spmv_bytes(lpp_engine* e);
+lpp_status alloc_work(lpp_engine* e);
+int spmv_launch(lpp_engine* e, const DevCsr& A, const void* src, void* x, const void* ydot, double* partial);
+} // namespace lpp

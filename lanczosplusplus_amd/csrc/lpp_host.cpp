@@ -1,0 +1,228 @@
+// lpp_host.cpp -- host-only parts of the engine (see lpp_host.h).
+#include "lpp_host.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <numeric>
+
+namespace lpp {
+
+static thread_local std::string g_last_error;
+
+void set_error(const std::string& msg) { g_last_error = msg; }
+lpp_status fail(lpp_status code, const std::string& msg)
+{
+	g_last_error = msg;
+	return code;
+}
+
+int sturm_count(int n, const double* d, const double* e, double x)
+{
+	int count = 0;
+	double q = 1.0;
+	const double tiny = std::numeric_limits<double>::min() * 1e16;
+	for (int i = 0; i < n; i++) {
+		const double off = (i == 0) ? 0.0 : e[i - 1] * e[i - 1];
+		q = d[i] - x - (i == 0 ? 0.0 : off / q);
+		if (std::fabs(q) < tiny) q = (q < 0 ? -tiny : tiny);
+		if (q < 0) count++;
+	}
+	return count;
+}
+
+double tridiag_kth(int n, const double* d, const double* e, int k)
+{
+	// Gershgorin interval
+	double lo = std::numeric_limits<double>::infinity(), hi = -lo;
+	for (int i = 0; i < n; i++) {
+		const double r = (i > 0 ? std::fabs(e[i - 1]) : 0.0) + (i + 1 < n ? std::fabs(e[i]) : 0.0);
+		lo = std::min(lo, d[i] - r);
+		hi = std::max(hi, d[i] + r);
+	}
+	const double span = std::max(std::fabs(lo), std::fabs(hi));
+	lo -= 1e-12 * span + 1e-300;
+	hi += 1e-12 * span + 1e-300;
+	for (int it = 0; it < 200; it++) {
+		const double mid = 0.5 * (lo + hi);
+		if (mid <= lo || mid >= hi) break; // interval exhausted in double precision
+		if (sturm_count(n, d, e, mid) > k)
+			hi = mid;
+		else
+			lo = mid;
+	}
+	return 0.5 * (lo + hi);
+}
+
+bool tridiag_qr(int n, const double* d_in, const double* e_in, double* w, double* z)
+{
+	if (n <= 0) return true;
+	std::vector<double> d(d_in, d_in + n), e(std::max(n - 1, 1), 0.0);
+	for (int i = 0; i + 1 < n; i++) e[i] = e_in[i];
+	std::vector<double> Z;
+	if (z) {
+		Z.assign((size_t)n * n, 0.0);
+		for (int i = 0; i < n; i++) Z[(size_t)i * n + i] = 1.0;
+	}
+	const double eps = std::numeric_limits<double>::epsilon();
+	int hi = n - 1;
+	int budget = 60 * n + 100;
+	while (hi > 0) {
+		for (int i = 0; i < hi; i++)
+			if (std::fabs(e[i]) <= eps * (std::fabs(d[i]) + std::fabs(d[i + 1]))) e[i] = 0.0;
+		if (e[hi - 1] == 0.0) {
+			hi--;
+			continue;
+		}
+		int lo = hi - 1;
+		while (lo > 0 && e[lo - 1] != 0.0) lo--;
+		if (--budget < 0) return false;
+		// Wilkinson shift from the trailing 2x2 of the active block
+		const double dd = 0.5 * (d[hi - 1] - d[hi]);
+		const double ee = e[hi - 1];
+		const double denom = dd + (dd >= 0 ? 1.0 : -1.0) * std::hypot(dd, ee);
+		const double mu = (denom != 0.0) ? d[hi] - ee * ee / denom : d[hi] - std::fabs(ee);
+		double x = d[lo] - mu;
+		double bulge = e[lo];
+		for (int k = lo; k < hi; k++) {
+			const double r = std::hypot(x, bulge);
+			const double c = (r == 0.0) ? 1.0 : x / r;
+			const double s = (r == 0.0) ? 0.0 : -bulge / r;
+			if (k > lo) e[k - 1] = r;
+			const double a = d[k], b = e[k], g = d[k + 1];
+			d[k] = c * c * a - 2.0 * c * s * b + s * s * g;
+			d[k + 1] = s * s * a + 2.0 * c * s * b + c * c * g;
+			e[k] = c * s * (a - g) + (c * c - s * s) * b;
+			if (k + 1 < hi) {
+				bulge = -s * e[k + 1];
+				e[k + 1] = c * e[k + 1];
+				x = e[k];
+			}
+			if (z) {
+				for (int i = 0; i < n; i++) {
+					const double t = Z[(size_t)i * n + k], u = Z[(size_t)i * n + k + 1];
+					Z[(size_t)i * n + k] = c * t - s * u;
+					Z[(size_t)i * n + k + 1] = s * t + c * u;
+				}
+			}
+		}
+	}
+	std::vector<int> order(n);
+	std::iota(order.begin(), order.end(), 0);
+	std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return d[a] < d[b]; });
+	for (int k = 0; k < n; k++) w[k] = d[order[k]];
+	if (z)
+		for (int i = 0; i < n; i++)
+			for (int k = 0; k < n; k++) z[(size_t)i * n + k] = Z[(size_t)i * n + order[k]];
+	return true;
+}
+
+} // namespace lpp
+
+using namespace lpp;
+
+extern "C" {
+
+const char* lpp_last_error(void) { return g_last_error.c_str(); }
+int32_t lpp_abi_version(void) { return LPP_ABI_VERSION; }
+
+void lpp_config_default(lpp_config* cfg)
+{
+	if (!cfg) return;
+	std::memset(cfg, 0, sizeof(*cfg));
+	cfg->abi_version = LPP_ABI_VERSION;
+	cfg->device = 0;
+	cfg->dtype = LPP_F64;
+	cfg->max_steps = 200;
+	cfg->min_steps = 4;
+	cfg->reortho = 0;
+	cfg->save_vectors = -1;
+	cfg->check_lag = 2;
+	cfg->spmv_kernel = LPP_SPMV_AUTO;
+	cfg->time_kernels = 0;
+	cfg->eps = 1e-12;
+	cfg->seed = 1234;
+	cfg->stream = nullptr;
+}
+
+lpp_status lpp_partition_rows(int64_t nrows, int32_t nranks, int64_t block, int64_t* starts)
+{
+	if (nrows < 0 || nranks <= 0 || block <= 0 || !starts) return fail(LPP_ERR_INVALID, "lpp_partition_rows: bad argument");
+	if (nrows % block != 0) return fail(LPP_ERR_INVALID, "lpp_partition_rows: nrows is not a multiple of block");
+	const int64_t nblocks = nrows / block;
+	const int64_t per = (nblocks + nranks - 1) / nranks; // ceil: every shard fits the common stride
+	for (int32_t r = 0; r <= nranks; r++) starts[r] = std::min<int64_t>((int64_t)r * per, nblocks) * block;
+	return LPP_OK;
+}
+
+lpp_status lpp_split_csr(int32_t rank, int32_t nranks, const int64_t* shard_starts, int64_t shard_stride,
+                         int64_t local_rows, const int64_t* rowptr, const int32_t* colind, const void* values,
+                         int32_t elem_bytes, int64_t* nnz_loc, int64_t* nnz_rem, int64_t* rowptr_loc,
+                         int32_t* colind_loc, void* values_loc, int64_t* rowptr_rem, int32_t* colind_rem,
+                         void* values_rem)
+{
+	if (rank < 0 || rank >= nranks || !shard_starts || !rowptr || (!colind && rowptr[local_rows] > 0))
+		return fail(LPP_ERR_INVALID, "lpp_split_csr: bad argument");
+	if (shard_starts[rank + 1] - shard_starts[rank] != local_rows)
+		return fail(LPP_ERR_INVALID, "lpp_split_csr: local_rows does not match shard_starts");
+	for (int32_t r = 0; r < nranks; r++)
+		if (shard_starts[r + 1] - shard_starts[r] > shard_stride)
+			return fail(LPP_ERR_INVALID, "lpp_split_csr: shard larger than shard_stride");
+	if ((int64_t)nranks * shard_stride > (int64_t)INT32_MAX)
+		return fail(LPP_ERR_INVALID, "lpp_split_csr: gathered vector exceeds 32-bit column range");
+	const int64_t lo = shard_starts[rank], hi = shard_starts[rank + 1];
+	const bool fill = rowptr_loc && rowptr_rem;
+	int64_t nl = 0, nr = 0;
+	const char* vin = (const char*)values;
+	for (int64_t i = 0; i < local_rows; i++) {
+		if (fill) {
+			rowptr_loc[i] = nl;
+			rowptr_rem[i] = nr;
+		}
+		for (int64_t p = rowptr[i]; p < rowptr[i + 1]; p++) {
+			const int64_t c = colind[p];
+			if (c >= lo && c < hi) {
+				if (fill) {
+					colind_loc[nl] = (int32_t)(c - lo);
+					std::memcpy((char*)values_loc + nl * elem_bytes, vin + p * elem_bytes, elem_bytes);
+				}
+				nl++;
+			} else {
+				if (fill) {
+					// owner by binary search over shard_starts
+					const int64_t* it = std::upper_bound(shard_starts, shard_starts + nranks + 1, c);
+					const int64_t owner = (it - shard_starts) - 1;
+					if (owner < 0 || owner >= nranks) return fail(LPP_ERR_INVALID, "lpp_split_csr: column out of range");
+					colind_rem[nr] = (int32_t)(owner * shard_stride + (c - shard_starts[owner]));
+					std::memcpy((char*)values_rem + nr * elem_bytes, vin + p * elem_bytes, elem_bytes);
+				}
+				nr++;
+			}
+		}
+	}
+	if (fill) {
+		rowptr_loc[local_rows] = nl;
+		rowptr_rem[local_rows] = nr;
+	}
+	if (nnz_loc) *nnz_loc = nl;
+	if (nnz_rem) *nnz_rem = nr;
+	return LPP_OK;
+}
+
+lpp_status lpp_tridiag_lowest(int32_t n, const double* d, const double* e, int32_t k, double* w, double* z)
+{
+	if (n <= 0 || k <= 0 || k > n || !d || !w || (n > 1 && !e)) return fail(LPP_ERR_INVALID, "lpp_tridiag_lowest: bad argument");
+	if (!z) {
+		for (int i = 0; i < k; i++) w[i] = tridiag_kth(n, d, e, i);
+		return LPP_OK;
+	}
+	std::vector<double> ww(n), zz((size_t)n * n);
+	if (!tridiag_qr(n, d, e, ww.data(), zz.data())) return fail(LPP_ERR_NOCONV, "lpp_tridiag_lowest: QR iteration did not converge");
+	for (int i = 0; i < k; i++) w[i] = ww[i];
+	for (int j = 0; j < n; j++)
+		for (int i = 0; i < k; i++) z[(size_t)j * k + i] = zz[(size_t)j * n + i];
+	return LPP_OK;
+}
+
+} // extern "C"

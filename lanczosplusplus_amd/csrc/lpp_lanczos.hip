@@ -1,0 +1,466 @@
+// lpp_lanczos.hip -- the device-resident Lanczos loop (A2/A3 of SURVEY 8(a)).
+//
+// Restates LanczosSolver::computeAllStatesBelow / decomposition [PsimagLite] as called from
+// reference src/Engine/Engine.h:626 and :478.  Per step j (all on the GPU, no host sync):
+//   x += H y_j                         (k_spmv_*; fused partial of a_j = Re<y_j|x>)
+//   x -= a_j y_j ;  b_j^2 = |x|^2      (k_axpy_nrm)          [+ blocked CGS2 when reortho]
+//   (y_{j+1}, x) <- (x/b_j, -b_j y_j)  (k_swap_scale; y_{j+1} lands directly in the Krylov basis)
+// The host diagonalises the (j+1)x(j+1) tridiagonal matrix `check_lag` steps behind the stream
+// and stops at the first step where |E_j - E_{j-1}| < eps with j >= min_steps, exactly the
+// reference's stopping rule; run-ahead steps are discarded.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "lpp_engine_impl.h"
+
+using namespace lpp;
+
+static int blas_blocks(int64_t n2)
+{
+	int64_t b = (n2 + kBlock - 1) / kBlock;
+	return (int)std::max<int64_t>(1, std::min<int64_t>(b, 2048));
+}
+
+lpp_status lpp_engine::adopt_comm(const lpp_comm* c)
+{
+	if (c->nranks < 1 || c->rank < 0 || c->rank >= c->nranks) return fail(LPP_ERR_INVALID, "lpp_comm: bad rank/nranks");
+	if (c->nranks > 1) {
+		if (!c->send_buf || !c->gath_buf || !c->red_buf || !c->allgather_begin || !c->allgather_end || !c->allreduce_sum)
+			return fail(LPP_ERR_INVALID, "lpp_comm: missing buffer or callback");
+		if (c->red_len < 4 * M + 8) return fail(LPP_ERR_INVALID, "lpp_comm: red_len < 4*(max_steps+2)+8");
+		if (c->shard_stride <= 0) return fail(LPP_ERR_INVALID, "lpp_comm: shard_stride <= 0");
+	}
+	comm = *c;
+	has_comm = true;
+	if (c->nranks > 1)
+		bind_scalars(c->red_buf);
+	else
+		bind_scalars(scal_own);
+	return LPP_OK;
+}
+
+void lpp_engine::collect_spmv_times()
+{
+	if (spmv_events_used == 0) return;
+	(void)hipStreamSynchronize(stream);
+	for (size_t i = 0; i < spmv_events_used; i++) {
+		float ms = 0;
+		if (hipEventElapsedTime(&ms, spmv_events[i].first, spmv_events[i].second) == hipSuccess) {
+			stats.spmv_ms_total += ms;
+			stats.spmv_launches += 1;
+		}
+	}
+	spmv_events_used = 0;
+}
+
+namespace {
+
+inline bool multi(const lpp_engine* e) { return e->has_comm && e->comm.nranks > 1; }
+
+lpp_status comm_allreduce(lpp_engine* e, int offset, int count)
+{
+	if (!multi(e)) return LPP_OK;
+	if (e->comm.allreduce_sum(e->comm.ctx, offset, count) != 0) return fail(LPP_ERR_COMM, "allreduce_sum callback failed");
+	return LPP_OK;
+}
+
+struct SpmvTimer {
+	lpp_engine* e;
+	bool on;
+	size_t idx = 0;
+	explicit SpmvTimer(lpp_engine* e_) : e(e_), on(e_->cfg.time_kernels != 0)
+	{
+		if (!on) return;
+		if (e->spmv_events_used == e->spmv_events.size()) {
+			hipEvent_t a = nullptr, b = nullptr;
+			if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) {
+				on = false;
+				return;
+			}
+			e->spmv_events.emplace_back(a, b);
+		}
+		idx = e->spmv_events_used++;
+		(void)hipEventRecord(e->spmv_events[idx].first, e->stream);
+	}
+	void stop()
+	{
+		if (on) (void)hipEventRecord(e->spmv_events[idx].second, e->stream);
+	}
+};
+
+// blocked classical Gram-Schmidt, two passes, of x against Krylov columns [0, ncol)
+lpp_status cgs2(lpp_engine* e, int ncol)
+{
+	const int nb = blas_blocks(e->n2);
+	const int64_t ldv2 = e->ldv / 2;
+	for (int pass = 0; pass < 2; pass++) {
+		for (int p0 = 0; p0 < ncol; p0 += kPanel) {
+			const int np = std::min(kPanel, ncol - p0);
+			const double2* v0 = (const double2*)(e->V + (int64_t)p0 * e->ldv);
+			if (e->is_complex)
+				k_multi_dot<true><<<nb, kBlock, 0, e->stream>>>((const double2*)e->x, v0, ldv2, np, e->n2, e->partial);
+			else
+				k_multi_dot<false><<<nb, kBlock, 0, e->stream>>>((const double2*)e->x, v0, ldv2, np, e->n2, e->partial);
+			k_reduce_final<<<1, kBlock, 0, e->stream>>>(e->partial, nb, 2 * kPanel, 2 * np, e->coef_dev + 2 * p0);
+		}
+		lpp_status st = comm_allreduce(e, e->coef_off, 2 * ncol);
+		if (st != LPP_OK) return st;
+		for (int p0 = 0; p0 < ncol; p0 += kPanel) {
+			const int np = std::min(kPanel, ncol - p0);
+			const double2* v0 = (const double2*)(e->V + (int64_t)p0 * e->ldv);
+			if (e->is_complex)
+				k_multi_axpy<true><<<nb, kBlock, 0, e->stream>>>((double2*)e->x, v0, ldv2, np, e->coef_dev + 2 * p0, -1.0, e->n2);
+			else
+				k_multi_axpy<false><<<nb, kBlock, 0, e->stream>>>((double2*)e->x, v0, ldv2, np, e->coef_dev + 2 * p0, -1.0, e->n2);
+		}
+	}
+	return LPP_OK;
+}
+
+// enqueue Lanczos step j = e->step.  ritz (optional): nst coefficients S(j,k) to accumulate
+// zwork_k += S(j,k) y_j during a second pass.
+lpp_status one_step(lpp_engine* e, const double* ritz, int nst)
+{
+	const int j = e->step;
+	const int nb = blas_blocks(e->n2);
+	hipStream_t st = e->stream;
+	double* ycur = e->ycur;
+	int np = 0;
+	if (ritz) {
+		for (int k = 0; k < nst; k++)
+			k_axpy_const<<<nb, kBlock, 0, st>>>((double2*)(e->zwork + (int64_t)k * e->nd_pad), (const double2*)ycur, ritz[k], e->n2);
+	}
+	if (multi(e)) {
+		// the slice of y_j was written to comm.send_buf by the previous k_swap_scale / k_scale_copy
+		if (e->comm.allgather_begin(e->comm.ctx) != 0) return fail(LPP_ERR_COMM, "allgather_begin callback failed");
+		{
+			SpmvTimer t(e);
+			spmv_launch(e, e->A_loc, ycur, e->x, nullptr, nullptr); // local columns: overlaps the all-gather
+			t.stop();
+		}
+		if (e->comm.allgather_end(e->comm.ctx) != 0) return fail(LPP_ERR_COMM, "allgather_end callback failed");
+		{
+			SpmvTimer t(e);
+			np = spmv_launch(e, e->A_rem, e->comm.gath_buf, e->x, ycur, e->partial);
+			t.stop();
+		}
+	} else {
+		SpmvTimer t(e);
+		np = spmv_launch(e, e->A_loc, ycur, e->x, ycur, e->partial);
+		t.stop();
+	}
+	double* a_ptr = e->ab_dev + 2 * j;
+	double* b2_ptr = e->ab_dev + 2 * j + 1;
+	k_reduce_final<<<1, kBlock, 0, st>>>(e->partial, np, 1, 1, a_ptr);
+	lpp_status rc = comm_allreduce(e, e->ab_off + 2 * j, 1);
+	if (rc != LPP_OK) return rc;
+	if (e->cfg.reortho) {
+		k_axpy_nrm<false><<<nb, kBlock, 0, st>>>((double2*)e->x, (const double2*)ycur, a_ptr, e->n2, nullptr);
+		rc = cgs2(e, j + 1);
+		if (rc != LPP_OK) return rc;
+		k_dot<<<nb, kBlock, 0, st>>>((const double2*)e->x, (const double2*)e->x, e->n2, e->partial);
+	} else {
+		k_axpy_nrm<true><<<nb, kBlock, 0, st>>>((double2*)e->x, (const double2*)ycur, a_ptr, e->n2, e->partial);
+	}
+	k_reduce_final<<<1, kBlock, 0, st>>>(e->partial, nb, 1, 1, b2_ptr);
+	rc = comm_allreduce(e, e->ab_off + 2 * j + 1, 1);
+	if (rc != LPP_OK) return rc;
+	double* ynext = e->saving ? e->V + (int64_t)(j + 1) * e->ldv : e->y;
+	k_swap_scale<<<nb, kBlock, 0, st>>>((double2*)e->x, (const double2*)ycur, (double2*)ynext,
+	                                   multi(e) ? (double2*)e->comm.send_buf : nullptr, b2_ptr, e->n2);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipMemcpyAsync(e->h_scal + 2 * j, e->ab_dev + 2 * j, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
+	if ((int)e->step_events.size() <= j) {
+		const size_t old = e->step_events.size();
+		e->step_events.resize(j + 1, nullptr);
+		for (size_t i = old; i < e->step_events.size(); i++) HIP_TRY(hipEventCreateWithFlags(&e->step_events[i], hipEventDisableTiming));
+	}
+	HIP_TRY(hipEventRecord(e->step_events[j], st));
+	e->ycur = ynext;
+	e->step = j + 1;
+	e->stats.steps_enqueued = e->step;
+	return LPP_OK;
+}
+
+int effective_max_steps(const lpp_engine* e)
+{
+	return (int)std::min<int64_t>(e->cfg.max_steps, std::max<int64_t>(e->n_global, 1));
+}
+
+lpp_status ensure_krylov(lpp_engine* e, int ncols, bool required, bool* got)
+{
+	*got = false;
+	const int64_t ldv = (e->nd_pad + 31) & ~(int64_t)31; // 256-byte aligned columns
+	if (e->V && e->vcap >= ncols && e->ldv == ldv) {
+		*got = true;
+		return LPP_OK;
+	}
+	if (e->V) {
+		(void)hipFree(e->V);
+		e->V = nullptr;
+		e->vcap = 0;
+	}
+	const size_t bytes = sizeof(double) * (size_t)ldv * (size_t)ncols;
+	if (!required) {
+		size_t free_b = 0, total_b = 0;
+		if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || bytes + (size_t(2) << 30) > free_b) return LPP_OK;
+	}
+	hipError_t err = hipMalloc(&e->V, std::max<size_t>(bytes, 16));
+	if (err != hipSuccess) {
+		e->V = nullptr;
+		(void)hipGetLastError();
+		if (required) return fail(LPP_ERR_NOMEM, "cannot allocate the on-device Krylov basis (reortho / save_vectors need max_steps+1 vectors)");
+		return LPP_OK;
+	}
+	e->ldv = ldv;
+	e->vcap = ncols;
+	*got = true;
+	return LPP_OK;
+}
+
+lpp_status begin_run(lpp_engine* e, const void* init, bool want_save)
+{
+	if (!e->A_loc.rowptr) return fail(LPP_ERR_STATE, "no matrix: call lpp_engine_set_csr / lpp_engine_assemble_* first");
+	HIP_TRY(hipSetDevice(e->cfg.device));
+	if (e->n_global <= 0) return fail(LPP_ERR_INVALID, "empty matrix");
+	const int maxs = effective_max_steps(e);
+	bool need = e->cfg.reortho != 0 || e->cfg.save_vectors == 1;
+	bool got = false;
+	if (need || (want_save && e->cfg.save_vectors != 0)) {
+		lpp_status st = ensure_krylov(e, maxs + 1, need, &got);
+		if (st != LPP_OK) return st;
+	}
+	e->saving = got;
+	e->ycur = e->saving ? e->V : e->y;
+	e->step = 0;
+	hipStream_t st = e->stream;
+	const int nb = blas_blocks(e->n2);
+	// start vector -> x (scratch), normalise into y_0
+	HIP_TRY(hipMemsetAsync(e->x, 0, sizeof(double) * (size_t)e->nd_pad, st));
+	if (init) {
+		HIP_TRY(hipMemcpyAsync(e->x, init, e->esz * (size_t)e->n_local, hipMemcpyHostToDevice, st));
+	} else if (e->nd > 0) {
+		k_fill_random<<<1024, 256, 0, st>>>(e->x, e->nd, e->row_start * (e->is_complex ? 2 : 1), e->cfg.seed);
+	}
+	k_dot<<<nb, kBlock, 0, st>>>((const double2*)e->x, (const double2*)e->x, e->n2, e->partial);
+	k_reduce_final<<<1, kBlock, 0, st>>>(e->partial, nb, 1, 1, e->tmp_dev);
+	lpp_status rc = comm_allreduce(e, e->tmp_off, 1);
+	if (rc != LPP_OK) return rc;
+	k_scale_copy<<<nb, kBlock, 0, st>>>((double2*)e->ycur, multi(e) ? (double2*)e->comm.send_buf : nullptr, (const double2*)e->x, e->tmp_dev, e->n2);
+	HIP_TRY(hipMemsetAsync(e->x, 0, sizeof(double) * (size_t)e->nd_pad, st));
+	HIP_TRY(hipGetLastError());
+	e->active = true;
+	e->spmv_events_used = 0;
+	std::memset(&e->stats, 0, sizeof(e->stats));
+	e->stats.vectors_saved = e->saving ? 1 : 0;
+	return LPP_OK;
+}
+
+struct SolveResult {
+	int steps = 0;
+	bool converged = false;
+	std::vector<double> a, b;
+};
+
+// run the recurrence with the lagged convergence test; fills res
+lpp_status run_recurrence(lpp_engine* e, SolveResult& res)
+{
+	const int maxs = effective_max_steps(e);
+	const int lag = e->cfg.check_lag;
+	res.a.assign(maxs, 0.0);
+	res.b.assign(maxs, 0.0);
+	double eold = 100.0;
+	int checked = 0;
+	int final_steps = -1;
+	auto check = [&](int k) -> lpp_status {
+		HIP_TRY(hipEventSynchronize(e->step_events[k]));
+		res.a[k] = e->h_scal[2 * k];
+		const double b2 = e->h_scal[2 * k + 1];
+		res.b[k] = std::sqrt(b2 > 0 ? b2 : 0.0);
+		if (!std::isfinite(res.a[k]) || !std::isfinite(b2)) return fail(LPP_ERR_NOCONV, "Lanczos produced a non-finite coefficient");
+		const double enew = tridiag_kth(k + 1, res.a.data(), res.b.data(), 0);
+		if (e->cfg.eps > 0) {
+			const bool exitFlag = std::fabs(enew - eold) < e->cfg.eps;
+			if (exitFlag && (e->n_global <= 4 || k >= e->cfg.min_steps)) {
+				final_steps = k + 1;
+				res.converged = true;
+			}
+		}
+		if (final_steps < 0 && std::fabs(res.b[k]) < 1e-10) { // invariant subspace exhausted
+			final_steps = k + 1;
+			res.converged = true;
+		}
+		eold = enew;
+		return LPP_OK;
+	};
+	for (int j = 0; j < maxs && final_steps < 0; j++) {
+		lpp_status st = one_step(e, nullptr, 0);
+		if (st != LPP_OK) return st;
+		while (final_steps < 0 && checked <= j - lag) {
+			st = check(checked++);
+			if (st != LPP_OK) return st;
+		}
+	}
+	while (final_steps < 0 && checked < e->step) {
+		lpp_status st = check(checked++);
+		if (st != LPP_OK) return st;
+	}
+	if (final_steps < 0) final_steps = e->step;
+	HIP_TRY(hipStreamSynchronize(e->stream));
+	res.steps = final_steps;
+	res.a.resize(final_steps);
+	res.b.resize(final_steps);
+	return LPP_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+lpp_status lpp_engine_lanczos_begin(lpp_engine* e, const void* init)
+{
+	if (!e) return fail(LPP_ERR_INVALID, "lpp_engine_lanczos_begin: null engine");
+	return begin_run(e, init, false);
+}
+
+lpp_status lpp_engine_lanczos_step(lpp_engine* e, int32_t nsteps)
+{
+	if (!e || nsteps < 0) return fail(LPP_ERR_INVALID, "lpp_engine_lanczos_step: bad argument");
+	if (!e->active) return fail(LPP_ERR_STATE, "lpp_engine_lanczos_step: call lpp_engine_lanczos_begin first");
+	HIP_TRY(hipSetDevice(e->cfg.device));
+	for (int i = 0; i < nsteps; i++) {
+		if (e->step >= effective_max_steps(e)) return fail(LPP_ERR_STATE, "lpp_engine_lanczos_step: max_steps reached");
+		lpp_status st = one_step(e, nullptr, 0);
+		if (st != LPP_OK) return st;
+	}
+	return LPP_OK;
+}
+
+lpp_status lpp_engine_lanczos_coeffs(lpp_engine* e, int32_t* steps, double* a, double* b)
+{
+	if (!e || !steps) return fail(LPP_ERR_INVALID, "lpp_engine_lanczos_coeffs: bad argument");
+	HIP_TRY(hipSetDevice(e->cfg.device));
+	HIP_TRY(hipStreamSynchronize(e->stream));
+	*steps = e->step;
+	for (int j = 0; j < e->step; j++) {
+		if (a) a[j] = e->h_scal[2 * j];
+		if (b) b[j] = std::sqrt(std::max(e->h_scal[2 * j + 1], 0.0));
+	}
+	return LPP_OK;
+}
+
+lpp_status lpp_engine_lanczos(lpp_engine* e, const void* init, int32_t nstates, double* eigs, void* ritz_vectors, lpp_stats* stats)
+{
+	if (!e || nstates < 1 || !eigs) return fail(LPP_ERR_INVALID, "lpp_engine_lanczos: bad argument");
+	const auto t0 = std::chrono::steady_clock::now();
+	lpp_status st = begin_run(e, init, ritz_vectors != nullptr);
+	if (st != LPP_OK) return st;
+	SolveResult res;
+	st = run_recurrence(e, res);
+	e->active = false;
+	if (st != LPP_OK) return st;
+	const int steps = res.steps;
+	if (steps < nstates) return fail(LPP_ERR_NOCONV, "Lanczos: fewer steps than requested states");
+	std::vector<double> w(nstates), S;
+	if (ritz_vectors) {
+		S.resize((size_t)steps * nstates);
+		st = lpp_tridiag_lowest(steps, res.a.data(), res.b.data(), nstates, w.data(), S.data());
+	} else {
+		st = lpp_tridiag_lowest(steps, res.a.data(), res.b.data(), nstates, w.data(), nullptr);
+	}
+	if (st != LPP_OK) return st;
+	for (int k = 0; k < nstates; k++) eigs[k] = w[k];
+	const int steps_enq = e->stats.steps_enqueued;
+	if (ritz_vectors) {
+		const int nb = blas_blocks(e->n2);
+		if (e->saving) {
+			// z_k = sum_j S(j,k) v_j from the on-device Krylov basis (x is free after the run)
+			std::vector<double> coef(2 * (size_t)steps);
+			for (int k = 0; k < nstates; k++) {
+				for (int j = 0; j < steps; j++) {
+					coef[2 * j] = S[(size_t)j * nstates + k];
+					coef[2 * j + 1] = 0.0;
+				}
+				HIP_TRY(hipMemcpyAsync(e->coef_dev, coef.data(), sizeof(double) * 2 * (size_t)steps, hipMemcpyHostToDevice, e->stream));
+				HIP_TRY(hipMemsetAsync(e->x, 0, sizeof(double) * (size_t)e->nd_pad, e->stream));
+				for (int p0 = 0; p0 < steps; p0 += kPanel) {
+					const int np = std::min(kPanel, steps - p0);
+					const double2* v0 = (const double2*)(e->V + (int64_t)p0 * e->ldv);
+					if (e->is_complex)
+						k_multi_axpy<true><<<nb, kBlock, 0, e->stream>>>((double2*)e->x, v0, e->ldv / 2, np, e->coef_dev + 2 * p0, 1.0, e->n2);
+					else
+						k_multi_axpy<false><<<nb, kBlock, 0, e->stream>>>((double2*)e->x, v0, e->ldv / 2, np, e->coef_dev + 2 * p0, 1.0, e->n2);
+				}
+				HIP_TRY(hipGetLastError());
+				HIP_TRY(hipMemcpyAsync((char*)ritz_vectors + (size_t)k * e->esz * (size_t)e->n_local, e->x, e->esz * (size_t)e->n_local,
+				                       hipMemcpyDeviceToHost, e->stream));
+				HIP_TRY(hipStreamSynchronize(e->stream));
+			}
+		} else {
+			// second pass: replay the recurrence (bitwise identical kernels) and accumulate z_k += S(j,k) y_j
+			if (e->zwork) (void)hipFree(e->zwork);
+			e->zwork = nullptr;
+			HIP_TRY_MEM(hipMalloc(&e->zwork, sizeof(double) * (size_t)e->nd_pad * (size_t)nstates));
+			lpp_stats keep = e->stats;
+			st = begin_run(e, init, false);
+			if (st != LPP_OK) return st;
+			e->saving = false;
+			e->ycur = e->y;
+			HIP_TRY(hipMemsetAsync(e->zwork, 0, sizeof(double) * (size_t)e->nd_pad * (size_t)nstates, e->stream));
+			for (int j = 0; j < steps; j++) {
+				st = one_step(e, &S[(size_t)j * nstates], nstates);
+				if (st != LPP_OK) return st;
+			}
+			HIP_TRY(hipStreamSynchronize(e->stream));
+			e->active = false;
+			e->collect_spmv_times();
+			keep.spmv_ms_total += e->stats.spmv_ms_total;
+			keep.spmv_launches += e->stats.spmv_launches;
+			e->stats = keep;
+			for (int k = 0; k < nstates; k++)
+				HIP_TRY(hipMemcpy((char*)ritz_vectors + (size_t)k * e->esz * (size_t)e->n_local, e->zwork + (int64_t)k * e->nd_pad,
+				                  e->esz * (size_t)e->n_local, hipMemcpyDeviceToHost));
+			(void)hipFree(e->zwork);
+			e->zwork = nullptr;
+		}
+	}
+	e->collect_spmv_times();
+	e->stats.steps = steps;
+	e->stats.steps_enqueued = steps_enq;
+	e->stats.converged = res.converged ? 1 : 0;
+	e->stats.seconds_total = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+	if (stats) lpp_engine_get_stats(e, stats);
+	return LPP_OK;
+}
+
+lpp_status lpp_engine_decomposition(lpp_engine* e, const void* init, int32_t* nsteps, double* a, double* b, lpp_stats* stats)
+{
+	if (!e || !nsteps || !a || !b) return fail(LPP_ERR_INVALID, "lpp_engine_decomposition: bad argument");
+	const auto t0 = std::chrono::steady_clock::now();
+	lpp_status st = begin_run(e, init, false);
+	if (st != LPP_OK) return st;
+	SolveResult res;
+	st = run_recurrence(e, res);
+	e->active = false;
+	if (st != LPP_OK) return st;
+	*nsteps = res.steps;
+	for (int j = 0; j < res.steps; j++) {
+		a[j] = res.a[j];
+		b[j] = res.b[j];
+	}
+	const int steps_enq = e->stats.steps_enqueued;
+	e->collect_spmv_times();
+	e->stats.steps = res.steps;
+	e->stats.steps_enqueued = steps_enq;
+	e->stats.converged = res.converged ? 1 : 0;
+	e->stats.seconds_total = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+	if (stats) lpp_engine_get_stats(e, stats);
+	return LPP_OK;
+}
+
+} // extern "C"

@@ -207,8 +207,9 @@ def tj_csr(L, nup, ndown, hop, jpm, jzz, w, potentialV=None, force_complex=False
     hr = _mat(hop.real, L)
     hi = _mat(hop.imag, L) if np.iscomplexobj(hop) else None
     pv = None if potentialV is None else np.ascontiguousarray(potentialV, np.float64)
+    assert pv is None or len(pv) == 2 * L
     h = lib().lppo_tj_setup(L, nup, ndown, _ptr(hr), _ptr(hi), _ptr(_mat(jpm, L)), _ptr(_mat(jzz, L)), _ptr(_mat(w, L)),
-                            _ptr(pv), 0 if pv is None else len(pv) // 2, int(cplx), int(literal_index))
+                            _ptr(pv), 0 if pv is None else len(pv), int(cplx), int(literal_index))
     return _take_csr(h)
 
 

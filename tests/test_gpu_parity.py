@@ -1,0 +1,213 @@
+"""-m gpu: parity of the HIP path (through the C ABI) against the CPU oracle on the same inputs.
+
+Tolerances: indices/structure bit-exact; matrix values bit-exact; SpMV 1e-13 relative per vector
+(summation order differs); energies 1e-10 relative (BASELINE.json north_star).
+"""
+import numpy as np
+import pytest
+
+import oracle
+from helpers import chain, rel, square
+from lanczosplusplus_amd import LanczosEngine, LppError
+
+pytestmark = pytest.mark.gpu
+
+E_TOL = 1e-10
+SPMV_TOL = 1e-13
+
+
+def models():
+    L = 8
+    out = {}
+    out["hubbard"] = oracle.hubbard_csr(L, 4, 4, chain(L, -1.0), np.full(L, 4.0), np.linspace(-0.3, 0.3, 2 * L))
+    out["heisenberg"] = oracle.heis_csr(12, 1, 6, chain(12, 1.0, True), chain(12, 1.0, True))
+    hop = chain(L, -1.0).astype(complex)
+    hop[0, 1] = -1.0 * np.exp(0.3j)
+    hop[1, 0] = np.conj(hop[0, 1])
+    out["tj_complex"] = oracle.tj_csr(L, 3, 3, chain(L, -1.0), chain(L, 0.4), chain(L, 0.4), chain(L, -0.1),
+                                      force_complex=True)
+    out["hubbard_complex"] = oracle.hubbard_csr(6, 3, 3, hop[:6, :6], np.full(6, 2.0))
+    return out
+
+
+@pytest.fixture(scope="module")
+def mats():
+    return models()
+
+
+@pytest.mark.parametrize("name", ["hubbard", "heisenberg", "tj_complex", "hubbard_complex"])
+@pytest.mark.parametrize("kernel", [1, 2])
+def test_spmv_acc_matches_oracle(mats, name, kernel):
+    A = mats[name]
+    dt = "c128" if A.is_complex else "f64"
+    with LanczosEngine(dtype=dt, spmv_kernel=kernel) as e:
+        e.set_csr(A.rowptr, A.colind, A.values)
+        assert e.rows() == A.nrows
+        x0 = oracle.fill_random(A.nrows, 7, A.is_complex)
+        y = oracle.fill_random(A.nrows, 8, A.is_complex)
+        xg = e.matrixVectorProduct(x0.copy(), y)
+        xo = oracle.spmv_acc(A, x0.copy(), y)
+        assert rel(xg, xo) < SPMV_TOL
+        # accumulate semantics: a second call adds H y again
+        xg2 = e.matrixVectorProduct(xg.copy(), y)
+        assert rel(xg2 - xg, xo - x0) < 1e-12
+
+
+def test_spmv_edge_cases():
+    # empty rows, a single dense row, 1x1 matrix
+    rowptr = np.array([0, 0, 3, 3, 4], np.int64)
+    col = np.array([0, 1, 3, 2], np.int32)
+    val = np.array([1.0, 2.0, 3.0, -1.0])
+    with LanczosEngine() as e:
+        e.set_csr(rowptr, col, val)
+        x = np.ones(4)
+        y = np.array([1.0, 10.0, 100.0, 1000.0])
+        e.matrixVectorProduct(x, y)
+        assert np.array_equal(x, np.array([1.0, 1 + 1 + 20 + 3000, 1.0, 1 - 100.0]))
+        e.set_csr(np.array([0, 1], np.int64), np.array([0], np.int32), np.array([2.5]))
+        x = np.array([1.0])
+        e.matrixVectorProduct(x, np.array([2.0]))
+        assert x[0] == 6.0
+        eigs, zs, st = e.lanczos(1)
+        assert abs(eigs[0] - 2.5) < 1e-14
+    n = 300
+    rowptr = np.zeros(n + 1, np.int64)
+    rowptr[1:] = n  # row 0 dense, others empty
+    col = np.arange(n, dtype=np.int32)
+    val = np.arange(1, n + 1, dtype=np.float64)
+    with LanczosEngine(spmv_kernel=2) as e:
+        e.set_csr(rowptr, col, val)
+        x = np.zeros(n)
+        e.matrixVectorProduct(x, np.ones(n))
+        assert x[0] == n * (n + 1) / 2 and not x[1:].any()
+
+
+def test_errors_are_loud():
+    with LanczosEngine() as e:
+        with pytest.raises(LppError):
+            e.lanczos(1)  # no matrix
+        with pytest.raises(LppError):
+            e.set_csr(np.array([0, 1], np.int64), np.array([5], np.int32), np.array([1.0]))  # column out of range
+
+
+@pytest.mark.parametrize("name", ["hubbard", "heisenberg", "tj_complex", "hubbard_complex"])
+@pytest.mark.parametrize("kernel", [1, 2])
+def test_lanczos_energy_and_coefficients(mats, name, kernel):
+    A = mats[name]
+    dt = "c128" if A.is_complex else "f64"
+    init = oracle.fill_random(A.nrows, 1234, A.is_complex)
+    eo, zo, so = oracle.lanczos_solve(A, init, nstates=1)
+    steps_o, ao, bo, _, _ = oracle.lanczos_decomposition(A, init)
+    with LanczosEngine(dtype=dt, spmv_kernel=kernel) as e:
+        e.set_csr(A.rowptr, A.colind, A.values)
+        # built-in start vector (init=None) is the same splitmix64 stream as the oracle's
+        eg, zg, st = e.lanczos(1, want_vectors=True)
+        assert abs(eg[0] - eo[0]) <= E_TOL * abs(eo[0])
+        assert st["steps"] == so
+        r = oracle.spmv_acc(A, np.zeros_like(zg[0]), zg[0]) - eg[0] * zg[0]
+        assert np.linalg.norm(r) < 1e-5
+        assert abs(np.linalg.norm(zg[0]) - 1) < 1e-8
+        ag, bg, st2 = e.decomposition(init)
+        assert len(ag) == steps_o
+        assert rel(ag, ao) < 1e-8 and rel(bg, bo) < 1e-8
+        # dense cross-check
+        ed = np.linalg.eigvalsh(A.to_scipy().toarray())[0]
+        assert abs(eg[0] - ed) <= 1e-10 * abs(ed)
+
+
+@pytest.mark.parametrize("save", [0, 1])
+def test_ritz_vectors_two_pass_equals_saved(mats, save):
+    A = mats["hubbard"]
+    with LanczosEngine(save_vectors=save) as e:
+        e.set_csr(A.rowptr, A.colind, A.values)
+        eg, zg, st = e.lanczos(1, want_vectors=True)
+        assert st["vectors_saved"] == save
+        r = oracle.spmv_acc(A, np.zeros_like(zg[0]), zg[0]) - eg[0] * zg[0]
+        assert np.linalg.norm(r) < 1e-5
+
+
+@pytest.mark.parametrize("name", ["hubbard", "tj_complex"])
+def test_reortho_and_excited_states(mats, name):
+    A = mats[name]
+    dt = "c128" if A.is_complex else "f64"
+    init = oracle.fill_random(A.nrows, 1234, A.is_complex)
+    dense = np.linalg.eigvalsh(A.to_scipy().toarray())
+    eo, _, so = oracle.lanczos_solve(A, init, nstates=3, max_steps=150, eps=1e-13, reortho=True)
+    with LanczosEngine(dtype=dt, reortho=True, max_steps=150, eps=1e-13) as e:
+        e.set_csr(A.rowptr, A.colind, A.values)
+        eg, zg, st = e.lanczos(3, want_vectors=True)
+        assert abs(eg[0] - dense[0]) <= E_TOL * abs(dense[0])
+        assert rel(eg, eo) < 1e-8
+        # with full re-orthogonalisation the Krylov basis stays orthonormal: Ritz vectors are orthonormal
+        G = zg.conj() @ zg.T
+        assert np.abs(G - np.eye(3)).max() < 1e-8
+
+
+def test_device_assembly_is_bit_exact():
+    L = 8
+    hop = square(2, 4, -1.0, pbc=False) + 0.0
+    U = np.linspace(1.0, 4.5, L)
+    V = np.linspace(-0.5, 0.5, 2 * L)
+    A = oracle.hubbard_csr(L, 3, 4, hop, U, V)
+    with LanczosEngine() as e:
+        e.assemble_hubbard(L, 3, 4, hop, U, V)
+        rp, ci, va = e.get_csr()
+        assert np.array_equal(rp, A.rowptr) and np.array_equal(ci, A.colind)
+        assert np.array_equal(va.view(np.uint64), A.values.view(np.uint64))
+    # complex hoppings
+    hc = chain(6, -1.0).astype(complex)
+    hc[2, 3] = -0.7 * np.exp(0.4j)
+    hc[3, 2] = np.conj(hc[2, 3])
+    A = oracle.hubbard_csr(6, 2, 3, hc, np.full(6, 3.0))
+    with LanczosEngine(dtype="c128") as e:
+        e.assemble_hubbard(6, 2, 3, hc, np.full(6, 3.0))
+        rp, ci, va = e.get_csr()
+        assert np.array_equal(rp, A.rowptr) and np.array_equal(ci, A.colind)
+        assert np.array_equal(va.view(np.uint64), A.values.view(np.uint64))
+    # Heisenberg ring with field
+    L = 12
+    jpm, jzz = chain(L, 1.0, True), chain(L, 0.7, True)
+    jpm[0, 5] = jpm[5, 0] = 0.3
+    field = np.linspace(-0.2, 0.2, L)
+    A = oracle.heis_csr(L, 1, 5, jpm, jzz, field=field, literal_index=True)
+    with LanczosEngine() as e:
+        e.assemble_heisenberg(L, 5, jpm, jzz, field)
+        rp, ci, va = e.get_csr()
+        assert np.array_equal(rp, A.rowptr) and np.array_equal(ci, A.colind)
+        assert np.array_equal(va.view(np.uint64), A.values.view(np.uint64))
+    # t-J, complex engine, real couplings (config 4 style) and potential
+    L = 8
+    pv = np.linspace(-0.1, 0.2, 2 * L)
+    A = oracle.tj_csr(L, 3, 2, square(2, 4, -1.0, False), square(2, 4, 0.4, False), square(2, 4, 0.4, False),
+                      square(2, 4, -0.1, False), potentialV=pv, force_complex=True, literal_index=True)
+    with LanczosEngine(dtype="c128") as e:
+        e.assemble_tj(L, 3, 2, square(2, 4, -1.0, False), square(2, 4, 0.4, False), square(2, 4, 0.4, False),
+                      square(2, 4, -0.1, False), pv)
+        rp, ci, va = e.get_csr()
+        assert np.array_equal(rp, A.rowptr) and np.array_equal(ci, A.colind)
+        assert np.array_equal(va.view(np.uint64), A.values.view(np.uint64))
+
+
+def test_config1_hubbard_chain_L12():
+    """BASELINE config 1 shape (N=853,776; Z=11,099,088): device assembly == oracle assembly, energy parity."""
+    L = 12
+    hop, U = chain(L, -1.0), np.full(L, 4.0)
+    A = oracle.hubbard_csr(L, 6, 6, hop, U)
+    assert (A.nrows, A.nnz) == (853776, 11099088)
+    eo, _, so = oracle.lanczos_solve(A, oracle.fill_random(A.nrows, 1234), want_vectors=False, nthreads=0)
+    with LanczosEngine() as e:
+        e.assemble_hubbard(L, 6, 6, hop, U)
+        rp, ci, va = e.get_csr()
+        assert np.array_equal(rp, A.rowptr) and np.array_equal(ci, A.colind) and np.array_equal(va, A.values)
+        eg, _, st = e.lanczos(1, want_vectors=False)
+        assert abs(eg[0] - eo[0]) <= E_TOL * abs(eo[0])
+        assert st["steps"] == so
+
+
+def test_input0_free_fermions():
+    """TestSuite/inputs/input0.inp parameters: L=4 OBC, t=-1, U=0, 2 up 2 down -> E0 = -2 sqrt(5)."""
+    with LanczosEngine() as e:
+        e.assemble_hubbard(4, 2, 2, chain(4, -1.0), np.zeros(4))
+        assert e.rows() == 36
+        eg, _, _ = e.lanczos(1)
+        assert abs(eg[0] + 2 * np.sqrt(5)) < 1e-12
