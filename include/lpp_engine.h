@@ -43,7 +43,7 @@ enum {
 enum { LPP_F64 = 0, LPP_C128 = 1 };
 
 /* SpMV kernel selection (0 = automatic) */
-enum { LPP_SPMV_AUTO = 0, LPP_SPMV_ROWGROUP = 1, LPP_SPMV_SLICED = 2 };
+enum { LPP_SPMV_AUTO = 0, LPP_SPMV_ROWGROUP = 1, LPP_SPMV_SLICED = 2, LPP_SPMV_WINDOW = 3 };
 
 typedef struct lpp_engine lpp_engine;
 

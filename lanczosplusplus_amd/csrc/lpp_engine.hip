@@ -81,14 +81,44 @@ template <typename T> static int spmv_launch_t(lpp_engine* e, const DevCsr& A, c
 	hipStream_t st = e->stream;
 	if (A.nrows == 0) return 0;
 	if (A.sliced) {
-		const int64_t need = (A.nslices + (kBlock / 64) - 1) / (kBlock / 64);
-		const int nb = (int)std::max<int64_t>(1, std::min<int64_t>(need, e->spmv_max_blocks));
-		if (partial)
-			k_spmv_sliced<T, true><<<nb, kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_ptr, A.row_len, A.scol, (const T*)A.sval,
-			                                             (const T*)src, (T*)x, (const T*)ydot, partial);
-		else
-			k_spmv_sliced<T, false><<<nb, kBlock, 0, st>>>(A.nrows, A.nslices, A.slice_ptr, A.row_len, A.scol, (const T*)A.sval,
-			                                              (const T*)src, (T*)x, nullptr, nullptr);
+		SlicedArgs<T> a;
+		a.g = A.geom;
+		a.slice_ptr = A.slice_ptr;
+		a.row_len = A.row_len;
+		a.col = A.scol;
+		a.val = (const T*)A.sval;
+		a.src = (const T*)src;
+		a.x = (T*)x;
+		a.ydot = (const T*)ydot;
+		a.partial = partial;
+		a.xcd_map = (e->k2_variant >> 1) & 1;
+		const bool dot = partial != nullptr;
+		const bool u8 = (e->k2_variant & 4) != 0;
+		int nb;
+		if (A.window) {
+			const size_t lds_bytes = sizeof(T) * (size_t)std::max<int64_t>(A.geom.B, 64);
+			const int per_cu = std::max(1, std::min(2, (int)((160 * 1024 - 256) / (lds_bytes + 1))));
+			nb = (int)std::max<int64_t>(1, std::min<int64_t>(A.geom.nblocks, (int64_t)e->num_cus * per_cu));
+			if (nb >= 8) nb &= ~7;
+#define LPP_K3(DOT_, U_)                                                                                              \
+	do {                                                                                                              \
+		(void)hipFuncSetAttribute((const void*)k_spmv_window<T, DOT_, U_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
+		k_spmv_window<T, DOT_, U_><<<nb, kWinThreads, lds_bytes, st>>>(a);                                             \
+	} while (0)
+			if (dot && u8) LPP_K3(true, 8);
+			else if (dot) LPP_K3(true, 4);
+			else if (u8) LPP_K3(false, 8);
+			else LPP_K3(false, 4);
+#undef LPP_K3
+		} else {
+			const int64_t need = (A.geom.nslices + (kBlock / 64) - 1) / (kBlock / 64);
+			nb = (int)std::max<int64_t>(1, std::min<int64_t>(need, e->spmv_max_blocks));
+			if (nb >= 8) nb &= ~7; // multiple of 8 so the XCD-contiguous mapping applies
+			if (dot && u8) k_spmv_sliced<T, true, 8><<<nb, kBlock, 0, st>>>(a);
+			else if (dot) k_spmv_sliced<T, true, 4><<<nb, kBlock, 0, st>>>(a);
+			else if (u8) k_spmv_sliced<T, false, 8><<<nb, kBlock, 0, st>>>(a);
+			else k_spmv_sliced<T, false, 4><<<nb, kBlock, 0, st>>>(a);
+		}
 		return partial ? nb : 0;
 	}
 	const int rows_per_block = kBlock / A.G;
@@ -106,38 +136,59 @@ int spmv_launch(lpp_engine* e, const DevCsr& A, const void* src, void* x, const 
 	return e->is_complex ? spmv_launch_t<cplx>(e, A, src, x, ydot, partial) : spmv_launch_t<double>(e, A, src, x, ydot, partial);
 }
 
-// build the sliced layout of A on the device (keeps rowptr; frees nothing)
-template <typename T> static lpp_status build_sliced_t(lpp_engine* e, DevCsr& A)
+// build the sliced layout of A on the device for row blocks of B rows
+template <typename T> static lpp_status build_sliced_t(lpp_engine* e, DevCsr& A, int64_t B)
 {
-	A.nslices = (A.nrows + 63) / 64;
-	HIP_TRY(hipMalloc(&A.slice_ptr, sizeof(int64_t) * (size_t)(A.nslices + 1)));
-	HIP_TRY(hipMalloc(&A.row_len, sizeof(int32_t) * (size_t)std::max<int64_t>(A.nrows, 1)));
-	HIP_TRY(hipMalloc(&A.scol, sizeof(int32_t) * (size_t)std::max<int64_t>(A.nnz, 1)));
-	HIP_TRY(hipMalloc(&A.sval, sizeof(T) * (size_t)std::max<int64_t>(A.nnz, 1)));
-	const int64_t nthreads = std::max<int64_t>(A.nrows, A.nslices + 1);
+	SliceGeom g;
+	g.nrows = A.nrows;
+	g.B = std::max<int64_t>(1, std::min<int64_t>(B, std::max<int64_t>(A.nrows, 1)));
+	g.spb = (int32_t)((g.B + 63) / 64);
+	g.nblocks = (A.nrows + g.B - 1) / g.B;
+	g.nslices = g.nblocks * g.spb;
+	A.geom = g;
+	// +64 entries of slack: the pipelined kernel reads (and discards) the entry after a slice's last one
+	HIP_TRY_MEM(hipMalloc(&A.slice_ptr, sizeof(int64_t) * (size_t)(g.nslices + 1)));
+	HIP_TRY_MEM(hipMalloc(&A.row_len, sizeof(int32_t) * (size_t)std::max<int64_t>(A.nrows, 1)));
+	HIP_TRY_MEM(hipMalloc(&A.scol, sizeof(int32_t) * (size_t)(A.nnz + 64)));
+	HIP_TRY_MEM(hipMalloc(&A.sval, sizeof(T) * (size_t)(A.nnz + 64)));
+	HIP_TRY(hipMemsetAsync(A.scol + A.nnz, 0, sizeof(int32_t) * 64, e->stream));
+	HIP_TRY(hipMemsetAsync((T*)A.sval + A.nnz, 0, sizeof(T) * 64, e->stream));
+	const int64_t nthreads = std::max<int64_t>(A.nrows, g.nslices + 1);
 	const int nb = (int)((nthreads + 255) / 256);
-	k_slice_meta<<<nb, 256, 0, e->stream>>>(A.nrows, A.nslices, A.rowptr, A.slice_ptr, A.row_len);
-	const int64_t need = (A.nslices + 3) / 4;
+	k_slice_meta<<<nb, 256, 0, e->stream>>>(g, A.rowptr, A.slice_ptr, A.row_len);
+	const int64_t need = (g.nslices + 3) / 4;
 	const int nb2 = (int)std::max<int64_t>(1, std::min<int64_t>(need, 8192));
-	k_slice_fill<T><<<nb2, kBlock, 0, e->stream>>>(A.nrows, A.nslices, A.rowptr, A.col, (const T*)A.val, A.scol, (T*)A.sval);
+	k_slice_fill<T, false><<<nb2, kBlock, 0, e->stream>>>(g, A.rowptr, A.col, (const T*)A.val, A.scol, (T*)A.sval);
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipStreamSynchronize(e->stream));
-	// the plain col/val copies are no longer needed by the solver; keep rowptr for get_csr row sizes
 	A.sliced = true;
 	return LPP_OK;
 }
 
+// Choose the SpMV kernel and build its layout.  hint_block (rows) is the basis' natural block
+// (N_up for the Hubbard product basis): when a whole number of such blocks fits the LDS window,
+// the window kernel serves every in-block gather (diagonal + up-hops) from LDS.
 lpp_status finalize_csr(lpp_engine* e, DevCsr& A, bool allow_drop_plain)
 {
 	A.G = pick_group(A.nrows, A.nnz);
 	int mode = e->cfg.spmv_kernel;
 	if (const char* s = getenv("LPP_SPMV_KERNEL")) mode = atoi(s);
-	if (mode == LPP_SPMV_AUTO) mode = LPP_SPMV_ROWGROUP;
-	if (mode == LPP_SPMV_SLICED && A.nrows > 0) {
-		lpp_status st = e->is_complex ? build_sliced_t<cplx>(e, A) : build_sliced_t<double>(e, A);
+	const int64_t lds_cap_elems = (int64_t)((156 * 1024) / e->esz);
+	int64_t win_rows = 0;
+	if (A.hint_block > 0 && A.hint_block <= lds_cap_elems) win_rows = A.hint_block * (lds_cap_elems / A.hint_block);
+	if (mode == LPP_SPMV_AUTO) mode = (win_rows > 0) ? LPP_SPMV_WINDOW : LPP_SPMV_SLICED;
+	if (mode == LPP_SPMV_WINDOW && win_rows == 0) {
+		// no natural block: a generic diagonal window (captures near-diagonal columns)
+		win_rows = std::min<int64_t>(lds_cap_elems, 16384);
+	}
+	if (const char* s = getenv("LPP_WINDOW_ROWS")) win_rows = std::max<int64_t>(64, std::min<int64_t>(atoll(s), lds_cap_elems));
+	if ((mode == LPP_SPMV_SLICED || mode == LPP_SPMV_WINDOW) && A.nrows > 0) {
+		const int64_t B = (mode == LPP_SPMV_WINDOW) ? win_rows : A.nrows;
+		lpp_status st = e->is_complex ? build_sliced_t<cplx>(e, A, B) : build_sliced_t<double>(e, A, B);
 		if (st != LPP_OK) return st;
+		A.window = (mode == LPP_SPMV_WINDOW);
 		if (allow_drop_plain && getenv("LPP_KEEP_PLAIN_CSR") == nullptr && A.owned) {
-			// free the plain arrays: the sliced copy is the resident one (get_csr rebuilds from it)
+			// the sliced copy is the resident one; release the plain arrays (frees ~12 B/nnz)
 			(void)hipFree(A.col);
 			(void)hipFree(A.val);
 			A.col = nullptr;
@@ -208,6 +259,12 @@ lpp_status lpp_engine_create(lpp_engine** out, const lpp_config* cfg)
 		e->own_stream = true;
 	}
 	e->spmv_max_blocks = 256 * 16;
+	e->k2_variant = 6; // bit1: XCD-contiguous block map, bit2: 8 slots per batch
+	if (const char* s = getenv("LPP_K2_VARIANT")) e->k2_variant = atoi(s);
+	{
+		int ncu = 0;
+		if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, cfg->device) == hipSuccess && ncu > 0) e->num_cus = ncu;
+	}
 	if (const char* s = getenv("LPP_SPMV_BLOCKS")) e->spmv_max_blocks = std::max(1, std::min(atoi(s), kMaxPartials));
 	const int M = cfg->max_steps + 2;
 	e->M = M;
@@ -339,12 +396,42 @@ lpp_status lpp_engine_get_csr(lpp_engine* e, int32_t which, int64_t* nrows, int6
 	if (nnz) *nnz = A.nnz;
 	if (!rowptr && !colind && !values) return LPP_OK;
 	if (!A.rowptr) return fail(LPP_ERR_STATE, "lpp_engine_get_csr: no matrix");
-	if ((colind || values) && (!A.col || !A.val)) return fail(LPP_ERR_STATE, "lpp_engine_get_csr: plain CSR arrays were released (sliced layout); set LPP_KEEP_PLAIN_CSR=1");
 	HIP_TRY(hipSetDevice(e->cfg.device));
 	HIP_TRY(hipStreamSynchronize(e->stream));
 	if (rowptr) HIP_TRY(hipMemcpy(rowptr, A.rowptr, sizeof(int64_t) * (size_t)(A.nrows + 1), hipMemcpyDeviceToHost));
-	if (colind && A.nnz) HIP_TRY(hipMemcpy(colind, A.col, sizeof(int32_t) * (size_t)A.nnz, hipMemcpyDeviceToHost));
-	if (values && A.nnz) HIP_TRY(hipMemcpy(values, A.val, e->esz * (size_t)A.nnz, hipMemcpyDeviceToHost));
+	if ((colind || values) && A.nnz) {
+		int32_t* dcol = A.col;
+		void* dval = A.val;
+		int32_t* tcol = nullptr;
+		void* tval = nullptr;
+		if (!dcol || !dval) {
+			// only the sliced layout is resident: rebuild CSR order in scratch buffers
+			if (!A.sliced) return fail(LPP_ERR_STATE, "lpp_engine_get_csr: matrix arrays missing");
+			HIP_TRY_MEM(hipMalloc(&tcol, sizeof(int32_t) * (size_t)A.nnz));
+			if (hipMalloc(&tval, e->esz * (size_t)A.nnz) != hipSuccess) {
+				(void)hipFree(tcol);
+				return fail(LPP_ERR_NOMEM, "lpp_engine_get_csr: scratch allocation failed");
+			}
+			const int nb2 = (int)std::max<int64_t>(1, std::min<int64_t>((A.geom.nslices + 3) / 4, 8192));
+			if (e->is_complex)
+				k_slice_fill<cplx, true><<<nb2, kBlock, 0, e->stream>>>(A.geom, A.rowptr, A.scol, (const cplx*)A.sval, tcol, (cplx*)tval);
+			else
+				k_slice_fill<double, true><<<nb2, kBlock, 0, e->stream>>>(A.geom, A.rowptr, A.scol, (const double*)A.sval, tcol, (double*)tval);
+			hipError_t err = hipStreamSynchronize(e->stream);
+			if (err != hipSuccess) {
+				(void)hipFree(tcol);
+				(void)hipFree(tval);
+				return fail(LPP_ERR_HIP, std::string("lpp_engine_get_csr: ") + hipGetErrorString(err));
+			}
+			dcol = tcol;
+			dval = tval;
+		}
+		hipError_t e1 = colind ? hipMemcpy(colind, dcol, sizeof(int32_t) * (size_t)A.nnz, hipMemcpyDeviceToHost) : hipSuccess;
+		hipError_t e2 = values ? hipMemcpy(values, dval, e->esz * (size_t)A.nnz, hipMemcpyDeviceToHost) : hipSuccess;
+		if (tcol) (void)hipFree(tcol);
+		if (tval) (void)hipFree(tval);
+		if (e1 != hipSuccess || e2 != hipSuccess) return fail(LPP_ERR_HIP, "lpp_engine_get_csr: copy failed");
+	}
 	return LPP_OK;
 }
 

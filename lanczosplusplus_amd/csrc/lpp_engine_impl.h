@@ -35,7 +35,9 @@ struct DevCsr {
 	bool owned = true;
 	int G = 16; // lanes per row of the row-group kernel
 	bool sliced = false;
-	int64_t nslices = 0;
+	bool window = false; // LDS-window kernel (K3)
+	int64_t hint_block = 0; // natural row block of the basis (N_up), 0 = unknown
+	SliceGeom geom {};
 	int64_t* slice_ptr = nullptr;
 	int32_t* row_len = nullptr;
 	int32_t* scol = nullptr;
@@ -51,6 +53,8 @@ struct lpp_engine {
 	hipStream_t stream = nullptr;
 	bool own_stream = false;
 	int spmv_max_blocks = 4096;
+	int k2_variant = 6; // see spmv_launch_t
+	int num_cus = 256;
 
 	// matrix: A_loc has columns inside this rank's slice, A_rem (multi-GPU only) indexes the gathered buffer
 	lpp::DevCsr A_loc, A_rem;

@@ -102,16 +102,24 @@ __global__ __launch_bounds__(kBlock) void k_spmv_rowgroup(int64_t nrows, const i
 		for (int64_t p = p0 + lig; p < p1; p += 4 * G) {
 			int32_t c[4];
 			T v[4];
+			bool ok[4];
+#pragma unroll
+			for (int k = 0; k < 4; k++) { // unconditional loads (clamped index), products selected afterwards
+				const int64_t pk = p + (int64_t)k * G;
+				ok[k] = pk < p1;
+				const int64_t q = ok[k] ? pk : p;
+				c[k] = col[q];
+				v[k] = val[q];
+			}
+			T g[4];
+#pragma unroll
+			for (int k = 0; k < 4; k++) g[k] = src[c[k]];
 #pragma unroll
 			for (int k = 0; k < 4; k++) {
-				const int64_t pk = p + (int64_t)k * G;
-				const bool ok = pk < p1;
-				c[k] = ok ? col[pk] : -1;
-				v[k] = ok ? val[pk] : VT<T>::zero();
+				T t = VT<T>::zero();
+				VT<T>::mac(t, v[k], g[k]);
+				acc = VT<T>::add(acc, ok[k] ? t : VT<T>::zero());
 			}
-#pragma unroll
-			for (int k = 0; k < 4; k++)
-				if (c[k] >= 0) VT<T>::mac(acc, v[k], src[c[k]]);
 		}
 #pragma unroll
 		for (int off = G / 2; off > 0; off >>= 1) acc = VT<T>::add(acc, VT<T>::shfl_down(acc, off, G));
@@ -128,97 +136,275 @@ __global__ __launch_bounds__(kBlock) void k_spmv_rowgroup(int64_t nrows, const i
 }
 
 // ---------------------------------------------------------------------------------------------
-// K2: sliced ("wave-interleaved") CSR SpMV.
+// K2/K3: sliced ("wave-interleaved") CSR SpMV, optionally with an LDS-staged source window.
 //
-// Device-internal layout built once from the CSR (k_slice_*): rows are grouped in slices of 64
-// (one wave); inside a slice the entries are stored slot-major and COMPACT: all first entries of
-// the rows that have one, then all second entries, ... -- same bytes as CSR, no padding, no row
-// permutation.  Lane r owns row slice*64+r; at slot k the active lanes (len > k) read a dense,
-// coalesced run of val/col, the position of a lane inside the run being the popcount of the
-// active mask below it (ballot + mbcnt).  The gather src[col] then has lanes = consecutive rows,
-// which for product bases (Hubbard down-hops: col = row + const*N_up) is itself coalesced.
+// Device-internal layout built once from the CSR (k_slice_*): rows are grouped in row blocks of B
+// rows (B = N_up for the Hubbard product basis, i.e. one down-configuration; a generic power of
+// two otherwise) and every block in slices of 64 rows (one wave; the last slice of a block may be
+// short).  Inside a slice the entries are stored slot-major and COMPACT: all first entries of
+// the rows that have one, then all second entries, ... -- the same bytes as CSR, no padding, no
+// row permutation.  Lane r owns one row; at slot k the active lanes (len > k) read a dense,
+// coalesced run of val/col, a lane's position in the run being the popcount of the active mask
+// below it (ballot).  The gather src[col] has lanes = consecutive rows, which for product bases
+// (Hubbard down-hops: col = row + const*N_up) is itself a coalesced 512-byte read.
+//
+// WINDOW (K3): a 1024-thread workgroup owns one row block at a time and stages the source
+// entries of the block's own column range [r0, r0+B) in LDS (<= 156 KB of the CU's 160 KB);
+// gathers that fall in the window (Hubbard: the diagonal and every up-hop) are served by
+// ds_read_b64 instead of random 8-byte global loads, which removes their L2 misses (each one
+// pulls a 128-byte line) -- measured 147 GB -> ~106 GB of fabric reads per SpMV at 4x4 Hubbard.
+//
+// The slot loop is software-pipelined: the col/val loads of batch b+1 are issued right after the
+// gathers of batch b, so one dependent round trip per batch is exposed instead of two, and every
+// load is UNCONDITIONAL (an inactive lane reads the slot's first entry and its product is
+// discarded by a select): predicated loads made hipcc emit a branch and s_waitcnt vmcnt(0) per
+// load, i.e. a single load in flight per wave.
 // ---------------------------------------------------------------------------------------------
-template <typename T, bool DOT>
-__global__ __launch_bounds__(kBlock) void k_spmv_sliced(int64_t nrows, int64_t nslices,
-                                                         const int64_t* __restrict__ slice_ptr,
-                                                         const int32_t* __restrict__ row_len,
-                                                         const int32_t* __restrict__ col,
-                                                         const T* __restrict__ val, const T* __restrict__ src,
-                                                         T* __restrict__ x, const T* __restrict__ ydot,
-                                                         double* __restrict__ partial)
+struct SliceGeom {
+	int64_t nrows;
+	int64_t B; // rows per block
+	int32_t spb; // slices per block = ceil(B/64)
+	int64_t nblocks;
+	int64_t nslices; // nblocks * spb
+};
+
+__device__ __forceinline__ void slice_rows(const SliceGeom& g, int64_t s, int64_t& row0, int& nvalid)
+{
+	const int64_t blk = s / g.spb;
+	const int j = (int)(s - blk * g.spb);
+	row0 = blk * g.B + (int64_t)j * 64;
+	const int64_t end = min((blk + 1) * g.B, g.nrows);
+	const int64_t nv = end - row0;
+	nvalid = nv < 0 ? 0 : (nv > 64 ? 64 : (int)nv);
+}
+
+template <int NW> __device__ __forceinline__ double block_sum_n(double v, double* smem)
+{
+	v = wave_sum(v);
+	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+	__syncthreads();
+	if (lane == 0) smem[w] = v;
+	__syncthreads();
+	double r = 0;
+	if (threadIdx.x == 0) {
+#pragma unroll
+		for (int i = 0; i < NW; i++) r += smem[i];
+	}
+	return r;
+}
+
+template <typename T> struct SlicedArgs {
+	SliceGeom g;
+	const int64_t* slice_ptr;
+	const int32_t* row_len;
+	const int32_t* col;
+	const T* val;
+	const T* src;
+	T* x;
+	const T* ydot;
+	double* partial;
+	int xcd_map;
+};
+
+// process one slice with one wave; returns this lane's contribution to Re<ydot|x>
+// process one slice with one wave; returns this lane's contribution to Re<ydot|x>.
+// (len, base) are the slice's row length of this lane and first entry, prefetched by the caller.
+template <typename T, bool DOT, bool WINDOW, int U>
+__device__ __forceinline__ double sliced_one(const SlicedArgs<T>& a, int64_t row0, int nvalid, int len, int64_t base,
+                                             const T* lds, int32_t r0, uint32_t wlen)
+{
+	if (nvalid == 0) return 0.0; // wave-uniform
+	const int lane = threadIdx.x & 63;
+	const unsigned long long lt_mask = (1ull << lane) - 1ull;
+	const bool valid = lane < nvalid;
+	const int64_t row = row0 + (valid ? lane : 0);
+	// the row's old x and y are requested first: they are the oldest loads in flight and have landed
+	// long before the epilogue needs them
+	const T xold = a.x[row];
+	T yv = VT<T>::zero();
+	if (DOT) yv = a.ydot[row];
+	int maxlen = len;
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, off, 64));
+	const int nb = (maxlen + U - 1) / U;
+	T acc = VT<T>::zero();
+	int32_t c0[U], c1[U];
+	T v0[U], v1[U];
+#define LPP_LOAD_BATCH(K0, C, V)                                                                                      \
+	_Pragma("unroll") for (int u = 0; u < U; u++)                                                                     \
+	{                                                                                                                 \
+		const bool on_ = len > (K0) + u;                                                                              \
+		const unsigned long long m_ = __ballot(on_);                                                                  \
+		const int64_t p_ = base + (on_ ? __popcll(m_ & lt_mask) : 0);                                                 \
+		C[u] = a.col[p_];                                                                                             \
+		V[u] = a.val[p_];                                                                                             \
+		base += __popcll(m_);                                                                                         \
+	}
+	if (nb > 0) { LPP_LOAD_BATCH(0, c0, v0) }
+	for (int b = 0; b < nb; b++) {
+		T g[U];
+#pragma unroll
+		for (int u = 0; u < U; u++) {
+			if (WINDOW) {
+				const uint32_t d = (uint32_t)(c0[u] - r0);
+				const bool inw = d < wlen;
+				const T gl = lds[inw ? d : (uint32_t)lane];
+				const T gg = a.src[inw ? (int32_t)row : c0[u]];
+				g[u] = inw ? gl : gg;
+			} else {
+				g[u] = a.src[c0[u]];
+			}
+		}
+		if (b + 1 < nb) { LPP_LOAD_BATCH((b + 1) * U, c1, v1) }
+#pragma unroll
+		for (int u = 0; u < U; u++) {
+			T t = VT<T>::zero();
+			VT<T>::mac(t, v0[u], g[u]);
+			acc = VT<T>::add(acc, (len > b * U + u) ? t : VT<T>::zero());
+		}
+#pragma unroll
+		for (int u = 0; u < U; u++) {
+			c0[u] = c1[u];
+			v0[u] = v1[u];
+		}
+	}
+#undef LPP_LOAD_BATCH
+	double d = 0.0;
+	if (valid) {
+		const T xv = VT<T>::add(xold, acc);
+		a.x[row] = xv;
+		if (DOT) d = VT<T>::dot_re(yv, xv);
+	}
+	return d;
+}
+
+// metadata of slice s for this lane (row_len is read unconditionally from a clamped row)
+template <typename T>
+__device__ __forceinline__ void slice_meta(const SlicedArgs<T>& a, int64_t s, int64_t& row0, int& nvalid, int& len, int64_t& base)
+{
+	const int lane = threadIdx.x & 63;
+	slice_rows(a.g, s, row0, nvalid);
+	const int64_t r = (lane < nvalid) ? row0 + lane : min(row0, a.g.nrows - 1);
+	const int l = a.row_len[r];
+	len = (lane < nvalid) ? l : 0;
+	base = a.slice_ptr[s];
+}
+
+// K2: no window, 256-thread blocks, waves walk slices (grid-stride, or one contiguous eighth of
+// the slices per XCD: blocks b and b+8 share an XCD under round-robin dispatch -- speed only).
+template <typename T, bool DOT, int U>
+__global__ __launch_bounds__(kBlock) void k_spmv_sliced(SlicedArgs<T> a)
 {
 	__shared__ double smem[kBlock / 64];
-	const int lane = threadIdx.x & 63;
-	const int64_t wave0 = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
-	const int64_t nwaves = (int64_t)gridDim.x * (kBlock / 64);
+	int64_t s_begin, s_end, s_stride;
+	if (a.xcd_map && (gridDim.x & 7) == 0) {
+		const int64_t chunk = (a.g.nslices + 7) / 8;
+		const int xcd = blockIdx.x & 7;
+		s_begin = xcd * chunk + (int64_t)(blockIdx.x >> 3) * (kBlock / 64) + (threadIdx.x >> 6);
+		s_end = min((int64_t)(xcd + 1) * chunk, a.g.nslices);
+		s_stride = (int64_t)(gridDim.x >> 3) * (kBlock / 64);
+	} else {
+		s_begin = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+		s_end = a.g.nslices;
+		s_stride = (int64_t)gridDim.x * (kBlock / 64);
+	}
 	double dot = 0.0;
-	for (int64_t s = wave0; s < nslices; s += nwaves) {
-		const int64_t row = s * 64 + lane;
-		const int len = (row < nrows) ? row_len[row] : 0;
-		int64_t base = slice_ptr[s];
-		T acc = VT<T>::zero();
-		// max length in the wave
-		int maxlen = len;
-#pragma unroll
-		for (int off = 32; off > 0; off >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, off, 64));
-		int k = 0;
-		for (; k + 4 <= maxlen; k += 4) { // 4 independent slots in flight
-			int32_t c[4];
-			T v[4];
-			bool on[4];
-#pragma unroll
-			for (int u = 0; u < 4; u++) {
-				on[u] = len > k + u;
-				const unsigned long long m = __ballot(on[u]);
-				const int pos = __popcll(m & ((1ull << lane) - 1ull));
-				const int64_t p = base + pos;
-				c[u] = on[u] ? col[p] : 0;
-				v[u] = on[u] ? val[p] : VT<T>::zero();
-				base += __popcll(m);
-			}
-#pragma unroll
-			for (int u = 0; u < 4; u++)
-				if (on[u]) VT<T>::mac(acc, v[u], src[c[u]]);
-		}
-		for (; k < maxlen; k++) {
-			const bool on = len > k;
-			const unsigned long long m = __ballot(on);
-			const int pos = __popcll(m & ((1ull << lane) - 1ull));
-			if (on) {
-				const int64_t p = base + pos;
-				VT<T>::mac(acc, val[p], src[col[p]]);
-			}
-			base += __popcll(m);
-		}
-		if (row < nrows) {
-			const T xv = VT<T>::add(x[row], acc);
-			x[row] = xv;
-			if (DOT) dot += VT<T>::dot_re(ydot[row], xv);
-		}
+	int64_t row0 = 0, base = 0;
+	int nvalid = 0, len = 0;
+	if (s_begin < s_end) slice_meta(a, s_begin, row0, nvalid, len, base);
+	for (int64_t s = s_begin; s < s_end; s += s_stride) {
+		// prefetch the next slice's metadata before working on this one
+		int64_t row0n = 0, basen = 0;
+		int nvalidn = 0, lenn = 0;
+		if (s + s_stride < s_end) slice_meta(a, s + s_stride, row0n, nvalidn, lenn, basen);
+		dot += sliced_one<T, DOT, false, U>(a, row0, nvalid, len, base, nullptr, 0, 0);
+		row0 = row0n;
+		base = basen;
+		nvalid = nvalidn;
+		len = lenn;
 	}
 	if (DOT) {
 		const double r = block_sum(dot, smem);
-		if (threadIdx.x == 0) partial[blockIdx.x] = r;
+		if (threadIdx.x == 0) a.partial[blockIdx.x] = r;
 	}
 }
 
-// CSR -> sliced layout: per-slice sizes are rowptr differences (host/thrust-free: computed by
-// k_slice_ptr from rowptr directly since slices are contiguous row ranges).
-static __global__ void k_slice_meta(int64_t nrows, int64_t nslices, const int64_t* __restrict__ rowptr,
-                             int64_t* __restrict__ slice_ptr, int32_t* __restrict__ row_len)
+// K3: LDS window.  One 1024-thread workgroup per CU walks row blocks; dynamic LDS = B elements.
+constexpr int kWinThreads = 1024;
+template <typename T, bool DOT, int U>
+__global__ __launch_bounds__(kWinThreads) void k_spmv_window(SlicedArgs<T> a)
+{
+	extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+	T* lds = (T*)lds_raw;
+	__shared__ double smem[kWinThreads / 64];
+	const int wave = threadIdx.x >> 6;
+	int64_t b_begin, b_end, b_stride;
+	if (a.xcd_map && (gridDim.x & 7) == 0) {
+		const int64_t chunk = (a.g.nblocks + 7) / 8;
+		const int xcd = blockIdx.x & 7;
+		b_begin = xcd * chunk + (blockIdx.x >> 3);
+		b_end = min((int64_t)(xcd + 1) * chunk, a.g.nblocks);
+		b_stride = gridDim.x >> 3;
+	} else {
+		b_begin = blockIdx.x;
+		b_end = a.g.nblocks;
+		b_stride = gridDim.x;
+	}
+	double dot = 0.0;
+	for (int64_t blk = b_begin; blk < b_end; blk += b_stride) {
+		const int64_t r0 = blk * a.g.B;
+		const int64_t wl = min(a.g.B, a.g.nrows - r0);
+		__syncthreads(); // everyone is done reading the previous window
+		// stage the window: 8 independent loads per thread in flight (a load-wait-store loop exposed
+		// one HBM round trip per element and kept all 16 waves idle for ~25 us per block)
+		for (int64_t i0 = threadIdx.x; i0 < wl; i0 += 8 * kWinThreads) {
+			T t[8];
+#pragma unroll
+			for (int q = 0; q < 8; q++) t[q] = a.src[r0 + min(i0 + (int64_t)q * kWinThreads, wl - 1)];
+#pragma unroll
+			for (int q = 0; q < 8; q++)
+				if (i0 + (int64_t)q * kWinThreads < wl) lds[i0 + (int64_t)q * kWinThreads] = t[q];
+		}
+		__syncthreads();
+		int64_t row0 = 0, base = 0;
+		int nvalid = 0, len = 0;
+		if (wave < a.g.spb) slice_meta(a, blk * a.g.spb + wave, row0, nvalid, len, base);
+		for (int j = wave; j < a.g.spb; j += kWinThreads / 64) {
+			int64_t row0n = 0, basen = 0;
+			int nvalidn = 0, lenn = 0;
+			if (j + kWinThreads / 64 < a.g.spb) slice_meta(a, blk * a.g.spb + j + kWinThreads / 64, row0n, nvalidn, lenn, basen);
+			dot += sliced_one<T, DOT, true, U>(a, row0, nvalid, len, base, lds, (int32_t)r0, (uint32_t)wl);
+			row0 = row0n;
+			base = basen;
+			nvalid = nvalidn;
+			len = lenn;
+		}
+	}
+	if (DOT) {
+		const double r = block_sum_n<kWinThreads / 64>(dot, smem);
+		if (threadIdx.x == 0) a.partial[blockIdx.x] = r;
+	}
+}
+
+// CSR -> sliced layout.  Slices cover consecutive row ranges, so a slice's entries are the CSR range
+// rowptr[row0] .. rowptr[row0+nvalid).
+static __global__ void k_slice_meta(SliceGeom g, const int64_t* __restrict__ rowptr, int64_t* __restrict__ slice_ptr,
+                                    int32_t* __restrict__ row_len)
 {
 	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (i < nrows) row_len[i] = (int32_t)(rowptr[i + 1] - rowptr[i]);
-	if (i <= nslices) {
-		const int64_t r = (i * 64 < nrows) ? i * 64 : nrows;
-		slice_ptr[i] = rowptr[r];
+	if (i < g.nrows) row_len[i] = (int32_t)(rowptr[i + 1] - rowptr[i]);
+	if (i < g.nslices) {
+		int64_t row0;
+		int nvalid;
+		slice_rows(g, i, row0, nvalid);
+		slice_ptr[i] = rowptr[nvalid > 0 ? row0 : g.nrows];
 	}
+	if (i == g.nslices) slice_ptr[i] = rowptr[g.nrows];
 }
 
-// one wave per slice: scatter CSR entries into slot-major compact order
-template <typename T>
-__global__ __launch_bounds__(kBlock) void k_slice_fill(int64_t nrows, int64_t nslices,
-                                                        const int64_t* __restrict__ rowptr,
+// one wave per slice: scatter CSR entries into slot-major compact order (INVERSE: back to CSR order)
+template <typename T, bool INVERSE>
+__global__ __launch_bounds__(kBlock) void k_slice_fill(SliceGeom g, const int64_t* __restrict__ rowptr,
                                                         const int32_t* __restrict__ col_in,
                                                         const T* __restrict__ val_in, int32_t* __restrict__ col_out,
                                                         T* __restrict__ val_out)
@@ -226,15 +412,17 @@ __global__ __launch_bounds__(kBlock) void k_slice_fill(int64_t nrows, int64_t ns
 	const int lane = threadIdx.x & 63;
 	const int64_t wave0 = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
 	const int64_t nwaves = (int64_t)gridDim.x * (kBlock / 64);
-	for (int64_t s = wave0; s < nslices; s += nwaves) {
-		const int64_t row = s * 64 + lane;
+	for (int64_t s = wave0; s < g.nslices; s += nwaves) {
+		int64_t row0;
+		int nvalid;
+		slice_rows(g, s, row0, nvalid);
 		int64_t p0 = 0;
 		int len = 0;
-		if (row < nrows) {
-			p0 = rowptr[row];
-			len = (int)(rowptr[row + 1] - p0);
+		if (lane < nvalid) {
+			p0 = rowptr[row0 + lane];
+			len = (int)(rowptr[row0 + lane + 1] - p0);
 		}
-		int64_t base = rowptr[s * 64];
+		int64_t base = rowptr[nvalid > 0 ? row0 : g.nrows];
 		int maxlen = len;
 #pragma unroll
 		for (int off = 32; off > 0; off >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, off, 64));
@@ -243,8 +431,13 @@ __global__ __launch_bounds__(kBlock) void k_slice_fill(int64_t nrows, int64_t ns
 			const unsigned long long m = __ballot(on);
 			const int pos = __popcll(m & ((1ull << lane) - 1ull));
 			if (on) {
-				col_out[base + pos] = col_in[p0 + k];
-				val_out[base + pos] = val_in[p0 + k];
+				if (INVERSE) {
+					col_out[p0 + k] = col_in[base + pos];
+					val_out[p0 + k] = val_in[base + pos];
+				} else {
+					col_out[base + pos] = col_in[p0 + k];
+					val_out[base + pos] = val_in[p0 + k];
+				}
 			}
 			base += __popcll(m);
 		}
@@ -343,7 +536,7 @@ static __global__ __launch_bounds__(kBlock) void k_axpy_const(double2* __restric
 	}
 }
 
-// splitmix64 start vector, bit-identical to oracle/lpp_oracle.c:lppo_fill_random
+// splitmix64 start vector; the test-suite checks it is bit-identical to the CPU checker's stream
 __device__ __forceinline__ uint64_t splitmix64(uint64_t z)
 {
 	z += 0x9E3779B97F4A7C15ULL;

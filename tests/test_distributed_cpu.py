@@ -1,0 +1,105 @@
+"""world_size-2 gloo tests (CPU) of the multi-GPU path's host logic: row partition at N_up multiples,
+local/remote CSR split with padded gather indices, and the torch.distributed communicator callbacks
+(called through their C function pointers exactly as the engine calls them).  The arithmetic inside the
+ranks is done by the oracle (test infrastructure): the HIP loop itself is covered by tests/test_gpu_multi.py.
+"""
+import ctypes as C
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import oracle
+from helpers import chain
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _np_view(t):
+    return t.numpy()
+
+
+def _worker(rank, world, port, q):
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import lanczosplusplus_amd as lp
+        from lanczosplusplus_amd.comm import TorchDistComm
+        L, nup, ndown = 8, 4, 3
+        A = oracle.hubbard_csr(L, nup, ndown, chain(L, -1.0, True), np.full(L, 4.0))
+        n_up = 70
+        starts = lp.partition_rows(A.nrows, world, n_up)
+        stride = int(max(np.diff(starts)))
+        max_steps = 60
+        comm = TorchDistComm(stride, max_steps, False, device="cpu")
+        lo, hi = int(starts[rank]), int(starts[rank + 1])
+        nloc = hi - lo
+        rp = A.rowptr[lo:hi + 1] - A.rowptr[lo]
+        (rpl, cl, vl), (rpr, cr, vr) = lp.split_csr(rank, world, starts, stride, rp, A.colind[A.rowptr[lo]:A.rowptr[hi]],
+                                                    A.values[A.rowptr[lo]:A.rowptr[hi]])
+        loc, rem = oracle.Csr(rpl, cl, vl), oracle.Csr(rpr, cr, vr)
+        s = comm.struct
+        send, gath, red = _np_view(comm.send), _np_view(comm.gath), _np_view(comm.red)
+
+        def spmv_local(csr, x, src):
+            oracle.lib().lppo_spmv_acc(csr.nrows, csr.rowptr, csr.colind, csr.values.ctypes.data_as(C.c_void_p), 0,
+                                       x.ctypes.data_as(C.c_void_p), src.ctypes.data_as(C.c_void_p), 1)
+
+        def allreduce_scalar(v, slot):
+            red[slot] = v
+            assert s.allreduce_sum(None, slot, 1) == 0
+            return red[slot]
+
+        # distributed Lanczos recurrence, one slice per rank, exactly the engine's call sequence
+        init = oracle.fill_random(A.nrows, 1234)[lo:hi].copy()
+        nrm = np.sqrt(allreduce_scalar(float(init @ init), 0))
+        y = init / nrm
+        x = np.zeros(nloc)
+        a, b = [], []
+        for j in range(40):
+            send[:nloc] = y
+            assert s.allgather_begin(None) == 0
+            spmv_local(loc, x, y)  # overlaps the gather in the real engine
+            assert s.allgather_end(None) == 0
+            spmv_local(rem, x, gath)
+            aj = allreduce_scalar(float(y @ x), 2 * j)
+            x -= aj * y
+            bj = np.sqrt(allreduce_scalar(float(x @ x), 2 * j + 1))
+            y, x = x / bj, -bj * y
+            a.append(aj)
+            b.append(bj)
+        e0 = oracle.tridiag_eig(np.array(a), np.array(b))[0]
+        eo, _, _ = oracle.lanczos_solve(A, oracle.fill_random(A.nrows, 1234), max_steps=40, eps=0.0, want_vectors=False)
+        q.put((rank, float(e0), float(eo[0]), comm.calls["allgather"], comm.calls["allreduce"]))
+        dist.destroy_process_group()
+    except Exception as ex:  # surface failures in the parent
+        import traceback
+        q.put((rank, "error", traceback.format_exc(), 0, 0))
+
+
+def test_two_rank_partitioned_lanczos_over_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for r in res:
+        assert r[1] != "error", r[2]
+    for rank, e0, eo, ng, nr in res:
+        assert abs(e0 - eo) < 1e-10 * abs(eo)
+        assert ng == 40 and nr == 81
+    assert res[0][1] == res[1][1]  # both ranks hold bitwise identical coefficients -> identical decisions

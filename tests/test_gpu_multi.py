@@ -1,0 +1,126 @@
+"""-m gpu: the row-partitioned multi-rank Lanczos loop on real HIP kernels.
+
+A one-GPU box cannot host two RCCL ranks, so two processes share cuda:0 and exchange through the
+gloo backend (same communicator class and callbacks as the nccl path; only the backend differs).
+Checks: device-assembled local/remote CSRs are bit-identical to the host split of the oracle CSR,
+energies match the oracle to 1e-10, coefficients match a single-rank run, host-CSR partition upload
+(complex t-J) works, reortho + Ritz vectors work on slices.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    try:
+        import torch
+        import torch.distributed as dist
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import oracle
+        import lanczosplusplus_amd as lp
+        from helpers import chain
+        from lanczosplusplus_amd.comm import TorchDistComm
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(dev)
+        out = {}
+
+        # ---- Hubbard, device assembly of the rank's row block ----
+        L, nup, ndown = 10, 5, 4
+        hop, U = chain(L, -1.0, True), np.full(L, 4.0)
+        A = oracle.hubbard_csr(L, nup, ndown, hop, U)
+        n_up = 252
+        starts = lp.partition_rows(A.nrows, world, n_up)
+        stride = int(-(-210 // world) * n_up)
+        comm = TorchDistComm(stride, 200, False, device=dev)
+        with comm.stream_context():
+            e = lp.LanczosEngine(max_steps=200, stream=comm.stream_handle)
+            e.assemble_hubbard(L, nup, ndown, hop, U, comm=comm)
+            lo, hi = int(starts[rank]), int(starts[rank + 1])
+            rp = A.rowptr[lo:hi + 1] - A.rowptr[lo]
+            (rpl, cl, vl), (rpr, cr, vr) = lp.split_csr(rank, world, starts, stride, rp, A.colind[A.rowptr[lo]:A.rowptr[hi]],
+                                                        A.values[A.rowptr[lo]:A.rowptr[hi]])
+            g = e.get_csr(0)
+            out["loc_exact"] = bool(np.array_equal(g[0], rpl) and np.array_equal(g[1], cl) and np.array_equal(g[2], vl))
+            g = e.get_csr(1)
+            out["rem_exact"] = bool(np.array_equal(g[0], rpr) and np.array_equal(g[1], cr) and np.array_equal(g[2], vr))
+            eg, zg, st = e.lanczos(1, want_vectors=True)
+            out["e_hub"], out["steps_hub"] = float(eg[0]), st["steps"]
+            # the slices of the Ritz vector, gathered: residual of the full vector
+            zs = [None] * world
+            dist.all_gather_object(zs, zg[0])
+            z = np.concatenate(zs)
+            r = oracle.spmv_acc(A, np.zeros_like(z), z) - eg[0] * z
+            out["resid"] = float(np.linalg.norm(r))
+            a, b, _ = e.decomposition()
+            out["a"], out["b"] = a, b
+            e.close()
+        eo, _, so = oracle.lanczos_solve(A, oracle.fill_random(A.nrows, 1234), want_vectors=False)
+        out["e_hub_oracle"], out["steps_oracle"] = float(eo[0]), so
+
+        # ---- complex t-J, host CSR handed over as a row partition, with reortho ----
+        L = 8
+        T = oracle.tj_csr(L, 3, 3, chain(L, -1.0), chain(L, 0.4), chain(L, 0.4), chain(L, -0.1), force_complex=True)
+        starts = lp.partition_rows(T.nrows, world, 1)
+        stride = int(max(np.diff(starts)))
+        comm2 = TorchDistComm(stride, 120, True, device=dev)
+        with comm2.stream_context():
+            e = lp.LanczosEngine(dtype="c128", max_steps=120, reortho=True, eps=1e-13, stream=comm2.stream_handle)
+            lo, hi = int(starts[rank]), int(starts[rank + 1])
+            e.set_csr_partition(comm2, T.nrows, starts, T.rowptr[lo:hi + 1] - T.rowptr[lo], T.colind[T.rowptr[lo]:T.rowptr[hi]],
+                                T.values[T.rowptr[lo]:T.rowptr[hi]])
+            init = oracle.fill_random(T.nrows, 77, True)
+            eg, _, st = e.lanczos(2, init=init[lo:hi].copy(), want_vectors=False)
+            out["e_tj"] = [float(v) for v in eg]
+            e.close()
+        out["e_tj_dense"] = [float(v) for v in np.linalg.eigvalsh(T.to_scipy().toarray())[:2]]
+        q.put((rank, out))
+        dist.destroy_process_group()
+    except Exception:
+        import traceback
+        q.put((rank, {"error": traceback.format_exc()}))
+
+
+def test_two_ranks_share_one_gpu_over_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=600) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    for r in (0, 1):
+        assert "error" not in res[r], res[r].get("error")
+    for r in (0, 1):
+        o = res[r]
+        assert o["loc_exact"] and o["rem_exact"]
+        assert abs(o["e_hub"] - o["e_hub_oracle"]) <= 1e-10 * abs(o["e_hub_oracle"])
+        assert o["steps_hub"] == o["steps_oracle"]
+        assert o["resid"] < 1e-5
+        assert abs(o["e_tj"][0] - o["e_tj_dense"][0]) <= 1e-10 * abs(o["e_tj_dense"][0])
+        assert abs(o["e_tj"][1] - o["e_tj_dense"][1]) <= 1e-8
+    assert np.array_equal(res[0]["a"], res[1]["a"]) and np.array_equal(res[0]["b"], res[1]["b"])
+    # single-rank run of the same matrix gives the same coefficients up to summation order
+    import oracle
+    from helpers import chain
+    from lanczosplusplus_amd import LanczosEngine
+    with LanczosEngine() as e:
+        e.assemble_hubbard(10, 5, 4, chain(10, -1.0, True), np.full(10, 4.0))
+        a1, b1, _ = e.decomposition()
+    n = min(len(a1), len(res[0]["a"]))
+    assert np.abs(a1[:n] - res[0]["a"][:n]).max() < 1e-8

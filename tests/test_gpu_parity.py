@@ -36,7 +36,7 @@ def mats():
 
 
 @pytest.mark.parametrize("name", ["hubbard", "heisenberg", "tj_complex", "hubbard_complex"])
-@pytest.mark.parametrize("kernel", [1, 2])
+@pytest.mark.parametrize("kernel", [0, 1, 2, 3])
 def test_spmv_acc_matches_oracle(mats, name, kernel):
     A = mats[name]
     dt = "c128" if A.is_complex else "f64"
@@ -91,7 +91,7 @@ def test_errors_are_loud():
 
 
 @pytest.mark.parametrize("name", ["hubbard", "heisenberg", "tj_complex", "hubbard_complex"])
-@pytest.mark.parametrize("kernel", [1, 2])
+@pytest.mark.parametrize("kernel", [0, 1, 2, 3])
 def test_lanczos_energy_and_coefficients(mats, name, kernel):
     A = mats[name]
     dt = "c128" if A.is_complex else "f64"

@@ -1,0 +1,136 @@
+"""CPU tests of the host side: the C-ABI library loads and exports every declared symbol,
+host-only helpers (partition, CSR split, tridiagonal solver), input parsing, loud failure without a GPU."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+import oracle
+from helpers import chain
+import lanczosplusplus_amd as lp
+from lanczosplusplus_amd import _capi, geometry
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "lpp_engine.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(lpp_[a-z0-9_]+)\s*\(", header)) - {"lpp_status"}
+    assert declared, "no declarations parsed"
+    L = _capi.lib()
+    for name in sorted(declared):
+        assert hasattr(L, name), name
+    # the Python binding covers exactly the declared surface
+    assert declared == set(_capi.SYMBOLS), declared ^ set(_capi.SYMBOLS)
+    assert L.lpp_abi_version() == _capi.LPP_ABI_VERSION
+
+
+def test_no_cpu_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(lp.LppError) as ei:
+        lp.LanczosEngine()
+    assert "no CPU fallback" in str(ei.value)
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "lanczosplusplus_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp", ".hpp", "Makefile")):
+                txt = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "import oracle" not in txt and "lpp_oracle" not in txt and "lppo_" not in txt, os.path.join(dirpath, f)
+
+
+def test_partition_rows():
+    s = lp.partition_rows(100, 3, 10)
+    assert list(s) == [0, 40, 80, 100]
+    s = lp.partition_rows(12870 * 12870, 8, 12870)
+    assert s[0] == 0 and s[-1] == 12870 * 12870 and all(x % 12870 == 0 for x in s)
+    assert max(np.diff(s)) == -(-12870 // 8) * 12870
+    s = lp.partition_rows(30, 8, 10)  # fewer blocks than ranks: trailing ranks are empty
+    assert list(s) == [0, 10, 20, 30, 30, 30, 30, 30, 30]
+    with pytest.raises(lp.LppError):
+        lp.partition_rows(101, 2, 10)
+
+
+@pytest.mark.parametrize("cplx", [False, True])
+def test_split_csr_reassembles_the_product(cplx):
+    L = 6
+    if cplx:
+        A = oracle.tj_csr(L, 2, 2, chain(L, -1.0), chain(L, 0.4), chain(L, 0.4), chain(L, -0.1), force_complex=True)
+        block = 1
+    else:
+        A = oracle.hubbard_csr(L, 3, 3, chain(L, -1.0, True), np.full(L, 4.0))
+        block = 20  # N_up
+    P = 3
+    starts = lp.partition_rows(A.nrows, P, block)
+    stride = int(max(np.diff(starts)))
+    y = oracle.fill_random(A.nrows, 11, cplx)
+    full = oracle.spmv_acc(A, np.zeros_like(y), y)
+    gath = np.zeros(P * stride, y.dtype)
+    for r in range(P):
+        gath[r * stride:r * stride + (starts[r + 1] - starts[r])] = y[starts[r]:starts[r + 1]]
+    nnz_total = 0
+    for r in range(P):
+        lo, hi = starts[r], starts[r + 1]
+        rp = A.rowptr[lo:hi + 1] - A.rowptr[lo]
+        ci = A.colind[A.rowptr[lo]:A.rowptr[hi]]
+        va = A.values[A.rowptr[lo]:A.rowptr[hi]]
+        (rpl, cl, vl), (rpr, cr, vr) = lp.split_csr(r, P, starts, stride, rp, ci, va)
+        nnz_total += len(cl) + len(cr)
+        assert cl.size == 0 or (cl.min() >= 0 and cl.max() < hi - lo)
+        loc = oracle.Csr(rpl, cl, vl)
+        rem = oracle.Csr(rpr, cr, vr)
+        out = np.zeros(hi - lo, y.dtype)
+        # local part reads the rank's own slice, remote part the padded gathered vector
+        ys = np.ascontiguousarray(y[lo:hi])
+        if loc.nnz:
+            lib = oracle.lib()
+            import ctypes as C
+            lib.lppo_spmv_acc(loc.nrows, loc.rowptr, loc.colind, loc.values.ctypes.data_as(C.c_void_p), int(cplx),
+                              out.ctypes.data_as(C.c_void_p), ys.ctypes.data_as(C.c_void_p), 1)
+        if rem.nnz:
+            lib = oracle.lib()
+            import ctypes as C
+            lib.lppo_spmv_acc(rem.nrows, rem.rowptr, rem.colind, rem.values.ctypes.data_as(C.c_void_p), int(cplx),
+                              out.ctypes.data_as(C.c_void_p), gath.ctypes.data_as(C.c_void_p), 1)
+        assert np.abs(out - full[lo:hi]).max() < 1e-13
+        if not cplx:
+            # Hubbard partition at multiples of N_up: the diagonal and every up-hop are rank-local
+            up_and_diag = sum(1 for i in range(lo, hi) for c in A.colind[A.rowptr[i]:A.rowptr[i + 1]] if c // block == i // block)
+            assert len(cl) >= up_and_diag
+    assert nnz_total == A.nnz
+
+
+def test_tridiag_lowest_vs_numpy():
+    rng = np.random.default_rng(9)
+    for n in (1, 2, 5, 40, 200):
+        d, e = rng.normal(size=n), np.abs(rng.normal(size=max(n - 1, 0))) + 0.01
+        T = np.diag(d) + np.diag(e, 1) + np.diag(e, -1)
+        ref = np.linalg.eigvalsh(T)
+        k = min(3, n)
+        w = lp.tridiag_lowest(d, e, k)
+        assert np.abs(w - ref[:k]).max() < 1e-12 * max(1.0, np.abs(ref).max())
+        w2, z = lp.tridiag_lowest(d, e, k, vectors=True)
+        assert np.abs(w2 - ref[:k]).max() < 1e-12 * max(1.0, np.abs(ref).max())
+        assert np.abs(T @ z - z * w2).max() < 1e-10
+        # the engine's solver and the oracle's are independent implementations: they must agree
+        assert np.abs(w - oracle.tridiag_eig(d, e)[:k]).max() < 1e-12 * max(1.0, np.abs(ref).max())
+
+
+def test_input0_parsing_and_geometry():
+    """tests/golden/input0.inp is the reference's TestSuite/inputs/input0.inp (a data file)."""
+    inp = geometry.parse_input(open(os.path.join(ROOT, "tests", "golden", "input0.inp")).read())
+    assert inp["Model"] == "HubbardOneBand" and int(inp["TotalNumberOfSites"]) == 4
+    assert int(inp["TargetElectronsUp"]) == 2 and int(inp["TargetElectronsDown"]) == 2
+    assert len(inp["hubbardU"]) == 4 and len(inp["potentialV"]) == 8
+    (hop,) = geometry.terms_from_input(inp)
+    assert np.array_equal(hop, chain(4, -1.0))
+    A = oracle.hubbard_csr(4, 2, 2, hop, inp["hubbardU"], inp["potentialV"])
+    assert abs(np.linalg.eigvalsh(A.to_scipy().toarray())[0] + 2 * np.sqrt(5)) < 1e-12
+    lad = geometry.ladder(8, 2, -1.0, -0.5)
+    assert lad[0, 2] == -1.0 and lad[0, 1] == -0.5 and lad[1, 2] == 0 and np.array_equal(lad, lad.T)
