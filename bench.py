@@ -94,21 +94,23 @@ def cpu_baseline(name, nrows, budget_s=15.0):
     Hubbard path) over the first M rows, or the oracle's stored-CSR Lanczos iteration for the other models."""
     import oracle
     try:
-        cores = len(os.sched_getaffinity(0))
+        avail = len(os.sched_getaffinity(0))
     except AttributeError:
-        cores = os.cpu_count() or 1
+        avail = os.cpu_count() or 1
+    # a one-GPU box's CPU share is 16 cores; LPP_CPU_THREADS overrides
+    cores = int(os.environ.get("LPP_CPU_THREADS", min(avail, 16)))
     model, p = WORKLOADS[name]
     if model == "hubbard":
         L = p["L"]
         hop, U, V = p["hop"](), np.full(L, p["U"]), np.zeros(L)
         y = oracle.fill_random(nrows, 99)
         x = np.zeros(nrows)
-        m = min(nrows, 200_000)
-        t0 = time.time()
-        oracle.hubbard_otf_mvp(L, p["nup"], p["ndown"], hop, U, V, x, y, 0, m, cores)
-        dt = time.time() - t0
-        rate = m / max(dt, 1e-9)
-        m2 = int(min(nrows, max(m, rate * budget_s)))
+        rate = 0.0
+        for m in (min(nrows, 100_000), min(nrows, 1_000_000)):  # warm-up, then calibration
+            t0 = time.time()
+            oracle.hubbard_otf_mvp(L, p["nup"], p["ndown"], hop, U, V, x, y, 0, m, cores)
+            rate = m / max(time.time() - t0, 1e-9)
+        m2 = int(min(nrows, max(1_000_000, rate * budget_s)))
         t0 = time.time()
         oracle.hubbard_otf_mvp(L, p["nup"], p["ndown"], hop, U, V, x, y, 0, m2, cores)
         dt = time.time() - t0
@@ -208,6 +210,14 @@ def main():
     spmv_ms_per_step = spmv_ms / max(args.steps, 1)
     achieved = (w1["spmv_bytes"] / 1e9) / (spmv_ms_per_step / 1e3) if spmv_ms_per_step > 0 else 0.0
 
+    traffic = None
+    try:  # per-launch HBM bytes of the SpMV kernel from the committed rocprofv3 PMC pass of this workload
+        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        if world == 1 and name in tj:
+            traffic = tj[name]["traffic_bytes_per_launch"]
+    except Exception:
+        traffic = None
+
     if rank == 0:
         e0 = float(tridiag_lowest(a, b[:-1] if len(b) > 1 else b, 1)[0]) if len(a) else float("nan")
         out = {
@@ -226,7 +236,7 @@ def main():
             "config": {"workload": name, "rows": nrows_g, "nnz": nnz_g, "parallelism": "1-D row partition x%d" % world,
                        "reortho": False, "assembly": "on-device", "assembly_s": round(t_asm, 3)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "k_spmv (x += H y, fused a_j partial)", "spmv_ms": spmv_ms_per_step,
                          "algorithmic_bytes_per_launch": w1["spmv_bytes"], "launches_timed": launches},
             "e0_after_steps": e0,

@@ -77,7 +77,7 @@ lpp_status run_assembly(lpp_engine* e, AsmParams P, DevCsr& A)
 {
 	hipStream_t st = e->stream;
 	free_csr(A);
-	A.hint_block = (MODEL == ASM_HEISENBERG || P.part == 2) ? 0 : P.n_up; // product-basis block: one down configuration
+	A.hint_block = (MODEL == ASM_HUBBARD && P.part != 2) ? P.n_up : 0; // Hubbard product basis: one down configuration per block
 	A.nrows = P.nloc;
 	A.owned = true;
 	HIP_TRY_MEM(hipMalloc(&A.rowptr, sizeof(int64_t) * (size_t)(P.nloc + 1)));

@@ -55,10 +55,13 @@ def parse_input(text):
     toks = text.split()
     i = 0
 
+    multi = set()
+
     def put(k, v):
         if k in out:
-            if not isinstance(out[k], list) or (out[k] and not isinstance(out[k][0], (list, np.ndarray))):
+            if k not in multi:
                 out[k] = [out[k]]
+                multi.add(k)
             out[k].append(v)
         else:
             out[k] = v

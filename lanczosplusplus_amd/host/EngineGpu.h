@@ -1,0 +1,289 @@
+// EngineGpu.h -- the reference's template concepts for the stored-CSR path, backed by the C ABI
+// (include/lpp_engine.h).  Class and member names follow the reference so a maintainer can map them 1:1:
+//   DefaultSymmetry        src/Engine/DefaultSymmetry.h:41-116   (owns the CSR, init() -> model.setupHamiltonian)
+//   InternalProductStored  src/Engine/InternalProductStored.h:93-132 (rows(), matrixVectorProduct: x += H y)
+//   ParametersForSolver    [PsimagLite] as used at src/Engine/Engine.h:609 and src/SpinOrbital.cpp:213-216
+//   LanczosSolver          [PsimagLite] computeAllStatesBelow / decomposition / computeOneState
+//   Engine                 src/Engine/Engine.h:84-98,601-657 (only the ground-state part)
+// The device boundary sits between Engine and the solver: the CSR is uploaded once by
+// InternalProductStored, the whole Lanczos loop runs on the GPU.  Errors surface as std::runtime_error.
+#ifndef LPP_HOST_ENGINE_GPU_H
+#define LPP_HOST_ENGINE_GPU_H
+
+#include <iostream>
+
+#include "../../include/lpp_engine.h"
+#include "Models.h"
+
+namespace LanczosPlusPlus {
+
+inline void lppCheck(lpp_status st)
+{
+	if (st != LPP_OK) throw std::runtime_error(std::string("lpp_engine: ") + lpp_last_error());
+}
+
+template <typename T> struct LppDtype {
+	enum { value = LPP_F64 };
+};
+template <> struct LppDtype<std::complex<double>> {
+	enum { value = LPP_C128 };
+};
+
+// RAII handle of one engine (one GPU)
+class EngineHandle {
+public:
+	explicit EngineHandle(const lpp_config& cfg) : e_(nullptr) { lppCheck(lpp_engine_create(&e_, &cfg)); }
+	~EngineHandle() { lpp_engine_destroy(e_); }
+	lpp_engine* get() const { return e_; }
+
+private:
+	EngineHandle(const EngineHandle&);
+	EngineHandle& operator=(const EngineHandle&);
+	lpp_engine* e_;
+};
+
+template <typename RealType> struct ParametersForSolver {
+	// labels Lanczos{Steps,Eps,MinSteps,Options}= with the given prefix; defaults as recalled from PsimagLite
+	ParametersForSolver() : steps(200), minSteps(4), tolerance(1e-12), lotaMemory(true), options("none") { }
+	ParametersForSolver(LppHost::InputReadable& io, const LppHost::String& prefix) : steps(200), minSteps(4), tolerance(1e-12), lotaMemory(true), options("none")
+	{
+		if (io.has(prefix + "Steps=")) io.readline(steps, prefix + "Steps=");
+		if (io.has(prefix + "Eps=")) io.readline(tolerance, prefix + "Eps=");
+		if (io.has(prefix + "MinSteps=")) io.readline(minSteps, prefix + "MinSteps=");
+		if (io.has(prefix + "Options=")) io.readline(options, prefix + "Options=");
+		int x = 0;
+		if (io.has(prefix + "NoSaveLanczosVectors=")) {
+			io.readline(x, prefix + "NoSaveLanczosVectors=");
+			lotaMemory = (x == 0);
+		}
+	}
+	SizeType steps, minSteps;
+	RealType tolerance;
+	bool lotaMemory;
+	LppHost::String options;
+};
+
+template <typename BasisType_, typename GeometryType_> class DefaultSymmetry {
+public:
+	typedef GeometryType_ GeometryType;
+	typedef typename GeometryType::ComplexOrRealType ComplexOrRealType;
+	typedef LppHost::CrsMatrix<ComplexOrRealType> SparseMatrixType;
+	typedef std::vector<ComplexOrRealType> VectorType;
+	typedef std::vector<VectorType> VectorVectorType;
+	typedef BasisType_ BasisType;
+
+	DefaultSymmetry(const BasisType&, const GeometryType&, LppHost::String) { }
+	template <typename SomeModelType> void init(const SomeModelType& model, const BasisType& basis) { model.setupHamiltonian(matrixStored_, basis); }
+	void transform(VectorVectorType&, SizeType) { }
+	SizeType sectors() const { return 1; }
+	void setPointer(SizeType) { }
+	LppHost::String name() const { return "default"; }
+	SizeType rows() const { return matrixStored_.rows(); }
+	const SparseMatrixType& storedMatrix() const { return matrixStored_; }
+	void releaseHostMatrix() { matrixStored_.resize(matrixStored_.rows(), matrixStored_.cols()); }
+
+private:
+	SparseMatrixType matrixStored_;
+};
+
+// x += H y with H resident on the GPU
+template <typename ModelType_, typename SpecialSymmetryType_> class InternalProductStored {
+public:
+	typedef ModelType_ ModelType;
+	typedef SpecialSymmetryType_ SpecialSymmetryType;
+	typedef typename ModelType::BasisBaseType BasisType;
+	typedef typename SpecialSymmetryType::SparseMatrixType SparseMatrixType;
+	typedef typename ModelType::RealType RealType;
+	typedef typename ModelType::GeometryType GeometryType;
+	typedef typename GeometryType::ComplexOrRealType ComplexOrRealType;
+	typedef std::vector<RealType> VectorRealType;
+	typedef std::vector<ComplexOrRealType> VectorType;
+
+	static lpp_config defaultConfig()
+	{
+		lpp_config cfg;
+		lpp_config_default(&cfg);
+		cfg.dtype = LppDtype<ComplexOrRealType>::value;
+		return cfg;
+	}
+	// the reference's two constructors (InternalProductStored.h:104-117) with the default solver configuration
+	InternalProductStored(const ModelType& model, SpecialSymmetryType& rs) : rs_(rs), engine_(defaultConfig()), rows_(0)
+	{
+		rs_.init(model, model.basis());
+		upload();
+	}
+	InternalProductStored(const ModelType& model, const BasisType& basis, SpecialSymmetryType& rs) : rs_(rs), engine_(defaultConfig()), rows_(0)
+	{
+		rs_.init(model, basis);
+		upload();
+	}
+	InternalProductStored(const ModelType& model, SpecialSymmetryType& rs, const lpp_config& cfg) : rs_(rs), engine_(cfg), rows_(0)
+	{
+		rs_.init(model, model.basis());
+		upload();
+	}
+	InternalProductStored(const ModelType& model, const BasisType& basis, SpecialSymmetryType& rs, const lpp_config& cfg) : rs_(rs), engine_(cfg), rows_(0)
+	{
+		rs_.init(model, basis);
+		upload();
+	}
+	SizeType rows() const { return rows_; }
+	void matrixVectorProduct(VectorType& x, const VectorType& y) const
+	{
+		if (x.size() != rows_ || y.size() != rows_) throw std::runtime_error("InternalProductStored::matrixVectorProduct: size mismatch\n");
+		lppCheck(lpp_engine_spmv_acc(engine_.get(), x.data(), y.data()));
+	}
+	void specialSymmetrySector(SizeType p) { rs_.setPointer(p); }
+	lpp_engine* engine() const { return engine_.get(); }
+
+private:
+	void upload()
+	{
+		const SparseMatrixType& m = rs_.storedMatrix();
+		rows_ = m.rows();
+		lppCheck(lpp_engine_set_csr(engine_.get(), (int64_t)m.rows(), m.rowptr().data(), m.colind().data(), m.values().data()));
+		rs_.releaseHostMatrix(); // the device copy is the resident one
+	}
+	SpecialSymmetryType& rs_;
+	EngineHandle engine_;
+	SizeType rows_;
+};
+
+struct TridiagonalMatrix {
+	std::vector<double> a_, b_;
+	void resize(SizeType n)
+	{
+		a_.assign(n, 0.0);
+		b_.assign(n, 0.0);
+	}
+	SizeType size() const { return a_.size(); }
+	double& a(SizeType i) { return a_[i]; }
+	double& b(SizeType i) { return b_[i]; }
+	const double& a(SizeType i) const { return a_[i]; }
+	const double& b(SizeType i) const { return b_[i]; }
+};
+
+template <typename SolverParametersType, typename MatrixType, typename VectorType> class LanczosSolver {
+public:
+	typedef typename VectorType::value_type ComplexOrRealType;
+	typedef typename LppHost::Real<ComplexOrRealType>::Type RealType;
+	typedef std::vector<RealType> VectorRealType;
+	typedef std::vector<VectorType> VectorVectorType;
+	typedef TridiagonalMatrix TridiagonalMatrixType;
+
+	LanczosSolver(const MatrixType& mat, const SolverParametersType& params) : mat_(mat), params_(params) { }
+
+	void computeAllStatesBelow(VectorRealType& eigs, VectorVectorType& zs, const VectorType& initial, SizeType nStates)
+	{
+		const SizeType n = mat_.rows();
+		if (initial.size() != n) throw std::runtime_error("LanczosSolver: initial vector has wrong size\n");
+		eigs.resize(nStates);
+		std::vector<ComplexOrRealType> flat(n * nStates);
+		lpp_stats st;
+		lppCheck(lpp_engine_lanczos(mat_.engine(), initial.data(), (int32_t)nStates, eigs.data(), flat.data(), &st));
+		zs.assign(nStates, VectorType(n));
+		for (SizeType k = 0; k < nStates; k++) std::copy(flat.begin() + k * n, flat.begin() + (k + 1) * n, zs[k].begin());
+		steps_ = st.steps;
+	}
+	void computeOneState(RealType& energy, VectorType& z, const VectorType& initial, SizeType excited)
+	{
+		VectorRealType eigs;
+		VectorVectorType zs;
+		computeAllStatesBelow(eigs, zs, initial, excited + 1);
+		energy = eigs[excited];
+		z = zs[excited];
+	}
+	void decomposition(const VectorType& initVector, TridiagonalMatrixType& ab)
+	{
+		ab.resize(params_.steps + 2);
+		int32_t n = 0;
+		lppCheck(lpp_engine_decomposition(mat_.engine(), initVector.data(), &n, &ab.a(0), &ab.b(0), nullptr));
+		ab.a_.resize(n);
+		ab.b_.resize(n);
+		steps_ = n;
+	}
+	SizeType steps() const { return steps_; }
+
+private:
+	const MatrixType& mat_;
+	const SolverParametersType& params_;
+	SizeType steps_ = 0;
+};
+
+// deterministic stand-in for PsimagLite::fillRandom (Engine.h:621): splitmix64 -> uniform(-0.5, 0.5), seed 1234
+template <typename VectorType> void fillRandom(VectorType& v, uint64_t seed = 1234)
+{
+	typedef typename VectorType::value_type T;
+	const SizeType ncomp = sizeof(T) / sizeof(double);
+	double* p = reinterpret_cast<double*>(v.data());
+	for (SizeType k = 0; k < v.size() * ncomp; k++) {
+		uint64_t z = seed * 0x2545F4914F6CDD1DULL + k + 0x9E3779B97F4A7C15ULL;
+		z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+		z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+		z ^= z >> 31;
+		p[k] = (double)(z >> 11) * (1.0 / 9007199254740992.0) - 0.5;
+	}
+}
+
+template <typename ModelType_, template <typename, typename> class InternalProductTemplate, typename SpecialSymmetryType_> class Engine {
+public:
+	typedef ModelType_ ModelType;
+	typedef SpecialSymmetryType_ SpecialSymmetryType;
+	typedef InternalProductTemplate<ModelType, SpecialSymmetryType> InternalProductType;
+	typedef typename ModelType::RealType RealType;
+	typedef typename ModelType::ComplexOrRealType ComplexOrRealType;
+	typedef std::vector<ComplexOrRealType> VectorType;
+	typedef std::vector<VectorType> VectorVectorType;
+	typedef std::vector<RealType> VectorRealType;
+	typedef ParametersForSolver<RealType> ParametersForSolverType;
+	typedef LanczosSolver<ParametersForSolverType, InternalProductType, VectorType> LanczosSolverType;
+	typedef typename LanczosSolverType::TridiagonalMatrixType TridiagonalMatrixType;
+
+	Engine(const ModelType& model, LppHost::InputReadable& io, int device = 0) : model_(model), io_(io), device_(device)
+	{
+		SizeType excited = 0;
+		if (io_.has("Excited=")) io_.readline(excited, "Excited=");
+		computeAllStatesBelow(excited); // Engine.h:91-97
+	}
+	RealType energies(SizeType ind) const { return energies_[ind]; }
+	const VectorType& eigenvector(SizeType ind) const { return vectors_[ind]; }
+	SizeType lanczosSteps() const { return steps_; }
+
+private:
+	void computeAllStatesBelow(SizeType excited)
+	{ // Engine.h:601-657 for sectors() == 1
+		const SizeType excitedPlusOne = excited + 1;
+		ParametersForSolverType params(io_, "Lanczos");
+		lpp_config cfg;
+		lpp_config_default(&cfg);
+		cfg.device = device_;
+		cfg.dtype = LppDtype<ComplexOrRealType>::value;
+		cfg.max_steps = (int32_t)params.steps;
+		cfg.min_steps = (int32_t)params.minSteps;
+		cfg.eps = params.tolerance;
+		cfg.reortho = params.options.find("reortho") != LppHost::String::npos;
+		cfg.save_vectors = params.lotaMemory ? -1 : 0;
+		SpecialSymmetryType rs(model_.basis(), model_.geometry(), "");
+		InternalProductType hamiltonian(model_, rs, cfg);
+		LanczosSolverType lanczosSolver(hamiltonian, params);
+		const SizeType n = hamiltonian.rows();
+		VectorType initial(n);
+		fillRandom(initial);
+		lanczosSolver.computeAllStatesBelow(energies_, vectors_, initial, excitedPlusOne);
+		steps_ = lanczosSolver.steps();
+		for (SizeType i = 0; i < excitedPlusOne; i++) { // printEnergiesAndNorms, Engine.h:666-674
+			RealType nrm = 0;
+			for (const ComplexOrRealType& z : vectors_[i]) nrm += LppHost::real(z * LppHost::conj(z));
+			std::cout << "E[" << i << "]=" << energies_[i] << " norm=" << nrm << "\n";
+		}
+	}
+	const ModelType& model_;
+	LppHost::InputReadable& io_;
+	int device_;
+	VectorRealType energies_;
+	VectorVectorType vectors_;
+	SizeType steps_ = 0;
+};
+
+} // namespace LanczosPlusPlus
+#endif
