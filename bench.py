@@ -144,6 +144,10 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
+    # rehearsal on a one-GPU box: LPP_BENCH_BACKEND=gloo lets several ranks share cuda:0 (RCCL needs one GPU per rank)
+    backend = os.environ.get("LPP_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     name = args.workload
     model, p = WORKLOADS[name]
@@ -154,7 +158,10 @@ def main():
     if world > 1:
         import torch.distributed as dist
         from lanczosplusplus_amd.comm import TorchDistComm
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
         from math import comb as binom
         n_up, n_dn = binom(p["L"], p["nup"]), binom(p["L"], p["ndown"])
         stride = -(-n_dn // world) * n_up

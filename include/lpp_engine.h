@@ -64,6 +64,8 @@ typedef struct lpp_config {
 	double eps; /* LanczosEps (default 1e-12); <= 0 disables the convergence test */
 	uint64_t seed; /* seed of the built-in start vector (used when init == NULL) */
 	void* stream; /* hipStream_t to run on; NULL = engine-owned stream */
+	int32_t compress_values; /* lossless 8-bit value dictionary when the matrix has <= 256 distinct doubles: -1 auto, 0 off, 1 on */
+	int32_t reserved;
 } lpp_config;
 
 typedef struct lpp_stats {

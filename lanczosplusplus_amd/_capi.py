@@ -28,7 +28,8 @@ class Config(C.Structure):
     _fields_ = [("abi_version", C.c_int32), ("device", C.c_int32), ("dtype", C.c_int32), ("max_steps", C.c_int32),
                 ("min_steps", C.c_int32), ("reortho", C.c_int32), ("save_vectors", C.c_int32),
                 ("check_lag", C.c_int32), ("spmv_kernel", C.c_int32), ("time_kernels", C.c_int32),
-                ("eps", C.c_double), ("seed", C.c_uint64), ("stream", C.c_void_p)]
+                ("eps", C.c_double), ("seed", C.c_uint64), ("stream", C.c_void_p),
+                ("compress_values", C.c_int32), ("reserved", C.c_int32)]
 
 
 class Stats(C.Structure):

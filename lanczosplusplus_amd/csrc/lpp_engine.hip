@@ -15,6 +15,7 @@
 #include <string>
 #include <vector>
 
+#include "lpp_assemble_kernels.h"
 #include "lpp_engine_impl.h"
 
 using namespace lpp;
@@ -43,6 +44,9 @@ void free_csr(DevCsr& A)
 	if (A.row_len) (void)hipFree(A.row_len);
 	if (A.scol) (void)hipFree(A.scol);
 	if (A.sval) (void)hipFree(A.sval);
+	if (A.codes) (void)hipFree(A.codes);
+	if (A.code_ptr) (void)hipFree(A.code_ptr);
+	if (A.dict) (void)hipFree(A.dict);
 	A = DevCsr();
 }
 
@@ -87,6 +91,9 @@ template <typename T> static int spmv_launch_t(lpp_engine* e, const DevCsr& A, c
 		a.row_len = A.row_len;
 		a.col = A.scol;
 		a.val = (const T*)A.sval;
+		a.codes = A.codes;
+		a.code_ptr = A.code_ptr;
+		a.dict = A.dict;
 		a.src = (const T*)src;
 		a.x = (T*)x;
 		a.ydot = (const T*)ydot;
@@ -94,30 +101,45 @@ template <typename T> static int spmv_launch_t(lpp_engine* e, const DevCsr& A, c
 		a.xcd_map = (e->k2_variant >> 1) & 1;
 		const bool dot = partial != nullptr;
 		const bool u8 = (e->k2_variant & 4) != 0;
+		const int sel = (dot ? 4 : 0) | (A.coded ? 2 : 0) | (u8 ? 1 : 0);
 		int nb;
 		if (A.window) {
 			const size_t lds_bytes = sizeof(T) * (size_t)std::max<int64_t>(A.geom.B, 64);
-			const int per_cu = std::max(1, std::min(2, (int)((160 * 1024 - 256) / (lds_bytes + 1))));
+			const int per_cu = std::max(1, std::min(2, (int)((160 * 1024 - 4096) / (lds_bytes + 1))));
 			nb = (int)std::max<int64_t>(1, std::min<int64_t>(A.geom.nblocks, (int64_t)e->num_cus * per_cu));
 			if (nb >= 8) nb &= ~7;
-#define LPP_K3(DOT_, U_)                                                                                              \
+#define LPP_K3(DOT_, CODED_, U_)                                                                                      \
 	do {                                                                                                              \
-		(void)hipFuncSetAttribute((const void*)k_spmv_window<T, DOT_, U_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
-		k_spmv_window<T, DOT_, U_><<<nb, kWinThreads, lds_bytes, st>>>(a);                                             \
+		(void)hipFuncSetAttribute((const void*)k_spmv_window<T, DOT_, CODED_, U_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
+		k_spmv_window<T, DOT_, CODED_, U_><<<nb, kWinThreads, lds_bytes, st>>>(a);                                      \
 	} while (0)
-			if (dot && u8) LPP_K3(true, 8);
-			else if (dot) LPP_K3(true, 4);
-			else if (u8) LPP_K3(false, 8);
-			else LPP_K3(false, 4);
+			switch (sel) {
+			case 0: LPP_K3(false, false, 4); break;
+			case 1: LPP_K3(false, false, 8); break;
+			case 2: LPP_K3(false, true, 4); break;
+			case 3: LPP_K3(false, true, 8); break;
+			case 4: LPP_K3(true, false, 4); break;
+			case 5: LPP_K3(true, false, 8); break;
+			case 6: LPP_K3(true, true, 4); break;
+			default: LPP_K3(true, true, 8); break;
+			}
 #undef LPP_K3
 		} else {
 			const int64_t need = (A.geom.nslices + (kBlock / 64) - 1) / (kBlock / 64);
 			nb = (int)std::max<int64_t>(1, std::min<int64_t>(need, e->spmv_max_blocks));
 			if (nb >= 8) nb &= ~7; // multiple of 8 so the XCD-contiguous mapping applies
-			if (dot && u8) k_spmv_sliced<T, true, 8><<<nb, kBlock, 0, st>>>(a);
-			else if (dot) k_spmv_sliced<T, true, 4><<<nb, kBlock, 0, st>>>(a);
-			else if (u8) k_spmv_sliced<T, false, 8><<<nb, kBlock, 0, st>>>(a);
-			else k_spmv_sliced<T, false, 4><<<nb, kBlock, 0, st>>>(a);
+#define LPP_K2(DOT_, CODED_, U_) k_spmv_sliced<T, DOT_, CODED_, U_><<<nb, kBlock, 0, st>>>(a)
+			switch (sel) {
+			case 0: LPP_K2(false, false, 4); break;
+			case 1: LPP_K2(false, false, 8); break;
+			case 2: LPP_K2(false, true, 4); break;
+			case 3: LPP_K2(false, true, 8); break;
+			case 4: LPP_K2(true, false, 4); break;
+			case 5: LPP_K2(true, false, 8); break;
+			case 6: LPP_K2(true, true, 4); break;
+			default: LPP_K2(true, true, 8); break;
+			}
+#undef LPP_K2
 		}
 		return partial ? nb : 0;
 	}
@@ -136,6 +158,48 @@ int spmv_launch(lpp_engine* e, const DevCsr& A, const void* src, void* x, const 
 	return e->is_complex ? spmv_launch_t<cplx>(e, A, src, x, ydot, partial) : spmv_launch_t<double>(e, A, src, x, ydot, partial);
 }
 
+// distinct values of A.val -> sorted dictionary on the device; returns false when there are more than 256
+template <typename T> static lpp_status try_build_dict(lpp_engine* e, DevCsr& A, bool* ok)
+{
+	*ok = false;
+	if (A.nnz == 0) return LPP_OK;
+	unsigned long long* table = nullptr;
+	int* overflow = nullptr;
+	HIP_TRY_MEM(hipMalloc(&table, sizeof(unsigned long long) * kDictTable));
+	if (hipMalloc(&overflow, sizeof(int)) != hipSuccess) {
+		(void)hipFree(table);
+		return fail(LPP_ERR_NOMEM, "dictionary scratch allocation failed");
+	}
+	(void)hipMemsetAsync(table, 0xff, sizeof(unsigned long long) * kDictTable, e->stream);
+	(void)hipMemsetAsync(overflow, 0, sizeof(int), e->stream);
+	const int64_t nd = A.nnz * (int64_t)(sizeof(T) / sizeof(double));
+	k_dict_collect<<<2048, kBlock, 0, e->stream>>>((const double*)A.val, nd, table, overflow);
+	std::vector<unsigned long long> host(kDictTable);
+	int ov = 0;
+	hipError_t e1 = hipMemcpyAsync(host.data(), table, sizeof(unsigned long long) * kDictTable, hipMemcpyDeviceToHost, e->stream);
+	hipError_t e2 = hipMemcpyAsync(&ov, overflow, sizeof(int), hipMemcpyDeviceToHost, e->stream);
+	hipError_t e3 = hipStreamSynchronize(e->stream);
+	(void)hipFree(table);
+	(void)hipFree(overflow);
+	if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) return fail(LPP_ERR_HIP, "dictionary collection failed");
+	std::vector<unsigned long long> keys;
+	for (unsigned long long k : host)
+		if (k != kDictEmpty) keys.push_back(k);
+	if (ov || keys.empty() || keys.size() > 256) return LPP_OK;
+	std::sort(keys.begin(), keys.end());
+	std::vector<double> dict(256);
+	for (size_t i = 0; i < 256; i++) {
+		const unsigned long long k = keys[std::min(i, keys.size() - 1)];
+		std::memcpy(&dict[i], &k, sizeof(double));
+	}
+	HIP_TRY_MEM(hipMalloc(&A.dict, sizeof(double) * 256));
+	HIP_TRY(hipMemcpyAsync(A.dict, dict.data(), sizeof(double) * 256, hipMemcpyHostToDevice, e->stream));
+	HIP_TRY(hipStreamSynchronize(e->stream));
+	A.ndict = (int)keys.size();
+	*ok = true;
+	return LPP_OK;
+}
+
 // build the sliced layout of A on the device for row blocks of B rows
 template <typename T> static lpp_status build_sliced_t(lpp_engine* e, DevCsr& A, int64_t B)
 {
@@ -146,19 +210,53 @@ template <typename T> static lpp_status build_sliced_t(lpp_engine* e, DevCsr& A,
 	g.nblocks = (A.nrows + g.B - 1) / g.B;
 	g.nslices = g.nblocks * g.spb;
 	A.geom = g;
+	int want = e->cfg.compress_values;
+	if (const char* s = getenv("LPP_COMPRESS_VALUES")) want = atoi(s);
+	bool coded = false;
+	if (want != 0) {
+		lpp_status st = try_build_dict<T>(e, A, &coded);
+		if (st != LPP_OK) return st;
+	}
 	// +64 entries of slack: the pipelined kernel reads (and discards) the entry after a slice's last one
 	HIP_TRY_MEM(hipMalloc(&A.slice_ptr, sizeof(int64_t) * (size_t)(g.nslices + 1)));
 	HIP_TRY_MEM(hipMalloc(&A.row_len, sizeof(int32_t) * (size_t)std::max<int64_t>(A.nrows, 1)));
 	HIP_TRY_MEM(hipMalloc(&A.scol, sizeof(int32_t) * (size_t)(A.nnz + 64)));
-	HIP_TRY_MEM(hipMalloc(&A.sval, sizeof(T) * (size_t)(A.nnz + 64)));
 	HIP_TRY(hipMemsetAsync(A.scol + A.nnz, 0, sizeof(int32_t) * 64, e->stream));
-	HIP_TRY(hipMemsetAsync((T*)A.sval + A.nnz, 0, sizeof(T) * 64, e->stream));
+	if (coded) HIP_TRY_MEM(hipMalloc(&A.code_ptr, sizeof(int64_t) * (size_t)(g.nslices + 1)));
 	const int64_t nthreads = std::max<int64_t>(A.nrows, g.nslices + 1);
 	const int nb = (int)((nthreads + 255) / 256);
-	k_slice_meta<<<nb, 256, 0, e->stream>>>(g, A.rowptr, A.slice_ptr, A.row_len);
+	k_slice_meta<<<nb, 256, 0, e->stream>>>(g, A.rowptr, A.slice_ptr, A.row_len, A.code_ptr, CodeTraits<T>::kSlotsPerWord);
 	const int64_t need = (g.nslices + 3) / 4;
 	const int nb2 = (int)std::max<int64_t>(1, std::min<int64_t>(need, 8192));
-	k_slice_fill<T, false><<<nb2, kBlock, 0, e->stream>>>(g, A.rowptr, A.col, (const T*)A.val, A.scol, (T*)A.sval);
+	if (coded) {
+		// exclusive scan of the per-slice word counts -> code_ptr; the grand total sizes the code array
+		const int64_t n = g.nslices + 1;
+		const int64_t nblk = (n + kScanChunk - 1) / kScanChunk;
+		int64_t *sums = nullptr, *total = nullptr;
+		HIP_TRY_MEM(hipMalloc(&sums, sizeof(int64_t) * (size_t)nblk));
+		if (hipMalloc(&total, sizeof(int64_t)) != hipSuccess) {
+			(void)hipFree(sums);
+			return fail(LPP_ERR_NOMEM, "scan scratch allocation failed");
+		}
+		k_scan_block_sums<<<(int)nblk, kBlock, 0, e->stream>>>(A.code_ptr, n, sums);
+		k_scan_sums<<<1, kBlock, 0, e->stream>>>(sums, nblk, total);
+		k_scan_apply<<<(int)nblk, kBlock, 0, e->stream>>>(A.code_ptr, n, sums, A.code_ptr);
+		int64_t nwords = 0;
+		hipError_t e1 = hipMemcpyAsync(&nwords, total, sizeof(int64_t), hipMemcpyDeviceToHost, e->stream);
+		hipError_t e2 = hipStreamSynchronize(e->stream);
+		(void)hipFree(sums);
+		(void)hipFree(total);
+		if (e1 != hipSuccess || e2 != hipSuccess) return fail(LPP_ERR_HIP, "code-pointer scan failed");
+		HIP_TRY_MEM(hipMalloc(&A.codes, sizeof(uint32_t) * (size_t)(nwords + 64 * 16)));
+		HIP_TRY(hipMemsetAsync(A.codes + nwords, 0, sizeof(uint32_t) * 64 * 16, e->stream));
+		k_slice_fill<T, false><<<nb2, kBlock, 0, e->stream>>>(g, A.rowptr, A.col, (const T*)nullptr, A.scol, (T*)nullptr);
+		k_slice_codes<T><<<nb2, kBlock, 0, e->stream>>>(g, A.rowptr, (const T*)A.val, A.code_ptr, A.dict, A.ndict, A.codes);
+		A.coded = true;
+	} else {
+		HIP_TRY_MEM(hipMalloc(&A.sval, sizeof(T) * (size_t)(A.nnz + 64)));
+		HIP_TRY(hipMemsetAsync((T*)A.sval + A.nnz, 0, sizeof(T) * 64, e->stream));
+		k_slice_fill<T, false><<<nb2, kBlock, 0, e->stream>>>(g, A.rowptr, A.col, (const T*)A.val, A.scol, (T*)A.sval);
+	}
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipStreamSynchronize(e->stream));
 	A.sliced = true;
@@ -426,10 +524,13 @@ lpp_status lpp_engine_get_csr(lpp_engine* e, int32_t which, int64_t* nrows, int6
 				return fail(LPP_ERR_NOMEM, "lpp_engine_get_csr: scratch allocation failed");
 			}
 			const int nb2 = (int)std::max<int64_t>(1, std::min<int64_t>((A.geom.nslices + 3) / 4, 8192));
-			if (e->is_complex)
-				k_slice_fill<cplx, true><<<nb2, kBlock, 0, e->stream>>>(A.geom, A.rowptr, A.scol, (const cplx*)A.sval, tcol, (cplx*)tval);
-			else
-				k_slice_fill<double, true><<<nb2, kBlock, 0, e->stream>>>(A.geom, A.rowptr, A.scol, (const double*)A.sval, tcol, (double*)tval);
+			if (e->is_complex) {
+				k_slice_fill<cplx, true><<<nb2, kBlock, 0, e->stream>>>(A.geom, A.rowptr, A.scol, (const cplx*)A.sval, tcol, A.coded ? nullptr : (cplx*)tval);
+				if (A.coded) k_slice_decode<cplx><<<nb2, kBlock, 0, e->stream>>>(A.geom, A.rowptr, A.codes, A.code_ptr, A.dict, (cplx*)tval);
+			} else {
+				k_slice_fill<double, true><<<nb2, kBlock, 0, e->stream>>>(A.geom, A.rowptr, A.scol, (const double*)A.sval, tcol, A.coded ? nullptr : (double*)tval);
+				if (A.coded) k_slice_decode<double><<<nb2, kBlock, 0, e->stream>>>(A.geom, A.rowptr, A.codes, A.code_ptr, A.dict, (double*)tval);
+			}
 			hipError_t err = hipStreamSynchronize(e->stream);
 			if (err != hipSuccess) {
 				(void)hipFree(tcol);

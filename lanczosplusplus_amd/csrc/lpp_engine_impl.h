@@ -42,6 +42,12 @@ struct DevCsr {
 	int32_t* row_len = nullptr;
 	int32_t* scol = nullptr;
 	void* sval = nullptr;
+	// value dictionary (coded layout): sval == nullptr, values = dict[codes]
+	bool coded = false;
+	uint32_t* codes = nullptr;
+	int64_t* code_ptr = nullptr;
+	double* dict = nullptr;
+	int ndict = 0;
 };
 
 } // namespace lpp

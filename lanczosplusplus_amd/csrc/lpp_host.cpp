@@ -144,6 +144,8 @@ void lpp_config_default(lpp_config* cfg)
 	cfg->eps = 1e-12;
 	cfg->seed = 1234;
 	cfg->stream = nullptr;
+	cfg->compress_values = -1;
+	cfg->reserved = 0;
 }
 
 lpp_status lpp_partition_rows(int64_t nrows, int32_t nranks, int64_t block, int64_t* starts)

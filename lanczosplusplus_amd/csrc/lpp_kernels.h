@@ -198,7 +198,10 @@ template <typename T> struct SlicedArgs {
 	const int64_t* slice_ptr;
 	const int32_t* row_len;
 	const int32_t* col;
-	const T* val;
+	const T* val; // plain values (null when the value dictionary is used)
+	const uint32_t* codes; // packed dictionary codes, [slice][slot group][lane]
+	const int64_t* code_ptr; // first code word of each slice
+	const double* dict; // <= 256 distinct doubles
 	const T* src;
 	T* x;
 	const T* ydot;
@@ -206,14 +209,37 @@ template <typename T> struct SlicedArgs {
 	int xcd_map;
 };
 
-// process one slice with one wave; returns this lane's contribution to Re<ydot|x>
+// Value dictionary ("coded" layout): the Hamiltonians of this path take very few distinct values
+// (+-t, J/2, U*k, ...), so when a matrix has <= 256 distinct doubles the 8-byte value of an entry is
+// replaced by an 8-bit code per real component (lossless).  Codes are packed 4 slots (real) / 2 slots
+// (complex, 8+8 bits) per 32-bit word, one word per lane and slot group, padded to the slice's longest
+// row so a wave reads one dense 256-byte run per slot group.
+template <typename T> struct CodeTraits;
+template <> struct CodeTraits<double> {
+	static constexpr int kBits = 8, kSlotsPerWord = 4;
+	static __device__ __forceinline__ double decode(uint32_t word, int slot_in_word, const double* dict)
+	{
+		return dict[(word >> (8 * slot_in_word)) & 0xffu];
+	}
+};
+template <> struct CodeTraits<cplx> {
+	static constexpr int kBits = 16, kSlotsPerWord = 2;
+	static __device__ __forceinline__ cplx decode(uint32_t word, int slot_in_word, const double* dict)
+	{
+		const uint32_t c = (word >> (16 * slot_in_word)) & 0xffffu;
+		return cplx { dict[c & 0xffu], dict[c >> 8] };
+	}
+};
+
 // process one slice with one wave; returns this lane's contribution to Re<ydot|x>.
-// (len, base) are the slice's row length of this lane and first entry, prefetched by the caller.
-template <typename T, bool DOT, bool WINDOW, int U>
-__device__ __forceinline__ double sliced_one(const SlicedArgs<T>& a, int64_t row0, int nvalid, int len, int64_t base,
-                                             const T* lds, int32_t r0, uint32_t wlen)
+// (len, base, cbase) = this lane's row length, the slice's first entry and first code word, prefetched by the caller.
+template <typename T, bool DOT, bool WINDOW, bool CODED, int U>
+__device__ __forceinline__ double sliced_one(const SlicedArgs<T>& a, int64_t row0, int nvalid, int len, int64_t base, int64_t cbase,
+                                             const T* lds, int32_t r0, uint32_t wlen, const double* dict)
 {
 	if (nvalid == 0) return 0.0; // wave-uniform
+	constexpr int SPW = CodeTraits<T>::kSlotsPerWord;
+	constexpr int NW = (U + SPW - 1) / SPW; // code words per batch
 	const int lane = threadIdx.x & 63;
 	const unsigned long long lt_mask = (1ull << lane) - 1ull;
 	const bool valid = lane < nvalid;
@@ -229,18 +255,22 @@ __device__ __forceinline__ double sliced_one(const SlicedArgs<T>& a, int64_t row
 	const int nb = (maxlen + U - 1) / U;
 	T acc = VT<T>::zero();
 	int32_t c0[U], c1[U];
-	T v0[U], v1[U];
-#define LPP_LOAD_BATCH(K0, C, V)                                                                                      \
+	T v0[CODED ? 1 : U], v1[CODED ? 1 : U];
+	uint32_t w0[CODED ? NW : 1], w1[CODED ? NW : 1];
+#define LPP_LOAD_BATCH(K0, C, V, W)                                                                                   \
 	_Pragma("unroll") for (int u = 0; u < U; u++)                                                                     \
 	{                                                                                                                 \
 		const bool on_ = len > (K0) + u;                                                                              \
 		const unsigned long long m_ = __ballot(on_);                                                                  \
 		const int64_t p_ = base + (on_ ? __popcll(m_ & lt_mask) : 0);                                                 \
 		C[u] = a.col[p_];                                                                                             \
-		V[u] = a.val[p_];                                                                                             \
+		if (!CODED) V[u] = a.val[p_];                                                                                 \
 		base += __popcll(m_);                                                                                         \
+	}                                                                                                                 \
+	if (CODED) {                                                                                                      \
+		_Pragma("unroll") for (int q = 0; q < NW; q++) W[q] = a.codes[cbase + ((int64_t)((K0) / SPW + q) << 6) + lane]; \
 	}
-	if (nb > 0) { LPP_LOAD_BATCH(0, c0, v0) }
+	if (nb > 0) { LPP_LOAD_BATCH(0, c0, v0, w0) }
 	for (int b = 0; b < nb; b++) {
 		T g[U];
 #pragma unroll
@@ -255,17 +285,26 @@ __device__ __forceinline__ double sliced_one(const SlicedArgs<T>& a, int64_t row
 				g[u] = a.src[c0[u]];
 			}
 		}
-		if (b + 1 < nb) { LPP_LOAD_BATCH((b + 1) * U, c1, v1) }
+		if (b + 1 < nb) { LPP_LOAD_BATCH((b + 1) * U, c1, v1, w1) }
 #pragma unroll
 		for (int u = 0; u < U; u++) {
+			T vv;
+			if (CODED)
+				vv = CodeTraits<T>::decode(w0[u / SPW], u % SPW, dict);
+			else
+				vv = v0[u];
 			T t = VT<T>::zero();
-			VT<T>::mac(t, v0[u], g[u]);
+			VT<T>::mac(t, vv, g[u]);
 			acc = VT<T>::add(acc, (len > b * U + u) ? t : VT<T>::zero());
 		}
 #pragma unroll
-		for (int u = 0; u < U; u++) {
-			c0[u] = c1[u];
-			v0[u] = v1[u];
+		for (int u = 0; u < U; u++) c0[u] = c1[u];
+		if (CODED) {
+#pragma unroll
+			for (int q = 0; q < NW; q++) w0[q] = w1[q];
+		} else {
+#pragma unroll
+			for (int u = 0; u < U; u++) v0[u] = v1[u];
 		}
 	}
 #undef LPP_LOAD_BATCH
@@ -279,8 +318,9 @@ __device__ __forceinline__ double sliced_one(const SlicedArgs<T>& a, int64_t row
 }
 
 // metadata of slice s for this lane (row_len is read unconditionally from a clamped row)
-template <typename T>
-__device__ __forceinline__ void slice_meta(const SlicedArgs<T>& a, int64_t s, int64_t& row0, int& nvalid, int& len, int64_t& base)
+template <typename T, bool CODED>
+__device__ __forceinline__ void slice_meta(const SlicedArgs<T>& a, int64_t s, int64_t& row0, int& nvalid, int& len, int64_t& base,
+                                           int64_t& cbase)
 {
 	const int lane = threadIdx.x & 63;
 	slice_rows(a.g, s, row0, nvalid);
@@ -288,14 +328,26 @@ __device__ __forceinline__ void slice_meta(const SlicedArgs<T>& a, int64_t s, in
 	const int l = a.row_len[r];
 	len = (lane < nvalid) ? l : 0;
 	base = a.slice_ptr[s];
+	cbase = CODED ? a.code_ptr[s] : 0;
+}
+
+// the dictionary lives in LDS (2 KB); decode reads are mostly broadcasts (few distinct values)
+template <bool CODED> __device__ __forceinline__ void load_dict(double* dict_s, const double* dict)
+{
+	if (CODED) {
+		for (int i = threadIdx.x; i < 256; i += blockDim.x) dict_s[i] = dict[i];
+		__syncthreads();
+	}
 }
 
 // K2: no window, 256-thread blocks, waves walk slices (grid-stride, or one contiguous eighth of
 // the slices per XCD: blocks b and b+8 share an XCD under round-robin dispatch -- speed only).
-template <typename T, bool DOT, int U>
+template <typename T, bool DOT, bool CODED, int U>
 __global__ __launch_bounds__(kBlock) void k_spmv_sliced(SlicedArgs<T> a)
 {
 	__shared__ double smem[kBlock / 64];
+	__shared__ double dict_s[CODED ? 256 : 1];
+	load_dict<CODED>(dict_s, a.dict);
 	int64_t s_begin, s_end, s_stride;
 	if (a.xcd_map && (gridDim.x & 7) == 0) {
 		const int64_t chunk = (a.g.nslices + 7) / 8;
@@ -309,17 +361,18 @@ __global__ __launch_bounds__(kBlock) void k_spmv_sliced(SlicedArgs<T> a)
 		s_stride = (int64_t)gridDim.x * (kBlock / 64);
 	}
 	double dot = 0.0;
-	int64_t row0 = 0, base = 0;
+	int64_t row0 = 0, base = 0, cbase = 0;
 	int nvalid = 0, len = 0;
-	if (s_begin < s_end) slice_meta(a, s_begin, row0, nvalid, len, base);
+	if (s_begin < s_end) slice_meta<T, CODED>(a, s_begin, row0, nvalid, len, base, cbase);
 	for (int64_t s = s_begin; s < s_end; s += s_stride) {
 		// prefetch the next slice's metadata before working on this one
-		int64_t row0n = 0, basen = 0;
+		int64_t row0n = 0, basen = 0, cbasen = 0;
 		int nvalidn = 0, lenn = 0;
-		if (s + s_stride < s_end) slice_meta(a, s + s_stride, row0n, nvalidn, lenn, basen);
-		dot += sliced_one<T, DOT, false, U>(a, row0, nvalid, len, base, nullptr, 0, 0);
+		if (s + s_stride < s_end) slice_meta<T, CODED>(a, s + s_stride, row0n, nvalidn, lenn, basen, cbasen);
+		dot += sliced_one<T, DOT, false, CODED, U>(a, row0, nvalid, len, base, cbase, nullptr, 0, 0, dict_s);
 		row0 = row0n;
 		base = basen;
+		cbase = cbasen;
 		nvalid = nvalidn;
 		len = lenn;
 	}
@@ -331,12 +384,14 @@ __global__ __launch_bounds__(kBlock) void k_spmv_sliced(SlicedArgs<T> a)
 
 // K3: LDS window.  One 1024-thread workgroup per CU walks row blocks; dynamic LDS = B elements.
 constexpr int kWinThreads = 1024;
-template <typename T, bool DOT, int U>
+template <typename T, bool DOT, bool CODED, int U>
 __global__ __launch_bounds__(kWinThreads) void k_spmv_window(SlicedArgs<T> a)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
 	T* lds = (T*)lds_raw;
 	__shared__ double smem[kWinThreads / 64];
+	__shared__ double dict_s[CODED ? 256 : 1];
+	load_dict<CODED>(dict_s, a.dict);
 	const int wave = threadIdx.x >> 6;
 	int64_t b_begin, b_end, b_stride;
 	if (a.xcd_map && (gridDim.x & 7) == 0) {
@@ -366,16 +421,17 @@ __global__ __launch_bounds__(kWinThreads) void k_spmv_window(SlicedArgs<T> a)
 				if (i0 + (int64_t)q * kWinThreads < wl) lds[i0 + (int64_t)q * kWinThreads] = t[q];
 		}
 		__syncthreads();
-		int64_t row0 = 0, base = 0;
+		int64_t row0 = 0, base = 0, cbase = 0;
 		int nvalid = 0, len = 0;
-		if (wave < a.g.spb) slice_meta(a, blk * a.g.spb + wave, row0, nvalid, len, base);
+		if (wave < a.g.spb) slice_meta<T, CODED>(a, blk * a.g.spb + wave, row0, nvalid, len, base, cbase);
 		for (int j = wave; j < a.g.spb; j += kWinThreads / 64) {
-			int64_t row0n = 0, basen = 0;
+			int64_t row0n = 0, basen = 0, cbasen = 0;
 			int nvalidn = 0, lenn = 0;
-			if (j + kWinThreads / 64 < a.g.spb) slice_meta(a, blk * a.g.spb + j + kWinThreads / 64, row0n, nvalidn, lenn, basen);
-			dot += sliced_one<T, DOT, true, U>(a, row0, nvalid, len, base, lds, (int32_t)r0, (uint32_t)wl);
+			if (j + kWinThreads / 64 < a.g.spb) slice_meta<T, CODED>(a, blk * a.g.spb + j + kWinThreads / 64, row0n, nvalidn, lenn, basen, cbasen);
+			dot += sliced_one<T, DOT, true, CODED, U>(a, row0, nvalid, len, base, cbase, lds, (int32_t)r0, (uint32_t)wl, dict_s);
 			row0 = row0n;
 			base = basen;
+			cbase = cbasen;
 			nvalid = nvalidn;
 			len = lenn;
 		}
@@ -387,9 +443,9 @@ __global__ __launch_bounds__(kWinThreads) void k_spmv_window(SlicedArgs<T> a)
 }
 
 // CSR -> sliced layout.  Slices cover consecutive row ranges, so a slice's entries are the CSR range
-// rowptr[row0] .. rowptr[row0+nvalid).
+// rowptr[row0] .. rowptr[row0+nvalid).  words[s] (optional) = code words of slice s = 64*ceil(maxlen/spw).
 static __global__ void k_slice_meta(SliceGeom g, const int64_t* __restrict__ rowptr, int64_t* __restrict__ slice_ptr,
-                                    int32_t* __restrict__ row_len)
+                                    int32_t* __restrict__ row_len, int64_t* __restrict__ words, int spw)
 {
 	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i < g.nrows) row_len[i] = (int32_t)(rowptr[i + 1] - rowptr[i]);
@@ -398,8 +454,16 @@ static __global__ void k_slice_meta(SliceGeom g, const int64_t* __restrict__ row
 		int nvalid;
 		slice_rows(g, i, row0, nvalid);
 		slice_ptr[i] = rowptr[nvalid > 0 ? row0 : g.nrows];
+		if (words) {
+			int64_t mx = 0;
+			for (int r = 0; r < nvalid; r++) mx = max(mx, rowptr[row0 + r + 1] - rowptr[row0 + r]);
+			words[i] = 64 * ((mx + spw - 1) / spw);
+		}
 	}
-	if (i == g.nslices) slice_ptr[i] = rowptr[g.nrows];
+	if (i == g.nslices) {
+		slice_ptr[i] = rowptr[g.nrows];
+		if (words) words[i] = 0;
+	}
 }
 
 // one wave per slice: scatter CSR entries into slot-major compact order (INVERSE: back to CSR order)
@@ -433,14 +497,131 @@ __global__ __launch_bounds__(kBlock) void k_slice_fill(SliceGeom g, const int64_
 			if (on) {
 				if (INVERSE) {
 					col_out[p0 + k] = col_in[base + pos];
-					val_out[p0 + k] = val_in[base + pos];
+					if (val_out) val_out[p0 + k] = val_in[base + pos];
 				} else {
 					col_out[base + pos] = col_in[p0 + k];
-					val_out[base + pos] = val_in[p0 + k];
+					if (val_out) val_out[base + pos] = val_in[p0 + k];
 				}
 			}
 			base += __popcll(m);
 		}
+	}
+}
+
+// ---- value dictionary ---------------------------------------------------------------------------
+constexpr int kDictTable = 4096; // open-addressing table of distinct 64-bit patterns
+constexpr unsigned long long kDictEmpty = ~0ull;
+
+__device__ __forceinline__ unsigned dict_hash(unsigned long long k)
+{
+	k ^= k >> 33;
+	k *= 0xff51afd7ed558ccdULL;
+	k ^= k >> 33;
+	return (unsigned)k & (kDictTable - 1);
+}
+
+// collect the distinct doubles of vals[0..n) into table (pre-filled with kDictEmpty); *overflow != 0 when full
+static __global__ __launch_bounds__(kBlock) void k_dict_collect(const double* __restrict__ vals, int64_t n,
+                                                                 unsigned long long* table, int* overflow)
+{
+	unsigned long long last = kDictEmpty;
+	for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+		const unsigned long long key = (unsigned long long)__double_as_longlong(vals[i]);
+		if (key == last) continue; // runs of equal values are the common case
+		last = key;
+		unsigned h = dict_hash(key);
+		int probes = 0;
+		for (; probes < kDictTable; probes++) {
+			const unsigned long long cur = table[h];
+			if (cur == key) break;
+			if (cur == kDictEmpty) {
+				const unsigned long long old = atomicCAS(&table[h], kDictEmpty, key);
+				if (old == kDictEmpty || old == key) break;
+			}
+			h = (h + 1) & (kDictTable - 1);
+		}
+		if (probes == kDictTable) *overflow = 1;
+	}
+}
+
+// code of v in the sorted dictionary (bit patterns compared as unsigned integers)
+__device__ __forceinline__ uint32_t dict_code(const double* dict, int ndict, double v)
+{
+	const unsigned long long key = (unsigned long long)__double_as_longlong(v);
+	int lo = 0, hi = ndict - 1;
+	while (lo < hi) {
+		const int mid = (lo + hi) >> 1;
+		if ((unsigned long long)__double_as_longlong(dict[mid]) < key)
+			lo = mid + 1;
+		else
+			hi = mid;
+	}
+	return (uint32_t)lo;
+}
+
+// one wave per slice: pack the codes of the slice's values (read in CSR order) into the padded word layout
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_slice_codes(SliceGeom g, const int64_t* __restrict__ rowptr,
+                                                         const T* __restrict__ val_in, const int64_t* __restrict__ code_ptr,
+                                                         const double* __restrict__ dict, int ndict,
+                                                         uint32_t* __restrict__ codes)
+{
+	constexpr int SPW = CodeTraits<T>::kSlotsPerWord;
+	constexpr int BITS = CodeTraits<T>::kBits;
+	const int lane = threadIdx.x & 63;
+	const int64_t wave0 = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+	const int64_t nwaves = (int64_t)gridDim.x * (kBlock / 64);
+	for (int64_t s = wave0; s < g.nslices; s += nwaves) {
+		int64_t row0;
+		int nvalid;
+		slice_rows(g, s, row0, nvalid);
+		int64_t p0 = 0;
+		int len = 0;
+		if (lane < nvalid) {
+			p0 = rowptr[row0 + lane];
+			len = (int)(rowptr[row0 + lane + 1] - p0);
+		}
+		int maxlen = len;
+#pragma unroll
+		for (int off = 32; off > 0; off >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, off, 64));
+		const int nwords = (maxlen + SPW - 1) / SPW;
+		const int64_t cbase = code_ptr[s];
+		for (int w = 0; w < nwords; w++) {
+			uint32_t word = 0;
+#pragma unroll
+			for (int q = 0; q < SPW; q++) {
+				const int k = w * SPW + q;
+				if (k < len) {
+					const double* pv = (const double*)(val_in + p0 + k);
+					uint32_t c = dict_code(dict, ndict, pv[0]);
+					if (sizeof(T) == 16) c |= dict_code(dict, ndict, pv[1]) << 8;
+					word |= c << (BITS * q);
+				}
+			}
+			codes[cbase + ((int64_t)w << 6) + lane] = word;
+		}
+	}
+}
+
+// decode back to CSR order (for lpp_engine_get_csr)
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_slice_decode(SliceGeom g, const int64_t* __restrict__ rowptr,
+                                                          const uint32_t* __restrict__ codes, const int64_t* __restrict__ code_ptr,
+                                                          const double* __restrict__ dict, T* __restrict__ val_out)
+{
+	constexpr int SPW = CodeTraits<T>::kSlotsPerWord;
+	const int lane = threadIdx.x & 63;
+	const int64_t wave0 = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+	const int64_t nwaves = (int64_t)gridDim.x * (kBlock / 64);
+	for (int64_t s = wave0; s < g.nslices; s += nwaves) {
+		int64_t row0;
+		int nvalid;
+		slice_rows(g, s, row0, nvalid);
+		if (lane >= nvalid) continue;
+		const int64_t p0 = rowptr[row0 + lane];
+		const int len = (int)(rowptr[row0 + lane + 1] - p0);
+		const int64_t cbase = code_ptr[s];
+		for (int k = 0; k < len; k++) val_out[p0 + k] = CodeTraits<T>::decode(codes[cbase + ((int64_t)(k / SPW) << 6) + lane], k % SPW, dict);
 	}
 }
 

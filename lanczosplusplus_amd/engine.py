@@ -26,7 +26,8 @@ class LanczosEngine:
     """One engine = one GPU (one process per GPU in the multi-GPU path)."""
 
     def __init__(self, dtype="f64", device=0, max_steps=200, min_steps=4, eps=1e-12, reortho=False,
-                 save_vectors=-1, check_lag=2, spmv_kernel=0, time_kernels=False, seed=1234, stream=None):
+                 save_vectors=-1, check_lag=2, spmv_kernel=0, time_kernels=False, seed=1234, stream=None,
+                 compress_values=-1):
         self._lib = _capi.lib()
         self._h = C.c_void_p()
         self.is_complex = dtype in ("c128", "complex128", np.complex128, LPP_C128)
@@ -45,6 +46,7 @@ class LanczosEngine:
         cfg.time_kernels = int(bool(time_kernels))
         cfg.seed = seed
         cfg.stream = stream
+        cfg.compress_values = int(compress_values)
         self.max_steps = max_steps
         self._comm_keepalive = None
         check(self._lib.lpp_engine_create(C.byref(self._h), C.byref(cfg)))

@@ -37,10 +37,11 @@ def mats():
 
 @pytest.mark.parametrize("name", ["hubbard", "heisenberg", "tj_complex", "hubbard_complex"])
 @pytest.mark.parametrize("kernel", [0, 1, 2, 3])
-def test_spmv_acc_matches_oracle(mats, name, kernel):
+@pytest.mark.parametrize("compress", [0, -1])
+def test_spmv_acc_matches_oracle(mats, name, kernel, compress):
     A = mats[name]
     dt = "c128" if A.is_complex else "f64"
-    with LanczosEngine(dtype=dt, spmv_kernel=kernel) as e:
+    with LanczosEngine(dtype=dt, spmv_kernel=kernel, compress_values=compress) as e:
         e.set_csr(A.rowptr, A.colind, A.values)
         assert e.rows() == A.nrows
         x0 = oracle.fill_random(A.nrows, 7, A.is_complex)
@@ -51,6 +52,28 @@ def test_spmv_acc_matches_oracle(mats, name, kernel):
         # accumulate semantics: a second call adds H y again
         xg2 = e.matrixVectorProduct(xg.copy(), y)
         assert rel(xg2 - xg, xo - x0) < 1e-12
+
+
+def test_value_dictionary_is_lossless_and_falls_back():
+    """<= 256 distinct doubles: values are stored as 8-bit codes and decode bit-exactly; otherwise plain storage."""
+    rng = np.random.default_rng(3)
+    n = 3000
+    import scipy.sparse as sp
+    M = sp.random(n, n, density=0.004, random_state=7, format="csr")
+    for distinct in (7, 5000):
+        pool = rng.normal(size=distinct)
+        M.data = pool[rng.integers(0, distinct, size=M.nnz)]
+        rp, ci, va = M.indptr.astype(np.int64), M.indices.astype(np.int32), M.data.copy()
+        y = rng.normal(size=n)
+        ref = M @ y
+        for kernel in (2, 3):
+            with LanczosEngine(spmv_kernel=kernel, compress_values=-1) as e:
+                e.set_csr(rp, ci, va)
+                g = e.get_csr()
+                assert np.array_equal(g[0], rp) and np.array_equal(g[1], ci)
+                assert np.array_equal(g[2].view(np.uint64), va.view(np.uint64))
+                x = e.matrixVectorProduct(np.zeros(n), y)
+                assert rel(x, ref) < 1e-13
 
 
 def test_spmv_edge_cases():
