@@ -70,10 +70,13 @@ WORKLOADS = {
 }
 
 
-def assemble(engine, name, comm=None):
+def assemble(engine, name, comm=None, onthefly=False):
     model, p = WORKLOADS[name]
     if model == "hubbard":
         L = p["L"]
+        if onthefly:
+            engine.setup_hubbard_onthefly(L, p["nup"], p["ndown"], p["hop"](), np.full(L, p["U"]), np.zeros(L), comm=comm)
+            return
         engine.assemble_hubbard(L, p["nup"], p["ndown"], p["hop"](), np.full(L, p["U"]), np.zeros(L), comm=comm)
     elif model == "heisenberg":
         if comm is not None:
@@ -128,6 +131,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default=os.environ.get("LPP_BENCH_WORKLOAD", "hubbard_4x4_half_filling_pbc_U4"))
     ap.add_argument("--spmv-kernel", type=int, default=int(os.environ.get("LPP_BENCH_KERNEL", "0")))
+    ap.add_argument("--engine", default=os.environ.get("LPP_BENCH_ENGINE", "stored"), choices=["stored", "onthefly"],
+                    help="stored CSR (default, the BASELINE metric) or the matrix-free Hubbard product")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     args = ap.parse_args()
@@ -178,7 +183,7 @@ def main():
         eng = LanczosEngine(dtype="c128" if is_complex else "f64", device=local_rank, max_steps=max_steps, eps=0.0,
                             save_vectors=0, spmv_kernel=args.spmv_kernel, time_kernels=True, stream=stream)
         t_asm = time.time()
-        assemble(eng, name, comm)
+        assemble(eng, name, comm, onthefly=(args.engine == "onthefly"))
         eng.sync()
         t_asm = time.time() - t_asm
         st0 = eng.stats()
@@ -220,7 +225,7 @@ def main():
     traffic = None
     try:  # per-launch HBM bytes of the SpMV kernel from the committed rocprofv3 PMC pass of this workload
         tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-        if world == 1 and name in tj:
+        if world == 1 and name in tj and args.engine == "stored":
             traffic = tj[name]["traffic_bytes_per_launch"]
     except Exception:
         traffic = None
@@ -241,7 +246,7 @@ def main():
             "dtype": "c128" if is_complex else "f64",
             "data": "synthetic",
             "config": {"workload": name, "rows": nrows_g, "nnz": nnz_g, "parallelism": "1-D row partition x%d" % world,
-                       "reortho": False, "assembly": "on-device", "assembly_s": round(t_asm, 3)},
+                       "reortho": False, "assembly": "on-device", "assembly_s": round(t_asm, 3), "engine": args.engine},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "k_spmv (x += H y, fused a_j partial)", "spmv_ms": spmv_ms_per_step,

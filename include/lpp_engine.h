@@ -132,6 +132,15 @@ lpp_status lpp_engine_assemble_hubbard(lpp_engine* e, const lpp_comm* comm, int3
                                        int32_t ndown, const double* hop_re, const double* hop_im, const double* U,
                                        const double* V);
 
+/* Matrix-free Hubbard product (the GPU counterpart of SolverOptions=InternalProductOnTheFly:
+ * InternalProductOnTheFly.h:120-123 -> HubbardHelper::matrixVectorProduct, HubbardHelper.h:105-134).
+ * No CSR is stored: H = H_up (x) 1 + 1 (x) H_down + diag(U n_up n_down) in the BasisHubbardLanczos ordering;
+ * only the two one-species matrices live in HBM.  Same arguments as lpp_engine_assemble_hubbard; every
+ * solver entry point works unchanged afterwards, lpp_engine_get_csr does not. */
+lpp_status lpp_engine_setup_hubbard_onthefly(lpp_engine* e, const lpp_comm* comm, int32_t nsites, int32_t nup,
+                                             int32_t ndown, const double* hop_re, const double* hop_im, const double* U,
+                                             const double* V);
+
 /* On-device assembly of the S=1/2 Heisenberg Hamiltonian (Heisenberg.h:80-114,242-307) in the
  * BasisHeisenberg ordering (ascending words of fixed popcount, BasisHeisenberg.h:38-46). */
 lpp_status lpp_engine_assemble_heisenberg(lpp_engine* e, int32_t nsites, int32_t szPlusConst, const double* jpm,

@@ -11,6 +11,7 @@
 
 #include "lpp_assemble_kernels.h"
 #include "lpp_engine_impl.h"
+#include "lpp_kron_kernels.h"
 
 using namespace lpp;
 
@@ -73,7 +74,7 @@ struct DevBuf {
 };
 
 template <int MODEL, typename T>
-lpp_status run_assembly(lpp_engine* e, AsmParams P, DevCsr& A)
+lpp_status run_assembly(lpp_engine* e, AsmParams P, DevCsr& A, int force_mode = 0, int64_t force_block = 0)
 {
 	hipStream_t st = e->stream;
 	free_csr(A);
@@ -103,12 +104,12 @@ lpp_status run_assembly(lpp_engine* e, AsmParams P, DevCsr& A)
 	if (P.nloc > 0) k_asm_fill<MODEL, T><<<nb, kBlock, 0, st>>>(P, A.rowptr, A.col, (T*)A.val);
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipStreamSynchronize(st));
-	return finalize_csr(e, A, true);
+	return finalize_csr(e, A, true, force_mode, force_block);
 }
 
-template <int MODEL> lpp_status dispatch(lpp_engine* e, const AsmParams& P, DevCsr& A)
+template <int MODEL> lpp_status dispatch(lpp_engine* e, const AsmParams& P, DevCsr& A, int force_mode = 0, int64_t force_block = 0)
 {
-	return e->is_complex ? run_assembly<MODEL, cplx>(e, P, A) : run_assembly<MODEL, double>(e, P, A);
+	return e->is_complex ? run_assembly<MODEL, cplx>(e, P, A, force_mode, force_block) : run_assembly<MODEL, double>(e, P, A, force_mode, force_block);
 }
 
 lpp_status upload(hipStream_t st, DevBuf& b, const void* src, size_t bytes)
@@ -139,6 +140,23 @@ uint64_t binom(const std::vector<uint64_t>& c, int n, int m)
 	return c[(size_t)n * kCombDim + m];
 }
 
+// terms of the Hubbard hopping: c^dagger_j c_i for every ordered pair with hoppings_(i,j) != 0, both species,
+// value h * doSign(ket,i) * doSign(ket^bit(i), j)   (HubbardHelper.h:205-243, ProgramGlobals.h:109-114)
+void hubbard_terms(int L, const double* hop_re, const double* hop_im, std::vector<HostProc>& hp)
+{
+	for (int i = 0; i < L; i++) {
+		for (int j = 0; j < L; j++) {
+			if (i == j) continue;
+			const double hr = hop_re[i * L + j], hi = hop_im ? hop_im[i * L + j] : 0.0;
+			if (hr == 0 && hi == 0) continue;
+			for (int spin = 0; spin < 2; spin++) {
+				const int sh = spin * L;
+				push(hp, bit(i + sh), bit(j + sh), bit(i + sh) | bit(j + sh), (below(i) ^ below(j)) << sh, 0, i < j ? 1 : 0, hr, hi);
+			}
+		}
+	}
+}
+
 lpp_status common_setup(lpp_engine* e, int64_t nrows, int is_complex_input)
 {
 	if (!e) return fail(LPP_ERR_INVALID, "assemble: null engine");
@@ -167,20 +185,8 @@ lpp_status lpp_engine_assemble_hubbard(lpp_engine* e, const lpp_comm* comm, int3
 	lpp_status st = common_setup(e, nrows, cplx_in);
 	if (st != LPP_OK) return st;
 
-	// terms: c^dagger_j c_i for every ordered pair with hoppings_(i,j) != 0, both species,
-	// value h * doSign(ket,i) * doSign(ket^bit(i), j)   (HubbardHelper.h:205-243, ProgramGlobals.h:109-114)
 	std::vector<HostProc> hp;
-	for (int i = 0; i < L; i++) {
-		for (int j = 0; j < L; j++) {
-			if (i == j) continue;
-			const double hr = hop_re[i * L + j], hi = hop_im ? hop_im[i * L + j] : 0.0;
-			if (hr == 0 && hi == 0) continue;
-			for (int spin = 0; spin < 2; spin++) {
-				const int sh = spin * L;
-				push(hp, bit(i + sh), bit(j + sh), bit(i + sh) | bit(j + sh), (below(i) ^ below(j)) << sh, 0, i < j ? 1 : 0, hr, hi);
-			}
-		}
-	}
+	hubbard_terms(L, hop_re, hop_im, hp);
 	std::vector<Proc> procs;
 	int nneg = 0;
 	st = finish_procs(hp, procs, &nneg);
@@ -211,6 +217,7 @@ lpp_status lpp_engine_assemble_hubbard(lpp_engine* e, const lpp_comm* comm, int3
 		e->has_comm = false;
 		e->bind_scalars(e->scal_own);
 		free_csr(e->A_rem);
+		free_kron(e);
 		P.row0 = 0;
 		P.nloc = nrows;
 		P.part = 0;
@@ -234,6 +241,7 @@ lpp_status lpp_engine_assemble_hubbard(lpp_engine* e, const lpp_comm* comm, int3
 		P.col_lo = starts[comm->rank];
 		P.col_hi = starts[comm->rank + 1];
 		P.part = 1;
+		free_kron(e);
 		st = dispatch<ASM_HUBBARD>(e, P, e->A_loc);
 		if (st != LPP_OK) return st;
 		P.part = 2;
@@ -296,6 +304,7 @@ lpp_status lpp_engine_assemble_heisenberg(lpp_engine* e, int32_t L, int32_t szPl
 	e->has_comm = false;
 	e->bind_scalars(e->scal_own);
 	free_csr(e->A_rem);
+	free_kron(e);
 	st = dispatch<ASM_HEISENBERG>(e, P, e->A_loc);
 	if (st != LPP_OK) return st;
 	e->n_local = e->n_global = nrows;
@@ -379,6 +388,7 @@ lpp_status lpp_engine_assemble_tj(lpp_engine* e, int32_t L, int32_t nup, int32_t
 	e->has_comm = false;
 	e->bind_scalars(e->scal_own);
 	free_csr(e->A_rem);
+	free_kron(e);
 	st = dispatch<ASM_TJ>(e, P, e->A_loc);
 	if (st != LPP_OK) return st;
 	e->n_local = e->n_global = nrows;
@@ -388,4 +398,185 @@ lpp_status lpp_engine_assemble_tj(lpp_engine* e, int32_t L, int32_t nup, int32_t
 	return alloc_work(e);
 }
 
+
+lpp_status lpp_engine_setup_hubbard_onthefly(lpp_engine* e, const lpp_comm* comm, int32_t L, int32_t nup, int32_t ndown,
+                                             const double* hop_re, const double* hop_im, const double* U, const double* V)
+{
+	if (!e || !hop_re || !U || !V || L < 1 || L > 31 || nup < 0 || ndown < 0 || nup > L || ndown > L)
+		return fail(LPP_ERR_INVALID, "lpp_engine_setup_hubbard_onthefly: bad argument (1 <= L <= 31)");
+	const std::vector<uint64_t> comb = comb_table();
+	const int64_t n_up = (int64_t)binom(comb, L, nup), n_dn = (int64_t)binom(comb, L, ndown);
+	bool cplx_in = false;
+	if (hop_im)
+		for (int k = 0; k < L * L; k++) cplx_in |= (hop_im[k] != 0);
+	if (cplx_in && !e->is_complex) return fail(LPP_ERR_INVALID, "setup_hubbard_onthefly: complex hoppings need a c128 engine");
+	if (n_up <= 0 || n_dn <= 0) return fail(LPP_ERR_INVALID, "setup_hubbard_onthefly: empty Hilbert space");
+	if (n_up > (int64_t)INT32_MAX || n_dn > (int64_t)INT32_MAX) return fail(LPP_ERR_INVALID, "setup_hubbard_onthefly: one-species space too large");
+	HIP_TRY(hipSetDevice(e->cfg.device));
+	const bool multi = comm && comm->nranks > 1;
+	lpp_status st = LPP_OK;
+	int64_t id0 = 0, nid = n_dn;
+	if (multi) {
+		st = e->adopt_comm(comm);
+		if (st != LPP_OK) return st;
+		const int64_t per = (n_dn + comm->nranks - 1) / comm->nranks;
+		if (comm->shard_stride != per * n_up) return fail(LPP_ERR_INVALID, "setup_hubbard_onthefly: comm.shard_stride must be ceil(N_down/nranks)*N_up");
+		id0 = std::min<int64_t>((int64_t)comm->rank * per, n_dn);
+		nid = std::min<int64_t>(id0 + per, n_dn) - id0;
+	} else {
+		e->has_comm = false;
+		e->bind_scalars(e->scal_own);
+	}
+	free_csr(e->A_loc);
+	free_csr(e->A_rem);
+	free_kron(e);
+	KronState& K = e->kron;
+
+	std::vector<HostProc> hp;
+	hubbard_terms(L, hop_re, hop_im, hp);
+	std::vector<Proc> procs;
+	int nneg = 0;
+	st = finish_procs(hp, procs, &nneg);
+	if (st != LPP_OK) return st;
+	std::vector<double> zeroU(L, 0.0);
+	DevBuf d_procs, d_comb, d_U0, d_V;
+	if ((st = upload(e->stream, d_procs, procs.data(), sizeof(Proc) * procs.size())) != LPP_OK) return st;
+	if ((st = upload(e->stream, d_comb, comb.data(), sizeof(uint64_t) * comb.size())) != LPP_OK) return st;
+	if ((st = upload(e->stream, d_U0, zeroU.data(), sizeof(double) * L)) != LPP_OK) return st;
+	if ((st = upload(e->stream, d_V, V, sizeof(double) * L)) != LPP_OK) return st;
+	// one-species matrices = the Hubbard assembler with the other species empty: hops of that species plus
+	// its potential diagonal sum_i V_i n_i (HubbardHelper.h:180-183); the U term is applied by the kernel
+	AsmParams P {};
+	P.model = ASM_HUBBARD;
+	P.L = L;
+	P.ndown = 0;
+	P.nproc = (int)procs.size();
+	P.nneg = nneg;
+	P.procs = (const Proc*)d_procs.p;
+	P.comb = (const uint64_t*)d_comb.p;
+	P.d0 = (const double*)d_U0.p;
+	P.d1 = (const double*)d_V.p;
+	P.part = 0;
+	P.row0 = 0;
+	P.nup = nup;
+	P.n_up = n_up;
+	P.nrows_global = P.nloc = n_up;
+	st = dispatch<ASM_HUBBARD>(e, P, K.up, LPP_SPMV_SLICED, n_up); // sliced, one block
+	if (st != LPP_OK) return st;
+	P.nup = ndown;
+	P.n_up = n_dn;
+	P.nrows_global = P.nloc = n_dn;
+	st = dispatch<ASM_HUBBARD>(e, P, K.dn, LPP_SPMV_ROWGROUP, 0); // plain CSR
+	if (st != LPP_OK) return st;
+	K.up.hint_block = K.dn.hint_block = 0;
+
+	HIP_TRY_MEM(hipMalloc(&K.up_words, sizeof(uint32_t) * (size_t)n_up));
+	HIP_TRY_MEM(hipMalloc(&K.dn_words, sizeof(uint32_t) * (size_t)n_dn));
+	HIP_TRY_MEM(hipMalloc(&K.U, sizeof(double) * 32));
+	std::vector<double> U32(32, 0.0);
+	for (int i = 0; i < L; i++) U32[i] = U[i];
+	HIP_TRY(hipMemcpyAsync(K.U, U32.data(), sizeof(double) * 32, hipMemcpyHostToDevice, e->stream));
+	k_basis_words<<<(int)((n_up + 255) / 256), 256, 0, e->stream>>>((const uint64_t*)d_comb.p, kCombDim, n_up, nup, L, K.up_words);
+	k_basis_words<<<(int)((n_dn + 255) / 256), 256, 0, e->stream>>>((const uint64_t*)d_comb.p, kCombDim, n_dn, ndown, L, K.dn_words);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipStreamSynchronize(e->stream));
+
+	K.L = L;
+	K.n_up = n_up;
+	K.n_dn = n_dn;
+	K.id0 = id0;
+	K.nid = nid;
+	K.window = (size_t)n_up * e->esz <= (size_t)156 * 1024;
+	if (getenv("LPP_KRON_NO_WINDOW")) K.window = false;
+	// entries of the stored CSR this product represents (one diagonal per row + all hops), for the local rows
+	const double off_up = (double)K.up.nnz - (double)n_up, off_dn_total = (double)K.dn.nnz - (double)n_dn;
+	K.equiv_nnz = (double)nid * ((double)n_up + off_up) + (double)n_up * off_dn_total * ((double)nid / (double)n_dn);
+	K.active = true;
+	e->n_local = nid * n_up;
+	e->n_global = n_up * n_dn;
+	e->row_start = id0 * n_up;
+	e->active = false;
+	set_spmv_bytes(e);
+	return alloc_work(e);
+}
+
 } // extern "C"
+
+namespace lpp {
+
+void free_kron(lpp_engine* e)
+{
+	KronState& K = e->kron;
+	free_csr(K.up);
+	free_csr(K.dn);
+	if (K.up_words) (void)hipFree(K.up_words);
+	if (K.dn_words) (void)hipFree(K.dn_words);
+	if (K.U) (void)hipFree(K.U);
+	K = KronState();
+}
+
+template <typename T> static int kron_launch_t(lpp_engine* e, const void* ywin, const void* ydown, void* x, double* partial)
+{
+	KronState& K = e->kron;
+	if (K.nid == 0) return 0;
+	KronArgs<T> a;
+	a.up.g = K.up.geom;
+	a.up.slice_ptr = K.up.slice_ptr;
+	a.up.row_len = K.up.row_len;
+	a.up.col = K.up.scol;
+	a.up.val = (const T*)K.up.sval;
+	a.up.codes = K.up.codes;
+	a.up.code_ptr = K.up.code_ptr;
+	a.up.dict = K.up.dict;
+	a.up.src = nullptr;
+	a.up.x = nullptr;
+	a.up.ydot = nullptr;
+	a.up.partial = nullptr;
+	a.up.xcd_map = 0;
+	a.n_up = K.n_up;
+	a.id0 = K.id0;
+	a.nid = K.nid;
+	a.dn_rowptr = K.dn.rowptr;
+	a.dn_col = K.dn.col;
+	a.dn_val = (const T*)K.dn.val;
+	a.up_words = K.up_words;
+	a.dn_words = K.dn_words;
+	a.U = K.U;
+	a.L = K.L;
+	a.ywin = (const T*)ywin;
+	a.ydown = (const T*)ydown;
+	a.x = (T*)x;
+	a.partial = partial;
+	a.xcd_map = (e->k2_variant >> 1) & 1;
+	const size_t lds_bytes = K.window ? sizeof(T) * (size_t)std::max<int64_t>(K.n_up, 64) : 64;
+	const int per_cu = std::max(1, std::min(2, (int)((160 * 1024 - 8192) / (lds_bytes + 1))));
+	int nb = (int)std::max<int64_t>(1, std::min<int64_t>(K.nid, (int64_t)e->num_cus * per_cu));
+	if (nb >= 8) nb &= ~7;
+	const bool dot = partial != nullptr;
+	const int sel = (dot ? 4 : 0) | (K.window ? 2 : 0) | (K.up.coded ? 1 : 0);
+	hipStream_t st = e->stream;
+#define LPP_KRON(DOT_, WIN_, CODED_)                                                                                   \
+	do {                                                                                                              \
+		(void)hipFuncSetAttribute((const void*)k_spmv_kron<T, DOT_, WIN_, CODED_, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
+		k_spmv_kron<T, DOT_, WIN_, CODED_, 8><<<nb, kWinThreads, lds_bytes, st>>>(a);                                   \
+	} while (0)
+	switch (sel) {
+	case 0: LPP_KRON(false, false, false); break;
+	case 1: LPP_KRON(false, false, true); break;
+	case 2: LPP_KRON(false, true, false); break;
+	case 3: LPP_KRON(false, true, true); break;
+	case 4: LPP_KRON(true, false, false); break;
+	case 5: LPP_KRON(true, false, true); break;
+	case 6: LPP_KRON(true, true, false); break;
+	default: LPP_KRON(true, true, true); break;
+	}
+#undef LPP_KRON
+	return dot ? nb : 0;
+}
+
+int kron_launch(lpp_engine* e, const void* ywin, const void* ydown, void* x, double* partial)
+{
+	return e->is_complex ? kron_launch_t<cplx>(e, ywin, ydown, x, partial) : kron_launch_t<double>(e, ywin, ydown, x, partial);
+}
+
+} // namespace lpp

@@ -266,11 +266,12 @@ template <typename T> static lpp_status build_sliced_t(lpp_engine* e, DevCsr& A,
 // Choose the SpMV kernel and build its layout.  hint_block (rows) is the basis' natural block
 // (N_up for the Hubbard product basis): when a whole number of such blocks fits the LDS window,
 // the window kernel serves every in-block gather (diagonal + up-hops) from LDS.
-lpp_status finalize_csr(lpp_engine* e, DevCsr& A, bool allow_drop_plain)
+lpp_status finalize_csr(lpp_engine* e, DevCsr& A, bool allow_drop_plain, int force_mode, int64_t force_block)
 {
 	A.G = pick_group(A.nrows, A.nnz);
 	int mode = e->cfg.spmv_kernel;
 	if (const char* s = getenv("LPP_SPMV_KERNEL")) mode = atoi(s);
+	if (force_mode) mode = force_mode;
 	const int64_t lds_cap_elems = (int64_t)((156 * 1024) / e->esz);
 	int64_t win_rows = 0;
 	if (A.hint_block > 0 && A.hint_block <= lds_cap_elems) {
@@ -292,9 +293,10 @@ lpp_status finalize_csr(lpp_engine* e, DevCsr& A, bool allow_drop_plain)
 		// no natural block: a generic diagonal window (captures near-diagonal columns)
 		win_rows = std::min<int64_t>(lds_cap_elems, 16384);
 	}
-	if (const char* s = getenv("LPP_WINDOW_ROWS")) win_rows = std::max<int64_t>(64, std::min<int64_t>(atoll(s), lds_cap_elems));
+	if (!force_mode)
+		if (const char* s = getenv("LPP_WINDOW_ROWS")) win_rows = std::max<int64_t>(64, std::min<int64_t>(atoll(s), lds_cap_elems));
 	if ((mode == LPP_SPMV_SLICED || mode == LPP_SPMV_WINDOW) && A.nrows > 0) {
-		const int64_t B = (mode == LPP_SPMV_WINDOW) ? win_rows : A.nrows;
+		const int64_t B = force_block > 0 ? force_block : ((mode == LPP_SPMV_WINDOW) ? win_rows : A.nrows);
 		lpp_status st = e->is_complex ? build_sliced_t<cplx>(e, A, B) : build_sliced_t<double>(e, A, B);
 		if (st != LPP_OK) return st;
 		A.window = (mode == LPP_SPMV_WINDOW);
@@ -312,7 +314,7 @@ lpp_status finalize_csr(lpp_engine* e, DevCsr& A, bool allow_drop_plain)
 void set_spmv_bytes(lpp_engine* e)
 {
 	const double s = (double)e->esz;
-	const double Z = (double)(e->A_loc.nnz + e->A_rem.nnz);
+	const double Z = e->kron.active ? e->kron.equiv_nnz : (double)(e->A_loc.nnz + e->A_rem.nnz);
 	const double N = (double)e->n_local;
 	e->spmv_bytes = Z * (s + 4.0) + (N + 1.0) * 8.0 + 3.0 * N * s;
 }
@@ -400,6 +402,7 @@ lpp_status lpp_engine_destroy(lpp_engine* e)
 	if (e->stream) (void)hipStreamSynchronize(e->stream);
 	free_csr(e->A_loc);
 	free_csr(e->A_rem);
+	free_kron(e);
 	for (double* p : { e->x, e->y, e->V, e->partial, e->scal_own, e->zwork })
 		if (p) (void)hipFree(p);
 	if (e->h_scal) (void)hipHostFree(e->h_scal);
@@ -456,6 +459,7 @@ lpp_status lpp_engine_set_csr(lpp_engine* e, int64_t nrows, const int64_t* rowpt
 	e->has_comm = false;
 	e->bind_scalars(e->scal_own);
 	free_csr(e->A_rem);
+	free_kron(e);
 	st = upload_csr(e, e->A_loc, nrows, rowptr, colind, values);
 	if (st != LPP_OK) return st;
 	e->n_local = e->n_global = nrows;
@@ -487,6 +491,7 @@ lpp_status lpp_engine_set_csr_partition(lpp_engine* e, const lpp_comm* comm, int
 	st = lpp_split_csr(r, P, shard_starts, comm->shard_stride, local, rowptr, colind, values, (int32_t)e->esz, &nl, &nr, rpl.data(),
 	                   cl.data(), vl.data(), rpr.data(), cr.data(), vr.data());
 	if (st != LPP_OK) return st;
+	free_kron(e);
 	st = upload_csr(e, e->A_loc, local, rpl.data(), cl.data(), vl.data());
 	if (st != LPP_OK) return st;
 	st = upload_csr(e, e->A_rem, local, rpr.data(), cr.data(), vr.data());
@@ -506,6 +511,7 @@ lpp_status lpp_engine_get_csr(lpp_engine* e, int32_t which, int64_t* nrows, int6
 	if (nrows) *nrows = A.nrows;
 	if (nnz) *nnz = A.nnz;
 	if (!rowptr && !colind && !values) return LPP_OK;
+	if (e->kron.active) return fail(LPP_ERR_STATE, "lpp_engine_get_csr: the matrix-free engine stores no CSR");
 	if (!A.rowptr) return fail(LPP_ERR_STATE, "lpp_engine_get_csr: no matrix");
 	HIP_TRY(hipSetDevice(e->cfg.device));
 	HIP_TRY(hipStreamSynchronize(e->stream));
@@ -552,14 +558,17 @@ lpp_status lpp_engine_get_csr(lpp_engine* e, int32_t which, int64_t* nrows, int6
 lpp_status lpp_engine_spmv_acc(lpp_engine* e, void* x_inout, const void* y)
 {
 	if (!e || !x_inout || !y) return fail(LPP_ERR_INVALID, "lpp_engine_spmv_acc: null argument");
-	if (!e->A_loc.rowptr) return fail(LPP_ERR_STATE, "lpp_engine_spmv_acc: no matrix (call lpp_engine_set_csr first)");
+	if (!e->has_matrix()) return fail(LPP_ERR_STATE, "lpp_engine_spmv_acc: no matrix (call lpp_engine_set_csr first)");
 	if (e->has_comm && e->comm.nranks > 1) return fail(LPP_ERR_STATE, "lpp_engine_spmv_acc: not available on a partitioned matrix");
 	if (e->active) return fail(LPP_ERR_STATE, "lpp_engine_spmv_acc: a Lanczos run is active");
 	HIP_TRY(hipSetDevice(e->cfg.device));
 	const size_t bytes = e->esz * (size_t)e->n_local;
 	HIP_TRY(hipMemcpyAsync(e->x, x_inout, bytes, hipMemcpyHostToDevice, e->stream));
 	HIP_TRY(hipMemcpyAsync(e->y, y, bytes, hipMemcpyHostToDevice, e->stream));
-	spmv_launch(e, e->A_loc, e->y, e->x, nullptr, nullptr);
+	if (e->kron.active)
+		kron_launch(e, e->y, e->y, e->x, nullptr);
+	else
+		spmv_launch(e, e->A_loc, e->y, e->x, nullptr, nullptr);
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipMemcpyAsync(x_inout, e->x, bytes, hipMemcpyDeviceToHost, e->stream));
 	HIP_TRY(hipStreamSynchronize(e->stream));
@@ -569,7 +578,7 @@ lpp_status lpp_engine_spmv_acc(lpp_engine* e, void* x_inout, const void* y)
 lpp_status lpp_engine_bench_spmv(lpp_engine* e, int32_t warmup, int32_t iters, double* ms_per_launch)
 {
 	if (!e || iters <= 0 || !ms_per_launch) return fail(LPP_ERR_INVALID, "lpp_engine_bench_spmv: bad argument");
-	if (!e->A_loc.rowptr) return fail(LPP_ERR_STATE, "lpp_engine_bench_spmv: no matrix");
+	if (!e->has_matrix()) return fail(LPP_ERR_STATE, "lpp_engine_bench_spmv: no matrix");
 	if (e->active) return fail(LPP_ERR_STATE, "lpp_engine_bench_spmv: a Lanczos run is active");
 	HIP_TRY(hipSetDevice(e->cfg.device));
 	k_fill_random<<<1024, 256, 0, e->stream>>>(e->y, e->nd, 0, 99);
@@ -581,6 +590,10 @@ lpp_status lpp_engine_bench_spmv(lpp_engine* e, int32_t warmup, int32_t iters, d
 	}
 	for (int i = 0; i < warmup + iters; i++) {
 		if (i == warmup) HIP_TRY(hipEventRecord(e->ev_t0, e->stream));
+		if (e->kron.active) {
+			kron_launch(e, e->y, (e->has_comm && e->comm.nranks > 1) ? e->comm.gath_buf : e->y, e->x, e->partial);
+			continue;
+		}
 		spmv_launch(e, e->A_loc, src, e->x, e->y, e->A_rem.nnz ? nullptr : e->partial);
 		if (e->A_rem.nnz) spmv_launch(e, e->A_rem, e->comm.gath_buf, e->x, e->y, e->partial);
 	}
@@ -610,7 +623,7 @@ lpp_status lpp_engine_get_stats(lpp_engine* e, lpp_stats* s)
 	e->collect_spmv_times();
 	*s = e->stats;
 	s->nrows = e->n_local;
-	s->nnz = e->A_loc.nnz + e->A_rem.nnz;
+	s->nnz = e->kron.active ? (int64_t)e->kron.equiv_nnz : e->A_loc.nnz + e->A_rem.nnz;
 	s->spmv_bytes = e->spmv_bytes;
 	return LPP_OK;
 }

@@ -50,6 +50,19 @@ struct DevCsr {
 	int ndict = 0;
 };
 
+// matrix-free Hubbard product state: two one-species matrices instead of the full CSR
+struct KronState {
+	bool active = false;
+	DevCsr up; // sliced H_up
+	DevCsr dn; // plain H_down
+	uint32_t *up_words = nullptr, *dn_words = nullptr;
+	double* U = nullptr;
+	int L = 0;
+	int64_t n_up = 0, n_dn = 0, id0 = 0, nid = 0;
+	bool window = false;
+	double equiv_nnz = 0; // nnz of the stored CSR this product stands for
+};
+
 } // namespace lpp
 
 struct lpp_engine {
@@ -64,6 +77,8 @@ struct lpp_engine {
 
 	// matrix: A_loc has columns inside this rank's slice, A_rem (multi-GPU only) indexes the gathered buffer
 	lpp::DevCsr A_loc, A_rem;
+	lpp::KronState kron;
+	bool has_matrix() const { return A_loc.rowptr != nullptr || kron.active; }
 	int64_t n_local = 0, n_global = 0, row_start = 0;
 	double spmv_bytes = 0;
 
@@ -115,7 +130,9 @@ struct lpp_engine {
 
 namespace lpp {
 void free_csr(DevCsr& A);
-lpp_status finalize_csr(lpp_engine* e, DevCsr& A, bool allow_drop_plain);
+lpp_status finalize_csr(lpp_engine* e, DevCsr& A, bool allow_drop_plain, int force_mode = 0, int64_t force_block = 0);
+void free_kron(lpp_engine* e);
+int kron_launch(lpp_engine* e, const void* ywin, const void* ydown, void* x, double* partial);
 void set_spmv_bytes(lpp_engine* e);
 lpp_status alloc_work(lpp_engine* e);
 int spmv_launch(lpp_engine* e, const DevCsr& A, const void* src, void* x, const void* ydot, double* partial);

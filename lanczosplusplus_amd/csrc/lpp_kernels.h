@@ -231,24 +231,17 @@ template <> struct CodeTraits<cplx> {
 	}
 };
 
-// process one slice with one wave; returns this lane's contribution to Re<ydot|x>.
-// (len, base, cbase) = this lane's row length, the slice's first entry and first code word, prefetched by the caller.
-template <typename T, bool DOT, bool WINDOW, bool CODED, int U>
-__device__ __forceinline__ double sliced_one(const SlicedArgs<T>& a, int64_t row0, int nvalid, int len, int64_t base, int64_t cbase,
-                                             const T* lds, int32_t r0, uint32_t wlen, const double* dict)
+// Accumulate one slice with one wave: returns sum_k val_k * src[col_k] of this lane's row.
+// (len, base, cbase) = this lane's row length, the slice's first entry and first code word, prefetched by
+// the caller; `safe` is a valid source index used by lanes whose gather is served from the LDS window.
+template <typename T, bool WINDOW, bool CODED, int U>
+__device__ __forceinline__ T sliced_accumulate(const SlicedArgs<T>& a, int len, int64_t base, int64_t cbase, const T* lds,
+                                               int32_t r0, uint32_t wlen, const double* dict, int32_t safe)
 {
-	if (nvalid == 0) return 0.0; // wave-uniform
 	constexpr int SPW = CodeTraits<T>::kSlotsPerWord;
 	constexpr int NW = (U + SPW - 1) / SPW; // code words per batch
 	const int lane = threadIdx.x & 63;
 	const unsigned long long lt_mask = (1ull << lane) - 1ull;
-	const bool valid = lane < nvalid;
-	const int64_t row = row0 + (valid ? lane : 0);
-	// the row's old x and y are requested first: they are the oldest loads in flight and have landed
-	// long before the epilogue needs them
-	const T xold = a.x[row];
-	T yv = VT<T>::zero();
-	if (DOT) yv = a.ydot[row];
 	int maxlen = len;
 #pragma unroll
 	for (int off = 32; off > 0; off >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, off, 64));
@@ -279,7 +272,7 @@ __device__ __forceinline__ double sliced_one(const SlicedArgs<T>& a, int64_t row
 				const uint32_t d = (uint32_t)(c0[u] - r0);
 				const bool inw = d < wlen;
 				const T gl = lds[inw ? d : (uint32_t)lane];
-				const T gg = a.src[inw ? (int32_t)row : c0[u]];
+				const T gg = a.src[inw ? safe : c0[u]];
 				g[u] = inw ? gl : gg;
 			} else {
 				g[u] = a.src[c0[u]];
@@ -308,6 +301,24 @@ __device__ __forceinline__ double sliced_one(const SlicedArgs<T>& a, int64_t row
 		}
 	}
 #undef LPP_LOAD_BATCH
+	return acc;
+}
+
+// process one slice with one wave (x[row] += acc); returns this lane's contribution to Re<ydot|x>.
+template <typename T, bool DOT, bool WINDOW, bool CODED, int U>
+__device__ __forceinline__ double sliced_one(const SlicedArgs<T>& a, int64_t row0, int nvalid, int len, int64_t base, int64_t cbase,
+                                             const T* lds, int32_t r0, uint32_t wlen, const double* dict)
+{
+	if (nvalid == 0) return 0.0; // wave-uniform
+	const int lane = threadIdx.x & 63;
+	const bool valid = lane < nvalid;
+	const int64_t row = row0 + (valid ? lane : 0);
+	// the row's old x and y are requested first: they are the oldest loads in flight and have landed
+	// long before the epilogue needs them
+	const T xold = a.x[row];
+	T yv = VT<T>::zero();
+	if (DOT) yv = a.ydot[row];
+	const T acc = sliced_accumulate<T, WINDOW, CODED, U>(a, len, base, cbase, lds, r0, wlen, dict, (int32_t)row);
 	double d = 0.0;
 	if (valid) {
 		const T xv = VT<T>::add(xold, acc);

@@ -1,0 +1,177 @@
+// lpp_kron_kernels.h -- matrix-free Hubbard product  x += H y  (SURVEY 8(f) N1).
+//
+// GPU counterpart of the reference's on-the-fly plug-in: InternalProductOnTheFly::matrixVectorProduct
+// (src/Engine/InternalProductOnTheFly.h:120-123) -> HubbardHelper::matrixVectorProduct
+// (src/Models/HubbardOneOrbital/HubbardHelper.h:105-134).  In the BasisHubbardLanczos ordering
+// index = rank(up) + rank(down)*N_up (BasisHubbardLanczos.h:59-63) and with no cross-species sign
+// (HubbardHelper.h:214-243) the Hamiltonian is exactly
+//     H = H_up (x) 1  +  1 (x) H_down  +  diag( sum_i U_i n_i,up n_i,down ),
+// H_s = one-species hopping matrix (+ its potential diagonal) of dimension C(L, n_s).  Only the two
+// one-species matrices are stored (a few MB, L2-resident), so an SpMV moves the vectors only:
+// ~3.5 GB + 23 GB of coalesced down-hop reads instead of 75 GB of CSR at 4x4 half filling.
+//
+// One 1024-thread workgroup owns one down-configuration (a block of N_up consecutive rows) at a time:
+//   * the block's source entries are staged in LDS (same window as k_spmv_window) -- every up-hop
+//     gather is a ds_read;
+//   * lane = row: the up part walks the sliced H_up (shared by all blocks), the down part walks the
+//     block's H_down row (wave-uniform column, coalesced 512-byte reads of y[jd*N_up + iu]);
+//   * the Hubbard-U diagonal comes from popcounts of the basis words.
+#pragma once
+#include "lpp_kernels.h"
+
+namespace lpp {
+
+constexpr int kKronDownCap = 128; // H_down row entries cached in LDS per block
+
+template <typename T> struct KronArgs {
+	SlicedArgs<T> up; // sliced H_up (single block of N_up rows); src / x / ydot are set per block by the kernel
+	int64_t n_up;
+	int64_t id0, nid; // this rank's first down index (global) and number of down indices
+	const int64_t* dn_rowptr; // H_down: plain CSR over global down indices
+	const int32_t* dn_col;
+	const T* dn_val;
+	const uint32_t* up_words; // basis words (L <= 31)
+	const uint32_t* dn_words;
+	const double* U;
+	int L;
+	const T* ywin; // local slice of y: (id-id0)*N_up + iu
+	const T* ydown; // y indexed globally (jd*N_up + iu): the gathered vector on several GPUs, == ywin on one
+	T* x; // local slice
+	double* partial;
+	int xcd_map;
+};
+
+template <typename T, bool DOT, bool WINDOW, bool CODED, int U>
+__global__ __launch_bounds__(kWinThreads) void k_spmv_kron(KronArgs<T> a)
+{
+	extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+	T* lds = (T*)lds_raw;
+	__shared__ double smem[kWinThreads / 64];
+	__shared__ double dict_s[CODED ? 256 : 1];
+	__shared__ double U_s[32];
+	__shared__ int32_t dcol_s[kKronDownCap];
+	__shared__ T dval_s[kKronDownCap];
+	load_dict<CODED>(dict_s, a.up.dict);
+	if (threadIdx.x < 32) U_s[threadIdx.x] = (int)threadIdx.x < a.L ? a.U[threadIdx.x] : 0.0;
+	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	const int spb = a.up.g.spb;
+	int64_t b_begin, b_end, b_stride;
+	if (a.xcd_map && (gridDim.x & 7) == 0) {
+		const int64_t chunk = (a.nid + 7) / 8;
+		const int xcd = blockIdx.x & 7;
+		b_begin = xcd * chunk + (blockIdx.x >> 3);
+		b_end = min((int64_t)(xcd + 1) * chunk, a.nid);
+		b_stride = gridDim.x >> 3;
+	} else {
+		b_begin = blockIdx.x;
+		b_end = a.nid;
+		b_stride = gridDim.x;
+	}
+	double dot = 0.0;
+	for (int64_t blk = b_begin; blk < b_end; blk += b_stride) {
+		const int64_t gid = a.id0 + blk;
+		const T* yblk = a.ywin + blk * a.n_up;
+		T* xblk = a.x + blk * a.n_up;
+		const int64_t p0 = a.dn_rowptr[gid];
+		const int ndn = (int)(a.dn_rowptr[gid + 1] - p0);
+		const uint32_t dnw = a.dn_words[gid];
+		__syncthreads(); // previous block fully consumed (window, H_down row)
+		if (WINDOW) {
+			for (int64_t i0 = threadIdx.x; i0 < a.n_up; i0 += 8 * kWinThreads) {
+				T t[8];
+#pragma unroll
+				for (int q = 0; q < 8; q++) t[q] = yblk[min(i0 + (int64_t)q * kWinThreads, a.n_up - 1)];
+#pragma unroll
+				for (int q = 0; q < 8; q++)
+					if (i0 + (int64_t)q * kWinThreads < a.n_up) lds[i0 + (int64_t)q * kWinThreads] = t[q];
+			}
+		}
+		if ((int)threadIdx.x < min(ndn, kKronDownCap)) {
+			dcol_s[threadIdx.x] = a.dn_col[p0 + threadIdx.x];
+			dval_s[threadIdx.x] = a.dn_val[p0 + threadIdx.x];
+		}
+		__syncthreads();
+		SlicedArgs<T> ua = a.up;
+		ua.src = yblk;
+		int64_t row0 = 0, base = 0, cbase = 0;
+		int nvalid = 0, len = 0;
+		if (wave < spb) slice_meta<T, CODED>(ua, wave, row0, nvalid, len, base, cbase);
+		for (int j = wave; j < spb; j += kWinThreads / 64) {
+			int64_t row0n = 0, basen = 0, cbasen = 0;
+			int nvalidn = 0, lenn = 0;
+			if (j + kWinThreads / 64 < spb) slice_meta<T, CODED>(ua, j + kWinThreads / 64, row0n, nvalidn, lenn, basen, cbasen);
+			if (nvalid > 0) {
+				const bool valid = lane < nvalid;
+				const int64_t iu = row0 + (valid ? lane : 0);
+				const T xold = xblk[iu];
+				const uint32_t upw = a.up_words[iu];
+				// down part first: wave-uniform column, coalesced reads of y[jd*N_up + iu] (all independent)
+				T acc = VT<T>::zero();
+				const int ncached = min(ndn, kKronDownCap);
+				int p = 0;
+				for (; p + 4 <= ncached; p += 4) {
+					T g[4];
+#pragma unroll
+					for (int q = 0; q < 4; q++) g[q] = a.ydown[(int64_t)dcol_s[p + q] * a.n_up + iu];
+#pragma unroll
+					for (int q = 0; q < 4; q++) VT<T>::mac(acc, dval_s[p + q], g[q]);
+				}
+				for (; p < ncached; p++) VT<T>::mac(acc, dval_s[p], a.ydown[(int64_t)dcol_s[p] * a.n_up + iu]);
+				for (p = ncached; p < ndn; p++) VT<T>::mac(acc, a.dn_val[p0 + p], a.ydown[(int64_t)a.dn_col[p0 + p] * a.n_up + iu]);
+				// up part: sliced H_up, gathers from the LDS window (or the L2-resident block)
+				const T accu = sliced_accumulate<T, WINDOW, CODED, U>(ua, len, base, cbase, lds, 0, (uint32_t)a.n_up, dict_s, (int32_t)iu);
+				acc = VT<T>::add(acc, accu);
+				// Hubbard U on the doubly occupied sites
+				const T yc = WINDOW ? lds[iu] : yblk[iu];
+				double ud = 0.0;
+				for (uint32_t m = upw & dnw; m; m &= m - 1) ud += U_s[__ffs((int)m) - 1];
+				T t = VT<T>::zero();
+				if (sizeof(T) == 16) {
+					cplx* tc = (cplx*)&t;
+					const cplx* yy = (const cplx*)&yc;
+					tc->re = ud * yy->re;
+					tc->im = ud * yy->im;
+				} else {
+					*(double*)&t = ud * *(const double*)&yc;
+				}
+				acc = VT<T>::add(acc, t);
+				if (valid) {
+					const T xv = VT<T>::add(xold, acc);
+					xblk[iu] = xv;
+					if (DOT) dot += VT<T>::dot_re(yc, xv);
+				}
+			}
+			row0 = row0n;
+			base = basen;
+			cbase = cbasen;
+			nvalid = nvalidn;
+			len = lenn;
+		}
+	}
+	if (DOT) {
+		const double r = block_sum_n<kWinThreads / 64>(dot, smem);
+		if (threadIdx.x == 0) a.partial[blockIdx.x] = r;
+	}
+}
+
+// basis words of one species: word(i) = i-th L-bit word with n set bits, ascending
+static __global__ void k_basis_words(const uint64_t* __restrict__ comb, int combdim, int64_t count, int nbits, int L,
+                                     uint32_t* __restrict__ out)
+{
+	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= count) return;
+	uint64_t w = 0;
+	int64_t r = i;
+	int k = nbits;
+	for (int b = L - 1; b >= 0 && k > 0; b--) {
+		const int64_t c = (int64_t)comb[b * combdim + k];
+		if (r >= c) {
+			w |= 1ull << b;
+			r -= c;
+			k--;
+		}
+	}
+	out[i] = (uint32_t)w;
+}
+
+} // namespace lpp

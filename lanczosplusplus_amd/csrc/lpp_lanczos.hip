@@ -135,7 +135,16 @@ lpp_status one_step(lpp_engine* e, const double* ritz, int nst)
 		for (int k = 0; k < nst; k++)
 			k_axpy_const<<<nb, kBlock, 0, st>>>((double2*)(e->zwork + (int64_t)k * e->nd_pad), (const double2*)ycur, ritz[k], e->n2);
 	}
-	if (multi(e)) {
+	if (e->kron.active) {
+		// matrix-free product: the down part needs the whole vector, so the gather completes first
+		if (multi(e)) {
+			if (e->comm.allgather_begin(e->comm.ctx) != 0) return fail(LPP_ERR_COMM, "allgather_begin callback failed");
+			if (e->comm.allgather_end(e->comm.ctx) != 0) return fail(LPP_ERR_COMM, "allgather_end callback failed");
+		}
+		SpmvTimer t(e);
+		np = kron_launch(e, ycur, multi(e) ? e->comm.gath_buf : ycur, e->x, e->partial);
+		t.stop();
+	} else if (multi(e)) {
 		// the slice of y_j was written to comm.send_buf by the previous k_swap_scale / k_scale_copy
 		if (e->comm.allgather_begin(e->comm.ctx) != 0) return fail(LPP_ERR_COMM, "allgather_begin callback failed");
 		{
@@ -225,7 +234,7 @@ lpp_status ensure_krylov(lpp_engine* e, int ncols, bool required, bool* got)
 
 lpp_status begin_run(lpp_engine* e, const void* init, bool want_save)
 {
-	if (!e->A_loc.rowptr) return fail(LPP_ERR_STATE, "no matrix: call lpp_engine_set_csr / lpp_engine_assemble_* first");
+	if (!e->has_matrix()) return fail(LPP_ERR_STATE, "no matrix: call lpp_engine_set_csr / lpp_engine_assemble_* first");
 	HIP_TRY(hipSetDevice(e->cfg.device));
 	if (e->n_global <= 0) return fail(LPP_ERR_INVALID, "empty matrix");
 	const int maxs = effective_max_steps(e);

@@ -98,6 +98,17 @@ class LanczosEngine:
         cs = C.byref(comm.struct) if comm is not None else None
         check(self._lib.lpp_engine_assemble_hubbard(self._h, cs, L, nup, ndown, _vp(hr), _vp(hi), _vp(U), _vp(V)))
 
+    def setup_hubbard_onthefly(self, L, nup, ndown, hop, U, V=None, comm=None):
+        """Matrix-free Hubbard product (InternalProductOnTheFly semantics): nothing but H_up and H_down is stored."""
+        hop = np.asarray(hop).reshape(L, L)
+        hr = _mat(hop.real, L)
+        hi = _mat(hop.imag, L) if np.iscomplexobj(hop) else None
+        U = np.ascontiguousarray(U, np.float64)
+        V = np.zeros(L) if V is None else np.ascontiguousarray(np.asarray(V, np.float64)[:L])
+        self._comm_keepalive = comm
+        cs = C.byref(comm.struct) if comm is not None else None
+        check(self._lib.lpp_engine_setup_hubbard_onthefly(self._h, cs, L, nup, ndown, _vp(hr), _vp(hi), _vp(U), _vp(V)))
+
     def assemble_heisenberg(self, L, szPlusConst, jpm, jzz, field=None):
         f = None if field is None else np.ascontiguousarray(field, np.float64)
         check(self._lib.lpp_engine_assemble_heisenberg(self._h, L, szPlusConst, _vp(_mat(jpm, L)), _vp(_mat(jzz, L)),

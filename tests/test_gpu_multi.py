@@ -67,6 +67,10 @@ def _worker(rank, world, port, q):
             out["resid"] = float(np.linalg.norm(r))
             a, b, _ = e.decomposition()
             out["a"], out["b"] = a, b
+            # matrix-free engine on the same partition
+            e.setup_hubbard_onthefly(L, nup, ndown, hop, U, comm=comm)
+            ek, _, stk = e.lanczos(1, want_vectors=False)
+            out["e_kron"], out["steps_kron"] = float(ek[0]), stk["steps"]
             e.close()
         eo, _, so = oracle.lanczos_solve(A, oracle.fill_random(A.nrows, 1234), want_vectors=False)
         out["e_hub_oracle"], out["steps_oracle"] = float(eo[0]), so
@@ -112,6 +116,7 @@ def test_two_ranks_share_one_gpu_over_gloo():
         assert abs(o["e_hub"] - o["e_hub_oracle"]) <= 1e-10 * abs(o["e_hub_oracle"])
         assert o["steps_hub"] == o["steps_oracle"]
         assert o["resid"] < 1e-5
+        assert abs(o["e_kron"] - o["e_hub_oracle"]) <= 1e-10 * abs(o["e_hub_oracle"]) and o["steps_kron"] == o["steps_oracle"]
         assert abs(o["e_tj"][0] - o["e_tj_dense"][0]) <= 1e-10 * abs(o["e_tj_dense"][0])
         assert abs(o["e_tj"][1] - o["e_tj_dense"][1]) <= 1e-8
     assert np.array_equal(res[0]["a"], res[1]["a"]) and np.array_equal(res[0]["b"], res[1]["b"])

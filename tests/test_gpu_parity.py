@@ -234,3 +234,50 @@ def test_input0_free_fermions():
         assert e.rows() == 36
         eg, _, _ = e.lanczos(1)
         assert abs(eg[0] + 2 * np.sqrt(5)) < 1e-12
+
+
+@pytest.mark.parametrize("case", ["chain_real", "square_complex", "tiny", "no_window"])
+def test_matrix_free_hubbard_matches_stored_and_otf(case, monkeypatch):
+    """N1: the on-the-fly (Kronecker) product equals the stored product and the oracle's restatement of
+    HubbardHelper::matrixVectorProduct; the Lanczos solve on it matches the oracle energy to 1e-10."""
+    if case == "chain_real":
+        L, nup, ndown = 10, 5, 4
+        hop, U, V = chain(L, -1.0, True), np.linspace(2.0, 5.0, L), np.linspace(-0.4, 0.4, 2 * L)
+    elif case == "square_complex":
+        L, nup, ndown = 8, 3, 4
+        hop = square(2, 4, -1.0, False).astype(complex)
+        hop[0, 1] *= np.exp(0.3j)
+        hop[1, 0] = np.conj(hop[0, 1])
+        U, V = np.full(L, 4.0), np.zeros(2 * L)
+    elif case == "tiny":
+        L, nup, ndown = 4, 2, 2
+        hop, U, V = chain(L, -1.0), np.zeros(L), np.zeros(2 * L)
+    else:
+        monkeypatch.setenv("LPP_KRON_NO_WINDOW", "1")
+        L, nup, ndown = 9, 4, 4
+        hop, U, V = chain(L, -1.0, True), np.full(L, 3.0), np.linspace(0, 0.3, 2 * L)
+    A = oracle.hubbard_csr(L, nup, ndown, hop, U, V)
+    dt = "c128" if A.is_complex else "f64"
+    x0 = oracle.fill_random(A.nrows, 7, A.is_complex)
+    y = oracle.fill_random(A.nrows, 8, A.is_complex)
+    xo = oracle.spmv_acc(A, x0.copy(), y)
+    with LanczosEngine(dtype=dt) as e:
+        e.setup_hubbard_onthefly(L, nup, ndown, hop, U, V)
+        assert e.rows() == A.nrows
+        xg = e.matrixVectorProduct(x0.copy(), y)
+        assert rel(xg, xo) < SPMV_TOL
+        if not A.is_complex:
+            xf = x0.copy()
+            oracle.hubbard_otf_mvp(L, nup, ndown, hop, U, V, xf, y, 0, 0, 2)
+            assert rel(xg, xf) < SPMV_TOL
+        with pytest.raises(LppError):
+            e.get_csr()
+        eo, _, so = oracle.lanczos_solve(A, oracle.fill_random(A.nrows, 1234, A.is_complex), want_vectors=False)
+        eg, zg, st = e.lanczos(1, want_vectors=True)
+        assert abs(eg[0] - eo[0]) <= E_TOL * abs(eo[0])
+        assert st["steps"] == so
+        r = oracle.spmv_acc(A, np.zeros_like(zg[0]), zg[0]) - eg[0] * zg[0]
+        assert np.linalg.norm(r) < 1e-5
+        assert st["nnz"] == A.nnz  # the equivalent stored CSR has exactly the oracle's entries
+    if case == "tiny":
+        assert abs(eg[0] + 2 * np.sqrt(5)) < 1e-12
