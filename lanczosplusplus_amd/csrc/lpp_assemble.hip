@@ -77,7 +77,9 @@ template <int MODEL, typename T>
 lpp_status run_assembly(lpp_engine* e, AsmParams P, DevCsr& A, int force_mode = 0, int64_t force_block = 0)
 {
 	hipStream_t st = e->stream;
+	const int64_t keep_src = A.src_elems;
 	free_csr(A);
+	A.src_elems = keep_src;
 	A.hint_block = (MODEL == ASM_HUBBARD && P.part != 2) ? P.n_up : 0; // Hubbard product basis: one down configuration per block
 	A.nrows = P.nloc;
 	A.owned = true;
@@ -245,6 +247,7 @@ lpp_status lpp_engine_assemble_hubbard(lpp_engine* e, const lpp_comm* comm, int3
 		st = dispatch<ASM_HUBBARD>(e, P, e->A_loc);
 		if (st != LPP_OK) return st;
 		P.part = 2;
+		e->A_rem.src_elems = (int64_t)comm->nranks * comm->shard_stride;
 		st = dispatch<ASM_HUBBARD>(e, P, e->A_rem);
 		if (st != LPP_OK) return st;
 		e->n_local = P.nloc;
@@ -399,6 +402,93 @@ lpp_status lpp_engine_assemble_tj(lpp_engine* e, int32_t L, int32_t nup, int32_t
 }
 
 
+} // extern "C"
+
+namespace {
+// H_up on the device in the layout the product kernel wants: packed (col16|code|code) when it qualifies,
+// otherwise the generic sliced layout.
+template <typename T> lpp_status build_kron_up(lpp_engine* e, int64_t n_up)
+{
+	KronState& K = e->kron;
+	DevCsr& A = K.up;
+	const int ncomp = (int)(sizeof(T) / sizeof(double));
+	bool packed_ok = n_up <= 65536 && getenv("LPP_KRON_NO_PACK") == nullptr;
+	std::vector<int64_t> rp;
+	std::vector<int32_t> ci;
+	std::vector<double> va;
+	std::vector<double> dict;
+	if (packed_ok) {
+		rp.resize(n_up + 1);
+		ci.resize(std::max<int64_t>(A.nnz, 1));
+		va.resize((size_t)std::max<int64_t>(A.nnz, 1) * ncomp);
+		HIP_TRY(hipMemcpy(rp.data(), A.rowptr, sizeof(int64_t) * (size_t)(n_up + 1), hipMemcpyDeviceToHost));
+		if (A.nnz) {
+			HIP_TRY(hipMemcpy(ci.data(), A.col, sizeof(int32_t) * (size_t)A.nnz, hipMemcpyDeviceToHost));
+			HIP_TRY(hipMemcpy(va.data(), A.val, sizeof(T) * (size_t)A.nnz, hipMemcpyDeviceToHost));
+		}
+		dict.push_back(0.0);
+		for (size_t k = 0; k < (size_t)A.nnz * ncomp && dict.size() <= 256; k++) {
+			bool found = false;
+			for (double d : dict)
+				if (std::memcmp(&d, &va[k], sizeof(double)) == 0) {
+					found = true;
+					break;
+				}
+			if (!found) dict.push_back(va[k]);
+		}
+		if (dict.size() > 256) packed_ok = false;
+	}
+	if (!packed_ok) {
+		K.packed = false;
+		return finalize_csr(e, A, true, LPP_SPMV_SLICED, n_up);
+	}
+	auto code_of = [&](double v) -> uint32_t {
+		for (size_t i = 0; i < dict.size(); i++)
+			if (std::memcmp(&dict[i], &v, sizeof(double)) == 0) return (uint32_t)i;
+		return 0;
+	};
+	const int spb = (int)((n_up + 63) / 64);
+	std::vector<int32_t> off(spb + 1, 0), len(spb, 0);
+	for (int s = 0; s < spb; s++) {
+		int64_t mx = 0;
+		for (int64_t r = (int64_t)s * 64; r < std::min<int64_t>(n_up, (int64_t)(s + 1) * 64); r++) mx = std::max(mx, rp[r + 1] - rp[r]);
+		len[s] = (int32_t)((mx + 7) / 8 * 8);
+		off[s + 1] = off[s] + len[s] * 64;
+	}
+	std::vector<uint32_t> words((size_t)off[spb] + 64, 0);
+	for (int s = 0; s < spb; s++) {
+		for (int lane = 0; lane < 64; lane++) {
+			const int64_t r = std::min<int64_t>((int64_t)s * 64 + lane, n_up - 1);
+			const bool valid = (int64_t)s * 64 + lane < n_up;
+			const int64_t l = valid ? rp[r + 1] - rp[r] : 0;
+			for (int k = 0; k < len[s]; k++) {
+				uint32_t w = (uint32_t)r; // padding: own column, value 0.0 (code 0)
+				if (k < l) {
+					const int64_t p = rp[r] + k;
+					w = (uint32_t)ci[p] | (code_of(va[(size_t)p * ncomp]) << 16);
+					if (ncomp == 2) w |= code_of(va[(size_t)p * 2 + 1]) << 24;
+				}
+				words[(size_t)off[s] + (size_t)k * 64 + lane] = w;
+			}
+		}
+	}
+	dict.resize(256, 0.0);
+	HIP_TRY_MEM(hipMalloc(&K.pk_words, sizeof(uint32_t) * words.size()));
+	HIP_TRY_MEM(hipMalloc(&K.pk_off, sizeof(int32_t) * off.size()));
+	HIP_TRY_MEM(hipMalloc(&K.pk_len, sizeof(int32_t) * std::max<size_t>(len.size(), 1)));
+	HIP_TRY_MEM(hipMalloc(&K.pk_dict, sizeof(double) * 256));
+	HIP_TRY(hipMemcpy(K.pk_words, words.data(), sizeof(uint32_t) * words.size(), hipMemcpyHostToDevice));
+	HIP_TRY(hipMemcpy(K.pk_off, off.data(), sizeof(int32_t) * off.size(), hipMemcpyHostToDevice));
+	HIP_TRY(hipMemcpy(K.pk_len, len.data(), sizeof(int32_t) * len.size(), hipMemcpyHostToDevice));
+	HIP_TRY(hipMemcpy(K.pk_dict, dict.data(), sizeof(double) * 256, hipMemcpyHostToDevice));
+	K.pk_spb = spb;
+	K.packed = true;
+	return LPP_OK;
+}
+} // namespace
+
+extern "C" {
+
 lpp_status lpp_engine_setup_hubbard_onthefly(lpp_engine* e, const lpp_comm* comm, int32_t L, int32_t nup, int32_t ndown,
                                              const double* hop_re, const double* hop_im, const double* U, const double* V)
 {
@@ -461,7 +551,7 @@ lpp_status lpp_engine_setup_hubbard_onthefly(lpp_engine* e, const lpp_comm* comm
 	P.nup = nup;
 	P.n_up = n_up;
 	P.nrows_global = P.nloc = n_up;
-	st = dispatch<ASM_HUBBARD>(e, P, K.up, LPP_SPMV_SLICED, n_up); // sliced, one block
+	st = dispatch<ASM_HUBBARD>(e, P, K.up, LPP_SPMV_ROWGROUP, 0); // plain CSR first; packed or sliced below
 	if (st != LPP_OK) return st;
 	P.nup = ndown;
 	P.n_up = n_dn;
@@ -469,6 +559,8 @@ lpp_status lpp_engine_setup_hubbard_onthefly(lpp_engine* e, const lpp_comm* comm
 	st = dispatch<ASM_HUBBARD>(e, P, K.dn, LPP_SPMV_ROWGROUP, 0); // plain CSR
 	if (st != LPP_OK) return st;
 	K.up.hint_block = K.dn.hint_block = 0;
+	st = e->is_complex ? build_kron_up<cplx>(e, n_up) : build_kron_up<double>(e, n_up);
+	if (st != LPP_OK) return st;
 
 	HIP_TRY_MEM(hipMalloc(&K.up_words, sizeof(uint32_t) * (size_t)n_up));
 	HIP_TRY_MEM(hipMalloc(&K.dn_words, sizeof(uint32_t) * (size_t)n_dn));
@@ -512,6 +604,10 @@ void free_kron(lpp_engine* e)
 	if (K.up_words) (void)hipFree(K.up_words);
 	if (K.dn_words) (void)hipFree(K.dn_words);
 	if (K.U) (void)hipFree(K.U);
+	if (K.pk_words) (void)hipFree(K.pk_words);
+	if (K.pk_off) (void)hipFree(K.pk_off);
+	if (K.pk_len) (void)hipFree(K.pk_len);
+	if (K.pk_dict) (void)hipFree(K.pk_dict);
 	K = KronState();
 }
 
@@ -519,6 +615,45 @@ template <typename T> static int kron_launch_t(lpp_engine* e, const void* ywin, 
 {
 	KronState& K = e->kron;
 	if (K.nid == 0) return 0;
+	if (K.packed) {
+		KronPackedArgs<T> pa;
+		pa.words = K.pk_words;
+		pa.slice_off = K.pk_off;
+		pa.slice_len = K.pk_len;
+		pa.dict = K.pk_dict;
+		pa.spb = K.pk_spb;
+		pa.n_up = K.n_up;
+		pa.id0 = K.id0;
+		pa.nid = K.nid;
+		pa.dn_rowptr = K.dn.rowptr;
+		pa.dn_col = K.dn.col;
+		pa.dn_val = (const T*)K.dn.val;
+		pa.up_words = K.up_words;
+		pa.dn_words = K.dn_words;
+		pa.U = K.U;
+		pa.L = K.L;
+		pa.ywin = (const T*)ywin;
+		pa.ydown = (const T*)ydown;
+		pa.x = (T*)x;
+		pa.partial = partial;
+		pa.xcd_map = (e->k2_variant >> 1) & 1;
+		const size_t ldsb = K.window ? sizeof(T) * (size_t)std::max<int64_t>(K.n_up, 64) : 64;
+		const int pcu = std::max(1, std::min(2, (int)((160 * 1024 - 8192) / (ldsb + 1))));
+		int nbp = (int)std::max<int64_t>(1, std::min<int64_t>(K.nid, (int64_t)e->num_cus * pcu));
+		if (nbp >= 8) nbp &= ~7;
+		const bool dotp = partial != nullptr;
+#define LPP_KP(DOT_, WIN_)                                                                                            \
+	do {                                                                                                              \
+		(void)hipFuncSetAttribute((const void*)k_spmv_kron_packed<T, DOT_, WIN_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb); \
+		k_spmv_kron_packed<T, DOT_, WIN_><<<nbp, kWinThreads, ldsb, e->stream>>>(pa);                                   \
+	} while (0)
+		if (dotp && K.window) LPP_KP(true, true);
+		else if (dotp) LPP_KP(true, false);
+		else if (K.window) LPP_KP(false, true);
+		else LPP_KP(false, false);
+#undef LPP_KP
+		return dotp ? nbp : 0;
+	}
 	KronArgs<T> a;
 	a.up.g = K.up.geom;
 	a.up.slice_ptr = K.up.slice_ptr;

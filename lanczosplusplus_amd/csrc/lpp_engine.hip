@@ -183,9 +183,10 @@ template <typename T> static lpp_status try_build_dict(lpp_engine* e, DevCsr& A,
 	(void)hipFree(overflow);
 	if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) return fail(LPP_ERR_HIP, "dictionary collection failed");
 	std::vector<unsigned long long> keys;
+	keys.push_back(0ull); // code 0 is reserved for +0.0: padded / inactive slots decode to an exact zero
 	for (unsigned long long k : host)
-		if (k != kDictEmpty) keys.push_back(k);
-	if (ov || keys.empty() || keys.size() > 256) return LPP_OK;
+		if (k != kDictEmpty && k != 0ull) keys.push_back(k);
+	if (ov || keys.size() > 256) return LPP_OK;
 	std::sort(keys.begin(), keys.end());
 	std::vector<double> dict(256);
 	for (size_t i = 0; i < 256; i++) {
@@ -272,6 +273,9 @@ lpp_status finalize_csr(lpp_engine* e, DevCsr& A, bool allow_drop_plain, int for
 	int mode = e->cfg.spmv_kernel;
 	if (const char* s = getenv("LPP_SPMV_KERNEL")) mode = atoi(s);
 	if (force_mode) mode = force_mode;
+	// the sliced kernels address the source vector with 32-bit byte offsets
+	const size_t src_elems = (size_t)std::max<int64_t>(A.src_elems, A.nrows);
+	const bool fits32 = src_elems * e->esz < ((size_t)1 << 32);
 	const int64_t lds_cap_elems = (int64_t)((156 * 1024) / e->esz);
 	int64_t win_rows = 0;
 	if (A.hint_block > 0 && A.hint_block <= lds_cap_elems) {
@@ -295,6 +299,7 @@ lpp_status finalize_csr(lpp_engine* e, DevCsr& A, bool allow_drop_plain, int for
 	}
 	if (!force_mode)
 		if (const char* s = getenv("LPP_WINDOW_ROWS")) win_rows = std::max<int64_t>(64, std::min<int64_t>(atoll(s), lds_cap_elems));
+	if (!fits32 && (mode == LPP_SPMV_AUTO || mode == LPP_SPMV_SLICED || mode == LPP_SPMV_WINDOW)) mode = LPP_SPMV_ROWGROUP;
 	if ((mode == LPP_SPMV_SLICED || mode == LPP_SPMV_WINDOW) && A.nrows > 0) {
 		const int64_t B = force_block > 0 ? force_block : ((mode == LPP_SPMV_WINDOW) ? win_rows : A.nrows);
 		lpp_status st = e->is_complex ? build_sliced_t<cplx>(e, A, B) : build_sliced_t<double>(e, A, B);
@@ -421,7 +426,9 @@ lpp_status lpp_engine_destroy(lpp_engine* e)
 
 static lpp_status upload_csr(lpp_engine* e, DevCsr& A, int64_t nrows, const int64_t* rowptr, const int32_t* colind, const void* values)
 {
+	const int64_t keep_src = A.src_elems;
 	free_csr(A);
+	A.src_elems = keep_src;
 	A.nrows = nrows;
 	A.nnz = rowptr ? rowptr[nrows] : 0;
 	A.owned = true;
@@ -494,6 +501,7 @@ lpp_status lpp_engine_set_csr_partition(lpp_engine* e, const lpp_comm* comm, int
 	free_kron(e);
 	st = upload_csr(e, e->A_loc, local, rpl.data(), cl.data(), vl.data());
 	if (st != LPP_OK) return st;
+	e->A_rem.src_elems = (int64_t)comm->nranks * comm->shard_stride;
 	st = upload_csr(e, e->A_rem, local, rpr.data(), cr.data(), vr.data());
 	if (st != LPP_OK) return st;
 	e->n_local = local;

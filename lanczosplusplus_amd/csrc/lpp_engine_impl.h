@@ -37,6 +37,7 @@ struct DevCsr {
 	bool sliced = false;
 	bool window = false; // LDS-window kernel (K3)
 	int64_t hint_block = 0; // natural row block of the basis (N_up), 0 = unknown
+	int64_t src_elems = 0; // length of the vector the columns index (0 = nrows)
 	SliceGeom geom {};
 	int64_t* slice_ptr = nullptr;
 	int32_t* row_len = nullptr;
@@ -61,6 +62,12 @@ struct KronState {
 	int64_t n_up = 0, n_dn = 0, id0 = 0, nid = 0;
 	bool window = false;
 	double equiv_nnz = 0; // nnz of the stored CSR this product stands for
+	// packed H_up (col16 | code8 | code8), see lpp_kron_kernels.h
+	bool packed = false;
+	uint32_t* pk_words = nullptr;
+	int32_t *pk_off = nullptr, *pk_len = nullptr;
+	double* pk_dict = nullptr;
+	int pk_spb = 0;
 };
 
 } // namespace lpp

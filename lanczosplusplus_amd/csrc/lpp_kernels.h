@@ -231,9 +231,26 @@ template <> struct CodeTraits<cplx> {
 	}
 };
 
+// 32-bit-offset load relative to a wave-uniform base pointer: lets hipcc use the scalar-base addressing
+// form instead of building a 64-bit vector address per load
+template <typename V> __device__ __forceinline__ V ld_off32(const V* base, uint32_t index)
+{
+	return *(const V*)((const char*)base + (size_t)(index * (uint32_t)sizeof(V)));
+}
+
+__device__ __forceinline__ uint32_t lane_prefix(unsigned long long m)
+{ // number of set bits of m below this lane (v_mbcnt_lo + v_mbcnt_hi)
+	return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
 // Accumulate one slice with one wave: returns sum_k val_k * src[col_k] of this lane's row.
 // (len, base, cbase) = this lane's row length, the slice's first entry and first code word, prefetched by
 // the caller; `safe` is a valid source index used by lanes whose gather is served from the LDS window.
+// Gathers use 32-bit byte offsets (the engine only selects these kernels for vectors < 4 GiB).
+// Per-entry instruction count matters here (measured: ~31 VALU instructions per entry made the kernel
+// issue-bound for 25-50 % of its time): mbcnt for the lane prefix, scalar base pointers, wave-uniform
+// skips of the global gather when a whole slot is inside the window (and of the LDS read when none is),
+// and -- coded layout -- no select at all: inactive lanes decode code 0 == +0.0.
 template <typename T, bool WINDOW, bool CODED, int U>
 __device__ __forceinline__ T sliced_accumulate(const SlicedArgs<T>& a, int len, int64_t base, int64_t cbase, const T* lds,
                                                int32_t r0, uint32_t wlen, const double* dict, int32_t safe)
@@ -241,11 +258,18 @@ __device__ __forceinline__ T sliced_accumulate(const SlicedArgs<T>& a, int len, 
 	constexpr int SPW = CodeTraits<T>::kSlotsPerWord;
 	constexpr int NW = (U + SPW - 1) / SPW; // code words per batch
 	const int lane = threadIdx.x & 63;
-	const unsigned long long lt_mask = (1ull << lane) - 1ull;
 	int maxlen = len;
 #pragma unroll
 	for (int off = 32; off > 0; off >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, off, 64));
 	const int nb = (maxlen + U - 1) / U;
+	// base / cbase are the same in every lane: move them to SGPRs so that every stream address is
+	// (scalar base pointer + 32-bit lane offset) instead of 64-bit vector arithmetic per load
+	const int64_t base_u = ((int64_t)__builtin_amdgcn_readfirstlane((int)(base >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+	const int64_t cbase_u = ((int64_t)__builtin_amdgcn_readfirstlane((int)(cbase >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)cbase);
+	const int32_t* colp = a.col + base_u;
+	const T* valp = CODED ? nullptr : a.val + base_u;
+	const uint32_t* codep = CODED ? a.codes + cbase_u : nullptr;
+	uint32_t run = 0; // entries of this slice consumed so far (wave-uniform)
 	T acc = VT<T>::zero();
 	int32_t c0[U], c1[U];
 	T v0[CODED ? 1 : U], v1[CODED ? 1 : U];
@@ -255,13 +279,16 @@ __device__ __forceinline__ T sliced_accumulate(const SlicedArgs<T>& a, int len, 
 	{                                                                                                                 \
 		const bool on_ = len > (K0) + u;                                                                              \
 		const unsigned long long m_ = __ballot(on_);                                                                  \
-		const int64_t p_ = base + (on_ ? __popcll(m_ & lt_mask) : 0);                                                 \
-		C[u] = a.col[p_];                                                                                             \
-		if (!CODED) V[u] = a.val[p_];                                                                                 \
-		base += __popcll(m_);                                                                                         \
+		const uint32_t p_ = run + (on_ ? lane_prefix(m_) : 0u);                                                       \
+		C[u] = ld_off32(colp, p_);                                                                                    \
+		if (!CODED) {                                                                                                 \
+			const T t_ = ld_off32(valp, p_);                                                                          \
+			V[u] = on_ ? t_ : VT<T>::zero();                                                                          \
+		}                                                                                                             \
+		run += (uint32_t)__popcll(m_);                                                                                \
 	}                                                                                                                 \
 	if (CODED) {                                                                                                      \
-		_Pragma("unroll") for (int q = 0; q < NW; q++) W[q] = a.codes[cbase + ((int64_t)((K0) / SPW + q) << 6) + lane]; \
+		_Pragma("unroll") for (int q = 0; q < NW; q++) W[q] = ld_off32(codep, (uint32_t)(((K0) / SPW + q) << 6) + (uint32_t)lane); \
 	}
 	if (nb > 0) { LPP_LOAD_BATCH(0, c0, v0, w0) }
 	for (int b = 0; b < nb; b++) {
@@ -271,24 +298,21 @@ __device__ __forceinline__ T sliced_accumulate(const SlicedArgs<T>& a, int len, 
 			if (WINDOW) {
 				const uint32_t d = (uint32_t)(c0[u] - r0);
 				const bool inw = d < wlen;
-				const T gl = lds[inw ? d : (uint32_t)lane];
-				const T gg = a.src[inw ? safe : c0[u]];
+				const unsigned long long min_ = __ballot(inw);
+				T gl = VT<T>::zero(), gg = VT<T>::zero();
+				if (min_ != 0ull) gl = lds[inw ? d : (uint32_t)lane]; // wave-uniform branches
+				if (min_ != ~0ull) gg = ld_off32(a.src, (uint32_t)(inw ? safe : c0[u]));
 				g[u] = inw ? gl : gg;
 			} else {
-				g[u] = a.src[c0[u]];
+				g[u] = ld_off32(a.src, (uint32_t)c0[u]);
 			}
 		}
 		if (b + 1 < nb) { LPP_LOAD_BATCH((b + 1) * U, c1, v1, w1) }
 #pragma unroll
 		for (int u = 0; u < U; u++) {
-			T vv;
-			if (CODED)
-				vv = CodeTraits<T>::decode(w0[u / SPW], u % SPW, dict);
-			else
-				vv = v0[u];
-			T t = VT<T>::zero();
-			VT<T>::mac(t, vv, g[u]);
-			acc = VT<T>::add(acc, (len > b * U + u) ? t : VT<T>::zero());
+			// inactive lanes carry a zero value (plain: selected at load; coded: code 0 decodes to +0.0)
+			const T vv = CODED ? CodeTraits<T>::decode(w0[u / SPW], u % SPW, dict) : v0[u];
+			VT<T>::mac(acc, vv, g[u]);
 		}
 #pragma unroll
 		for (int u = 0; u < U; u++) c0[u] = c1[u];
@@ -393,6 +417,14 @@ __global__ __launch_bounds__(kBlock) void k_spmv_sliced(SlicedArgs<T> a)
 	}
 }
 
+// one lane takes the next slice index from the workgroup's LDS counter and broadcasts it to its wave
+__device__ __forceinline__ int next_slice_claim(int* counter)
+{
+	int v = 0;
+	if ((threadIdx.x & 63) == 0) v = atomicAdd(counter, 1);
+	return __builtin_amdgcn_readfirstlane(v);
+}
+
 // K3: LDS window.  One 1024-thread workgroup per CU walks row blocks; dynamic LDS = B elements.
 constexpr int kWinThreads = 1024;
 template <typename T, bool DOT, bool CODED, int U>
@@ -402,8 +434,8 @@ __global__ __launch_bounds__(kWinThreads) void k_spmv_window(SlicedArgs<T> a)
 	T* lds = (T*)lds_raw;
 	__shared__ double smem[kWinThreads / 64];
 	__shared__ double dict_s[CODED ? 256 : 1];
+	__shared__ int next_slice;
 	load_dict<CODED>(dict_s, a.dict);
-	const int wave = threadIdx.x >> 6;
 	int64_t b_begin, b_end, b_stride;
 	if (a.xcd_map && (gridDim.x & 7) == 0) {
 		const int64_t chunk = (a.g.nblocks + 7) / 8;
@@ -421,6 +453,7 @@ __global__ __launch_bounds__(kWinThreads) void k_spmv_window(SlicedArgs<T> a)
 		const int64_t r0 = blk * a.g.B;
 		const int64_t wl = min(a.g.B, a.g.nrows - r0);
 		__syncthreads(); // everyone is done reading the previous window
+		if (threadIdx.x == 0) next_slice = 0;
 		// stage the window: 8 independent loads per thread in flight (a load-wait-store loop exposed
 		// one HBM round trip per element and kept all 16 waves idle for ~25 us per block)
 		for (int64_t i0 = threadIdx.x; i0 < wl; i0 += 8 * kWinThreads) {
@@ -432,19 +465,24 @@ __global__ __launch_bounds__(kWinThreads) void k_spmv_window(SlicedArgs<T> a)
 				if (i0 + (int64_t)q * kWinThreads < wl) lds[i0 + (int64_t)q * kWinThreads] = t[q];
 		}
 		__syncthreads();
+		// slices are handed out dynamically (LDS counter): with 201 slices on 16 waves a static split leaves
+		// the waves that got 12 instead of 13 slices idle at the block's closing barrier (~8 % of the time)
 		int64_t row0 = 0, base = 0, cbase = 0;
 		int nvalid = 0, len = 0;
-		if (wave < a.g.spb) slice_meta<T, CODED>(a, blk * a.g.spb + wave, row0, nvalid, len, base, cbase);
-		for (int j = wave; j < a.g.spb; j += kWinThreads / 64) {
+		int j = next_slice_claim(&next_slice);
+		if (j < a.g.spb) slice_meta<T, CODED>(a, blk * a.g.spb + j, row0, nvalid, len, base, cbase);
+		while (j < a.g.spb) {
+			const int jn = next_slice_claim(&next_slice);
 			int64_t row0n = 0, basen = 0, cbasen = 0;
 			int nvalidn = 0, lenn = 0;
-			if (j + kWinThreads / 64 < a.g.spb) slice_meta<T, CODED>(a, blk * a.g.spb + j + kWinThreads / 64, row0n, nvalidn, lenn, basen, cbasen);
+			if (jn < a.g.spb) slice_meta<T, CODED>(a, blk * a.g.spb + jn, row0n, nvalidn, lenn, basen, cbasen);
 			dot += sliced_one<T, DOT, true, CODED, U>(a, row0, nvalid, len, base, cbase, lds, (int32_t)r0, (uint32_t)wl, dict_s);
 			row0 = row0n;
 			base = basen;
 			cbase = cbasen;
 			nvalid = nvalidn;
 			len = lenn;
+			j = jn;
 		}
 	}
 	if (DOT) {
@@ -468,7 +506,7 @@ static __global__ void k_slice_meta(SliceGeom g, const int64_t* __restrict__ row
 		if (words) {
 			int64_t mx = 0;
 			for (int r = 0; r < nvalid; r++) mx = max(mx, rowptr[row0 + r + 1] - rowptr[row0 + r]);
-			words[i] = 64 * ((mx + spw - 1) / spw);
+			words[i] = 64 * ((mx + 7) / 8) * (8 / spw); // padded to whole batches of 8 slots: trailing codes are 0
 		}
 	}
 	if (i == g.nslices) {
@@ -595,7 +633,7 @@ __global__ __launch_bounds__(kBlock) void k_slice_codes(SliceGeom g, const int64
 		int maxlen = len;
 #pragma unroll
 		for (int off = 32; off > 0; off >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, off, 64));
-		const int nwords = (maxlen + SPW - 1) / SPW;
+		const int nwords = ((maxlen + 7) / 8) * (8 / SPW);
 		const int64_t cbase = code_ptr[s];
 		for (int w = 0; w < nwords; w++) {
 			uint32_t word = 0;

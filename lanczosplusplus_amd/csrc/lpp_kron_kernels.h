@@ -86,9 +86,10 @@ __global__ __launch_bounds__(kWinThreads) void k_spmv_kron(KronArgs<T> a)
 					if (i0 + (int64_t)q * kWinThreads < a.n_up) lds[i0 + (int64_t)q * kWinThreads] = t[q];
 			}
 		}
-		if ((int)threadIdx.x < min(ndn, kKronDownCap)) {
-			dcol_s[threadIdx.x] = a.dn_col[p0 + threadIdx.x];
-			dval_s[threadIdx.x] = a.dn_val[p0 + threadIdx.x];
+		if ((int)threadIdx.x < kKronDownCap) { // entries beyond the row are zero-valued and point at the own block
+			const bool in = (int)threadIdx.x < ndn;
+			dcol_s[threadIdx.x] = in ? a.dn_col[p0 + threadIdx.x] : (int32_t)gid;
+			dval_s[threadIdx.x] = in ? a.dn_val[p0 + threadIdx.x] : VT<T>::zero();
 		}
 		__syncthreads();
 		SlicedArgs<T> ua = a.up;
@@ -105,19 +106,27 @@ __global__ __launch_bounds__(kWinThreads) void k_spmv_kron(KronArgs<T> a)
 				const int64_t iu = row0 + (valid ? lane : 0);
 				const T xold = xblk[iu];
 				const uint32_t upw = a.up_words[iu];
-				// down part first: wave-uniform column, coalesced reads of y[jd*N_up + iu] (all independent)
+				// down part first: wave-uniform column, coalesced reads of y[jd*N_up + iu].  The cached H_down row is
+				// padded with zero-valued entries to a multiple of 8; groups of 8 loads are double-buffered so
+				// up to 16 independent 512-byte reads are in flight per wave.
 				T acc = VT<T>::zero();
-				const int ncached = min(ndn, kKronDownCap);
-				int p = 0;
-				for (; p + 4 <= ncached; p += 4) {
-					T g[4];
+				const int ngroups = (min(ndn, kKronDownCap) + 7) >> 3;
+				T g0[8], g1[8];
+				if (ngroups > 0) {
 #pragma unroll
-					for (int q = 0; q < 4; q++) g[q] = a.ydown[(int64_t)dcol_s[p + q] * a.n_up + iu];
-#pragma unroll
-					for (int q = 0; q < 4; q++) VT<T>::mac(acc, dval_s[p + q], g[q]);
+					for (int q = 0; q < 8; q++) g0[q] = a.ydown[(int64_t)dcol_s[q] * a.n_up + iu];
 				}
-				for (; p < ncached; p++) VT<T>::mac(acc, dval_s[p], a.ydown[(int64_t)dcol_s[p] * a.n_up + iu]);
-				for (p = ncached; p < ndn; p++) VT<T>::mac(acc, a.dn_val[p0 + p], a.ydown[(int64_t)a.dn_col[p0 + p] * a.n_up + iu]);
+				for (int gk = 0; gk < ngroups; gk++) {
+					if (gk + 1 < ngroups) {
+#pragma unroll
+						for (int q = 0; q < 8; q++) g1[q] = a.ydown[(int64_t)dcol_s[(gk + 1) * 8 + q] * a.n_up + iu];
+					}
+#pragma unroll
+					for (int q = 0; q < 8; q++) VT<T>::mac(acc, dval_s[gk * 8 + q], g0[q]);
+#pragma unroll
+					for (int q = 0; q < 8; q++) g0[q] = g1[q];
+				}
+				for (int p = kKronDownCap; p < ndn; p++) VT<T>::mac(acc, a.dn_val[p0 + p], a.ydown[(int64_t)a.dn_col[p0 + p] * a.n_up + iu]);
 				// up part: sliced H_up, gathers from the LDS window (or the L2-resident block)
 				const T accu = sliced_accumulate<T, WINDOW, CODED, U>(ua, len, base, cbase, lds, 0, (uint32_t)a.n_up, dict_s, (int32_t)iu);
 				acc = VT<T>::add(acc, accu);
@@ -146,6 +155,172 @@ __global__ __launch_bounds__(kWinThreads) void k_spmv_kron(KronArgs<T> a)
 			cbase = cbasen;
 			nvalid = nvalidn;
 			len = lenn;
+		}
+	}
+	if (DOT) {
+		const double r = block_sum_n<kWinThreads / 64>(dot, smem);
+		if (threadIdx.x == 0) a.partial[blockIdx.x] = r;
+	}
+}
+
+// ---------------------------------------------------------------------------------------------
+// Packed variant (the common case: N_up <= 65536 and <= 256 distinct matrix values).
+// H_up is tiny (a few hundred KB), so it is stored PADDED, slice-major [slice][slot][lane], one 32-bit
+// word per entry:  column (16 bit) | code_re (8 bit) << 16 | code_im (8 bit) << 24.  Padding entries carry
+// the code of 0.0 and the row's own column.  Per up-hop the inner loop is: one coalesced 4-byte load
+// (L2 hit), two LDS reads (dictionary, window) and an FMA -- no ballot/popcount compaction, no 64-bit
+// address arithmetic (measured: the compact sliced walk cost ~27 VALU instructions per entry).
+// The down part reads the block's H_down row from LDS as precomputed 64-bit element offsets jd*N_up.
+// ---------------------------------------------------------------------------------------------
+template <typename T> struct KronPackedArgs {
+	const uint32_t* words; // packed H_up
+	const int32_t* slice_off; // first word of slice j (in words), spb+1 entries
+	const int32_t* slice_len; // padded slots of slice j
+	const double* dict; // 256 doubles
+	int spb;
+	int64_t n_up;
+	int64_t id0, nid;
+	const int64_t* dn_rowptr;
+	const int32_t* dn_col;
+	const T* dn_val;
+	const uint32_t* up_words;
+	const uint32_t* dn_words;
+	const double* U;
+	int L;
+	const T* ywin;
+	const T* ydown;
+	T* x;
+	double* partial;
+	int xcd_map;
+};
+
+template <typename T> __device__ __forceinline__ T kron_decode(uint32_t w, const double* dict);
+template <> __device__ __forceinline__ double kron_decode<double>(uint32_t w, const double* dict) { return dict[(w >> 16) & 0xffu]; }
+template <> __device__ __forceinline__ cplx kron_decode<cplx>(uint32_t w, const double* dict)
+{
+	return cplx { dict[(w >> 16) & 0xffu], dict[w >> 24] };
+}
+
+template <typename T, bool DOT, bool WINDOW>
+__global__ __launch_bounds__(kWinThreads) void k_spmv_kron_packed(KronPackedArgs<T> a)
+{
+	extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+	T* lds = (T*)lds_raw;
+	__shared__ double smem[kWinThreads / 64];
+	__shared__ double dict_s[256];
+	__shared__ double U_s[32];
+	__shared__ long long doff_s[kKronDownCap]; // jd * N_up
+	__shared__ T dval_s[kKronDownCap];
+	__shared__ int next_slice;
+	for (int i = threadIdx.x; i < 256; i += kWinThreads) dict_s[i] = a.dict[i];
+	if (threadIdx.x < 32) U_s[threadIdx.x] = (int)threadIdx.x < a.L ? a.U[threadIdx.x] : 0.0;
+	const int lane = threadIdx.x & 63;
+	int64_t b_begin, b_end, b_stride;
+	if (a.xcd_map && (gridDim.x & 7) == 0) {
+		const int64_t chunk = (a.nid + 7) / 8;
+		const int xcd = blockIdx.x & 7;
+		b_begin = xcd * chunk + (blockIdx.x >> 3);
+		b_end = min((int64_t)(xcd + 1) * chunk, a.nid);
+		b_stride = gridDim.x >> 3;
+	} else {
+		b_begin = blockIdx.x;
+		b_end = a.nid;
+		b_stride = gridDim.x;
+	}
+	double dot = 0.0;
+	for (int64_t blk = b_begin; blk < b_end; blk += b_stride) {
+		const int64_t gid = a.id0 + blk;
+		const T* yblk = a.ywin + blk * a.n_up;
+		T* xblk = a.x + blk * a.n_up;
+		const int64_t p0 = a.dn_rowptr[gid];
+		const int ndn = (int)(a.dn_rowptr[gid + 1] - p0);
+		const uint32_t dnw = a.dn_words[gid];
+		__syncthreads(); // previous block fully consumed (window, H_down row)
+		if (threadIdx.x == 0) next_slice = 0;
+		if (WINDOW) {
+			for (int64_t i0 = threadIdx.x; i0 < a.n_up; i0 += 8 * kWinThreads) {
+				T t[8];
+#pragma unroll
+				for (int q = 0; q < 8; q++) t[q] = yblk[min(i0 + (int64_t)q * kWinThreads, a.n_up - 1)];
+#pragma unroll
+				for (int q = 0; q < 8; q++)
+					if (i0 + (int64_t)q * kWinThreads < a.n_up) lds[i0 + (int64_t)q * kWinThreads] = t[q];
+			}
+		}
+		if ((int)threadIdx.x < kKronDownCap) { // entries beyond the row are zero-valued and point at the own block
+			const bool in = (int)threadIdx.x < ndn;
+			doff_s[threadIdx.x] = (long long)(in ? a.dn_col[p0 + threadIdx.x] : (int32_t)gid) * a.n_up;
+			dval_s[threadIdx.x] = in ? a.dn_val[p0 + threadIdx.x] : VT<T>::zero();
+		}
+		__syncthreads();
+		const int ngroups = (min(ndn, kKronDownCap) + 7) >> 3;
+		// slices are claimed dynamically (see k_spmv_window)
+		for (int j = next_slice_claim(&next_slice); j < a.spb; j = next_slice_claim(&next_slice)) {
+			const int iu_raw = j * 64 + lane;
+			const bool valid = iu_raw < a.n_up;
+			const int iu = valid ? iu_raw : (int)a.n_up - 1;
+			const T xold = xblk[iu];
+			const uint32_t upw = a.up_words[iu];
+			const uint32_t* wp = a.words + a.slice_off[j] + lane;
+			const int ml = a.slice_len[j]; // multiple of 8
+			// first batch of H_up words and of down reads are requested together
+			uint32_t w0[8], w1[8];
+			if (ml > 0) {
+#pragma unroll
+				for (int q = 0; q < 8; q++) w0[q] = wp[q * 64];
+			}
+			T acc = VT<T>::zero();
+			T g0[8], g1[8];
+			const T* yd = a.ydown + iu;
+			if (ngroups > 0) {
+#pragma unroll
+				for (int q = 0; q < 8; q++) g0[q] = yd[doff_s[q]];
+			}
+			for (int gk = 0; gk < ngroups; gk++) {
+				if (gk + 1 < ngroups) {
+#pragma unroll
+					for (int q = 0; q < 8; q++) g1[q] = yd[doff_s[(gk + 1) * 8 + q]];
+				}
+#pragma unroll
+				for (int q = 0; q < 8; q++) VT<T>::mac(acc, dval_s[gk * 8 + q], g0[q]);
+#pragma unroll
+				for (int q = 0; q < 8; q++) g0[q] = g1[q];
+			}
+			for (int p = kKronDownCap; p < ndn; p++) VT<T>::mac(acc, a.dn_val[p0 + p], yd[(int64_t)a.dn_col[p0 + p] * a.n_up]);
+			// up part
+			for (int k = 0; k < ml; k += 8) {
+				if (k + 8 < ml) {
+#pragma unroll
+					for (int q = 0; q < 8; q++) w1[q] = wp[(k + 8 + q) * 64];
+				}
+#pragma unroll
+				for (int q = 0; q < 8; q++) {
+					const uint32_t c = w0[q] & 0xffffu;
+					const T g = WINDOW ? lds[c] : yblk[c];
+					VT<T>::mac(acc, kron_decode<T>(w0[q], dict_s), g);
+				}
+#pragma unroll
+				for (int q = 0; q < 8; q++) w0[q] = w1[q];
+			}
+			// Hubbard U on the doubly occupied sites
+			const T yc = WINDOW ? lds[iu] : yblk[iu];
+			double ud = 0.0;
+			for (uint32_t m = upw & dnw; m; m &= m - 1) ud += U_s[__ffs((int)m) - 1];
+			T t = VT<T>::zero();
+			if (sizeof(T) == 16) {
+				cplx* tc = (cplx*)&t;
+				const cplx* yy = (const cplx*)&yc;
+				tc->re = ud * yy->re;
+				tc->im = ud * yy->im;
+			} else {
+				*(double*)&t = ud * *(const double*)&yc;
+			}
+			acc = VT<T>::add(acc, t);
+			if (valid) {
+				const T xv = VT<T>::add(xold, acc);
+				xblk[iu] = xv;
+				if (DOT) dot += VT<T>::dot_re(yc, xv);
+			}
 		}
 	}
 	if (DOT) {

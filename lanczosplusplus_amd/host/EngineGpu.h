@@ -149,6 +149,47 @@ private:
 	SizeType rows_;
 };
 
+// x += H y without a stored matrix: SolverOptions=InternalProductOnTheFly (src/Engine/InternalProductOnTheFly.h:93-133).
+// In scope for HubbardOneBand only (the reference's threaded HubbardHelper::matrixVectorProduct, HubbardHelper.h:105-134).
+template <typename ModelType_, typename SpecialSymmetryType_> class InternalProductOnTheFly {
+public:
+	typedef ModelType_ ModelType;
+	typedef SpecialSymmetryType_ SpecialSymmetryType;
+	typedef typename ModelType::BasisBaseType BasisType;
+	typedef typename ModelType::RealType RealType;
+	typedef typename ModelType::GeometryType GeometryType;
+	typedef typename GeometryType::ComplexOrRealType ComplexOrRealType;
+	typedef std::vector<ComplexOrRealType> VectorType;
+
+	InternalProductOnTheFly(const ModelType& model, SpecialSymmetryType& rs, const lpp_config& cfg) : rs_(rs), engine_(cfg), rows_(model.size())
+	{
+		const HubbardOneOrbital<ComplexOrRealType>* hub = dynamic_cast<const HubbardOneOrbital<ComplexOrRealType>*>(&model);
+		if (!hub) throw std::runtime_error("InternalProductOnTheFly: only Model=HubbardOneBand has an on-the-fly product\n");
+		const SizeType n = model.geometry().numberOfSites();
+		std::vector<double> hr(n * n), hi(n * n);
+		for (SizeType k = 0; k < n * n; k++) {
+			hr[k] = LppHost::real(hub->hoppings()[k]);
+			hi[k] = LppHost::imag(hub->hoppings()[k]);
+		}
+		const typename BasisType::PairIntType parts = model.basis().parts();
+		lppCheck(lpp_engine_setup_hubbard_onthefly(engine_.get(), nullptr, (int32_t)n, parts.first, parts.second, hr.data(),
+		                                           sizeof(ComplexOrRealType) == 16 ? hi.data() : nullptr, hub->hubbardU.data(), hub->potentialV.data()));
+	}
+	SizeType rows() const { return rows_; }
+	void matrixVectorProduct(VectorType& x, const VectorType& y) const
+	{
+		if (x.size() != rows_ || y.size() != rows_) throw std::runtime_error("InternalProductOnTheFly::matrixVectorProduct: size mismatch\n");
+		lppCheck(lpp_engine_spmv_acc(engine_.get(), x.data(), y.data()));
+	}
+	void specialSymmetrySector(SizeType p) { rs_.setPointer(p); }
+	lpp_engine* engine() const { return engine_.get(); }
+
+private:
+	SpecialSymmetryType& rs_;
+	EngineHandle engine_;
+	SizeType rows_;
+};
+
 struct TridiagonalMatrix {
 	std::vector<double> a_, b_;
 	void resize(SizeType n)

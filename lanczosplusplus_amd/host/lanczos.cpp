@@ -13,21 +13,30 @@
 
 using namespace LanczosPlusPlus;
 
-template <typename ComplexOrRealType> int mainLoop0(LppHost::InputReadable& io, int device, int precision)
+// mainLoop3 (LanczosDriver1.h:47-66): build the engine, print the ground-state energy
+template <typename ModelType, typename SymmetryType, template <typename, typename> class InternalProductTemplate>
+int mainLoop3(const ModelType& model, LppHost::InputReadable& io, int device, int precision)
 {
-	typedef LppHost::Geometry<ComplexOrRealType> GeometryType;
-	typedef ModelBase<ComplexOrRealType> ModelType;
-	typedef DefaultSymmetry<typename ModelType::BasisBaseType, GeometryType> SymmetryType;
-	typedef Engine<ModelType, InternalProductStored, SymmetryType> EngineType;
-	GeometryType geometry(io);
-	ModelSelector<ComplexOrRealType> modelSelector(io, geometry);
-	const ModelType& model = modelSelector();
-	model.print(std::cout);
+	typedef Engine<ModelType, InternalProductTemplate, SymmetryType> EngineType;
 	std::cout.precision(precision);
 	EngineType engine(model, io, device);
 	std::cout << "Energy=" << engine.energies(0) << "\n";
 	std::cerr << "#LanczosSteps=" << engine.lanczosSteps() << " rows=" << model.size() << "\n";
 	return 0;
+}
+
+template <typename ComplexOrRealType> int mainLoop0(LppHost::InputReadable& io, int device, int precision, bool onthefly)
+{
+	typedef LppHost::Geometry<ComplexOrRealType> GeometryType;
+	typedef ModelBase<ComplexOrRealType> ModelType;
+	typedef DefaultSymmetry<typename ModelType::BasisBaseType, GeometryType> SymmetryType;
+	GeometryType geometry(io);
+	ModelSelector<ComplexOrRealType> modelSelector(io, geometry);
+	const ModelType& model = modelSelector();
+	model.print(std::cout);
+	// stored / on-the-fly switch on the SolverOptions substring (LanczosDriver1.h:217-239)
+	if (onthefly) return mainLoop3<ModelType, SymmetryType, InternalProductOnTheFly>(model, io, device, precision);
+	return mainLoop3<ModelType, SymmetryType, InternalProductStored>(model, io, device, precision);
 }
 
 int main(int argc, char** argv)
@@ -50,10 +59,9 @@ int main(int argc, char** argv)
 		LppHost::InputReadable io(file);
 		LppHost::String options("none");
 		if (io.has("SolverOptions=")) io.readline(options, "SolverOptions=");
-		if (options.find("InternalProductOnTheFly") != LppHost::String::npos)
-			throw LppHost::RuntimeError("SolverOptions=InternalProductOnTheFly is out of scope of the GPU engine (stored path only)\n");
+		const bool onthefly = options.find("InternalProductOnTheFly") != LppHost::String::npos;
 		const bool isComplex = options.find("useComplex") != LppHost::String::npos;
-		return isComplex ? mainLoop0<std::complex<double>>(io, device, precision) : mainLoop0<double>(io, device, precision);
+		return isComplex ? mainLoop0<std::complex<double>>(io, device, precision, onthefly) : mainLoop0<double>(io, device, precision, onthefly);
 	} catch (std::exception& e) {
 		std::cerr << "lanczos: " << e.what();
 		return 2;

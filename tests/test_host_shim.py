@@ -57,7 +57,8 @@ def test_host_assembly_bit_exact(name, tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["input0.inp", "hubbard_ladder_2x4.inp", "heisenberg_chain_L12.inp", "tj_chain_L8_complex.inp"])
+@pytest.mark.parametrize("name", ["input0.inp", "hubbard_ladder_2x4.inp", "hubbard_ladder_2x4_onthefly.inp", "heisenberg_chain_L12.inp",
+                                  "tj_chain_L8_complex.inp"])
 def test_lanczos_driver_prints_reference_energy_line(name):
     exe = os.path.join(HOST, "lanczos")
     assert os.path.exists(exe)
