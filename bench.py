@@ -225,8 +225,8 @@ def main():
     traffic = None
     try:  # per-launch HBM bytes of the SpMV kernel from the committed rocprofv3 PMC pass of this workload
         tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-        if world == 1 and name in tj and args.engine == "stored":
-            traffic = tj[name]["traffic_bytes_per_launch"]
+        if world == 1 and name in tj.get(args.engine, {}) and os.environ.get("LPP_COMPRESS_VALUES", "-1") != "0":
+            traffic = tj[args.engine][name]["traffic_bytes_per_launch"]
     except Exception:
         traffic = None
 
@@ -249,7 +249,9 @@ def main():
                        "reortho": False, "assembly": "on-device", "assembly_s": round(t_asm, 3), "engine": args.engine},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "k_spmv (x += H y, fused a_j partial)", "spmv_ms": spmv_ms_per_step,
+                         "kernel": ("k_spmv_kron_packed (matrix-free x += H y; bytes = vector-streaming model N*s*(3 + down-hops/row))"
+                                    if args.engine == "onthefly" else "k_spmv_window/k_spmv_sliced (stored CSR x += H y, fused a_j partial)"),
+                         "spmv_ms": spmv_ms_per_step,
                          "algorithmic_bytes_per_launch": w1["spmv_bytes"], "launches_timed": launches},
             "e0_after_steps": e0,
         }

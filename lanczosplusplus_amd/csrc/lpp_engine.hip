@@ -319,8 +319,16 @@ lpp_status finalize_csr(lpp_engine* e, DevCsr& A, bool allow_drop_plain, int for
 void set_spmv_bytes(lpp_engine* e)
 {
 	const double s = (double)e->esz;
-	const double Z = e->kron.active ? e->kron.equiv_nnz : (double)(e->A_loc.nnz + e->A_rem.nnz);
 	const double N = (double)e->n_local;
+	if (e->kron.active) {
+		// matrix-free product: no matrix stream.  Vector-streaming model: x in/out and y once (3 N s) plus one
+		// coalesced pass over the source block of every connected down-configuration (H_down off-diagonals).
+		const KronState& K = e->kron;
+		const double avg_down = K.n_dn > 0 ? ((double)K.dn.nnz - (double)K.n_dn) / (double)K.n_dn : 0.0;
+		e->spmv_bytes = N * s * (3.0 + avg_down);
+		return;
+	}
+	const double Z = (double)(e->A_loc.nnz + e->A_rem.nnz);
 	e->spmv_bytes = Z * (s + 4.0) + (N + 1.0) * 8.0 + 3.0 * N * s;
 }
 
