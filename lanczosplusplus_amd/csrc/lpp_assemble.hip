@@ -611,7 +611,7 @@ void free_kron(lpp_engine* e)
 	K = KronState();
 }
 
-template <typename T> static int kron_launch_t(lpp_engine* e, const void* ywin, const void* ydown, void* x, double* partial)
+template <typename T> static int kron_launch_t(lpp_engine* e, const void* ywin, const void* ydown, void* x, double* partial, const EpiScale& sc)
 {
 	KronState& K = e->kron;
 	if (K.nid == 0) return 0;
@@ -637,6 +637,7 @@ template <typename T> static int kron_launch_t(lpp_engine* e, const void* ywin, 
 		pa.x = (T*)x;
 		pa.partial = partial;
 		pa.xcd_map = (e->k2_variant >> 1) & 1;
+		pa.sc = sc;
 		const size_t ldsb = K.window ? sizeof(T) * (size_t)std::max<int64_t>(K.n_up, 64) : 64;
 		const int pcu = std::max(1, std::min(2, (int)((160 * 1024 - 8192) / (ldsb + 1))));
 		int nbp = (int)std::max<int64_t>(1, std::min<int64_t>(K.nid, (int64_t)e->num_cus * pcu));
@@ -668,6 +669,7 @@ template <typename T> static int kron_launch_t(lpp_engine* e, const void* ywin, 
 	a.up.ydot = nullptr;
 	a.up.partial = nullptr;
 	a.up.xcd_map = 0;
+	a.up.sc = EpiScale { nullptr, nullptr, 0 };
 	a.n_up = K.n_up;
 	a.id0 = K.id0;
 	a.nid = K.nid;
@@ -683,6 +685,7 @@ template <typename T> static int kron_launch_t(lpp_engine* e, const void* ywin, 
 	a.x = (T*)x;
 	a.partial = partial;
 	a.xcd_map = (e->k2_variant >> 1) & 1;
+	a.sc = sc;
 	const size_t lds_bytes = K.window ? sizeof(T) * (size_t)std::max<int64_t>(K.n_up, 64) : 64;
 	const int per_cu = std::max(1, std::min(2, (int)((160 * 1024 - 8192) / (lds_bytes + 1))));
 	int nb = (int)std::max<int64_t>(1, std::min<int64_t>(K.nid, (int64_t)e->num_cus * per_cu));
@@ -709,9 +712,9 @@ template <typename T> static int kron_launch_t(lpp_engine* e, const void* ywin, 
 	return dot ? nb : 0;
 }
 
-int kron_launch(lpp_engine* e, const void* ywin, const void* ydown, void* x, double* partial)
+int kron_launch(lpp_engine* e, const void* ywin, const void* ydown, void* x, double* partial, const EpiScale& sc)
 {
-	return e->is_complex ? kron_launch_t<cplx>(e, ywin, ydown, x, partial) : kron_launch_t<double>(e, ywin, ydown, x, partial);
+	return e->is_complex ? kron_launch_t<cplx>(e, ywin, ydown, x, partial, sc) : kron_launch_t<double>(e, ywin, ydown, x, partial, sc);
 }
 
 } // namespace lpp

@@ -64,23 +64,23 @@ static int pick_group(int64_t nrows, int64_t nnz)
 
 template <typename T, bool DOT>
 static void launch_rowgroup(const DevCsr& A, const T* src, T* x, const T* ydot, double* partial, int nblocks,
-                            hipStream_t st)
+                            hipStream_t st, const EpiScale& sc)
 {
 	const int64_t* rp = A.rowptr;
 	const int32_t* col = A.col;
 	const T* val = (const T*)A.val;
 	switch (A.G) {
-	case 4: k_spmv_rowgroup<T, 4, DOT><<<nblocks, kBlock, 0, st>>>(A.nrows, rp, col, val, src, x, ydot, partial); break;
-	case 8: k_spmv_rowgroup<T, 8, DOT><<<nblocks, kBlock, 0, st>>>(A.nrows, rp, col, val, src, x, ydot, partial); break;
-	case 16: k_spmv_rowgroup<T, 16, DOT><<<nblocks, kBlock, 0, st>>>(A.nrows, rp, col, val, src, x, ydot, partial); break;
-	case 32: k_spmv_rowgroup<T, 32, DOT><<<nblocks, kBlock, 0, st>>>(A.nrows, rp, col, val, src, x, ydot, partial); break;
-	default: k_spmv_rowgroup<T, 64, DOT><<<nblocks, kBlock, 0, st>>>(A.nrows, rp, col, val, src, x, ydot, partial); break;
+	case 4: k_spmv_rowgroup<T, 4, DOT><<<nblocks, kBlock, 0, st>>>(A.nrows, rp, col, val, src, x, ydot, partial, sc); break;
+	case 8: k_spmv_rowgroup<T, 8, DOT><<<nblocks, kBlock, 0, st>>>(A.nrows, rp, col, val, src, x, ydot, partial, sc); break;
+	case 16: k_spmv_rowgroup<T, 16, DOT><<<nblocks, kBlock, 0, st>>>(A.nrows, rp, col, val, src, x, ydot, partial, sc); break;
+	case 32: k_spmv_rowgroup<T, 32, DOT><<<nblocks, kBlock, 0, st>>>(A.nrows, rp, col, val, src, x, ydot, partial, sc); break;
+	default: k_spmv_rowgroup<T, 64, DOT><<<nblocks, kBlock, 0, st>>>(A.nrows, rp, col, val, src, x, ydot, partial, sc); break;
 	}
 }
 
 // x += A * src ; if partial != nullptr also partial[b] = block sums of Re<ydot|x>.
 // Returns the number of partials written (0 when partial == nullptr).
-template <typename T> static int spmv_launch_t(lpp_engine* e, const DevCsr& A, const void* src, void* x, const void* ydot, double* partial)
+template <typename T> static int spmv_launch_t(lpp_engine* e, const DevCsr& A, const void* src, void* x, const void* ydot, double* partial, const EpiScale& sc)
 {
 	hipStream_t st = e->stream;
 	if (A.nrows == 0) return 0;
@@ -99,6 +99,7 @@ template <typename T> static int spmv_launch_t(lpp_engine* e, const DevCsr& A, c
 		a.ydot = (const T*)ydot;
 		a.partial = partial;
 		a.xcd_map = (e->k2_variant >> 1) & 1;
+		a.sc = sc;
 		const bool dot = partial != nullptr;
 		const bool u8 = (e->k2_variant & 4) != 0;
 		const int sel = (dot ? 4 : 0) | (A.coded ? 2 : 0) | (u8 ? 1 : 0);
@@ -147,15 +148,15 @@ template <typename T> static int spmv_launch_t(lpp_engine* e, const DevCsr& A, c
 	const int64_t need = (A.nrows + rows_per_block - 1) / rows_per_block;
 	const int nb = (int)std::max<int64_t>(1, std::min<int64_t>(need, e->spmv_max_blocks));
 	if (partial)
-		launch_rowgroup<T, true>(A, (const T*)src, (T*)x, (const T*)ydot, partial, nb, st);
+		launch_rowgroup<T, true>(A, (const T*)src, (T*)x, (const T*)ydot, partial, nb, st, sc);
 	else
-		launch_rowgroup<T, false>(A, (const T*)src, (T*)x, nullptr, nullptr, nb, st);
+		launch_rowgroup<T, false>(A, (const T*)src, (T*)x, nullptr, nullptr, nb, st, sc);
 	return partial ? nb : 0;
 }
 
-int spmv_launch(lpp_engine* e, const DevCsr& A, const void* src, void* x, const void* ydot, double* partial)
+int spmv_launch(lpp_engine* e, const DevCsr& A, const void* src, void* x, const void* ydot, double* partial, const EpiScale& sc)
 {
-	return e->is_complex ? spmv_launch_t<cplx>(e, A, src, x, ydot, partial) : spmv_launch_t<double>(e, A, src, x, ydot, partial);
+	return e->is_complex ? spmv_launch_t<cplx>(e, A, src, x, ydot, partial, sc) : spmv_launch_t<double>(e, A, src, x, ydot, partial, sc);
 }
 
 // distinct values of A.val -> sorted dictionary on the device; returns false when there are more than 256
@@ -396,7 +397,7 @@ lpp_status lpp_engine_create(lpp_engine** out, const lpp_config* cfg)
 	e->M = M;
 	err = hipMalloc(&e->partial, sizeof(double) * (size_t)kMaxPartials * 2 * kPanel);
 	if (err == hipSuccess) err = hipMalloc(&e->scal_own, sizeof(double) * (size_t)(6 * M + 8));
-	if (err == hipSuccess) err = hipHostMalloc(&e->h_scal, sizeof(double) * (size_t)(2 * M), hipHostMallocDefault);
+	if (err == hipSuccess) err = hipHostMalloc(&e->h_scal, sizeof(double) * (size_t)(2 * M + 2), hipHostMallocDefault);
 	if (err != hipSuccess) {
 		lpp_engine_destroy(e);
 		return fail(LPP_ERR_NOMEM, std::string("lpp_engine_create: allocation failed: ") + hipGetErrorString(err));

@@ -114,6 +114,8 @@ struct lpp_engine {
 	bool saving = false; // Lanczos vectors kept in V
 	int step = 0; // steps enqueued so far
 	double* ycur = nullptr; // current Lanczos vector (V column or e->y)
+	double* xcur = nullptr; // accumulator vector of the recurrence (e->x, or e->y/e->x alternating when scale-free)
+	bool scalefree = false; // unnormalised Lanczos vectors, scalings folded into the SpMV epilogue (no swap pass)
 	std::vector<hipEvent_t> step_events;
 	std::vector<std::pair<hipEvent_t, hipEvent_t>> spmv_events;
 	size_t spmv_events_used = 0;
@@ -139,8 +141,8 @@ namespace lpp {
 void free_csr(DevCsr& A);
 lpp_status finalize_csr(lpp_engine* e, DevCsr& A, bool allow_drop_plain, int force_mode = 0, int64_t force_block = 0);
 void free_kron(lpp_engine* e);
-int kron_launch(lpp_engine* e, const void* ywin, const void* ydown, void* x, double* partial);
+int kron_launch(lpp_engine* e, const void* ywin, const void* ydown, void* x, double* partial, const EpiScale& sc = EpiScale { nullptr, nullptr, 0 });
 void set_spmv_bytes(lpp_engine* e);
 lpp_status alloc_work(lpp_engine* e);
-int spmv_launch(lpp_engine* e, const DevCsr& A, const void* src, void* x, const void* ydot, double* partial);
+int spmv_launch(lpp_engine* e, const DevCsr& A, const void* src, void* x, const void* ydot, double* partial, const EpiScale& sc = EpiScale { nullptr, nullptr, 0 });
 } // namespace lpp

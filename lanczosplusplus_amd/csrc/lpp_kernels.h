@@ -75,6 +75,40 @@ template <> struct VT<cplx> {
 	}
 };
 
+// Epilogue scaling of the SpMV kernels:  x_new = beta * x_old + alpha * (H y)_row.
+// Plain products use alpha = beta = 1 (x += H y).  The scale-free Lanczos recurrence keeps the Lanczos
+// vectors unnormalised (r_j = b_{j-1} y_j) and folds the scalings into this epilogue:
+// alpha = 1/b_{j-1}, beta = -b_{j-1}/b_{j-2}, both derived in-kernel from b^2 values in device memory,
+// which removes the separate swap/scale pass (4 N s bytes per step).
+struct EpiScale {
+	const double* b2_prev; // b_{j-1}^2 (null: alpha = 1)
+	const double* b2_prev2; // b_{j-2}^2 (null: beta = 0 when b2_prev is set)
+	int beta_one; // 1: beta = 1 regardless (second kernel of a split product)
+};
+
+__device__ __forceinline__ void epi_coeffs(const EpiScale& sc, double& alpha, double& beta)
+{
+	alpha = 1.0;
+	beta = 1.0;
+	if (sc.b2_prev) {
+		const double b1 = sqrt(*sc.b2_prev);
+		alpha = (fabs(b1) < 1e-10) ? 1.0 : 1.0 / b1;
+		if (!sc.beta_one) {
+			beta = 0.0;
+			if (sc.b2_prev2) {
+				const double b2 = sqrt(*sc.b2_prev2);
+				beta = (fabs(b2) < 1e-10) ? -b1 : -b1 / b2;
+			}
+		}
+	}
+}
+
+__device__ __forceinline__ double epi_lin(double beta, double xold, double alpha, double acc) { return beta * xold + alpha * acc; }
+__device__ __forceinline__ cplx epi_lin(double beta, cplx xold, double alpha, cplx acc)
+{
+	return cplx { beta * xold.re + alpha * acc.re, beta * xold.im + alpha * acc.im };
+}
+
 // ---------------------------------------------------------------------------------------------
 // K1: row-group CSR SpMV   x[row] += sum_k val[k] * src[col[k]]   (+ fused partial of Re<ydot|x>)
 //
@@ -90,9 +124,11 @@ __global__ __launch_bounds__(kBlock) void k_spmv_rowgroup(int64_t nrows, const i
                                                            const int32_t* __restrict__ col,
                                                            const T* __restrict__ val, const T* __restrict__ src,
                                                            T* __restrict__ x, const T* __restrict__ ydot,
-                                                           double* __restrict__ partial)
+                                                           double* __restrict__ partial, EpiScale sc)
 {
 	__shared__ double smem[kBlock / 64];
+	double alpha, beta;
+	epi_coeffs(sc, alpha, beta);
 	const int lig = threadIdx.x % G;
 	const int64_t ngroups = (int64_t)gridDim.x * (kBlock / G);
 	double dot = 0.0;
@@ -124,7 +160,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv_rowgroup(int64_t nrows, const i
 #pragma unroll
 		for (int off = G / 2; off > 0; off >>= 1) acc = VT<T>::add(acc, VT<T>::shfl_down(acc, off, G));
 		if (lig == 0) {
-			const T xv = VT<T>::add(x[row], acc);
+			const T xv = epi_lin(beta, x[row], alpha, acc);
 			x[row] = xv;
 			if (DOT) dot += VT<T>::dot_re(ydot[row], xv);
 		}
@@ -207,6 +243,7 @@ template <typename T> struct SlicedArgs {
 	const T* ydot;
 	double* partial;
 	int xcd_map;
+	EpiScale sc;
 };
 
 // Value dictionary ("coded" layout): the Hamiltonians of this path take very few distinct values
@@ -331,7 +368,7 @@ __device__ __forceinline__ T sliced_accumulate(const SlicedArgs<T>& a, int len, 
 // process one slice with one wave (x[row] += acc); returns this lane's contribution to Re<ydot|x>.
 template <typename T, bool DOT, bool WINDOW, bool CODED, int U>
 __device__ __forceinline__ double sliced_one(const SlicedArgs<T>& a, int64_t row0, int nvalid, int len, int64_t base, int64_t cbase,
-                                             const T* lds, int32_t r0, uint32_t wlen, const double* dict)
+                                             const T* lds, int32_t r0, uint32_t wlen, const double* dict, double alpha, double beta)
 {
 	if (nvalid == 0) return 0.0; // wave-uniform
 	const int lane = threadIdx.x & 63;
@@ -345,7 +382,7 @@ __device__ __forceinline__ double sliced_one(const SlicedArgs<T>& a, int64_t row
 	const T acc = sliced_accumulate<T, WINDOW, CODED, U>(a, len, base, cbase, lds, r0, wlen, dict, (int32_t)row);
 	double d = 0.0;
 	if (valid) {
-		const T xv = VT<T>::add(xold, acc);
+		const T xv = epi_lin(beta, xold, alpha, acc);
 		a.x[row] = xv;
 		if (DOT) d = VT<T>::dot_re(yv, xv);
 	}
@@ -383,6 +420,8 @@ __global__ __launch_bounds__(kBlock) void k_spmv_sliced(SlicedArgs<T> a)
 	__shared__ double smem[kBlock / 64];
 	__shared__ double dict_s[CODED ? 256 : 1];
 	load_dict<CODED>(dict_s, a.dict);
+	double alpha, beta;
+	epi_coeffs(a.sc, alpha, beta);
 	int64_t s_begin, s_end, s_stride;
 	if (a.xcd_map && (gridDim.x & 7) == 0) {
 		const int64_t chunk = (a.g.nslices + 7) / 8;
@@ -404,7 +443,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv_sliced(SlicedArgs<T> a)
 		int64_t row0n = 0, basen = 0, cbasen = 0;
 		int nvalidn = 0, lenn = 0;
 		if (s + s_stride < s_end) slice_meta<T, CODED>(a, s + s_stride, row0n, nvalidn, lenn, basen, cbasen);
-		dot += sliced_one<T, DOT, false, CODED, U>(a, row0, nvalid, len, base, cbase, nullptr, 0, 0, dict_s);
+		dot += sliced_one<T, DOT, false, CODED, U>(a, row0, nvalid, len, base, cbase, nullptr, 0, 0, dict_s, alpha, beta);
 		row0 = row0n;
 		base = basen;
 		cbase = cbasen;
@@ -436,6 +475,8 @@ __global__ __launch_bounds__(kWinThreads) void k_spmv_window(SlicedArgs<T> a)
 	__shared__ double dict_s[CODED ? 256 : 1];
 	__shared__ int next_slice;
 	load_dict<CODED>(dict_s, a.dict);
+	double alpha, beta;
+	epi_coeffs(a.sc, alpha, beta);
 	int64_t b_begin, b_end, b_stride;
 	if (a.xcd_map && (gridDim.x & 7) == 0) {
 		const int64_t chunk = (a.g.nblocks + 7) / 8;
@@ -476,7 +517,7 @@ __global__ __launch_bounds__(kWinThreads) void k_spmv_window(SlicedArgs<T> a)
 			int64_t row0n = 0, basen = 0, cbasen = 0;
 			int nvalidn = 0, lenn = 0;
 			if (jn < a.g.spb) slice_meta<T, CODED>(a, blk * a.g.spb + jn, row0n, nvalidn, lenn, basen, cbasen);
-			dot += sliced_one<T, DOT, true, CODED, U>(a, row0, nvalid, len, base, cbase, lds, (int32_t)r0, (uint32_t)wl, dict_s);
+			dot += sliced_one<T, DOT, true, CODED, U>(a, row0, nvalid, len, base, cbase, lds, (int32_t)r0, (uint32_t)wl, dict_s, alpha, beta);
 			row0 = row0n;
 			base = basen;
 			cbase = cbasen;
@@ -678,14 +719,20 @@ __global__ __launch_bounds__(kBlock) void k_slice_decode(SliceGeom g, const int6
 // fused BLAS-1 of the three-term recurrence (double2 = 16 B per lane)
 // ---------------------------------------------------------------------------------------------
 
-// x -= a*y ;  partial[b] = sum |x|^2     (a read from device memory: no host round trip)
+// x -= g*y ;  partial[b] = sum |x|^2     (scalars read from device memory: no host round trip)
+// g = *a_ptr (normalised recurrence) or *a_ptr / *b2_prev (scale-free recurrence: raw dot <r_j|w> over b_{j-1}^2).
+// `send` (optional) receives a copy of the new x: the slice handed to the next all-gather.
 template <bool NRM>
 __global__ __launch_bounds__(kBlock) void k_axpy_nrm(double2* __restrict__ x, const double2* __restrict__ y,
-                                                      const double* __restrict__ a_ptr, int64_t n2,
-                                                      double* __restrict__ partial)
+                                                      const double* __restrict__ a_ptr, const double* __restrict__ b2_prev,
+                                                      double2* __restrict__ send, int64_t n2, double* __restrict__ partial)
 {
 	__shared__ double smem[kBlock / 64];
-	const double a = *a_ptr;
+	double a = *a_ptr;
+	if (b2_prev) {
+		const double b2 = *b2_prev;
+		if (sqrt(b2) >= 1e-10) a /= b2;
+	}
 	double s = 0.0;
 	for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n2; i += (int64_t)gridDim.x * kBlock) {
 		double2 xv = x[i];
@@ -693,6 +740,7 @@ __global__ __launch_bounds__(kBlock) void k_axpy_nrm(double2* __restrict__ x, co
 		xv.x -= a * yv.x;
 		xv.y -= a * yv.y;
 		x[i] = xv;
+		if (send) send[i] = xv;
 		if (NRM) s += xv.x * xv.x + xv.y * xv.y;
 	}
 	if (NRM) {

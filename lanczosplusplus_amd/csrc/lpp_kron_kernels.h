@@ -39,6 +39,7 @@ template <typename T> struct KronArgs {
 	T* x; // local slice
 	double* partial;
 	int xcd_map;
+	EpiScale sc;
 };
 
 template <typename T, bool DOT, bool WINDOW, bool CODED, int U>
@@ -52,6 +53,8 @@ __global__ __launch_bounds__(kWinThreads) void k_spmv_kron(KronArgs<T> a)
 	__shared__ int32_t dcol_s[kKronDownCap];
 	__shared__ T dval_s[kKronDownCap];
 	load_dict<CODED>(dict_s, a.up.dict);
+	double alpha, beta;
+	epi_coeffs(a.sc, alpha, beta);
 	if (threadIdx.x < 32) U_s[threadIdx.x] = (int)threadIdx.x < a.L ? a.U[threadIdx.x] : 0.0;
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 	const int spb = a.up.g.spb;
@@ -145,7 +148,7 @@ __global__ __launch_bounds__(kWinThreads) void k_spmv_kron(KronArgs<T> a)
 				}
 				acc = VT<T>::add(acc, t);
 				if (valid) {
-					const T xv = VT<T>::add(xold, acc);
+					const T xv = epi_lin(beta, xold, alpha, acc);
 					xblk[iu] = xv;
 					if (DOT) dot += VT<T>::dot_re(yc, xv);
 				}
@@ -192,6 +195,7 @@ template <typename T> struct KronPackedArgs {
 	T* x;
 	double* partial;
 	int xcd_map;
+	EpiScale sc;
 };
 
 template <typename T> __device__ __forceinline__ T kron_decode(uint32_t w, const double* dict);
@@ -213,6 +217,8 @@ __global__ __launch_bounds__(kWinThreads) void k_spmv_kron_packed(KronPackedArgs
 	__shared__ T dval_s[kKronDownCap];
 	__shared__ int next_slice;
 	for (int i = threadIdx.x; i < 256; i += kWinThreads) dict_s[i] = a.dict[i];
+	double alpha, beta;
+	epi_coeffs(a.sc, alpha, beta);
 	if (threadIdx.x < 32) U_s[threadIdx.x] = (int)threadIdx.x < a.L ? a.U[threadIdx.x] : 0.0;
 	const int lane = threadIdx.x & 63;
 	int64_t b_begin, b_end, b_stride;
@@ -317,7 +323,7 @@ __global__ __launch_bounds__(kWinThreads) void k_spmv_kron_packed(KronPackedArgs
 			}
 			acc = VT<T>::add(acc, t);
 			if (valid) {
-				const T xv = VT<T>::add(xold, acc);
+				const T xv = epi_lin(beta, xold, alpha, acc);
 				xblk[iu] = xv;
 				if (DOT) dot += VT<T>::dot_re(yc, xv);
 			}

@@ -122,18 +122,34 @@ lpp_status cgs2(lpp_engine* e, int ncol)
 	return LPP_OK;
 }
 
-// enqueue Lanczos step j = e->step.  ritz (optional): nst coefficients S(j,k) to accumulate
-// zwork_k += S(j,k) y_j during a second pass.
+// enqueue Lanczos step j = e->step.  ritz (optional): nst coefficients to accumulate
+// zwork_k += ritz[k] * (current Lanczos vector) during a second pass.
+//
+// Two forms of the same recurrence:
+//  normalised (vectors kept / reortho):  x += H y_j; a_j = <y_j|x>; x -= a_j y_j; b_j = |x|; (y_{j+1}, x) <- (x/b_j, -b_j y_j)
+//  scale-free (no vectors kept):         r_j = b_{j-1} y_j stays unnormalised;  w = H r_j / b_{j-1} - (b_{j-1}/b_{j-2}) r_{j-1}
+//                                        is formed by the SpMV epilogue in the buffer of r_{j-1}; raw_j = <r_j|w> = a_j b_{j-1};
+//                                        r_{j+1} = w - (raw_j / b_{j-1}^2) r_j; b_j = |r_{j+1}|.  No swap/scale pass.
 lpp_status one_step(lpp_engine* e, const double* ritz, int nst)
 {
 	const int j = e->step;
 	const int nb = blas_blocks(e->n2);
 	hipStream_t st = e->stream;
 	double* ycur = e->ycur;
+	double* xcur = e->xcur;
 	int np = 0;
 	if (ritz) {
 		for (int k = 0; k < nst; k++)
 			k_axpy_const<<<nb, kBlock, 0, st>>>((double2*)(e->zwork + (int64_t)k * e->nd_pad), (const double2*)ycur, ritz[k], e->n2);
+	}
+	double* a_ptr = e->ab_dev + 2 * j;
+	double* b2_ptr = e->ab_dev + 2 * j + 1;
+	EpiScale sc { nullptr, nullptr, 0 };
+	const double* b2_prev = nullptr;
+	if (e->scalefree) {
+		b2_prev = (j == 0) ? e->tmp_dev : e->ab_dev + 2 * (j - 1) + 1;
+		sc.b2_prev = b2_prev;
+		sc.b2_prev2 = (j == 0) ? nullptr : ((j == 1) ? e->tmp_dev : e->ab_dev + 2 * (j - 2) + 1);
 	}
 	if (e->kron.active) {
 		// matrix-free product: the down part needs the whole vector, so the gather completes first
@@ -142,46 +158,56 @@ lpp_status one_step(lpp_engine* e, const double* ritz, int nst)
 			if (e->comm.allgather_end(e->comm.ctx) != 0) return fail(LPP_ERR_COMM, "allgather_end callback failed");
 		}
 		SpmvTimer t(e);
-		np = kron_launch(e, ycur, multi(e) ? e->comm.gath_buf : ycur, e->x, e->partial);
+		np = kron_launch(e, ycur, multi(e) ? e->comm.gath_buf : ycur, xcur, e->partial, sc);
 		t.stop();
 	} else if (multi(e)) {
-		// the slice of y_j was written to comm.send_buf by the previous k_swap_scale / k_scale_copy
+		// the slice of the current vector was written to comm.send_buf by the previous step's last kernel
 		if (e->comm.allgather_begin(e->comm.ctx) != 0) return fail(LPP_ERR_COMM, "allgather_begin callback failed");
 		{
 			SpmvTimer t(e);
-			spmv_launch(e, e->A_loc, ycur, e->x, nullptr, nullptr); // local columns: overlaps the all-gather
+			spmv_launch(e, e->A_loc, ycur, xcur, nullptr, nullptr, sc); // local columns: overlaps the all-gather
 			t.stop();
 		}
 		if (e->comm.allgather_end(e->comm.ctx) != 0) return fail(LPP_ERR_COMM, "allgather_end callback failed");
 		{
+			EpiScale sc2 = sc;
+			sc2.beta_one = 1; // x already holds beta*x_old + alpha*(A_loc y)
 			SpmvTimer t(e);
-			np = spmv_launch(e, e->A_rem, e->comm.gath_buf, e->x, ycur, e->partial);
+			np = spmv_launch(e, e->A_rem, e->comm.gath_buf, xcur, ycur, e->partial, sc2);
 			t.stop();
 		}
 	} else {
 		SpmvTimer t(e);
-		np = spmv_launch(e, e->A_loc, ycur, e->x, ycur, e->partial);
+		np = spmv_launch(e, e->A_loc, ycur, xcur, ycur, e->partial, sc);
 		t.stop();
 	}
-	double* a_ptr = e->ab_dev + 2 * j;
-	double* b2_ptr = e->ab_dev + 2 * j + 1;
 	k_reduce_final<<<1, kBlock, 0, st>>>(e->partial, np, 1, 1, a_ptr);
 	lpp_status rc = comm_allreduce(e, e->ab_off + 2 * j, 1);
 	if (rc != LPP_OK) return rc;
-	if (e->cfg.reortho) {
-		k_axpy_nrm<false><<<nb, kBlock, 0, st>>>((double2*)e->x, (const double2*)ycur, a_ptr, e->n2, nullptr);
+	if (e->scalefree) {
+		k_axpy_nrm<true><<<nb, kBlock, 0, st>>>((double2*)xcur, (const double2*)ycur, a_ptr, b2_prev,
+		                                       multi(e) ? (double2*)e->comm.send_buf : nullptr, e->n2, e->partial);
+	} else if (e->cfg.reortho) {
+		k_axpy_nrm<false><<<nb, kBlock, 0, st>>>((double2*)xcur, (const double2*)ycur, a_ptr, nullptr, nullptr, e->n2, nullptr);
 		rc = cgs2(e, j + 1);
 		if (rc != LPP_OK) return rc;
-		k_dot<<<nb, kBlock, 0, st>>>((const double2*)e->x, (const double2*)e->x, e->n2, e->partial);
+		k_dot<<<nb, kBlock, 0, st>>>((const double2*)xcur, (const double2*)xcur, e->n2, e->partial);
 	} else {
-		k_axpy_nrm<true><<<nb, kBlock, 0, st>>>((double2*)e->x, (const double2*)ycur, a_ptr, e->n2, e->partial);
+		k_axpy_nrm<true><<<nb, kBlock, 0, st>>>((double2*)xcur, (const double2*)ycur, a_ptr, nullptr, nullptr, e->n2, e->partial);
 	}
 	k_reduce_final<<<1, kBlock, 0, st>>>(e->partial, nb, 1, 1, b2_ptr);
 	rc = comm_allreduce(e, e->ab_off + 2 * j + 1, 1);
 	if (rc != LPP_OK) return rc;
-	double* ynext = e->saving ? e->V + (int64_t)(j + 1) * e->ldv : e->y;
-	k_swap_scale<<<nb, kBlock, 0, st>>>((double2*)e->x, (const double2*)ycur, (double2*)ynext,
-	                                   multi(e) ? (double2*)e->comm.send_buf : nullptr, b2_ptr, e->n2);
+	if (e->scalefree) {
+		// roles swap: the buffer that held r_{j-1} now holds r_{j+1}
+		e->ycur = xcur;
+		e->xcur = ycur;
+	} else {
+		double* ynext = e->saving ? e->V + (int64_t)(j + 1) * e->ldv : e->y;
+		k_swap_scale<<<nb, kBlock, 0, st>>>((double2*)xcur, (const double2*)ycur, (double2*)ynext,
+		                                   multi(e) ? (double2*)e->comm.send_buf : nullptr, b2_ptr, e->n2);
+		e->ycur = ynext;
+	}
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipMemcpyAsync(e->h_scal + 2 * j, e->ab_dev + 2 * j, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
 	if ((int)e->step_events.size() <= j) {
@@ -190,10 +216,19 @@ lpp_status one_step(lpp_engine* e, const double* ritz, int nst)
 		for (size_t i = old; i < e->step_events.size(); i++) HIP_TRY(hipEventCreateWithFlags(&e->step_events[i], hipEventDisableTiming));
 	}
 	HIP_TRY(hipEventRecord(e->step_events[j], st));
-	e->ycur = ynext;
 	e->step = j + 1;
 	e->stats.steps_enqueued = e->step;
 	return LPP_OK;
+}
+
+// coefficients (a_j, b_j) of step k from the pinned mirror; in the scale-free form the device holds raw_k = a_k b_{k-1}
+void host_coeffs(const lpp_engine* e, int k, double b_prev, double* a, double* b)
+{
+	const double b2 = e->h_scal[2 * k + 1];
+	*b = std::sqrt(b2 > 0 ? b2 : 0.0);
+	double av = e->h_scal[2 * k];
+	if (e->scalefree && std::fabs(b_prev) >= 1e-10) av /= b_prev;
+	*a = av;
 }
 
 int effective_max_steps(const lpp_engine* e)
@@ -245,11 +280,11 @@ lpp_status begin_run(lpp_engine* e, const void* init, bool want_save)
 		if (st != LPP_OK) return st;
 	}
 	e->saving = got;
-	e->ycur = e->saving ? e->V : e->y;
+	e->scalefree = !e->saving && !e->cfg.reortho && getenv("LPP_NO_SCALE_FREE") == nullptr;
 	e->step = 0;
 	hipStream_t st = e->stream;
 	const int nb = blas_blocks(e->n2);
-	// start vector -> x (scratch), normalise into y_0
+	// start vector -> x (scratch)
 	HIP_TRY(hipMemsetAsync(e->x, 0, sizeof(double) * (size_t)e->nd_pad, st));
 	if (init) {
 		HIP_TRY(hipMemcpyAsync(e->x, init, e->esz * (size_t)e->n_local, hipMemcpyHostToDevice, st));
@@ -260,8 +295,19 @@ lpp_status begin_run(lpp_engine* e, const void* init, bool want_save)
 	k_reduce_final<<<1, kBlock, 0, st>>>(e->partial, nb, 1, 1, e->tmp_dev);
 	lpp_status rc = comm_allreduce(e, e->tmp_off, 1);
 	if (rc != LPP_OK) return rc;
-	k_scale_copy<<<nb, kBlock, 0, st>>>((double2*)e->ycur, multi(e) ? (double2*)e->comm.send_buf : nullptr, (const double2*)e->x, e->tmp_dev, e->n2);
-	HIP_TRY(hipMemsetAsync(e->x, 0, sizeof(double) * (size_t)e->nd_pad, st));
+	HIP_TRY(hipMemcpyAsync(e->h_scal + 2 * e->M, e->tmp_dev, sizeof(double), hipMemcpyDeviceToHost, st)); // |init|^2 = b_{-1}^2
+	if (e->scalefree) {
+		// r_0 = init stays unnormalised in e->x; e->y is the (zero) buffer of r_{-1}
+		e->ycur = e->x;
+		e->xcur = e->y;
+		HIP_TRY(hipMemsetAsync(e->y, 0, sizeof(double) * (size_t)e->nd_pad, st));
+		if (multi(e)) HIP_TRY(hipMemcpyAsync(e->comm.send_buf, e->x, sizeof(double) * (size_t)e->nd, hipMemcpyDeviceToDevice, st));
+	} else {
+		e->ycur = e->saving ? e->V : e->y;
+		e->xcur = e->x;
+		k_scale_copy<<<nb, kBlock, 0, st>>>((double2*)e->ycur, multi(e) ? (double2*)e->comm.send_buf : nullptr, (const double2*)e->x, e->tmp_dev, e->n2);
+		HIP_TRY(hipMemsetAsync(e->x, 0, sizeof(double) * (size_t)e->nd_pad, st));
+	}
 	HIP_TRY(hipGetLastError());
 	e->active = true;
 	e->spmv_events_used = 0;
@@ -288,10 +334,9 @@ lpp_status run_recurrence(lpp_engine* e, SolveResult& res)
 	int final_steps = -1;
 	auto check = [&](int k) -> lpp_status {
 		HIP_TRY(hipEventSynchronize(e->step_events[k]));
-		res.a[k] = e->h_scal[2 * k];
-		const double b2 = e->h_scal[2 * k + 1];
-		res.b[k] = std::sqrt(b2 > 0 ? b2 : 0.0);
-		if (!std::isfinite(res.a[k]) || !std::isfinite(b2)) return fail(LPP_ERR_NOCONV, "Lanczos produced a non-finite coefficient");
+		const double b_prev = (k == 0) ? std::sqrt(std::max(e->h_scal[2 * e->M], 0.0)) : res.b[k - 1];
+		host_coeffs(e, k, b_prev, &res.a[k], &res.b[k]);
+		if (!std::isfinite(res.a[k]) || !std::isfinite(res.b[k])) return fail(LPP_ERR_NOCONV, "Lanczos produced a non-finite coefficient");
 		const double enew = tridiag_kth(k + 1, res.a.data(), res.b.data(), 0);
 		if (e->cfg.eps > 0) {
 			const bool exitFlag = std::fabs(enew - eold) < e->cfg.eps;
@@ -356,9 +401,13 @@ lpp_status lpp_engine_lanczos_coeffs(lpp_engine* e, int32_t* steps, double* a, d
 	HIP_TRY(hipSetDevice(e->cfg.device));
 	HIP_TRY(hipStreamSynchronize(e->stream));
 	*steps = e->step;
+	double b_prev = std::sqrt(std::max(e->h_scal[2 * e->M], 0.0));
 	for (int j = 0; j < e->step; j++) {
-		if (a) a[j] = e->h_scal[2 * j];
-		if (b) b[j] = std::sqrt(std::max(e->h_scal[2 * j + 1], 0.0));
+		double av = 0, bv = 0;
+		host_coeffs(e, j, b_prev, &av, &bv);
+		if (a) a[j] = av;
+		if (b) b[j] = bv;
+		b_prev = bv;
 	}
 	return LPP_OK;
 }
@@ -418,11 +467,15 @@ lpp_status lpp_engine_lanczos(lpp_engine* e, const void* init, int32_t nstates, 
 			lpp_stats keep = e->stats;
 			st = begin_run(e, init, false);
 			if (st != LPP_OK) return st;
-			e->saving = false;
-			e->ycur = e->y;
 			HIP_TRY(hipMemsetAsync(e->zwork, 0, sizeof(double) * (size_t)e->nd_pad * (size_t)nstates, e->stream));
+			std::vector<double> coefk(nstates);
+			const double binit = std::sqrt(std::max(e->h_scal[2 * e->M], 0.0));
 			for (int j = 0; j < steps; j++) {
-				st = one_step(e, &S[(size_t)j * nstates], nstates);
+				// scale-free form: the vector in hand is r_j = b_{j-1} y_j (b_{-1} = |init|)
+				const double bprev = (j == 0) ? binit : res.b[j - 1];
+				const double sc = (e->scalefree && std::fabs(bprev) >= 1e-10) ? 1.0 / bprev : 1.0;
+				for (int k = 0; k < nstates; k++) coefk[k] = S[(size_t)j * nstates + k] * sc;
+				st = one_step(e, coefk.data(), nstates);
 				if (st != LPP_OK) return st;
 			}
 			HIP_TRY(hipStreamSynchronize(e->stream));

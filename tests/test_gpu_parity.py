@@ -281,3 +281,32 @@ def test_matrix_free_hubbard_matches_stored_and_otf(case, monkeypatch):
         assert st["nnz"] == A.nnz  # the equivalent stored CSR has exactly the oracle's entries
     if case == "tiny":
         assert abs(eg[0] + 2 * np.sqrt(5)) < 1e-12
+
+
+@pytest.mark.parametrize("name", ["hubbard", "tj_complex"])
+def test_scale_free_recurrence_equals_normalised(mats, name, monkeypatch):
+    """The scale-free form (unnormalised Lanczos vectors, no swap pass) yields the same tridiagonal matrix."""
+    A = mats[name]
+    dt = "c128" if A.is_complex else "f64"
+    init = oracle.fill_random(A.nrows, 1234, A.is_complex)
+    with LanczosEngine(dtype=dt, max_steps=60, eps=0.0, save_vectors=0) as e:
+        e.set_csr(A.rowptr, A.colind, A.values)
+        a1, b1, _ = e.decomposition(init)
+        monkeypatch.setenv("LPP_NO_SCALE_FREE", "1")
+        a2, b2, _ = e.decomposition(init)
+        monkeypatch.delenv("LPP_NO_SCALE_FREE")
+        assert len(a1) == len(a2) == 60
+        assert rel(a1[:40], a2[:40]) < 1e-9 and rel(b1[:40], b2[:40]) < 1e-9
+        # incremental interface reports the same coefficients
+        e.begin(init)
+        e.step(25)
+        e.sync()
+        a3, b3 = e.coeffs()
+        assert rel(a3, a1[:25]) < 1e-12 and rel(b3, b1[:25]) < 1e-12
+        # two-pass Ritz vector (scale-free second pass) is an eigenvector
+    with LanczosEngine(dtype=dt, save_vectors=0) as e:
+        e.set_csr(A.rowptr, A.colind, A.values)
+        eg, zg, st = e.lanczos(1, init=init, want_vectors=True)
+        assert st["vectors_saved"] == 0
+        r = oracle.spmv_acc(A, np.zeros_like(zg[0]), zg[0]) - eg[0] * zg[0]
+        assert np.linalg.norm(r) < 1e-5 and abs(np.linalg.norm(zg[0]) - 1) < 1e-8
