@@ -61,6 +61,8 @@ WORKLOADS = {
     # name: (model, params)
     "hubbard_4x4_half_filling_pbc_U4": ("hubbard", dict(L=16, nup=8, ndown=8, hop=lambda: square_lattice(4, 4, -1.0), U=4.0)),
     "hubbard_4x4_7up7down_pbc_U4": ("hubbard", dict(L=16, nup=7, ndown=7, hop=lambda: square_lattice(4, 4, -1.0), U=4.0)),
+    # 2.36e9 states: 14x more than fits one GPU as a stored CSR (would be ~1 TB); matrix-free engine only
+    "hubbard_3x6_half_filling_pbc_U4": ("hubbard", dict(L=18, nup=9, ndown=9, hop=lambda: square_lattice(3, 6, -1.0), U=4.0)),
     "hubbard_chain_L12_half_filling_U4": ("hubbard", dict(L=12, nup=6, ndown=6, hop=lambda: chain(12, -1.0), U=4.0)),
     "hubbard_chain_L14_half_filling_U4": ("hubbard", dict(L=14, nup=7, ndown=7, hop=lambda: chain(14, -1.0), U=4.0)),
     "heisenberg_chain_L28_sz0_obc": ("heisenberg", dict(L=28, sz=14, j=1.0, pbc=False)),
