@@ -91,12 +91,17 @@ def test_two_rank_partitioned_lanczos_over_gloo():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q), daemon=True) for r in range(2)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=300) for _ in procs]
-    for p in procs:
-        p.join(timeout=60)
+    try:
+        res = [q.get(timeout=300) for _ in procs]
+    finally:
+        for p in procs:
+            p.join(timeout=20)
+        for p in procs:
+            if p.is_alive():
+                p.kill()
     for r in res:
         assert r[1] != "error", r[2]
     for rank, e0, eo, ng, nr in res:

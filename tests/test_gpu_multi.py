@@ -24,6 +24,28 @@ def _free_port():
     return p
 
 
+def _run_ranks(target, world, timeout=300):
+    """Spawn `world` ranks; never leave a hung child behind (a deadlocked collective must fail the test, not the run)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=target, args=(r, world, port, q), daemon=True) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    try:
+        for _ in procs:
+            r, out = q.get(timeout=timeout)
+            res[r] = out
+    finally:
+        for p in procs:
+            p.join(timeout=20)
+        for p in procs:
+            if p.is_alive():
+                p.kill()
+    return res
+
+
 def _worker(rank, world, port, q):
     try:
         import torch
@@ -99,15 +121,7 @@ def _worker(rank, world, port, q):
 
 
 def test_two_ranks_share_one_gpu_over_gloo():
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    res = dict(q.get(timeout=600) for _ in procs)
-    for p in procs:
-        p.join(timeout=60)
+    res = _run_ranks(_worker, 2)
     for r in (0, 1):
         assert "error" not in res[r], res[r].get("error")
     for r in (0, 1):
@@ -129,3 +143,55 @@ def test_two_ranks_share_one_gpu_over_gloo():
         a1, b1, _ = e.decomposition()
     n = min(len(a1), len(res[0]["a"]))
     assert np.abs(a1[:n] - res[0]["a"][:n]).max() < 1e-8
+
+
+def _worker_uneven(rank, world, port, q):
+    """4 ranks, shards of unequal size (210 down-configurations -> 53,53,53,51), stored and matrix-free engines."""
+    try:
+        import torch
+        import torch.distributed as dist
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import oracle
+        import lanczosplusplus_amd as lp
+        from helpers import chain
+        from lanczosplusplus_amd.comm import TorchDistComm
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(dev)
+        L, nup, ndown = 10, 5, 4
+        hop, U = chain(L, -1.0, True), np.linspace(3.0, 5.0, L)
+        n_up = 252
+        stride = int(-(-210 // world) * n_up)
+        comm = TorchDistComm(stride, 200, False, device=dev)
+        out = {}
+        with comm.stream_context():
+            e = lp.LanczosEngine(max_steps=200, stream=comm.stream_handle)
+            e.assemble_hubbard(L, nup, ndown, hop, U, comm=comm)
+            out["rows"] = e.rows()
+            eg, _, st = e.lanczos(1, want_vectors=False)
+            out["e_stored"], out["steps_stored"] = float(eg[0]), st["steps"]
+            e.setup_hubbard_onthefly(L, nup, ndown, hop, U, comm=comm)
+            eg, zg, st = e.lanczos(2, want_vectors=True)  # keeps vectors: normalised recurrence on the matrix-free product
+            out["e_kron"], out["steps_kron"] = [float(v) for v in eg], st["steps"]
+            e.close()
+        A = oracle.hubbard_csr(L, nup, ndown, hop, U)
+        eo, _, so = oracle.lanczos_solve(A, oracle.fill_random(A.nrows, 1234), want_vectors=False)
+        out["e_oracle"], out["steps_oracle"] = float(eo[0]), so
+        q.put((rank, out))
+        dist.destroy_process_group()
+    except Exception:
+        import traceback
+        q.put((rank, {"error": traceback.format_exc()}))
+
+
+def test_four_ranks_uneven_shards():
+    world = 4
+    res = _run_ranks(_worker_uneven, world)
+    for r in range(world):
+        assert "error" not in res[r], res[r].get("error")
+    assert [res[r]["rows"] for r in range(world)] == [53 * 252, 53 * 252, 53 * 252, 51 * 252]
+    for r in range(world):
+        o = res[r]
+        assert abs(o["e_stored"] - o["e_oracle"]) <= 1e-10 * abs(o["e_oracle"]) and o["steps_stored"] == o["steps_oracle"]
+        assert abs(o["e_kron"][0] - o["e_oracle"]) <= 1e-10 * abs(o["e_oracle"])
+    assert all(res[r]["e_kron"] == res[0]["e_kron"] for r in range(world))

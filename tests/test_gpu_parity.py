@@ -310,3 +310,21 @@ def test_scale_free_recurrence_equals_normalised(mats, name, monkeypatch):
         assert st["vectors_saved"] == 0
         r = oracle.spmv_acc(A, np.zeros_like(zg[0]), zg[0]) - eg[0] * zg[0]
         assert np.linalg.norm(r) < 1e-5 and abs(np.linalg.norm(zg[0]) - 1) < 1e-8
+
+
+def test_matrix_free_with_reortho_and_excited_states():
+    """The matrix-free product under the vector-keeping (normalised) recurrence: reortho, 3 lowest states."""
+    L, nup, ndown = 8, 4, 3
+    hop, U = chain(L, -1.0, True), np.full(L, 4.0)
+    A = oracle.hubbard_csr(L, nup, ndown, hop, U)
+    dense = np.linalg.eigvalsh(A.to_scipy().toarray())
+    with LanczosEngine(reortho=True, max_steps=150, eps=1e-13) as e:
+        e.setup_hubbard_onthefly(L, nup, ndown, hop, U)
+        eg, zg, st = e.lanczos(3, want_vectors=True)
+    assert abs(eg[0] - dense[0]) <= E_TOL * abs(dense[0])
+    assert np.abs(zg @ zg.T - np.eye(3)).max() < 1e-8
+    # the run stops when the GROUND state has converged (reference rule); excited Ritz pairs are cruder
+    r = oracle.spmv_acc(A, np.zeros_like(zg[0]), zg[0]) - eg[0] * zg[0]
+    assert np.linalg.norm(r) < 1e-5
+    eo, _, _ = oracle.lanczos_solve(A, oracle.fill_random(A.nrows, 1234), nstates=3, max_steps=150, eps=1e-13, reortho=True)
+    assert rel(eg, eo) < 1e-8
