@@ -386,7 +386,10 @@ lpp_status lpp_engine_create(lpp_engine** out, const lpp_config* cfg)
 		e->own_stream = true;
 	}
 	e->spmv_max_blocks = 256 * 16;
-	e->k2_variant = 6; // bit1: XCD-contiguous block map, bit2: 8 slots per batch
+	// bit1: XCD-contiguous slice/block map, bit2: 8 slots per batch.  Measured (profiles/README.md): the plain
+	// round-robin map is faster for every real-valued workload (4x4 Hubbard 10.8 vs 11.6 ms, matrix-free 4.47 vs
+	// 4.70, Heisenberg L=28 1.29 vs 1.36), the XCD-contiguous map for the complex t-J matrix (0.62 vs 0.68).
+	e->k2_variant = e->is_complex ? 6 : 4;
 	if (const char* s = getenv("LPP_K2_VARIANT")) e->k2_variant = atoi(s);
 	{
 		int ncu = 0;
