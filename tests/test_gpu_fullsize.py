@@ -52,3 +52,6 @@ def test_config2_shape_matrix_free_equals_stored_energy_with_U():
         e.assemble_hubbard(L, 8, 8, hop, U)
         e2, _, s2 = e.lanczos(1, want_vectors=False)
     assert abs(e1[0] - e2[0]) <= 1e-10 * abs(e2[0]) and s1["steps"] == s2["steps"]
+    # literature cross-check: the 4x4 periodic Hubbard cluster at U=4t, half filling, has E0 = -13.6219 t
+    # (E0/N = -0.8514, exact diagonalisation results quoted since Fano, Ortolani & Parola 1990)
+    assert abs(e2[0] - (-13.62185)) < 2e-4
