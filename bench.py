@@ -193,7 +193,11 @@ def main():
         from math import comb as binom
         n_up, n_dn = binom(p["L"], p["nup"]), binom(p["L"], p["ndown"])
         stride = -(-n_dn // world) * n_up
-        comm = TorchDistComm(stride, max_steps, is_complex, device=torch.device("cuda", local_rank))
+        # exchange per step: all-gather of the vector (N/P per rank out, N in) or the transposition scheme (two
+        # all-to-alls of N/P each; 2/P of the volume, pays from 4 ranks on).  LPP_EXCHANGE overrides.
+        exchange = os.environ.get("LPP_EXCHANGE", "transpose" if (world >= 4 and args.engine == "stored") else "allgather")
+        chunk = (-(-n_dn // world)) * (-(-n_up // world)) if (exchange == "transpose" and args.engine == "stored") else 0
+        comm = TorchDistComm(stride, max_steps, is_complex, device=torch.device("cuda", local_rank), xchg_chunk=chunk)
 
     def barrier():
         if world > 1:
@@ -269,7 +273,8 @@ def main():
             "dtype": "c128" if is_complex else "f64",
             "data": "synthetic",
             "config": {"workload": name, "rows": nrows_g, "nnz": nnz_g, "parallelism": "1-D row partition x%d" % world,
-                       "reortho": False, "assembly": "on-device", "assembly_s": round(t_asm, 3), "engine": args.engine},
+                       "reortho": False, "assembly": "on-device", "assembly_s": round(t_asm, 3), "engine": args.engine,
+                       "exchange": (("transpose" if comm.xchg_chunk > 0 else "allgather") if comm is not None else None)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": ("k_spmv_kron_packed (matrix-free x += H y; bytes = vector-streaming model N*s*(3 + down-hops/row))"

@@ -99,6 +99,16 @@ typedef struct lpp_comm {
 	int32_t (*allgather_begin)(void* ctx);
 	int32_t (*allgather_end)(void* ctx);
 	int32_t (*allreduce_sum)(void* ctx, int32_t offset, int32_t count); /* in place on red_buf[offset..] */
+	/* Optional transposition exchange (lpp_engine_assemble_hubbard only; all four NULL/0 = all-gather path).
+	 * Two all-to-alls of nranks equal chunks of xchg_chunk elements each:
+	 *   which 0: chunk p of send_buf  -> rank p, received into chunk (sender) of gath_buf
+	 *   which 1: chunk p of send2_buf -> rank p, received into chunk (sender) of recv2_buf
+	 * send_buf, gath_buf, send2_buf, recv2_buf then hold nranks*xchg_chunk elements (zero-initialised by the owner). */
+	void* send2_buf;
+	void* recv2_buf;
+	int64_t xchg_chunk;
+	int32_t (*exchange_begin)(void* ctx, int32_t which);
+	int32_t (*exchange_end)(void* ctx, int32_t which);
 } lpp_comm;
 
 const char* lpp_last_error(void);

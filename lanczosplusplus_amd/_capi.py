@@ -44,13 +44,15 @@ class Stats(C.Structure):
 
 CB_VOID = C.CFUNCTYPE(C.c_int32, C.c_void_p)
 CB_REDUCE = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_int32, C.c_int32)
+CB_XCHG = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_int32)
 
 
 class Comm(C.Structure):
     _fields_ = [("rank", C.c_int32), ("nranks", C.c_int32), ("ctx", C.c_void_p), ("send_buf", C.c_void_p),
                 ("gath_buf", C.c_void_p), ("red_buf", C.c_void_p), ("shard_stride", C.c_int64),
                 ("red_len", C.c_int32), ("allgather_begin", CB_VOID), ("allgather_end", CB_VOID),
-                ("allreduce_sum", CB_REDUCE)]
+                ("allreduce_sum", CB_REDUCE), ("send2_buf", C.c_void_p), ("recv2_buf", C.c_void_p),
+                ("xchg_chunk", C.c_int64), ("exchange_begin", CB_XCHG), ("exchange_end", CB_XCHG)]
 
 
 # every symbol include/lpp_engine.h declares: (restype, argtypes)

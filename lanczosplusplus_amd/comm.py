@@ -18,23 +18,36 @@ import traceback
 import torch
 import torch.distributed as dist
 
-from ._capi import CB_REDUCE, CB_VOID, Comm
+from ._capi import CB_REDUCE, CB_VOID, CB_XCHG, Comm
 
 
 class TorchDistComm:
-    def __init__(self, shard_stride, max_steps, is_complex=False, device=None, group=None):
+    def __init__(self, shard_stride, max_steps, is_complex=False, device=None, group=None, xchg_chunk=0):
+        """xchg_chunk > 0 selects the transposition exchange (Hubbard device assembly only): two all-to-alls of
+        nranks chunks of xchg_chunk = ceil(N_down/P)*ceil(N_up/P) elements replace the all-gather."""
         self.group = group
         self.rank = dist.get_rank(group)
         self.nranks = dist.get_world_size(group)
         self.device = torch.device(device if device is not None else "cpu")
         ncomp = 2 if is_complex else 1
         self.shard_stride = int(shard_stride)
-        self.send = torch.zeros(self.shard_stride * ncomp, dtype=torch.float64, device=self.device)
-        self.gath = torch.zeros(self.nranks * self.shard_stride * ncomp, dtype=torch.float64, device=self.device)
+        self.xchg_chunk = int(xchg_chunk)
+        if self.xchg_chunk > 0:
+            n = self.nranks * self.xchg_chunk * ncomp
+            self.send = torch.zeros(n, dtype=torch.float64, device=self.device)
+            self.gath = torch.zeros(n, dtype=torch.float64, device=self.device)
+            self.send2 = torch.zeros(n, dtype=torch.float64, device=self.device)
+            self.recv2 = torch.zeros(n, dtype=torch.float64, device=self.device)
+        else:
+            self.send = torch.zeros(self.shard_stride * ncomp, dtype=torch.float64, device=self.device)
+            self.gath = torch.zeros(self.nranks * self.shard_stride * ncomp, dtype=torch.float64, device=self.device)
+            self.send2 = self.recv2 = None
         self.red = torch.zeros(6 * (max_steps + 2) + 8, dtype=torch.float64, device=self.device)
         self._work = None
         self.stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
-        self.calls = {"allgather": 0, "allreduce": 0}
+        self.calls = {"allgather": 0, "allreduce": 0, "exchange": 0}
+        self._xwork = None
+        self._xstage = None
 
         def _begin(_ctx):
             try:
@@ -68,8 +81,51 @@ class TorchDistComm:
                 traceback.print_exc(file=sys.stderr)
                 return 1
 
+        def _xbegin(_ctx, which):
+            """all-to-all of nranks equal chunks: chunk p of the source goes to rank p, chunk q of the destination
+            comes from rank q.  nccl: all_to_all_single; gloo (tests): point-to-point with host staging."""
+            try:
+                self.calls["exchange"] += 1
+                src, dst = (self.send, self.gath) if which == 0 else (self.send2, self.recv2)
+                if dist.get_backend(self.group) == "nccl":
+                    self._xwork = dist.all_to_all_single(dst, src, group=self.group, async_op=True)
+                    self._xstage = None
+                else:
+                    sc, dc = src.chunk(self.nranks), dst.chunk(self.nranks)
+                    dc[self.rank].copy_(sc[self.rank])
+                    outs = {p: sc[p].cpu() for p in range(self.nranks) if p != self.rank}
+                    ins = {p: torch.empty_like(outs[p]) for p in outs}
+                    reqs = []
+                    for p in outs:
+                        reqs.append(dist.isend(outs[p], dst=p, group=self.group))
+                        reqs.append(dist.irecv(ins[p], src=p, group=self.group))
+                    self._xwork = reqs
+                    self._xstage = (ins, dc, outs)
+                return 0
+            except Exception:
+                traceback.print_exc(file=sys.stderr)
+                return 1
+
+        def _xend(_ctx, which):
+            try:
+                if self._xstage is None:
+                    if self._xwork is not None:
+                        self._xwork.wait()
+                else:
+                    for r in self._xwork:
+                        r.wait()
+                    ins, dc, _ = self._xstage
+                    for p, t in ins.items():
+                        dc[p].copy_(t)
+                self._xwork = None
+                self._xstage = None
+                return 0
+            except Exception:
+                traceback.print_exc(file=sys.stderr)
+                return 1
+
         # keep references: ctypes callbacks must outlive the engine
-        self._cb = (CB_VOID(_begin), CB_VOID(_end), CB_REDUCE(_reduce))
+        self._cb = (CB_VOID(_begin), CB_VOID(_end), CB_REDUCE(_reduce), CB_XCHG(_xbegin), CB_XCHG(_xend))
         s = Comm()
         s.rank, s.nranks, s.ctx = self.rank, self.nranks, None
         s.send_buf = self.send.data_ptr()
@@ -77,7 +133,12 @@ class TorchDistComm:
         s.red_buf = self.red.data_ptr()
         s.shard_stride = self.shard_stride
         s.red_len = self.red.numel()
-        s.allgather_begin, s.allgather_end, s.allreduce_sum = self._cb
+        s.allgather_begin, s.allgather_end, s.allreduce_sum = self._cb[:3]
+        if self.xchg_chunk > 0:
+            s.send2_buf = self.send2.data_ptr()
+            s.recv2_buf = self.recv2.data_ptr()
+            s.xchg_chunk = self.xchg_chunk
+            s.exchange_begin, s.exchange_end = self._cb[3], self._cb[4]
         self.struct = s
 
     @property

@@ -144,7 +144,7 @@ uint64_t binom(const std::vector<uint64_t>& c, int n, int m)
 
 // terms of the Hubbard hopping: c^dagger_j c_i for every ordered pair with hoppings_(i,j) != 0, both species,
 // value h * doSign(ket,i) * doSign(ket^bit(i), j)   (HubbardHelper.h:205-243, ProgramGlobals.h:109-114)
-void hubbard_terms(int L, const double* hop_re, const double* hop_im, std::vector<HostProc>& hp)
+void hubbard_terms(int L, const double* hop_re, const double* hop_im, std::vector<HostProc>& hp, int species_mask = 3)
 {
 	for (int i = 0; i < L; i++) {
 		for (int j = 0; j < L; j++) {
@@ -152,6 +152,7 @@ void hubbard_terms(int L, const double* hop_re, const double* hop_im, std::vecto
 			const double hr = hop_re[i * L + j], hi = hop_im ? hop_im[i * L + j] : 0.0;
 			if (hr == 0 && hi == 0) continue;
 			for (int spin = 0; spin < 2; spin++) {
+				if (!(species_mask & (1 << spin))) continue;
 				const int sh = spin * L;
 				push(hp, bit(i + sh), bit(j + sh), bit(i + sh) | bit(j + sh), (below(i) ^ below(j)) << sh, 0, i < j ? 1 : 0, hr, hi);
 			}
@@ -242,14 +243,64 @@ lpp_status lpp_engine_assemble_hubbard(lpp_engine* e, const lpp_comm* comm, int3
 		P.nloc = starts[comm->rank + 1] - starts[comm->rank];
 		P.col_lo = starts[comm->rank];
 		P.col_hi = starts[comm->rank + 1];
-		P.part = 1;
+		const bool transpose = comm->exchange_begin && comm->exchange_end && comm->xchg_chunk > 0;
 		free_kron(e);
-		st = dispatch<ASM_HUBBARD>(e, P, e->A_loc);
-		if (st != LPP_OK) return st;
-		P.part = 2;
-		e->A_rem.src_elems = (int64_t)comm->nranks * comm->shard_stride;
-		st = dispatch<ASM_HUBBARD>(e, P, e->A_rem);
-		if (st != LPP_OK) return st;
+		if (!transpose) {
+			e->tx = false;
+			P.part = 1;
+			st = dispatch<ASM_HUBBARD>(e, P, e->A_loc);
+			if (st != LPP_OK) return st;
+			P.part = 2;
+			e->A_rem.src_elems = (int64_t)comm->nranks * comm->shard_stride;
+			st = dispatch<ASM_HUBBARD>(e, P, e->A_rem);
+			if (st != LPP_OK) return st;
+		} else {
+			// Transposition scheme: the up-hop + diagonal part acts on the rank's own slice (down-index partition);
+			// the down-hop part is assembled for the rank's UP-index range over ALL down indices, in the layout
+			// row = id*peru + (iu - iu0), and acts on the transposed slice delivered by the first all-to-all.
+			const int64_t peru = (n_up + comm->nranks - 1) / comm->nranks;
+			if (!comm->send2_buf || !comm->recv2_buf || comm->xchg_chunk != per * peru)
+				return fail(LPP_ERR_INVALID, "assemble_hubbard: transposition exchange needs send2/recv2 buffers and xchg_chunk == ceil(N_down/P)*ceil(N_up/P)");
+			if ((int64_t)comm->nranks * per * peru > (int64_t)INT32_MAX) return fail(LPP_ERR_INVALID, "assemble_hubbard: transposed slice exceeds 32-bit column range");
+			std::vector<HostProc> hu, hd;
+			hubbard_terms(L, hop_re, hop_im, hu, 1);
+			hubbard_terms(L, hop_re, hop_im, hd, 2);
+			std::vector<Proc> pu, pd;
+			int nnegu = 0, nnegd = 0;
+			if ((st = finish_procs(hu, pu, &nnegu)) != LPP_OK) return st;
+			if ((st = finish_procs(hd, pd, &nnegd)) != LPP_OK) return st;
+			DevBuf d_pu, d_pd;
+			if ((st = upload(e->stream, d_pu, pu.data(), sizeof(Proc) * pu.size())) != LPP_OK) return st;
+			if ((st = upload(e->stream, d_pd, pd.data(), sizeof(Proc) * pd.size())) != LPP_OK) return st;
+			AsmParams Pu = P;
+			Pu.procs = (const Proc*)d_pu.p;
+			Pu.nproc = (int)pu.size();
+			Pu.nneg = nnegu;
+			Pu.part = 1;
+			st = dispatch<ASM_HUBBARD>(e, Pu, e->A_loc);
+			if (st != LPP_OK) return st;
+			AsmParams Pd = P;
+			Pd.procs = (const Proc*)d_pd.p;
+			Pd.nproc = (int)pd.size();
+			Pd.nneg = nnegd;
+			Pd.part = 0;
+			Pd.no_diag = 1;
+			Pd.tr = 1;
+			Pd.peru = peru;
+			Pd.iu0 = std::min<int64_t>((int64_t)comm->rank * peru, n_up);
+			Pd.nu = std::min<int64_t>(Pd.iu0 + peru, n_up) - Pd.iu0;
+			Pd.n_dn = n_dn;
+			Pd.row0 = 0;
+			Pd.nloc = (int64_t)comm->nranks * per * peru;
+			e->A_rem.src_elems = Pd.nloc;
+			st = dispatch<ASM_HUBBARD>(e, Pd, e->A_rem, LPP_SPMV_SLICED, peru);
+			if (st != LPP_OK) return st;
+			e->A_rem.hint_block = 0;
+			e->tx = true;
+			e->tx_per = per;
+			e->tx_peru = peru;
+			e->kron_n_up_tx = n_up;
+		}
 		e->n_local = P.nloc;
 		e->n_global = nrows;
 		e->row_start = P.row0;

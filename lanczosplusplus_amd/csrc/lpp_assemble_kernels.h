@@ -47,6 +47,11 @@ struct AsmParams {
 	const double* d1; // Hubbard V[L] | Heisenberg anisotropy[L] (nd1 valid) | t-J jzz[L*L]
 	const double* d2; // Heisenberg jzz[L*L] | t-J w[L*L]
 	int nd0, nd1;
+	// Hubbard, transposed row layout (multi-GPU transposition scheme): row = id*peru + (iu - iu0) for the rank's
+	// UP-index range [iu0, iu0+nu) and ALL down indices id < n_dn; rows with iu_l >= nu or id >= n_dn are padding
+	int tr;
+	int64_t iu0, nu, peru, n_dn;
+	int no_diag; // 1: do not emit the diagonal (the down-hop part of a split matrix)
 };
 
 __device__ __forceinline__ uint64_t comb_at(const uint64_t* comb, int n, int m) { return comb[n * kCombDim + m]; }
@@ -122,8 +127,24 @@ template <int MODEL> __device__ __forceinline__ int64_t index_of(const AsmParams
 	if (MODEL == ASM_HEISENBERG) return rank_comb(P.comb, w);
 	const uint64_t lowmask = (1ull << P.L) - 1;
 	const uint64_t up = w & lowmask, down = w >> P.L;
+	if (MODEL == ASM_HUBBARD && P.tr) return rank_comb(P.comb, down) * P.peru + (rank_comb(P.comb, up) - P.iu0);
 	if (MODEL == ASM_HUBBARD) return rank_comb(P.comb, up) + rank_comb(P.comb, down) * P.n_up;
 	return rank_comb(P.comb, pext_sw(up, ~down & lowmask)) + rank_comb(P.comb, down) * P.n_up;
+}
+
+// state of (global or transposed-layout) row `row`; false for a padding row of the transposed layout
+template <int MODEL> __device__ __forceinline__ bool row_state(const AsmParams& P, int64_t row, uint64_t& ket)
+{
+	if (MODEL == ASM_HUBBARD && P.tr) {
+		const int64_t iul = row % P.peru, id = row / P.peru;
+		if (iul >= P.nu || id >= P.n_dn) return false;
+		const uint64_t down = unrank_comb(P.comb, id, P.ndown, P.L);
+		const uint64_t up = unrank_comb(P.comb, P.iu0 + iul, P.nup, P.L);
+		ket = (down << P.L) | up;
+		return true;
+	}
+	ket = state_of<MODEL>(P, row);
+	return true;
 }
 
 // Diagonal elements, additions in the reference's loop order so the doubles are bit-identical
@@ -183,7 +204,11 @@ __global__ __launch_bounds__(kBlock) void k_asm_count(AsmParams P, int64_t* __re
 {
 	for (int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x; r < P.nloc; r += (int64_t)gridDim.x * kBlock) {
 		const int64_t row = P.row0 + r;
-		const uint64_t ket = state_of<MODEL>(P, row);
+		uint64_t ket;
+		if (!row_state<MODEL>(P, row, ket)) {
+			len[r] = 0;
+			continue;
+		}
 		int n = 0;
 		for (int p = 0; p < P.nproc; p++) {
 			const Proc& pr = P.procs[p];
@@ -195,7 +220,7 @@ __global__ __launch_bounds__(kBlock) void k_asm_count(AsmParams P, int64_t* __re
 				if (col_selected(P, c)) n++;
 			}
 		}
-		if (col_selected(P, row)) n++; // the diagonal is always stored (HubbardHelper.h:93)
+		if (!P.no_diag && col_selected(P, row)) n++; // the diagonal is always stored (HubbardHelper.h:93)
 		len[r] = n;
 	}
 }
@@ -207,12 +232,13 @@ __global__ __launch_bounds__(kBlock) void k_asm_fill(AsmParams P, const int64_t*
 {
 	for (int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x; r < P.nloc; r += (int64_t)gridDim.x * kBlock) {
 		const int64_t row = P.row0 + r;
-		const uint64_t ket = state_of<MODEL>(P, row);
+		uint64_t ket;
+		if (!row_state<MODEL>(P, row, ket)) continue;
 		int64_t q = rowptr[r];
 		const int64_t shift = (P.part == 1) ? P.col_lo : 0;
 		for (int p = 0; p <= P.nproc; p++) {
 			if (p == P.nneg) { // diagonal sits between negative and positive deltas
-				if (col_selected(P, row)) {
+				if (!P.no_diag && col_selected(P, row)) {
 					col[q] = (int32_t)(row - shift);
 					T v;
 					if constexpr (sizeof(T) == 16) {

@@ -600,6 +600,7 @@ lpp_status lpp_engine_bench_spmv(lpp_engine* e, int32_t warmup, int32_t iters, d
 	if (!e || iters <= 0 || !ms_per_launch) return fail(LPP_ERR_INVALID, "lpp_engine_bench_spmv: bad argument");
 	if (!e->has_matrix()) return fail(LPP_ERR_STATE, "lpp_engine_bench_spmv: no matrix");
 	if (e->active) return fail(LPP_ERR_STATE, "lpp_engine_bench_spmv: a Lanczos run is active");
+	if (e->has_comm && e->comm.nranks > 1 && e->tx) return fail(LPP_ERR_STATE, "lpp_engine_bench_spmv: not available with the transposition exchange");
 	HIP_TRY(hipSetDevice(e->cfg.device));
 	k_fill_random<<<1024, 256, 0, e->stream>>>(e->y, e->nd, 0, 99);
 	HIP_TRY(hipMemsetAsync(e->x, 0, sizeof(double) * (size_t)e->nd_pad, e->stream));

@@ -85,6 +85,11 @@ struct lpp_engine {
 	// matrix: A_loc has columns inside this rank's slice, A_rem (multi-GPU only) indexes the gathered buffer
 	lpp::DevCsr A_loc, A_rem;
 	lpp::KronState kron;
+	// transposition exchange (multi-GPU Hubbard): A_loc = diagonal + up-hops on the rank's slice, A_rem = down-hops
+	// on the UP-partitioned transposed slice; see lpp_assemble.hip / one_step
+	bool tx = false;
+	int64_t tx_per = 0, tx_peru = 0;
+	int64_t kron_n_up_tx = 1; // N_up of the transposition layout
 	bool has_matrix() const { return A_loc.rowptr != nullptr || kron.active; }
 	int64_t n_local = 0, n_global = 0, row_start = 0;
 	double spmv_bytes = 0;

@@ -814,6 +814,47 @@ static __global__ __launch_bounds__(kBlock) void k_axpy_const(double2* __restric
 	}
 }
 
+// ---------------------------------------------------------------------------------------------
+// Transposition exchange (multi-GPU Hubbard): the rank's slice y[(id-id0)*N_up + iu] is re-cut by UP index.
+// Chunk p of the send buffer holds the sub-block iu in [p*peru, (p+1)*peru) of every local down index:
+//   send[p*C + id_l*peru + iu_lp],  C = per*peru (padded, padding never written and pre-zeroed).
+// After the all-to-all, chunk q of the receive buffer holds the rank's own UP range for rank q's down indices,
+// i.e. the transposed slice yT[id*peru + iu_l] with id running over ALL down indices.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_pack_transpose(const T* __restrict__ y, T* __restrict__ send, int64_t nid,
+                                                            int64_t n_up, int64_t peru, int64_t chunk)
+{
+	const int64_t n = nid * n_up;
+	for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+		const int64_t idl = i / n_up, iu = i - idl * n_up;
+		const int64_t p = iu / peru, iul = iu - p * peru;
+		send[p * chunk + idl * peru + iul] = y[i];
+	}
+}
+
+// x[i] += recv[...] (the down-hop part computed on the UP-partitioned layout and sent back), fused Re<y|x> partial
+template <typename T, bool DOT>
+__global__ __launch_bounds__(kBlock) void k_unpack_add_dot(T* __restrict__ x, const T* __restrict__ recv,
+                                                            const T* __restrict__ y, int64_t nid, int64_t n_up,
+                                                            int64_t peru, int64_t chunk, double* __restrict__ partial)
+{
+	__shared__ double smem[kBlock / 64];
+	const int64_t n = nid * n_up;
+	double dot = 0.0;
+	for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+		const int64_t idl = i / n_up, iu = i - idl * n_up;
+		const int64_t p = iu / peru, iul = iu - p * peru;
+		const T xv = VT<T>::add(x[i], recv[p * chunk + idl * peru + iul]);
+		x[i] = xv;
+		if (DOT) dot += VT<T>::dot_re(y[i], xv);
+	}
+	if (DOT) {
+		const double r = block_sum(dot, smem);
+		if (threadIdx.x == 0) partial[blockIdx.x] = r;
+	}
+}
+
 // splitmix64 start vector; the test-suite checks it is bit-identical to the CPU checker's stream
 __device__ __forceinline__ uint64_t splitmix64(uint64_t z)
 {

@@ -37,6 +37,7 @@ lpp_status lpp_engine::adopt_comm(const lpp_comm* c)
 	}
 	comm = *c;
 	has_comm = true;
+	tx = false;
 	if (c->nranks > 1)
 		bind_scalars(c->red_buf);
 	else
@@ -160,6 +161,36 @@ lpp_status one_step(lpp_engine* e, const double* ritz, int nst)
 		SpmvTimer t(e);
 		np = kron_launch(e, ycur, multi(e) ? e->comm.gath_buf : ycur, xcur, e->partial, sc);
 		t.stop();
+	} else if (multi(e) && e->tx) {
+		// transposition exchange: two all-to-alls of N/P elements instead of an all-gather of N
+		const int64_t nid = e->n_local / e->kron_n_up_tx, n_up = e->kron_n_up_tx, chunk = e->comm.xchg_chunk;
+		const int nbp = (int)std::max<int64_t>(1, std::min<int64_t>((e->n_local + kBlock - 1) / kBlock, 2048));
+		if (e->is_complex)
+			k_pack_transpose<cplx><<<nbp, kBlock, 0, st>>>((const cplx*)ycur, (cplx*)e->comm.send_buf, nid, n_up, e->tx_peru, chunk);
+		else
+			k_pack_transpose<double><<<nbp, kBlock, 0, st>>>((const double*)ycur, (double*)e->comm.send_buf, nid, n_up, e->tx_peru, chunk);
+		if (e->comm.exchange_begin(e->comm.ctx, 0) != 0) return fail(LPP_ERR_COMM, "exchange_begin(0) callback failed");
+		{
+			SpmvTimer t(e);
+			spmv_launch(e, e->A_loc, ycur, xcur, nullptr, nullptr, sc); // diagonal + up-hops: overlaps the first all-to-all
+			t.stop();
+		}
+		if (e->comm.exchange_end(e->comm.ctx, 0) != 0) return fail(LPP_ERR_COMM, "exchange_end(0) callback failed");
+		HIP_TRY(hipMemsetAsync(e->comm.send2_buf, 0, e->esz * (size_t)chunk * (size_t)e->comm.nranks, st));
+		{
+			EpiScale sc2 = sc;
+			sc2.beta_one = 1; // wT = alpha * (A_down^T-layout) yT into the zeroed buffer
+			SpmvTimer t(e);
+			spmv_launch(e, e->A_rem, e->comm.gath_buf, e->comm.send2_buf, nullptr, nullptr, sc2);
+			t.stop();
+		}
+		if (e->comm.exchange_begin(e->comm.ctx, 1) != 0) return fail(LPP_ERR_COMM, "exchange_begin(1) callback failed");
+		if (e->comm.exchange_end(e->comm.ctx, 1) != 0) return fail(LPP_ERR_COMM, "exchange_end(1) callback failed");
+		if (e->is_complex)
+			k_unpack_add_dot<cplx, true><<<nbp, kBlock, 0, st>>>((cplx*)xcur, (const cplx*)e->comm.recv2_buf, (const cplx*)ycur, nid, n_up, e->tx_peru, chunk, e->partial);
+		else
+			k_unpack_add_dot<double, true><<<nbp, kBlock, 0, st>>>((double*)xcur, (const double*)e->comm.recv2_buf, (const double*)ycur, nid, n_up, e->tx_peru, chunk, e->partial);
+		np = nbp;
 	} else if (multi(e)) {
 		// the slice of the current vector was written to comm.send_buf by the previous step's last kernel
 		if (e->comm.allgather_begin(e->comm.ctx) != 0) return fail(LPP_ERR_COMM, "allgather_begin callback failed");
@@ -186,7 +217,7 @@ lpp_status one_step(lpp_engine* e, const double* ritz, int nst)
 	if (rc != LPP_OK) return rc;
 	if (e->scalefree) {
 		k_axpy_nrm<true><<<nb, kBlock, 0, st>>>((double2*)xcur, (const double2*)ycur, a_ptr, b2_prev,
-		                                       multi(e) ? (double2*)e->comm.send_buf : nullptr, e->n2, e->partial);
+		                                       (multi(e) && !e->tx) ? (double2*)e->comm.send_buf : nullptr, e->n2, e->partial);
 	} else if (e->cfg.reortho) {
 		k_axpy_nrm<false><<<nb, kBlock, 0, st>>>((double2*)xcur, (const double2*)ycur, a_ptr, nullptr, nullptr, e->n2, nullptr);
 		rc = cgs2(e, j + 1);
@@ -205,7 +236,7 @@ lpp_status one_step(lpp_engine* e, const double* ritz, int nst)
 	} else {
 		double* ynext = e->saving ? e->V + (int64_t)(j + 1) * e->ldv : e->y;
 		k_swap_scale<<<nb, kBlock, 0, st>>>((double2*)xcur, (const double2*)ycur, (double2*)ynext,
-		                                   multi(e) ? (double2*)e->comm.send_buf : nullptr, b2_ptr, e->n2);
+		                                   (multi(e) && !e->tx) ? (double2*)e->comm.send_buf : nullptr, b2_ptr, e->n2);
 		e->ycur = ynext;
 	}
 	HIP_TRY(hipGetLastError());
@@ -301,11 +332,11 @@ lpp_status begin_run(lpp_engine* e, const void* init, bool want_save)
 		e->ycur = e->x;
 		e->xcur = e->y;
 		HIP_TRY(hipMemsetAsync(e->y, 0, sizeof(double) * (size_t)e->nd_pad, st));
-		if (multi(e)) HIP_TRY(hipMemcpyAsync(e->comm.send_buf, e->x, sizeof(double) * (size_t)e->nd, hipMemcpyDeviceToDevice, st));
+		if (multi(e) && !e->tx) HIP_TRY(hipMemcpyAsync(e->comm.send_buf, e->x, sizeof(double) * (size_t)e->nd, hipMemcpyDeviceToDevice, st));
 	} else {
 		e->ycur = e->saving ? e->V : e->y;
 		e->xcur = e->x;
-		k_scale_copy<<<nb, kBlock, 0, st>>>((double2*)e->ycur, multi(e) ? (double2*)e->comm.send_buf : nullptr, (const double2*)e->x, e->tmp_dev, e->n2);
+		k_scale_copy<<<nb, kBlock, 0, st>>>((double2*)e->ycur, (multi(e) && !e->tx) ? (double2*)e->comm.send_buf : nullptr, (const double2*)e->x, e->tmp_dev, e->n2);
 		HIP_TRY(hipMemsetAsync(e->x, 0, sizeof(double) * (size_t)e->nd_pad, st));
 	}
 	HIP_TRY(hipGetLastError());

@@ -174,9 +174,42 @@ def _worker_uneven(rank, world, port, q):
             eg, zg, st = e.lanczos(2, want_vectors=True)  # keeps vectors: normalised recurrence on the matrix-free product
             out["e_kron"], out["steps_kron"] = [float(v) for v in eg], st["steps"]
             e.close()
+        # transposition exchange: same matrix, two all-to-alls per step instead of the all-gather
+        per, peru = -(-210 // world), -(-n_up // world)
+        comm_t = TorchDistComm(stride, 200, False, device=dev, xchg_chunk=per * peru)
+        with comm_t.stream_context():
+            e = lp.LanczosEngine(max_steps=200, stream=comm_t.stream_handle)
+            e.assemble_hubbard(L, nup, ndown, hop, U, comm=comm_t)
+            eg, _, st = e.lanczos(1, want_vectors=False)  # scale-free recurrence
+            out["e_tx"], out["steps_tx"] = float(eg[0]), st["steps"]
+            eg, zg, st = e.lanczos(1, want_vectors=True)  # normalised recurrence, Krylov basis kept
+            out["e_tx2"] = float(eg[0])
+            zs = [None] * world
+            dist.all_gather_object(zs, zg[0])
+            out["z_tx"] = np.concatenate(zs)
+            out["xchg_calls"] = comm_t.calls["exchange"]
+            e.close()
         A = oracle.hubbard_csr(L, nup, ndown, hop, U)
         eo, _, so = oracle.lanczos_solve(A, oracle.fill_random(A.nrows, 1234), want_vectors=False)
         out["e_oracle"], out["steps_oracle"] = float(eo[0]), so
+        # complex hoppings, both index ranges uneven (126 = 32+32+32+30), transposition exchange
+        L2 = 9
+        hc = chain(L2, -1.0, True).astype(complex)
+        hc[0, 1] *= np.exp(0.4j)
+        hc[1, 0] = np.conj(hc[0, 1])
+        U2 = np.full(L2, 3.0)
+        per = peru = -(-126 // world)
+        comm_c = TorchDistComm(per * 126, 200, True, device=dev, xchg_chunk=per * peru)
+        with comm_c.stream_context():
+            e = lp.LanczosEngine(dtype="c128", max_steps=200, stream=comm_c.stream_handle)
+            e.assemble_hubbard(L2, 4, 4, hc, U2, comm=comm_c)
+            out["rows_c"] = e.rows()
+            eg, _, st = e.lanczos(1, want_vectors=False)
+            out["e_tx_c"], out["steps_tx_c"] = float(eg[0]), st["steps"]
+            e.close()
+        Ac = oracle.hubbard_csr(L2, 4, 4, hc, U2)
+        ec, _, sc = oracle.lanczos_solve(Ac, oracle.fill_random(Ac.nrows, 1234, True), want_vectors=False)
+        out["e_oracle_c"], out["steps_oracle_c"] = float(ec[0]), sc
         q.put((rank, out))
         dist.destroy_process_group()
     except Exception:
@@ -194,4 +227,16 @@ def test_four_ranks_uneven_shards():
         o = res[r]
         assert abs(o["e_stored"] - o["e_oracle"]) <= 1e-10 * abs(o["e_oracle"]) and o["steps_stored"] == o["steps_oracle"]
         assert abs(o["e_kron"][0] - o["e_oracle"]) <= 1e-10 * abs(o["e_oracle"])
+        assert abs(o["e_tx"] - o["e_oracle"]) <= 1e-10 * abs(o["e_oracle"]) and o["steps_tx"] == o["steps_oracle"]
+        assert abs(o["e_tx2"] - o["e_oracle"]) <= 1e-10 * abs(o["e_oracle"])
+        assert o["xchg_calls"] > 0
+        assert abs(o["e_tx_c"] - o["e_oracle_c"]) <= 1e-10 * abs(o["e_oracle_c"]) and o["steps_tx_c"] == o["steps_oracle_c"]
+    assert [res[r]["rows_c"] for r in range(world)] == [32 * 126, 32 * 126, 32 * 126, 30 * 126]
     assert all(res[r]["e_kron"] == res[0]["e_kron"] for r in range(world))
+    # the Ritz vector assembled from the four slices is an eigenvector of the full matrix
+    import oracle
+    from helpers import chain
+    A = oracle.hubbard_csr(10, 5, 4, chain(10, -1.0, True), np.linspace(3.0, 5.0, 10))
+    z = res[0]["z_tx"]
+    r = oracle.spmv_acc(A, np.zeros_like(z), z) - res[0]["e_tx2"] * z
+    assert np.linalg.norm(r) < 1e-5
