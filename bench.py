@@ -183,6 +183,7 @@ def main():
     max_steps = args.steps + args.warmup + 2
 
     comm = None
+    exchanges = [None]
     if world > 1:
         import torch.distributed as dist
         from lanczosplusplus_amd.comm import TorchDistComm
@@ -195,29 +196,61 @@ def main():
         stride = -(-n_dn // world) * n_up
         # exchange per step: all-gather of the vector (N/P per rank out, N in) or the transposition scheme (two
         # all-to-alls of N/P each; 2/P of the volume, pays from 4 ranks on).  LPP_EXCHANGE overrides.
-        exchange = os.environ.get("LPP_EXCHANGE", "transpose" if (world >= 4 and args.engine == "stored") else "allgather")
-        chunk = (-(-n_dn // world)) * (-(-n_up // world)) if (exchange == "transpose" and args.engine == "stored") else 0
-        comm = TorchDistComm(stride, max_steps, is_complex, device=torch.device("cuda", local_rank), xchg_chunk=chunk)
+        first = os.environ.get("LPP_EXCHANGE", "transpose" if (world >= 4 and args.engine == "stored") else "allgather")
+        if args.engine != "stored":
+            first = "allgather"
+        exchanges = [first] + (["allgather"] if first != "allgather" else [])
 
     def barrier():
         if world > 1:
             import torch.distributed as dist
             dist.barrier()
 
-    stream = comm.stream_handle if comm is not None else None
+    def setup(exchange):
+        """communicator + engine + resident matrix + warm-up steps; returns everything the timed region needs"""
+        c = None
+        if world > 1:
+            chunk = (-(-n_dn // world)) * (-(-n_up // world)) if exchange == "transpose" else 0
+            c = TorchDistComm(stride, max_steps, is_complex, device=torch.device("cuda", local_rank), xchg_chunk=chunk)
+        strm = c.stream_handle if c is not None else None
+        cm = c.stream_context() if c is not None else __import__("contextlib").nullcontext()
+        with cm:
+            en = LanczosEngine(dtype="c128" if is_complex else "f64", device=local_rank, max_steps=max_steps, eps=0.0,
+                               save_vectors=0, spmv_kernel=args.spmv_kernel, time_kernels=True, stream=strm)
+            t_a = time.time()
+            assemble(en, name, c, onthefly=(args.engine == "onthefly"))
+            en.sync()
+            t_a = time.time() - t_a
+            s0 = en.stats()
+            en.begin(None)
+            en.step(args.warmup)
+            en.sync()
+        return c, cm, en, t_a, s0
+
+    comm = eng = None
+    for exchange in exchanges:
+        ok, err = 1, None
+        try:
+            comm, ctx, eng, t_asm, st0 = setup(exchange)
+        except Exception as ex:  # e.g. a collective the backend lacks: every rank falls back together
+            ok, err = 0, ex
+        if world > 1:
+            import torch.distributed as dist
+            flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok = int(flag.item())
+        if ok:
+            break
+        if rank == 0:
+            sys.stderr.write("bench: exchange %r failed (%r); falling back\n" % (exchange, err))
+        if eng is not None:
+            eng.close()
+        comm = eng = None
+    if eng is None:
+        raise SystemExit("bench: could not set up the engine")
+
     ctx = comm.stream_context() if comm is not None else __import__("contextlib").nullcontext()
     with ctx:
-        eng = LanczosEngine(dtype="c128" if is_complex else "f64", device=local_rank, max_steps=max_steps, eps=0.0,
-                            save_vectors=0, spmv_kernel=args.spmv_kernel, time_kernels=True, stream=stream)
-        t_asm = time.time()
-        assemble(eng, name, comm, onthefly=(args.engine == "onthefly"))
-        eng.sync()
-        t_asm = time.time() - t_asm
-        st0 = eng.stats()
-
-        eng.begin(None)
-        eng.step(args.warmup)
-        eng.sync()
         eng.stats()  # drains the warmup SpMV event timings
         w0 = eng.stats()
         torch.cuda.synchronize()
