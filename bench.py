@@ -196,9 +196,7 @@ def main():
         stride = -(-n_dn // world) * n_up
         # exchange per step: all-gather of the vector (N/P per rank out, N in) or the transposition scheme (two
         # all-to-alls of N/P each; 2/P of the volume, pays from 4 ranks on).  LPP_EXCHANGE overrides.
-        first = os.environ.get("LPP_EXCHANGE", "transpose" if (world >= 4 and args.engine == "stored") else "allgather")
-        if args.engine != "stored":
-            first = "allgather"
+        first = os.environ.get("LPP_EXCHANGE", "transpose" if world >= 4 else "allgather")
         exchanges = [first] + (["allgather"] if first != "allgather" else [])
 
     def barrier():

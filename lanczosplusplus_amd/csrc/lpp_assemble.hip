@@ -463,7 +463,7 @@ template <typename T> lpp_status build_kron_up(lpp_engine* e, int64_t n_up)
 	KronState& K = e->kron;
 	DevCsr& A = K.up;
 	const int ncomp = (int)(sizeof(T) / sizeof(double));
-	bool packed_ok = n_up <= 65536 && getenv("LPP_KRON_NO_PACK") == nullptr;
+	bool packed_ok = n_up <= (ncomp == 2 ? 65536 : (1 << 24)) && getenv("LPP_KRON_NO_PACK") == nullptr;
 	std::vector<int64_t> rp;
 	std::vector<int32_t> ci;
 	std::vector<double> va;
@@ -516,8 +516,10 @@ template <typename T> lpp_status build_kron_up(lpp_engine* e, int64_t n_up)
 				uint32_t w = (uint32_t)r; // padding: own column, value 0.0 (code 0)
 				if (k < l) {
 					const int64_t p = rp[r] + k;
-					w = (uint32_t)ci[p] | (code_of(va[(size_t)p * ncomp]) << 16);
-					if (ncomp == 2) w |= code_of(va[(size_t)p * 2 + 1]) << 24;
+					if (ncomp == 2)
+						w = (uint32_t)ci[p] | (code_of(va[(size_t)p * 2]) << 16) | (code_of(va[(size_t)p * 2 + 1]) << 24);
+					else
+						w = (uint32_t)ci[p] | (code_of(va[p]) << 24);
 				}
 				words[(size_t)off[s] + (size_t)k * 64 + lane] = w;
 			}
@@ -634,6 +636,16 @@ lpp_status lpp_engine_setup_hubbard_onthefly(lpp_engine* e, const lpp_comm* comm
 	// entries of the stored CSR this product represents (one diagonal per row + all hops), for the local rows
 	const double off_up = (double)K.up.nnz - (double)n_up, off_dn_total = (double)K.dn.nnz - (double)n_dn;
 	K.equiv_nnz = (double)nid * ((double)n_up + off_up) + (double)n_up * off_dn_total * ((double)nid / (double)n_dn);
+	if (multi && comm->exchange_begin && comm->exchange_end && comm->xchg_chunk > 0) {
+		const int64_t per = (n_dn + comm->nranks - 1) / comm->nranks, peru = (n_up + comm->nranks - 1) / comm->nranks;
+		if (!K.packed) return fail(LPP_ERR_INVALID, "setup_hubbard_onthefly: the transposition exchange needs the packed H_up layout");
+		if (!comm->send2_buf || !comm->recv2_buf || comm->xchg_chunk != per * peru)
+			return fail(LPP_ERR_INVALID, "setup_hubbard_onthefly: transposition exchange needs send2/recv2 buffers and xchg_chunk == ceil(N_down/P)*ceil(N_up/P)");
+		e->tx = true;
+		e->tx_per = per;
+		e->tx_peru = peru;
+		e->kron_n_up_tx = n_up;
+	}
 	K.active = true;
 	e->n_local = nid * n_up;
 	e->n_global = n_up * n_dn;
@@ -662,10 +674,11 @@ void free_kron(lpp_engine* e)
 	K = KronState();
 }
 
-template <typename T> static int kron_launch_t(lpp_engine* e, const void* ywin, const void* ydown, void* x, double* partial, const EpiScale& sc)
+template <typename T> static int kron_launch_t(lpp_engine* e, const void* ywin, const void* ydown, void* x, double* partial, const EpiScale& sc, int part)
 {
 	KronState& K = e->kron;
-	if (K.nid == 0) return 0;
+	if (K.nid == 0 && part != 2) return 0;
+	if (part != 0 && !K.packed) return -1;
 	if (K.packed) {
 		KronPackedArgs<T> pa;
 		pa.words = K.pk_words;
@@ -689,9 +702,19 @@ template <typename T> static int kron_launch_t(lpp_engine* e, const void* ywin, 
 		pa.partial = partial;
 		pa.xcd_map = (e->k2_variant >> 1) & 1;
 		pa.sc = sc;
-		const size_t ldsb = K.window ? sizeof(T) * (size_t)std::max<int64_t>(K.n_up, 64) : 64;
+		pa.part = part;
+		pa.n_dn = K.n_dn;
+		bool use_window = K.window;
+		if (part == 2) { // down-hops on the transposed slice: rows per down index = peru, all (padded) down indices
+			pa.n_up = e->tx_peru;
+			pa.id0 = 0;
+			pa.nid = e->tx_per * (int64_t)e->comm.nranks;
+			pa.spb = (int)((e->tx_peru + 63) / 64);
+			use_window = false;
+		}
+		const size_t ldsb = use_window ? sizeof(T) * (size_t)std::max<int64_t>(K.n_up, 64) : 64;
 		const int pcu = std::max(1, std::min(2, (int)((160 * 1024 - 8192) / (ldsb + 1))));
-		int nbp = (int)std::max<int64_t>(1, std::min<int64_t>(K.nid, (int64_t)e->num_cus * pcu));
+		int nbp = (int)std::max<int64_t>(1, std::min<int64_t>(pa.nid, (int64_t)e->num_cus * pcu));
 		if (nbp >= 8) nbp &= ~7;
 		const bool dotp = partial != nullptr;
 #define LPP_KP(DOT_, WIN_)                                                                                            \
@@ -699,9 +722,9 @@ template <typename T> static int kron_launch_t(lpp_engine* e, const void* ywin, 
 		(void)hipFuncSetAttribute((const void*)k_spmv_kron_packed<T, DOT_, WIN_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb); \
 		k_spmv_kron_packed<T, DOT_, WIN_><<<nbp, kWinThreads, ldsb, e->stream>>>(pa);                                   \
 	} while (0)
-		if (dotp && K.window) LPP_KP(true, true);
+		if (dotp && use_window) LPP_KP(true, true);
 		else if (dotp) LPP_KP(true, false);
-		else if (K.window) LPP_KP(false, true);
+		else if (use_window) LPP_KP(false, true);
 		else LPP_KP(false, false);
 #undef LPP_KP
 		return dotp ? nbp : 0;
@@ -763,9 +786,9 @@ template <typename T> static int kron_launch_t(lpp_engine* e, const void* ywin, 
 	return dot ? nb : 0;
 }
 
-int kron_launch(lpp_engine* e, const void* ywin, const void* ydown, void* x, double* partial, const EpiScale& sc)
+int kron_launch(lpp_engine* e, const void* ywin, const void* ydown, void* x, double* partial, const EpiScale& sc, int part)
 {
-	return e->is_complex ? kron_launch_t<cplx>(e, ywin, ydown, x, partial, sc) : kron_launch_t<double>(e, ywin, ydown, x, partial, sc);
+	return e->is_complex ? kron_launch_t<cplx>(e, ywin, ydown, x, partial, sc, part) : kron_launch_t<double>(e, ywin, ydown, x, partial, sc, part);
 }
 
 } // namespace lpp

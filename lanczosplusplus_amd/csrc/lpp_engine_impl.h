@@ -146,7 +146,7 @@ namespace lpp {
 void free_csr(DevCsr& A);
 lpp_status finalize_csr(lpp_engine* e, DevCsr& A, bool allow_drop_plain, int force_mode = 0, int64_t force_block = 0);
 void free_kron(lpp_engine* e);
-int kron_launch(lpp_engine* e, const void* ywin, const void* ydown, void* x, double* partial, const EpiScale& sc = EpiScale { nullptr, nullptr, 0 });
+int kron_launch(lpp_engine* e, const void* ywin, const void* ydown, void* x, double* partial, const EpiScale& sc = EpiScale { nullptr, nullptr, 0 }, int part = 0);
 void set_spmv_bytes(lpp_engine* e);
 lpp_status alloc_work(lpp_engine* e);
 int spmv_launch(lpp_engine* e, const DevCsr& A, const void* src, void* x, const void* ydot, double* partial, const EpiScale& sc = EpiScale { nullptr, nullptr, 0 });

@@ -167,9 +167,9 @@ __global__ __launch_bounds__(kWinThreads) void k_spmv_kron(KronArgs<T> a)
 }
 
 // ---------------------------------------------------------------------------------------------
-// Packed variant (the common case: N_up <= 65536 and <= 256 distinct matrix values).
+// Packed variant (the common case: <= 256 distinct matrix values; N_up < 2^24 real, <= 65536 complex).
 // H_up is tiny (a few hundred KB), so it is stored PADDED, slice-major [slice][slot][lane], one 32-bit
-// word per entry:  column (16 bit) | code_re (8 bit) << 16 | code_im (8 bit) << 24.  Padding entries carry
+// word per entry:  real: column (24 bit) | code << 24;  complex: column (16 bit) | code_re << 16 | code_im << 24.  Padding entries carry
 // the code of 0.0 and the row's own column.  Per up-hop the inner loop is: one coalesced 4-byte load
 // (L2 hit), two LDS reads (dictionary, window) and an FMA -- no ballot/popcount compaction, no 64-bit
 // address arithmetic (measured: the compact sliced walk cost ~27 VALU instructions per entry).
@@ -196,10 +196,15 @@ template <typename T> struct KronPackedArgs {
 	double* partial;
 	int xcd_map;
 	EpiScale sc;
+	// 0: whole product.  Transposition exchange: 1 = up-hops + U diagonal only (own slice); 2 = down-hops only, on the
+	// transposed slice (n_up = rows per down index = peru, id0 = 0, nid = padded number of down indices, n_dn valid)
+	int part;
+	int64_t n_dn;
 };
 
 template <typename T> __device__ __forceinline__ T kron_decode(uint32_t w, const double* dict);
-template <> __device__ __forceinline__ double kron_decode<double>(uint32_t w, const double* dict) { return dict[(w >> 16) & 0xffu]; }
+template <> __device__ __forceinline__ double kron_decode<double>(uint32_t w, const double* dict) { return dict[w >> 24]; }
+template <typename T> __device__ __forceinline__ uint32_t kron_col(uint32_t w) { return sizeof(T) == 16 ? (w & 0xffffu) : (w & 0xffffffu); }
 template <> __device__ __forceinline__ cplx kron_decode<cplx>(uint32_t w, const double* dict)
 {
 	return cplx { dict[(w >> 16) & 0xffu], dict[w >> 24] };
@@ -236,6 +241,7 @@ __global__ __launch_bounds__(kWinThreads) void k_spmv_kron_packed(KronPackedArgs
 	double dot = 0.0;
 	for (int64_t blk = b_begin; blk < b_end; blk += b_stride) {
 		const int64_t gid = a.id0 + blk;
+		if (a.part == 2 && gid >= a.n_dn) continue; // padded down index of the transposed layout (uniform per workgroup)
 		const T* yblk = a.ywin + blk * a.n_up;
 		T* xblk = a.x + blk * a.n_up;
 		const int64_t p0 = a.dn_rowptr[gid];
@@ -243,7 +249,7 @@ __global__ __launch_bounds__(kWinThreads) void k_spmv_kron_packed(KronPackedArgs
 		const uint32_t dnw = a.dn_words[gid];
 		__syncthreads(); // previous block fully consumed (window, H_down row)
 		if (threadIdx.x == 0) next_slice = 0;
-		if (WINDOW) {
+		if (WINDOW && a.part != 2) {
 			for (int64_t i0 = threadIdx.x; i0 < a.n_up; i0 += 8 * kWinThreads) {
 				T t[8];
 #pragma unroll
@@ -259,16 +265,16 @@ __global__ __launch_bounds__(kWinThreads) void k_spmv_kron_packed(KronPackedArgs
 			dval_s[threadIdx.x] = in ? a.dn_val[p0 + threadIdx.x] : VT<T>::zero();
 		}
 		__syncthreads();
-		const int ngroups = (min(ndn, kKronDownCap) + 7) >> 3;
+		const int ngroups = (a.part == 1) ? 0 : ((min(ndn, kKronDownCap) + 7) >> 3);
 		// slices are claimed dynamically (see k_spmv_window)
 		for (int j = next_slice_claim(&next_slice); j < a.spb; j = next_slice_claim(&next_slice)) {
 			const int iu_raw = j * 64 + lane;
 			const bool valid = iu_raw < a.n_up;
 			const int iu = valid ? iu_raw : (int)a.n_up - 1;
 			const T xold = xblk[iu];
-			const uint32_t upw = a.up_words[iu];
+			const uint32_t upw = (a.part == 2) ? 0u : a.up_words[iu];
 			const uint32_t* wp = a.words + a.slice_off[j] + lane;
-			const int ml = a.slice_len[j]; // multiple of 8
+			const int ml = (a.part == 2) ? 0 : a.slice_len[j]; // multiple of 8
 			// first batch of H_up words and of down reads are requested together
 			uint32_t w0[8], w1[8];
 			if (ml > 0) {
@@ -292,7 +298,8 @@ __global__ __launch_bounds__(kWinThreads) void k_spmv_kron_packed(KronPackedArgs
 #pragma unroll
 				for (int q = 0; q < 8; q++) g0[q] = g1[q];
 			}
-			for (int p = kKronDownCap; p < ndn; p++) VT<T>::mac(acc, a.dn_val[p0 + p], yd[(int64_t)a.dn_col[p0 + p] * a.n_up]);
+			if (a.part != 1)
+				for (int p = kKronDownCap; p < ndn; p++) VT<T>::mac(acc, a.dn_val[p0 + p], yd[(int64_t)a.dn_col[p0 + p] * a.n_up]);
 			// up part
 			for (int k = 0; k < ml; k += 8) {
 				if (k + 8 < ml) {
@@ -301,7 +308,7 @@ __global__ __launch_bounds__(kWinThreads) void k_spmv_kron_packed(KronPackedArgs
 				}
 #pragma unroll
 				for (int q = 0; q < 8; q++) {
-					const uint32_t c = w0[q] & 0xffffu;
+					const uint32_t c = kron_col<T>(w0[q]);
 					const T g = WINDOW ? lds[c] : yblk[c];
 					VT<T>::mac(acc, kron_decode<T>(w0[q], dict_s), g);
 				}
@@ -309,7 +316,7 @@ __global__ __launch_bounds__(kWinThreads) void k_spmv_kron_packed(KronPackedArgs
 				for (int q = 0; q < 8; q++) w0[q] = w1[q];
 			}
 			// Hubbard U on the doubly occupied sites
-			const T yc = WINDOW ? lds[iu] : yblk[iu];
+			const T yc = (a.part == 2) ? VT<T>::zero() : (WINDOW ? lds[iu] : yblk[iu]);
 			double ud = 0.0;
 			for (uint32_t m = upw & dnw; m; m &= m - 1) ud += U_s[__ffs((int)m) - 1];
 			T t = VT<T>::zero();

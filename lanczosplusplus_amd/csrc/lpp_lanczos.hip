@@ -152,7 +152,37 @@ lpp_status one_step(lpp_engine* e, const double* ritz, int nst)
 		sc.b2_prev = b2_prev;
 		sc.b2_prev2 = (j == 0) ? nullptr : ((j == 1) ? e->tmp_dev : e->ab_dev + 2 * (j - 2) + 1);
 	}
-	if (e->kron.active) {
+	if (e->kron.active && multi(e) && e->tx) {
+		// matrix-free product with the transposition exchange: nothing of size N ever exists on a rank
+		const int64_t n_up = e->kron_n_up_tx, nid = e->n_local / n_up, chunk = e->comm.xchg_chunk;
+		const int nbp = (int)std::max<int64_t>(1, std::min<int64_t>((e->n_local + kBlock - 1) / kBlock, 2048));
+		if (e->is_complex)
+			k_pack_transpose<cplx><<<nbp, kBlock, 0, st>>>((const cplx*)ycur, (cplx*)e->comm.send_buf, nid, n_up, e->tx_peru, chunk);
+		else
+			k_pack_transpose<double><<<nbp, kBlock, 0, st>>>((const double*)ycur, (double*)e->comm.send_buf, nid, n_up, e->tx_peru, chunk);
+		if (e->comm.exchange_begin(e->comm.ctx, 0) != 0) return fail(LPP_ERR_COMM, "exchange_begin(0) callback failed");
+		{
+			SpmvTimer t(e);
+			kron_launch(e, ycur, ycur, xcur, nullptr, sc, 1); // up-hops + U diagonal on the own slice: overlaps all-to-all #1
+			t.stop();
+		}
+		if (e->comm.exchange_end(e->comm.ctx, 0) != 0) return fail(LPP_ERR_COMM, "exchange_end(0) callback failed");
+		HIP_TRY(hipMemsetAsync(e->comm.send2_buf, 0, e->esz * (size_t)chunk * (size_t)e->comm.nranks, st));
+		{
+			EpiScale sc2 = sc;
+			sc2.beta_one = 1;
+			SpmvTimer t(e);
+			kron_launch(e, nullptr, e->comm.gath_buf, e->comm.send2_buf, nullptr, sc2, 2); // down-hops on the transposed slice
+			t.stop();
+		}
+		if (e->comm.exchange_begin(e->comm.ctx, 1) != 0) return fail(LPP_ERR_COMM, "exchange_begin(1) callback failed");
+		if (e->comm.exchange_end(e->comm.ctx, 1) != 0) return fail(LPP_ERR_COMM, "exchange_end(1) callback failed");
+		if (e->is_complex)
+			k_unpack_add_dot<cplx, true><<<nbp, kBlock, 0, st>>>((cplx*)xcur, (const cplx*)e->comm.recv2_buf, (const cplx*)ycur, nid, n_up, e->tx_peru, chunk, e->partial);
+		else
+			k_unpack_add_dot<double, true><<<nbp, kBlock, 0, st>>>((double*)xcur, (const double*)e->comm.recv2_buf, (const double*)ycur, nid, n_up, e->tx_peru, chunk, e->partial);
+		np = nbp;
+	} else if (e->kron.active) {
 		// matrix-free product: the down part needs the whole vector, so the gather completes first
 		if (multi(e)) {
 			if (e->comm.allgather_begin(e->comm.ctx) != 0) return fail(LPP_ERR_COMM, "allgather_begin callback failed");

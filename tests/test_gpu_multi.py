@@ -188,6 +188,10 @@ def _worker_uneven(rank, world, port, q):
             dist.all_gather_object(zs, zg[0])
             out["z_tx"] = np.concatenate(zs)
             out["xchg_calls"] = comm_t.calls["exchange"]
+            # matrix-free engine with the same exchange: no buffer of the full vector length anywhere
+            e.setup_hubbard_onthefly(L, nup, ndown, hop, U, comm=comm_t)
+            eg, _, st = e.lanczos(1, want_vectors=False)
+            out["e_kron_tx"], out["steps_kron_tx"] = float(eg[0]), st["steps"]
             e.close()
         A = oracle.hubbard_csr(L, nup, ndown, hop, U)
         eo, _, so = oracle.lanczos_solve(A, oracle.fill_random(A.nrows, 1234), want_vectors=False)
@@ -206,6 +210,9 @@ def _worker_uneven(rank, world, port, q):
             out["rows_c"] = e.rows()
             eg, _, st = e.lanczos(1, want_vectors=False)
             out["e_tx_c"], out["steps_tx_c"] = float(eg[0]), st["steps"]
+            e.setup_hubbard_onthefly(L2, 4, 4, hc, U2, comm=comm_c)
+            eg, _, st = e.lanczos(1, want_vectors=False)
+            out["e_kron_tx_c"] = float(eg[0])
             e.close()
         Ac = oracle.hubbard_csr(L2, 4, 4, hc, U2)
         ec, _, sc = oracle.lanczos_solve(Ac, oracle.fill_random(Ac.nrows, 1234, True), want_vectors=False)
@@ -230,7 +237,9 @@ def test_four_ranks_uneven_shards():
         assert abs(o["e_tx"] - o["e_oracle"]) <= 1e-10 * abs(o["e_oracle"]) and o["steps_tx"] == o["steps_oracle"]
         assert abs(o["e_tx2"] - o["e_oracle"]) <= 1e-10 * abs(o["e_oracle"])
         assert o["xchg_calls"] > 0
+        assert abs(o["e_kron_tx"] - o["e_oracle"]) <= 1e-10 * abs(o["e_oracle"]) and o["steps_kron_tx"] == o["steps_oracle"]
         assert abs(o["e_tx_c"] - o["e_oracle_c"]) <= 1e-10 * abs(o["e_oracle_c"]) and o["steps_tx_c"] == o["steps_oracle_c"]
+        assert abs(o["e_kron_tx_c"] - o["e_oracle_c"]) <= 1e-10 * abs(o["e_oracle_c"])
     assert [res[r]["rows_c"] for r in range(world)] == [32 * 126, 32 * 126, 32 * 126, 30 * 126]
     assert all(res[r]["e_kron"] == res[0]["e_kron"] for r in range(world))
     # the Ritz vector assembled from the four slices is an eigenvector of the full matrix
