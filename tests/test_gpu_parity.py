@@ -328,4 +328,5 @@ def test_matrix_free_with_reortho_and_excited_states():
     assert np.linalg.norm(r) < 1e-5
     # (their values depend on the exact stopping step, which sits at the rounding floor for eps=1e-13):
     # variational upper bounds of the exact levels, already close
-    assert np.all(eg[1:] >= dense[1:3] - 1e-9) and np.abs(eg[1:] - dense[1:3]).max() < 5e-2
+    lev = np.unique(np.round(dense, 8))  # a single start vector sees each degenerate level once
+    assert np.all(eg[1:] >= lev[1:3] - 1e-7) and np.abs(eg[1:] - lev[1:3]).max() < 5e-2
