@@ -2,7 +2,8 @@
 E0 must equal twice the sum of the nine lowest single-particle levels."""
 import sys, time
 import numpy as np
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import square_lattice
 from lanczosplusplus_amd import LanczosEngine
 L = 18

@@ -1,7 +1,8 @@
 """End-to-end convergence-checked solve on config 2 (both engines): steps, wall time, SpMV share."""
 import sys, time
 import numpy as np
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import square_lattice
 from lanczosplusplus_amd import LanczosEngine
 L = 16
