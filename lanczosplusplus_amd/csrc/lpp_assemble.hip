@@ -220,7 +220,7 @@ lpp_status lpp_engine_assemble_hubbard(lpp_engine* e, const lpp_comm* comm, int3
 		e->has_comm = false;
 		e->bind_scalars(e->scal_own);
 		free_csr(e->A_rem);
-		free_kron(e);
+		drop_product(e);
 		P.row0 = 0;
 		P.nloc = nrows;
 		P.part = 0;
@@ -244,7 +244,7 @@ lpp_status lpp_engine_assemble_hubbard(lpp_engine* e, const lpp_comm* comm, int3
 		P.col_lo = starts[comm->rank];
 		P.col_hi = starts[comm->rank + 1];
 		const bool transpose = comm->exchange_begin && comm->exchange_end && comm->xchg_chunk > 0;
-		free_kron(e);
+		drop_product(e);
 		if (!transpose) {
 			e->tx = false;
 			P.part = 1;
@@ -358,7 +358,7 @@ lpp_status lpp_engine_assemble_heisenberg(lpp_engine* e, int32_t L, int32_t szPl
 	e->has_comm = false;
 	e->bind_scalars(e->scal_own);
 	free_csr(e->A_rem);
-	free_kron(e);
+	drop_product(e);
 	st = dispatch<ASM_HEISENBERG>(e, P, e->A_loc);
 	if (st != LPP_OK) return st;
 	e->n_local = e->n_global = nrows;
@@ -442,7 +442,7 @@ lpp_status lpp_engine_assemble_tj(lpp_engine* e, int32_t L, int32_t nup, int32_t
 	e->has_comm = false;
 	e->bind_scalars(e->scal_own);
 	free_csr(e->A_rem);
-	free_kron(e);
+	drop_product(e);
 	st = dispatch<ASM_TJ>(e, P, e->A_loc);
 	if (st != LPP_OK) return st;
 	e->n_local = e->n_global = nrows;
@@ -572,7 +572,7 @@ lpp_status lpp_engine_setup_hubbard_onthefly(lpp_engine* e, const lpp_comm* comm
 	}
 	free_csr(e->A_loc);
 	free_csr(e->A_rem);
-	free_kron(e);
+	drop_product(e);
 	KronState& K = e->kron;
 
 	std::vector<HostProc> hp;
@@ -658,6 +658,12 @@ lpp_status lpp_engine_setup_hubbard_onthefly(lpp_engine* e, const lpp_comm* comm
 } // extern "C"
 
 namespace lpp {
+
+void drop_product(lpp_engine* e)
+{
+	free_kron(e);
+	e->tx = false;
+}
 
 void free_kron(lpp_engine* e)
 {

@@ -419,7 +419,7 @@ lpp_status lpp_engine_destroy(lpp_engine* e)
 	if (e->stream) (void)hipStreamSynchronize(e->stream);
 	free_csr(e->A_loc);
 	free_csr(e->A_rem);
-	free_kron(e);
+	drop_product(e);
 	for (double* p : { e->x, e->y, e->V, e->partial, e->scal_own, e->zwork })
 		if (p) (void)hipFree(p);
 	if (e->h_scal) (void)hipHostFree(e->h_scal);
@@ -478,7 +478,7 @@ lpp_status lpp_engine_set_csr(lpp_engine* e, int64_t nrows, const int64_t* rowpt
 	e->has_comm = false;
 	e->bind_scalars(e->scal_own);
 	free_csr(e->A_rem);
-	free_kron(e);
+	drop_product(e);
 	st = upload_csr(e, e->A_loc, nrows, rowptr, colind, values);
 	if (st != LPP_OK) return st;
 	e->n_local = e->n_global = nrows;
@@ -510,7 +510,7 @@ lpp_status lpp_engine_set_csr_partition(lpp_engine* e, const lpp_comm* comm, int
 	st = lpp_split_csr(r, P, shard_starts, comm->shard_stride, local, rowptr, colind, values, (int32_t)e->esz, &nl, &nr, rpl.data(),
 	                   cl.data(), vl.data(), rpr.data(), cr.data(), vr.data());
 	if (st != LPP_OK) return st;
-	free_kron(e);
+	drop_product(e);
 	st = upload_csr(e, e->A_loc, local, rpl.data(), cl.data(), vl.data());
 	if (st != LPP_OK) return st;
 	e->A_rem.src_elems = (int64_t)comm->nranks * comm->shard_stride;

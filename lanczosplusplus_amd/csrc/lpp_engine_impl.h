@@ -79,7 +79,7 @@ struct lpp_engine {
 	hipStream_t stream = nullptr;
 	bool own_stream = false;
 	int spmv_max_blocks = 4096;
-	int k2_variant = 6; // see spmv_launch_t
+	int k2_variant = 4; // bit1: XCD-contiguous map, bit2: 8 slots per batch (set in lpp_engine_create)
 	int num_cus = 256;
 
 	// matrix: A_loc has columns inside this rank's slice, A_rem (multi-GPU only) indexes the gathered buffer
@@ -146,6 +146,7 @@ namespace lpp {
 void free_csr(DevCsr& A);
 lpp_status finalize_csr(lpp_engine* e, DevCsr& A, bool allow_drop_plain, int force_mode = 0, int64_t force_block = 0);
 void free_kron(lpp_engine* e);
+void drop_product(lpp_engine* e); // matrix-free state, split flags: called by every matrix setup
 int kron_launch(lpp_engine* e, const void* ywin, const void* ydown, void* x, double* partial, const EpiScale& sc = EpiScale { nullptr, nullptr, 0 }, int part = 0);
 void set_spmv_bytes(lpp_engine* e);
 lpp_status alloc_work(lpp_engine* e);

@@ -152,8 +152,11 @@ lpp_status one_step(lpp_engine* e, const double* ritz, int nst)
 		sc.b2_prev = b2_prev;
 		sc.b2_prev2 = (j == 0) ? nullptr : ((j == 1) ? e->tmp_dev : e->ab_dev + 2 * (j - 2) + 1);
 	}
-	if (e->kron.active && multi(e) && e->tx) {
-		// matrix-free product with the transposition exchange: nothing of size N ever exists on a rank
+	if (multi(e) && e->tx) {
+		// Transposition exchange (stored and matrix-free engines): two all-to-alls of N/P elements instead of an
+		// all-gather of N; with the matrix-free engine nothing of size N ever exists on a rank.
+		//   pack -> all-to-all #1  ||  local part (diagonal/U + up-hops on the own slice)
+		//   -> down-hops on the received transposed slice -> all-to-all #2 -> unpack-add (+ fused a_j partial)
 		const int64_t n_up = e->kron_n_up_tx, nid = e->n_local / n_up, chunk = e->comm.xchg_chunk;
 		const int nbp = (int)std::max<int64_t>(1, std::min<int64_t>((e->n_local + kBlock - 1) / kBlock, 2048));
 		if (e->is_complex)
@@ -162,17 +165,23 @@ lpp_status one_step(lpp_engine* e, const double* ritz, int nst)
 			k_pack_transpose<double><<<nbp, kBlock, 0, st>>>((const double*)ycur, (double*)e->comm.send_buf, nid, n_up, e->tx_peru, chunk);
 		if (e->comm.exchange_begin(e->comm.ctx, 0) != 0) return fail(LPP_ERR_COMM, "exchange_begin(0) callback failed");
 		{
-			SpmvTimer t(e);
-			kron_launch(e, ycur, ycur, xcur, nullptr, sc, 1); // up-hops + U diagonal on the own slice: overlaps all-to-all #1
+			SpmvTimer t(e); // overlaps all-to-all #1
+			if (e->kron.active)
+				kron_launch(e, ycur, ycur, xcur, nullptr, sc, 1);
+			else
+				spmv_launch(e, e->A_loc, ycur, xcur, nullptr, nullptr, sc);
 			t.stop();
 		}
 		if (e->comm.exchange_end(e->comm.ctx, 0) != 0) return fail(LPP_ERR_COMM, "exchange_end(0) callback failed");
 		HIP_TRY(hipMemsetAsync(e->comm.send2_buf, 0, e->esz * (size_t)chunk * (size_t)e->comm.nranks, st));
 		{
 			EpiScale sc2 = sc;
-			sc2.beta_one = 1;
+			sc2.beta_one = 1; // wT = alpha * (down-hop part) yT into the zeroed buffer
 			SpmvTimer t(e);
-			kron_launch(e, nullptr, e->comm.gath_buf, e->comm.send2_buf, nullptr, sc2, 2); // down-hops on the transposed slice
+			if (e->kron.active)
+				kron_launch(e, nullptr, e->comm.gath_buf, e->comm.send2_buf, nullptr, sc2, 2);
+			else
+				spmv_launch(e, e->A_rem, e->comm.gath_buf, e->comm.send2_buf, nullptr, nullptr, sc2);
 			t.stop();
 		}
 		if (e->comm.exchange_begin(e->comm.ctx, 1) != 0) return fail(LPP_ERR_COMM, "exchange_begin(1) callback failed");
@@ -183,7 +192,7 @@ lpp_status one_step(lpp_engine* e, const double* ritz, int nst)
 			k_unpack_add_dot<double, true><<<nbp, kBlock, 0, st>>>((double*)xcur, (const double*)e->comm.recv2_buf, (const double*)ycur, nid, n_up, e->tx_peru, chunk, e->partial);
 		np = nbp;
 	} else if (e->kron.active) {
-		// matrix-free product: the down part needs the whole vector, so the gather completes first
+		// matrix-free product with the all-gather: the down part needs the whole vector, so the gather completes first
 		if (multi(e)) {
 			if (e->comm.allgather_begin(e->comm.ctx) != 0) return fail(LPP_ERR_COMM, "allgather_begin callback failed");
 			if (e->comm.allgather_end(e->comm.ctx) != 0) return fail(LPP_ERR_COMM, "allgather_end callback failed");
@@ -191,36 +200,6 @@ lpp_status one_step(lpp_engine* e, const double* ritz, int nst)
 		SpmvTimer t(e);
 		np = kron_launch(e, ycur, multi(e) ? e->comm.gath_buf : ycur, xcur, e->partial, sc);
 		t.stop();
-	} else if (multi(e) && e->tx) {
-		// transposition exchange: two all-to-alls of N/P elements instead of an all-gather of N
-		const int64_t nid = e->n_local / e->kron_n_up_tx, n_up = e->kron_n_up_tx, chunk = e->comm.xchg_chunk;
-		const int nbp = (int)std::max<int64_t>(1, std::min<int64_t>((e->n_local + kBlock - 1) / kBlock, 2048));
-		if (e->is_complex)
-			k_pack_transpose<cplx><<<nbp, kBlock, 0, st>>>((const cplx*)ycur, (cplx*)e->comm.send_buf, nid, n_up, e->tx_peru, chunk);
-		else
-			k_pack_transpose<double><<<nbp, kBlock, 0, st>>>((const double*)ycur, (double*)e->comm.send_buf, nid, n_up, e->tx_peru, chunk);
-		if (e->comm.exchange_begin(e->comm.ctx, 0) != 0) return fail(LPP_ERR_COMM, "exchange_begin(0) callback failed");
-		{
-			SpmvTimer t(e);
-			spmv_launch(e, e->A_loc, ycur, xcur, nullptr, nullptr, sc); // diagonal + up-hops: overlaps the first all-to-all
-			t.stop();
-		}
-		if (e->comm.exchange_end(e->comm.ctx, 0) != 0) return fail(LPP_ERR_COMM, "exchange_end(0) callback failed");
-		HIP_TRY(hipMemsetAsync(e->comm.send2_buf, 0, e->esz * (size_t)chunk * (size_t)e->comm.nranks, st));
-		{
-			EpiScale sc2 = sc;
-			sc2.beta_one = 1; // wT = alpha * (A_down^T-layout) yT into the zeroed buffer
-			SpmvTimer t(e);
-			spmv_launch(e, e->A_rem, e->comm.gath_buf, e->comm.send2_buf, nullptr, nullptr, sc2);
-			t.stop();
-		}
-		if (e->comm.exchange_begin(e->comm.ctx, 1) != 0) return fail(LPP_ERR_COMM, "exchange_begin(1) callback failed");
-		if (e->comm.exchange_end(e->comm.ctx, 1) != 0) return fail(LPP_ERR_COMM, "exchange_end(1) callback failed");
-		if (e->is_complex)
-			k_unpack_add_dot<cplx, true><<<nbp, kBlock, 0, st>>>((cplx*)xcur, (const cplx*)e->comm.recv2_buf, (const cplx*)ycur, nid, n_up, e->tx_peru, chunk, e->partial);
-		else
-			k_unpack_add_dot<double, true><<<nbp, kBlock, 0, st>>>((double*)xcur, (const double*)e->comm.recv2_buf, (const double*)ycur, nid, n_up, e->tx_peru, chunk, e->partial);
-		np = nbp;
 	} else if (multi(e)) {
 		// the slice of the current vector was written to comm.send_buf by the previous step's last kernel
 		if (e->comm.allgather_begin(e->comm.ctx) != 0) return fail(LPP_ERR_COMM, "allgather_begin callback failed");
