@@ -491,6 +491,7 @@ template <typename T> lpp_status build_kron_up(lpp_engine* e, int64_t n_up)
 	}
 	if (!packed_ok) {
 		K.packed = false;
+		A.no_dia = true; // the matrix-free kernel walks the plain sliced layout
 		return finalize_csr(e, A, true, LPP_SPMV_SLICED, n_up);
 	}
 	auto code_of = [&](double v) -> uint32_t {
@@ -750,6 +751,9 @@ template <typename T> static int kron_launch_t(lpp_engine* e, const void* ywin, 
 	a.up.partial = nullptr;
 	a.up.xcd_map = 0;
 	a.up.sc = EpiScale { nullptr, nullptr, 0 };
+	a.up.dia_stride = 0;
+	a.up.dia_off = nullptr;
+	a.up.dia_val = nullptr;
 	a.n_up = K.n_up;
 	a.id0 = K.id0;
 	a.nid = K.nid;

@@ -11,6 +11,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
+#include <cstdio>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -47,6 +48,9 @@ void free_csr(DevCsr& A)
 	if (A.codes) (void)hipFree(A.codes);
 	if (A.code_ptr) (void)hipFree(A.code_ptr);
 	if (A.dict) (void)hipFree(A.dict);
+	if (A.rrowptr) (void)hipFree(A.rrowptr);
+	if (A.dia_off) (void)hipFree(A.dia_off);
+	if (A.dia_val) (void)hipFree(A.dia_val);
 	A = DevCsr();
 }
 
@@ -100,6 +104,9 @@ template <typename T> static int spmv_launch_t(lpp_engine* e, const DevCsr& A, c
 		a.partial = partial;
 		a.xcd_map = (e->k2_variant >> 1) & 1;
 		a.sc = sc;
+		a.dia_stride = A.dia_stride;
+		a.dia_off = A.dia_off;
+		a.dia_val = (const T*)A.dia_val;
 		const bool dot = partial != nullptr;
 		const bool u8 = (e->k2_variant & 4) != 0;
 		const int sel = (dot ? 4 : 0) | (A.coded ? 2 : 0) | (u8 ? 1 : 0);
@@ -111,8 +118,13 @@ template <typename T> static int spmv_launch_t(lpp_engine* e, const DevCsr& A, c
 			if (nb >= 8) nb &= ~7;
 #define LPP_K3(DOT_, CODED_, U_)                                                                                      \
 	do {                                                                                                              \
-		(void)hipFuncSetAttribute((const void*)k_spmv_window<T, DOT_, CODED_, U_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
-		k_spmv_window<T, DOT_, CODED_, U_><<<nb, kWinThreads, lds_bytes, st>>>(a);                                      \
+		if (A.local16) {                                                                                              \
+			(void)hipFuncSetAttribute((const void*)k_spmv_window<T, DOT_, CODED_, U_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
+			k_spmv_window<T, DOT_, CODED_, U_, true><<<nb, kWinThreads, lds_bytes, st>>>(a);                            \
+		} else {                                                                                                      \
+			(void)hipFuncSetAttribute((const void*)k_spmv_window<T, DOT_, CODED_, U_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
+			k_spmv_window<T, DOT_, CODED_, U_, false><<<nb, kWinThreads, lds_bytes, st>>>(a);                           \
+		}                                                                                                             \
 	} while (0)
 			switch (sel) {
 			case 0: LPP_K3(false, false, 4); break;
@@ -160,10 +172,10 @@ int spmv_launch(lpp_engine* e, const DevCsr& A, const void* src, void* x, const 
 }
 
 // distinct values of A.val -> sorted dictionary on the device; returns false when there are more than 256
-template <typename T> static lpp_status try_build_dict(lpp_engine* e, DevCsr& A, bool* ok)
+template <typename T> static lpp_status try_build_dict(lpp_engine* e, DevCsr& A, const T* vals, int64_t nvals, bool* ok)
 {
 	*ok = false;
-	if (A.nnz == 0) return LPP_OK;
+	if (nvals == 0) return LPP_OK;
 	unsigned long long* table = nullptr;
 	int* overflow = nullptr;
 	HIP_TRY_MEM(hipMalloc(&table, sizeof(unsigned long long) * kDictTable));
@@ -173,8 +185,8 @@ template <typename T> static lpp_status try_build_dict(lpp_engine* e, DevCsr& A,
 	}
 	(void)hipMemsetAsync(table, 0xff, sizeof(unsigned long long) * kDictTable, e->stream);
 	(void)hipMemsetAsync(overflow, 0, sizeof(int), e->stream);
-	const int64_t nd = A.nnz * (int64_t)(sizeof(T) / sizeof(double));
-	k_dict_collect<<<2048, kBlock, 0, e->stream>>>((const double*)A.val, nd, table, overflow);
+	const int64_t nd = nvals * (int64_t)(sizeof(T) / sizeof(double));
+	k_dict_collect<<<2048, kBlock, 0, e->stream>>>((const double*)vals, nd, table, overflow);
 	std::vector<unsigned long long> host(kDictTable);
 	int ov = 0;
 	hipError_t e1 = hipMemcpyAsync(host.data(), table, sizeof(unsigned long long) * kDictTable, hipMemcpyDeviceToHost, e->stream);
@@ -202,8 +214,93 @@ template <typename T> static lpp_status try_build_dict(lpp_engine* e, DevCsr& A,
 	return LPP_OK;
 }
 
+// in-place exclusive scan of arr[0..n) (arr[n-1] must be 0 on entry and receives the total, also returned)
+static lpp_status scan_exclusive(lpp_engine* e, int64_t* arr, int64_t n, int64_t* total_out)
+{
+	const int64_t nblk = (n + kScanChunk - 1) / kScanChunk;
+	int64_t *sums = nullptr, *total = nullptr;
+	HIP_TRY_MEM(hipMalloc(&sums, sizeof(int64_t) * (size_t)nblk));
+	if (hipMalloc(&total, sizeof(int64_t)) != hipSuccess) {
+		(void)hipFree(sums);
+		return fail(LPP_ERR_NOMEM, "scan scratch allocation failed");
+	}
+	k_scan_block_sums<<<(int)nblk, kBlock, 0, e->stream>>>(arr, n, sums);
+	k_scan_sums<<<1, kBlock, 0, e->stream>>>(sums, nblk, total);
+	k_scan_apply<<<(int)nblk, kBlock, 0, e->stream>>>(arr, n, sums, arr);
+	hipError_t e1 = hipMemcpyAsync(total_out, total, sizeof(int64_t), hipMemcpyDeviceToHost, e->stream);
+	hipError_t e2 = hipStreamSynchronize(e->stream);
+	(void)hipFree(sums);
+	(void)hipFree(total);
+	if (e1 != hipSuccess || e2 != hipSuccess) return fail(LPP_ERR_HIP, "device scan failed");
+	return LPP_OK;
+}
+
+static void drop_dia(DevCsr& A)
+{
+	for (void* p : { (void*)A.rrowptr, (void*)A.dia_off, A.dia_val })
+		if (p) (void)hipFree(p);
+	A.rrowptr = nullptr;
+	A.dia_off = nullptr;
+	A.dia_val = nullptr;
+	A.rnnz = A.ndia = 0;
+	A.dia_stride = 0;
+}
+
+// Split the shared-offset entries off the plain CSR of A (see k_dia_split).  On success with A.rrowptr != nullptr the
+// rest CSR is (A.rrowptr, *rcol, *rval) -- the caller frees rcol / rval -- and A.dia_* hold the shared lists.
+// Leaves A untouched (rrowptr == nullptr) when rows are unsorted or fewer than 10 % of the entries are shared.
+template <typename T> static lpp_status split_dia_t(lpp_engine* e, DevCsr& A, const SliceGeom& g, bool for_window, int32_t** rcol, T** rval)
+{
+	*rcol = nullptr;
+	*rval = nullptr;
+	unsigned long long* flags = nullptr; // [0] unsorted, [1] max shared per slice, [2] total shared
+	HIP_TRY_MEM(hipMalloc(&flags, sizeof(unsigned long long) * 3));
+	struct Free {
+		void* p;
+		~Free() { (void)hipFree(p); }
+	} free_flags { flags };
+	HIP_TRY(hipMemsetAsync(flags, 0, sizeof(unsigned long long) * 3, e->stream));
+	k_rows_sorted<<<(int)((A.nrows + 255) / 256), 256, 0, e->stream>>>(A.nrows, A.rowptr, A.col, (int*)flags);
+	unsigned long long h[3] = { 0, 0, 0 };
+	HIP_TRY(hipMemcpyAsync(h, flags, sizeof(unsigned long long), hipMemcpyDeviceToHost, e->stream));
+	HIP_TRY(hipStreamSynchronize(e->stream));
+	if (h[0] != 0) return LPP_OK;
+	HIP_TRY_MEM(hipMalloc(&A.rrowptr, sizeof(int64_t) * (size_t)(A.nrows + 1)));
+	HIP_TRY(hipMemsetAsync(A.rrowptr, 0, sizeof(int64_t) * (size_t)(A.nrows + 1), e->stream));
+	const int nbw = (int)std::max<int64_t>(1, std::min<int64_t>((g.nslices + 3) / 4, 16384));
+	const int win = for_window ? 1 : 0;
+	k_dia_split<T, false><<<nbw, kBlock, 0, e->stream>>>(g, A.rowptr, A.col, (const T*)A.val, win, 0, A.rrowptr, flags + 1, nullptr, nullptr,
+	                                                    nullptr, nullptr, nullptr);
+	HIP_TRY(hipGetLastError());
+	lpp_status st = scan_exclusive(e, A.rrowptr, A.nrows + 1, &A.rnnz);
+	if (st != LPP_OK) return st;
+	HIP_TRY(hipMemcpyAsync(h, flags, sizeof(unsigned long long) * 3, hipMemcpyDeviceToHost, e->stream));
+	HIP_TRY(hipStreamSynchronize(e->stream));
+	A.ndia = (int64_t)h[2];
+	A.dia_stride = (int)((h[1] + 3) & ~3ull);
+	if (getenv("LPP_VERBOSE"))
+		fprintf(stderr, "lpp: shared-offset split: nnz %lld -> per-row %lld + %lld per-slice entries (%lld slices, <= %d per slice)\n",
+		        (long long)A.nnz, (long long)A.rnnz, (long long)A.ndia, (long long)g.nslices, (int)h[1]);
+	if ((double)(A.nnz - A.rnnz) < 0.10 * (double)A.nnz || A.dia_stride == 0) {
+		drop_dia(A);
+		return LPP_OK;
+	}
+	const size_t places = (size_t)g.nslices * (size_t)A.dia_stride;
+	HIP_TRY_MEM(hipMalloc(rcol, sizeof(int32_t) * (size_t)std::max<int64_t>(A.rnnz, 1)));
+	HIP_TRY_MEM(hipMalloc(rval, sizeof(T) * (size_t)std::max<int64_t>(A.rnnz, 1)));
+	HIP_TRY_MEM(hipMalloc(&A.dia_off, sizeof(int32_t) * places));
+	HIP_TRY_MEM(hipMalloc(&A.dia_val, sizeof(T) * places));
+	HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)A.dia_off, (int)kDiaNone, places, e->stream));
+	HIP_TRY(hipMemsetAsync(A.dia_val, 0, sizeof(T) * places, e->stream));
+	k_dia_split<T, true><<<nbw, kBlock, 0, e->stream>>>(g, A.rowptr, A.col, (const T*)A.val, win, A.dia_stride, nullptr, nullptr, A.rrowptr,
+	                                                   *rcol, *rval, A.dia_off, (T*)A.dia_val);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipStreamSynchronize(e->stream));
+	return LPP_OK;
+}
+
 // build the sliced layout of A on the device for row blocks of B rows
-template <typename T> static lpp_status build_sliced_t(lpp_engine* e, DevCsr& A, int64_t B)
+template <typename T> static lpp_status build_sliced_t(lpp_engine* e, DevCsr& A, int64_t B, bool for_window)
 {
 	SliceGeom g;
 	g.nrows = A.nrows;
@@ -212,52 +309,88 @@ template <typename T> static lpp_status build_sliced_t(lpp_engine* e, DevCsr& A,
 	g.nblocks = (A.nrows + g.B - 1) / g.B;
 	g.nslices = g.nblocks * g.spb;
 	A.geom = g;
+	// entries shared by all rows of a slice are split off first; the sliced arrays then hold the rest
+	const int64_t* rp = A.rowptr;
+	const int32_t* cc = A.col;
+	const T* vv = (const T*)A.val;
+	int64_t nz = A.nnz;
+	int32_t* rcol = nullptr;
+	T* rval = nullptr;
+	struct Scratch {
+		int32_t*& c;
+		T*& v;
+		~Scratch()
+		{
+			if (c) (void)hipFree(c);
+			if (v) (void)hipFree(v);
+		}
+	} scratch { rcol, rval };
+	int want_dia = A.no_dia ? 0 : 1;
+	if (const char* s = getenv("LPP_SHARED_OFFSETS")) want_dia = A.no_dia ? 0 : atoi(s);
+	if (want_dia && A.nnz > 0) {
+		lpp_status st = split_dia_t<T>(e, A, g, for_window, &rcol, &rval);
+		if (st != LPP_OK) return st;
+		if (A.rrowptr) {
+			rp = A.rrowptr;
+			cc = rcol;
+			vv = rval;
+			nz = A.rnnz;
+		}
+	}
 	int want = e->cfg.compress_values;
 	if (const char* s = getenv("LPP_COMPRESS_VALUES")) want = atoi(s);
 	bool coded = false;
 	if (want != 0) {
-		lpp_status st = try_build_dict<T>(e, A, &coded);
+		lpp_status st = try_build_dict<T>(e, A, vv, nz, &coded);
 		if (st != LPP_OK) return st;
 	}
+	// window kernel: 16-bit window-local columns when every per-row entry stays inside its row block
+	bool l16 = false;
+	if (for_window && g.B <= 65536 && nz > 0 && !(getenv("LPP_LOCAL16") && atoi(getenv("LPP_LOCAL16")) == 0)) {
+		int* outside = nullptr;
+		HIP_TRY_MEM(hipMalloc(&outside, sizeof(int)));
+		(void)hipMemsetAsync(outside, 0, sizeof(int), e->stream);
+		k_cols_local<<<(int)((A.nrows + 255) / 256), 256, 0, e->stream>>>(g, rp, cc, outside);
+		int bad = 0;
+		hipError_t e1 = hipMemcpyAsync(&bad, outside, sizeof(int), hipMemcpyDeviceToHost, e->stream);
+		hipError_t e2 = hipStreamSynchronize(e->stream);
+		(void)hipFree(outside);
+		if (e1 != hipSuccess || e2 != hipSuccess) return fail(LPP_ERR_HIP, "column locality check failed");
+		l16 = !bad;
+	}
+	A.local16 = l16;
 	// +64 entries of slack: the pipelined kernel reads (and discards) the entry after a slice's last one
 	HIP_TRY_MEM(hipMalloc(&A.slice_ptr, sizeof(int64_t) * (size_t)(g.nslices + 1)));
 	HIP_TRY_MEM(hipMalloc(&A.row_len, sizeof(int32_t) * (size_t)std::max<int64_t>(A.nrows, 1)));
-	HIP_TRY_MEM(hipMalloc(&A.scol, sizeof(int32_t) * (size_t)(A.nnz + 64)));
-	HIP_TRY(hipMemsetAsync(A.scol + A.nnz, 0, sizeof(int32_t) * 64, e->stream));
+	const size_t colsz = l16 ? sizeof(uint16_t) : sizeof(int32_t);
+	HIP_TRY_MEM(hipMalloc(&A.scol, colsz * (size_t)(nz + 64)));
+	HIP_TRY(hipMemsetAsync((char*)A.scol + colsz * (size_t)nz, 0, colsz * 64, e->stream));
 	if (coded) HIP_TRY_MEM(hipMalloc(&A.code_ptr, sizeof(int64_t) * (size_t)(g.nslices + 1)));
 	const int64_t nthreads = std::max<int64_t>(A.nrows, g.nslices + 1);
 	const int nb = (int)((nthreads + 255) / 256);
-	k_slice_meta<<<nb, 256, 0, e->stream>>>(g, A.rowptr, A.slice_ptr, A.row_len, A.code_ptr, CodeTraits<T>::kSlotsPerWord);
+	k_slice_meta<<<nb, 256, 0, e->stream>>>(g, rp, A.slice_ptr, A.row_len, A.code_ptr, CodeTraits<T>::kSlotsPerWord);
 	const int64_t need = (g.nslices + 3) / 4;
 	const int nb2 = (int)std::max<int64_t>(1, std::min<int64_t>(need, 8192));
 	if (coded) {
 		// exclusive scan of the per-slice word counts -> code_ptr; the grand total sizes the code array
-		const int64_t n = g.nslices + 1;
-		const int64_t nblk = (n + kScanChunk - 1) / kScanChunk;
-		int64_t *sums = nullptr, *total = nullptr;
-		HIP_TRY_MEM(hipMalloc(&sums, sizeof(int64_t) * (size_t)nblk));
-		if (hipMalloc(&total, sizeof(int64_t)) != hipSuccess) {
-			(void)hipFree(sums);
-			return fail(LPP_ERR_NOMEM, "scan scratch allocation failed");
-		}
-		k_scan_block_sums<<<(int)nblk, kBlock, 0, e->stream>>>(A.code_ptr, n, sums);
-		k_scan_sums<<<1, kBlock, 0, e->stream>>>(sums, nblk, total);
-		k_scan_apply<<<(int)nblk, kBlock, 0, e->stream>>>(A.code_ptr, n, sums, A.code_ptr);
 		int64_t nwords = 0;
-		hipError_t e1 = hipMemcpyAsync(&nwords, total, sizeof(int64_t), hipMemcpyDeviceToHost, e->stream);
-		hipError_t e2 = hipStreamSynchronize(e->stream);
-		(void)hipFree(sums);
-		(void)hipFree(total);
-		if (e1 != hipSuccess || e2 != hipSuccess) return fail(LPP_ERR_HIP, "code-pointer scan failed");
+		lpp_status st = scan_exclusive(e, A.code_ptr, g.nslices + 1, &nwords);
+		if (st != LPP_OK) return st;
 		HIP_TRY_MEM(hipMalloc(&A.codes, sizeof(uint32_t) * (size_t)(nwords + 64 * 16)));
 		HIP_TRY(hipMemsetAsync(A.codes + nwords, 0, sizeof(uint32_t) * 64 * 16, e->stream));
-		k_slice_fill<T, false><<<nb2, kBlock, 0, e->stream>>>(g, A.rowptr, A.col, (const T*)nullptr, A.scol, (T*)nullptr);
-		k_slice_codes<T><<<nb2, kBlock, 0, e->stream>>>(g, A.rowptr, (const T*)A.val, A.code_ptr, A.dict, A.ndict, A.codes);
+		if (l16)
+			k_slice_fill<T, false, true><<<nb2, kBlock, 0, e->stream>>>(g, rp, cc, (const T*)nullptr, A.scol, (T*)nullptr);
+		else
+			k_slice_fill<T, false><<<nb2, kBlock, 0, e->stream>>>(g, rp, cc, (const T*)nullptr, A.scol, (T*)nullptr);
+		k_slice_codes<T><<<nb2, kBlock, 0, e->stream>>>(g, rp, vv, A.code_ptr, A.dict, A.ndict, A.codes);
 		A.coded = true;
 	} else {
-		HIP_TRY_MEM(hipMalloc(&A.sval, sizeof(T) * (size_t)(A.nnz + 64)));
-		HIP_TRY(hipMemsetAsync((T*)A.sval + A.nnz, 0, sizeof(T) * 64, e->stream));
-		k_slice_fill<T, false><<<nb2, kBlock, 0, e->stream>>>(g, A.rowptr, A.col, (const T*)A.val, A.scol, (T*)A.sval);
+		HIP_TRY_MEM(hipMalloc(&A.sval, sizeof(T) * (size_t)(nz + 64)));
+		HIP_TRY(hipMemsetAsync((T*)A.sval + nz, 0, sizeof(T) * 64, e->stream));
+		if (l16)
+			k_slice_fill<T, false, true><<<nb2, kBlock, 0, e->stream>>>(g, rp, cc, vv, A.scol, (T*)A.sval);
+		else
+			k_slice_fill<T, false><<<nb2, kBlock, 0, e->stream>>>(g, rp, cc, vv, A.scol, (T*)A.sval);
 	}
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipStreamSynchronize(e->stream));
@@ -303,7 +436,8 @@ lpp_status finalize_csr(lpp_engine* e, DevCsr& A, bool allow_drop_plain, int for
 	if (!fits32 && (mode == LPP_SPMV_AUTO || mode == LPP_SPMV_SLICED || mode == LPP_SPMV_WINDOW)) mode = LPP_SPMV_ROWGROUP;
 	if ((mode == LPP_SPMV_SLICED || mode == LPP_SPMV_WINDOW) && A.nrows > 0) {
 		const int64_t B = force_block > 0 ? force_block : ((mode == LPP_SPMV_WINDOW) ? win_rows : A.nrows);
-		lpp_status st = e->is_complex ? build_sliced_t<cplx>(e, A, B) : build_sliced_t<double>(e, A, B);
+		const bool win = (mode == LPP_SPMV_WINDOW);
+		lpp_status st = e->is_complex ? build_sliced_t<cplx>(e, A, B, win) : build_sliced_t<double>(e, A, B, win);
 		if (st != LPP_OK) return st;
 		A.window = (mode == LPP_SPMV_WINDOW);
 		if (allow_drop_plain && getenv("LPP_KEEP_PLAIN_CSR") == nullptr && A.owned) {
@@ -544,20 +678,50 @@ lpp_status lpp_engine_get_csr(lpp_engine* e, int32_t which, int64_t* nrows, int6
 		if (!dcol || !dval) {
 			// only the sliced layout is resident: rebuild CSR order in scratch buffers
 			if (!A.sliced) return fail(LPP_ERR_STATE, "lpp_engine_get_csr: matrix arrays missing");
-			HIP_TRY_MEM(hipMalloc(&tcol, sizeof(int32_t) * (size_t)A.nnz));
-			if (hipMalloc(&tval, e->esz * (size_t)A.nnz) != hipSuccess) {
+			const int64_t* rp = A.rrowptr ? A.rrowptr : A.rowptr; // the sliced arrays hold the rest CSR when entries were split off
+			const int64_t nz = A.rrowptr ? A.rnnz : A.nnz;
+			HIP_TRY_MEM(hipMalloc(&tcol, sizeof(int32_t) * (size_t)std::max<int64_t>(nz, 1)));
+			if (hipMalloc(&tval, e->esz * (size_t)std::max<int64_t>(nz, 1)) != hipSuccess) {
 				(void)hipFree(tcol);
 				return fail(LPP_ERR_NOMEM, "lpp_engine_get_csr: scratch allocation failed");
 			}
 			const int nb2 = (int)std::max<int64_t>(1, std::min<int64_t>((A.geom.nslices + 3) / 4, 8192));
 			if (e->is_complex) {
-				k_slice_fill<cplx, true><<<nb2, kBlock, 0, e->stream>>>(A.geom, A.rowptr, A.scol, (const cplx*)A.sval, tcol, A.coded ? nullptr : (cplx*)tval);
-				if (A.coded) k_slice_decode<cplx><<<nb2, kBlock, 0, e->stream>>>(A.geom, A.rowptr, A.codes, A.code_ptr, A.dict, (cplx*)tval);
+				if (A.local16)
+					k_slice_fill<cplx, true, true><<<nb2, kBlock, 0, e->stream>>>(A.geom, rp, A.scol, (const cplx*)A.sval, tcol, A.coded ? nullptr : (cplx*)tval);
+				else
+					k_slice_fill<cplx, true><<<nb2, kBlock, 0, e->stream>>>(A.geom, rp, A.scol, (const cplx*)A.sval, tcol, A.coded ? nullptr : (cplx*)tval);
+				if (A.coded) k_slice_decode<cplx><<<nb2, kBlock, 0, e->stream>>>(A.geom, rp, A.codes, A.code_ptr, A.dict, (cplx*)tval);
 			} else {
-				k_slice_fill<double, true><<<nb2, kBlock, 0, e->stream>>>(A.geom, A.rowptr, A.scol, (const double*)A.sval, tcol, A.coded ? nullptr : (double*)tval);
-				if (A.coded) k_slice_decode<double><<<nb2, kBlock, 0, e->stream>>>(A.geom, A.rowptr, A.codes, A.code_ptr, A.dict, (double*)tval);
+				if (A.local16)
+					k_slice_fill<double, true, true><<<nb2, kBlock, 0, e->stream>>>(A.geom, rp, A.scol, (const double*)A.sval, tcol, A.coded ? nullptr : (double*)tval);
+				else
+					k_slice_fill<double, true><<<nb2, kBlock, 0, e->stream>>>(A.geom, rp, A.scol, (const double*)A.sval, tcol, A.coded ? nullptr : (double*)tval);
+				if (A.coded) k_slice_decode<double><<<nb2, kBlock, 0, e->stream>>>(A.geom, rp, A.codes, A.code_ptr, A.dict, (double*)tval);
+			}
+			if (A.rrowptr) {
+				// merge the shared-offset entries back into every row
+				int32_t* fcol = nullptr;
+				void* fval = nullptr;
+				if (hipMalloc(&fcol, sizeof(int32_t) * (size_t)A.nnz) != hipSuccess || hipMalloc(&fval, e->esz * (size_t)A.nnz) != hipSuccess) {
+					(void)hipFree(tcol);
+					(void)hipFree(tval);
+					if (fcol) (void)hipFree(fcol);
+					return fail(LPP_ERR_NOMEM, "lpp_engine_get_csr: scratch allocation failed");
+				}
+				const int nbm = (int)((A.nrows + 255) / 256);
+				if (e->is_complex)
+					k_dia_merge<cplx><<<nbm, 256, 0, e->stream>>>(A.geom, A.rowptr, rp, tcol, (const cplx*)tval, A.dia_stride, A.dia_off, (const cplx*)A.dia_val, fcol, (cplx*)fval);
+				else
+					k_dia_merge<double><<<nbm, 256, 0, e->stream>>>(A.geom, A.rowptr, rp, tcol, (const double*)tval, A.dia_stride, A.dia_off, (const double*)A.dia_val, fcol, (double*)fval);
+				(void)hipStreamSynchronize(e->stream);
+				(void)hipFree(tcol);
+				(void)hipFree(tval);
+				tcol = fcol;
+				tval = fval;
 			}
 			hipError_t err = hipStreamSynchronize(e->stream);
+			if (err == hipSuccess) err = hipGetLastError();
 			if (err != hipSuccess) {
 				(void)hipFree(tcol);
 				(void)hipFree(tval);

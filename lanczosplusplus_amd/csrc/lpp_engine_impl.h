@@ -36,6 +36,7 @@ struct DevCsr {
 	int G = 16; // lanes per row of the row-group kernel
 	bool sliced = false;
 	bool window = false; // LDS-window kernel (K3)
+	bool local16 = false; // scol holds 16-bit window-local columns (window kernel, every per-row entry inside its block)
 	int64_t hint_block = 0; // natural row block of the basis (N_up), 0 = unknown
 	int64_t src_elems = 0; // length of the vector the columns index (0 = nrows)
 	SliceGeom geom {};
@@ -49,6 +50,14 @@ struct DevCsr {
 	int64_t* code_ptr = nullptr;
 	double* dict = nullptr;
 	int ndict = 0;
+	// shared-offset entries (k_dia_split): the sliced arrays then hold the "rest" CSR described by rrowptr
+	bool no_dia = false;
+	int64_t* rrowptr = nullptr; // row pointers of the rest CSR (null: nothing was split off)
+	int64_t rnnz = 0; // its entries
+	int64_t ndia = 0; // shared entries, summed over slices
+	int dia_stride = 0; // places per slice in dia_off / dia_val
+	int32_t* dia_off = nullptr;
+	void* dia_val = nullptr;
 };
 
 // matrix-free Hubbard product state: two one-species matrices instead of the full CSR

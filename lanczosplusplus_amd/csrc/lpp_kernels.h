@@ -244,7 +244,15 @@ template <typename T> struct SlicedArgs {
 	double* partial;
 	int xcd_map;
 	EpiScale sc;
+	// shared-offset entries ("diagonals", see k_dia_split): slice s owns dia_off/dia_val[s*dia_stride .. +dia_stride),
+	// unused places hold kDiaNone; dia_stride == 0: none
+	int dia_stride;
+	const int32_t* dia_off; // column - row, the same for every row of the slice
+	const T* dia_val;
 };
+
+constexpr int32_t kDiaNone = INT32_MIN;
+constexpr int kDiaMax = 64; // shared entries per slice (one per lane of the metadata load)
 
 // Value dictionary ("coded" layout): the Hamiltonians of this path take very few distinct values
 // (+-t, J/2, U*k, ...), so when a matrix has <= 256 distinct doubles the 8-byte value of an entry is
@@ -288,7 +296,9 @@ __device__ __forceinline__ uint32_t lane_prefix(unsigned long long m)
 // issue-bound for 25-50 % of its time): mbcnt for the lane prefix, scalar base pointers, wave-uniform
 // skips of the global gather when a whole slot is inside the window (and of the LDS read when none is),
 // and -- coded layout -- no select at all: inactive lanes decode code 0 == +0.0.
-template <typename T, bool WINDOW, bool CODED, int U>
+// LOCAL16 (window kernel only): every entry's column lies in the row block's own window and columns are stored as
+// 16-bit window-local indices -- 2 bytes per entry and no in-window test, select or global gather in the loop.
+template <typename T, bool WINDOW, bool CODED, int U, bool LOCAL16 = false>
 __device__ __forceinline__ T sliced_accumulate(const SlicedArgs<T>& a, int len, int64_t base, int64_t cbase, const T* lds,
                                                int32_t r0, uint32_t wlen, const double* dict, int32_t safe)
 {
@@ -303,7 +313,8 @@ __device__ __forceinline__ T sliced_accumulate(const SlicedArgs<T>& a, int len, 
 	// (scalar base pointer + 32-bit lane offset) instead of 64-bit vector arithmetic per load
 	const int64_t base_u = ((int64_t)__builtin_amdgcn_readfirstlane((int)(base >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
 	const int64_t cbase_u = ((int64_t)__builtin_amdgcn_readfirstlane((int)(cbase >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)cbase);
-	const int32_t* colp = a.col + base_u;
+	const int32_t* colp = LOCAL16 ? nullptr : a.col + base_u;
+	const uint16_t* colp16 = LOCAL16 ? (const uint16_t*)a.col + base_u : nullptr;
 	const T* valp = CODED ? nullptr : a.val + base_u;
 	const uint32_t* codep = CODED ? a.codes + cbase_u : nullptr;
 	uint32_t run = 0; // entries of this slice consumed so far (wave-uniform)
@@ -317,7 +328,7 @@ __device__ __forceinline__ T sliced_accumulate(const SlicedArgs<T>& a, int len, 
 		const bool on_ = len > (K0) + u;                                                                              \
 		const unsigned long long m_ = __ballot(on_);                                                                  \
 		const uint32_t p_ = run + (on_ ? lane_prefix(m_) : 0u);                                                       \
-		C[u] = ld_off32(colp, p_);                                                                                    \
+		C[u] = LOCAL16 ? (int32_t)ld_off32(colp16, p_) : ld_off32(colp, p_);                                          \
 		if (!CODED) {                                                                                                 \
 			const T t_ = ld_off32(valp, p_);                                                                          \
 			V[u] = on_ ? t_ : VT<T>::zero();                                                                          \
@@ -332,7 +343,9 @@ __device__ __forceinline__ T sliced_accumulate(const SlicedArgs<T>& a, int len, 
 		T g[U];
 #pragma unroll
 		for (int u = 0; u < U; u++) {
-			if (WINDOW) {
+			if (LOCAL16) {
+				g[u] = lds[c0[u]];
+			} else if (WINDOW) {
 				const uint32_t d = (uint32_t)(c0[u] - r0);
 				const bool inw = d < wlen;
 				const unsigned long long min_ = __ballot(inw);
@@ -365,10 +378,91 @@ __device__ __forceinline__ T sliced_accumulate(const SlicedArgs<T>& a, int len, 
 	return acc;
 }
 
+// Shared-offset entries of a slice: entry d contributes val_d * src[row + off_d] to EVERY row of the slice, so the gather
+// is one contiguous 64-element run and needs no column load.  The slice's (off, val) list is fetched by ONE vector load
+// (lane l takes entry l, a slice ahead, together with the other slice metadata) and handed out with v_readlane, i.e.
+// offsets and values are scalar operands.  The first 8*kChunks gathers are requested before the slice's per-row
+// entries are walked and consumed after them.
+template <typename T> struct DiaMeta {
+	int32_t off; // lane l: offset of shared entry l, kDiaNone past the end
+	T val;
+};
+
+__device__ __forceinline__ double readlane_t(double v, int l)
+{
+	const long long b = __double_as_longlong(v);
+	const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)b, l);
+	const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(b >> 32), l);
+	return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+__device__ __forceinline__ cplx readlane_t(cplx v, int l) { return cplx { readlane_t(v.re, l), readlane_t(v.im, l) }; }
+
+template <typename T> __device__ __forceinline__ void dia_meta(const SlicedArgs<T>& a, int64_t s, DiaMeta<T>& m)
+{
+	m.off = kDiaNone;
+	m.val = VT<T>::zero();
+	if (a.dia_stride > 0) { // wave-uniform
+		const int lane = threadIdx.x & 63;
+		const int64_t i = s * a.dia_stride + min(lane, a.dia_stride - 1);
+		const int32_t o = a.dia_off[i];
+		m.val = a.dia_val[i];
+		m.off = lane < a.dia_stride ? o : kDiaNone;
+	}
+}
+
+template <typename T> struct DiaPre {
+	static constexpr int kChunks = sizeof(T) == 8 ? 2 : 1; // chunks of 8 gathers kept in flight
+	T g[8 * kChunks];
+};
+
+template <typename T>
+__device__ __forceinline__ void dia_request(const SlicedArgs<T>& a, const DiaMeta<T>& m, int dcnt, uint32_t row, DiaPre<T>& pre)
+{
+#pragma unroll
+	for (int ch = 0; ch < DiaPre<T>::kChunks; ch++) {
+		if (ch * 8 < dcnt) { // wave-uniform
+#pragma unroll
+			for (int q = 0; q < 8; q++) {
+				// clamped: the tail of a chunk repeats the last entry (its value is selected to 0 in dia_consume)
+				const int32_t o = __builtin_amdgcn_readlane(m.off, min(ch * 8 + q, dcnt - 1));
+				pre.g[ch * 8 + q] = ld_off32(a.src, row + (uint32_t)o);
+			}
+		}
+	}
+}
+
+template <typename T>
+__device__ __forceinline__ void dia_consume(const SlicedArgs<T>& a, const DiaMeta<T>& m, int dcnt, uint32_t row, const DiaPre<T>& pre, T& acc)
+{
+	constexpr int NPRE = 8 * DiaPre<T>::kChunks;
+	for (int d0 = NPRE; d0 < dcnt; d0 += 8) { // rare: more shared entries than prefetch places
+		T g[8];
+#pragma unroll
+		for (int q = 0; q < 8; q++) g[q] = ld_off32(a.src, row + (uint32_t)__builtin_amdgcn_readlane(m.off, min(d0 + q, dcnt - 1)));
+#pragma unroll
+		for (int q = 0; q < 8; q++) {
+			const T v = d0 + q < dcnt ? readlane_t(m.val, min(d0 + q, dcnt - 1)) : VT<T>::zero();
+			VT<T>::mac(acc, v, g[q]);
+		}
+	}
+#pragma unroll
+	for (int ch = 0; ch < DiaPre<T>::kChunks; ch++) {
+		if (ch * 8 < dcnt) {
+#pragma unroll
+			for (int q = 0; q < 8; q++) {
+				const int d = ch * 8 + q;
+				const T v = d < dcnt ? readlane_t(m.val, min(d, dcnt - 1)) : VT<T>::zero();
+				VT<T>::mac(acc, v, pre.g[d]);
+			}
+		}
+	}
+}
+
 // process one slice with one wave (x[row] += acc); returns this lane's contribution to Re<ydot|x>.
-template <typename T, bool DOT, bool WINDOW, bool CODED, int U>
+template <typename T, bool DOT, bool WINDOW, bool CODED, int U, bool LOCAL16 = false>
 __device__ __forceinline__ double sliced_one(const SlicedArgs<T>& a, int64_t row0, int nvalid, int len, int64_t base, int64_t cbase,
-                                             const T* lds, int32_t r0, uint32_t wlen, const double* dict, double alpha, double beta)
+                                             const T* lds, int32_t r0, uint32_t wlen, const double* dict, double alpha, double beta,
+                                             const DiaMeta<T>& dm)
 {
 	if (nvalid == 0) return 0.0; // wave-uniform
 	const int lane = threadIdx.x & 63;
@@ -379,7 +473,11 @@ __device__ __forceinline__ double sliced_one(const SlicedArgs<T>& a, int64_t row
 	const T xold = a.x[row];
 	T yv = VT<T>::zero();
 	if (DOT) yv = a.ydot[row];
-	const T acc = sliced_accumulate<T, WINDOW, CODED, U>(a, len, base, cbase, lds, r0, wlen, dict, (int32_t)row);
+	DiaPre<T> pre;
+	const int dcnt = __popcll(__ballot(dm.off != kDiaNone)); // wave-uniform
+	dia_request<T>(a, dm, dcnt, (uint32_t)row, pre);
+	T acc = sliced_accumulate<T, WINDOW, CODED, U, LOCAL16>(a, len, base, cbase, lds, r0, wlen, dict, (int32_t)row);
+	dia_consume<T>(a, dm, dcnt, (uint32_t)row, pre, acc);
 	double d = 0.0;
 	if (valid) {
 		const T xv = epi_lin(beta, xold, alpha, acc);
@@ -437,18 +535,27 @@ __global__ __launch_bounds__(kBlock) void k_spmv_sliced(SlicedArgs<T> a)
 	double dot = 0.0;
 	int64_t row0 = 0, base = 0, cbase = 0;
 	int nvalid = 0, len = 0;
-	if (s_begin < s_end) slice_meta<T, CODED>(a, s_begin, row0, nvalid, len, base, cbase);
+	DiaMeta<T> dm { kDiaNone, VT<T>::zero() };
+	if (s_begin < s_end) {
+		slice_meta<T, CODED>(a, s_begin, row0, nvalid, len, base, cbase);
+		dia_meta<T>(a, s_begin, dm);
+	}
 	for (int64_t s = s_begin; s < s_end; s += s_stride) {
 		// prefetch the next slice's metadata before working on this one
 		int64_t row0n = 0, basen = 0, cbasen = 0;
 		int nvalidn = 0, lenn = 0;
-		if (s + s_stride < s_end) slice_meta<T, CODED>(a, s + s_stride, row0n, nvalidn, lenn, basen, cbasen);
-		dot += sliced_one<T, DOT, false, CODED, U>(a, row0, nvalid, len, base, cbase, nullptr, 0, 0, dict_s, alpha, beta);
+		DiaMeta<T> dmn { kDiaNone, VT<T>::zero() };
+		if (s + s_stride < s_end) {
+			slice_meta<T, CODED>(a, s + s_stride, row0n, nvalidn, lenn, basen, cbasen);
+			dia_meta<T>(a, s + s_stride, dmn);
+		}
+		dot += sliced_one<T, DOT, false, CODED, U>(a, row0, nvalid, len, base, cbase, nullptr, 0, 0, dict_s, alpha, beta, dm);
 		row0 = row0n;
 		base = basen;
 		cbase = cbasen;
 		nvalid = nvalidn;
 		len = lenn;
+		dm = dmn;
 	}
 	if (DOT) {
 		const double r = block_sum(dot, smem);
@@ -466,7 +573,7 @@ __device__ __forceinline__ int next_slice_claim(int* counter)
 
 // K3: LDS window.  One 1024-thread workgroup per CU walks row blocks; dynamic LDS = B elements.
 constexpr int kWinThreads = 1024;
-template <typename T, bool DOT, bool CODED, int U>
+template <typename T, bool DOT, bool CODED, int U, bool LOCAL16>
 __global__ __launch_bounds__(kWinThreads) void k_spmv_window(SlicedArgs<T> a)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -510,19 +617,28 @@ __global__ __launch_bounds__(kWinThreads) void k_spmv_window(SlicedArgs<T> a)
 		// the waves that got 12 instead of 13 slices idle at the block's closing barrier (~8 % of the time)
 		int64_t row0 = 0, base = 0, cbase = 0;
 		int nvalid = 0, len = 0;
+		DiaMeta<T> dm { kDiaNone, VT<T>::zero() };
 		int j = next_slice_claim(&next_slice);
-		if (j < a.g.spb) slice_meta<T, CODED>(a, blk * a.g.spb + j, row0, nvalid, len, base, cbase);
+		if (j < a.g.spb) {
+			slice_meta<T, CODED>(a, blk * a.g.spb + j, row0, nvalid, len, base, cbase);
+			dia_meta<T>(a, blk * a.g.spb + j, dm);
+		}
 		while (j < a.g.spb) {
 			const int jn = next_slice_claim(&next_slice);
 			int64_t row0n = 0, basen = 0, cbasen = 0;
 			int nvalidn = 0, lenn = 0;
-			if (jn < a.g.spb) slice_meta<T, CODED>(a, blk * a.g.spb + jn, row0n, nvalidn, lenn, basen, cbasen);
-			dot += sliced_one<T, DOT, true, CODED, U>(a, row0, nvalid, len, base, cbase, lds, (int32_t)r0, (uint32_t)wl, dict_s, alpha, beta);
+			DiaMeta<T> dmn { kDiaNone, VT<T>::zero() };
+			if (jn < a.g.spb) {
+				slice_meta<T, CODED>(a, blk * a.g.spb + jn, row0n, nvalidn, lenn, basen, cbasen);
+				dia_meta<T>(a, blk * a.g.spb + jn, dmn);
+			}
+			dot += sliced_one<T, DOT, true, CODED, U, LOCAL16>(a, row0, nvalid, len, base, cbase, lds, (int32_t)r0, (uint32_t)wl, dict_s, alpha, beta, dm);
 			row0 = row0n;
 			base = basen;
 			cbase = cbasen;
 			nvalid = nvalidn;
 			len = lenn;
+			dm = dmn;
 			j = jn;
 		}
 	}
@@ -557,7 +673,8 @@ static __global__ void k_slice_meta(SliceGeom g, const int64_t* __restrict__ row
 }
 
 // one wave per slice: scatter CSR entries into slot-major compact order (INVERSE: back to CSR order)
-template <typename T, bool INVERSE>
+// L16: the sliced side holds 16-bit window-local columns (column - first row of the row block)
+template <typename T, bool INVERSE, bool L16 = false>
 __global__ __launch_bounds__(kBlock) void k_slice_fill(SliceGeom g, const int64_t* __restrict__ rowptr,
                                                         const int32_t* __restrict__ col_in,
                                                         const T* __restrict__ val_in, int32_t* __restrict__ col_out,
@@ -585,17 +702,165 @@ __global__ __launch_bounds__(kBlock) void k_slice_fill(SliceGeom g, const int64_
 			const unsigned long long m = __ballot(on);
 			const int pos = __popcll(m & ((1ull << lane) - 1ull));
 			if (on) {
+				const int32_t r0 = L16 ? (int32_t)((s / g.spb) * g.B) : 0;
 				if (INVERSE) {
-					col_out[p0 + k] = col_in[base + pos];
+					col_out[p0 + k] = L16 ? (int32_t)((const uint16_t*)col_in)[base + pos] + r0 : col_in[base + pos];
 					if (val_out) val_out[p0 + k] = val_in[base + pos];
 				} else {
-					col_out[base + pos] = col_in[p0 + k];
+					if (L16)
+						((uint16_t*)col_out)[base + pos] = (uint16_t)(col_in[p0 + k] - r0);
+					else
+						col_out[base + pos] = col_in[p0 + k];
 					if (val_out) val_out[base + pos] = val_in[p0 + k];
 				}
 			}
 			base += __popcll(m);
 		}
 	}
+}
+
+// ---- shared-offset ("diagonal") entries -----------------------------------------------------------
+// Product-basis Hamiltonians repeat themselves: in the Hubbard basis every row of one down-configuration block has
+// the same down-hops, i.e. the entries (column - row, value) are identical for all 64 rows of a slice.  Such an entry
+// is stored once per slice (12 or 20 bytes) instead of once per row, its gather needs no column load at all, and
+// offset and value live in scalar registers.  The split is structural (no model knowledge) and lossless:
+//   CSR = per-row "rest" entries (sliced layout as before) + per-slice shared entries, merged back by k_dia_merge.
+// An entry of the slice's first row is shared when every other valid row holds an entry with the same offset and
+// bit-identical value.  Rows must be strictly sorted by column (checked by k_rows_sorted; otherwise disabled).
+template <typename T> __device__ __forceinline__ bool same_bits(const T& x, const T& y);
+template <> __device__ __forceinline__ bool same_bits<double>(const double& x, const double& y)
+{
+	return __double_as_longlong(x) == __double_as_longlong(y);
+}
+template <> __device__ __forceinline__ bool same_bits<cplx>(const cplx& x, const cplx& y)
+{
+	return __double_as_longlong(x.re) == __double_as_longlong(y.re) && __double_as_longlong(x.im) == __double_as_longlong(y.im);
+}
+
+static __global__ void k_rows_sorted(int64_t nrows, const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col, int* unsorted)
+{
+	const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= nrows) return;
+	bool bad = false;
+	for (int64_t p = rowptr[r] + 1; p < rowptr[r + 1]; p++) bad |= col[p] <= col[p - 1];
+	if (bad) *unsorted = 1;
+}
+
+// One wave per slice.  FILL == false: rest_len[row] = entries the row keeps; stats[0] = max shared entries of any slice,
+// stats[1] = shared entries summed over slices.  FILL == true (after the scan of rest_len): writes the rest CSR
+// (rcol/rval at rrowptr) and the shared lists at dia_off/dia_val[s*stride ..] (pre-filled with kDiaNone / 0).
+// win != 0: the matrix is built for the LDS-window kernel; entries whose whole 64-row run lies inside the row block stay
+// per-row entries (served from LDS, 3 bytes each) instead of becoming global gathers.
+template <typename T, bool FILL>
+__global__ __launch_bounds__(kBlock) void k_dia_split(SliceGeom g, const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                       const T* __restrict__ val, int win, int stride, int64_t* __restrict__ rest_len,
+                                                       unsigned long long* __restrict__ stats, const int64_t* __restrict__ rrowptr,
+                                                       int32_t* __restrict__ rcol, T* __restrict__ rval, int32_t* __restrict__ dia_off,
+                                                       T* __restrict__ dia_val)
+{
+	const int lane = threadIdx.x & 63;
+	const int64_t wave0 = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+	const int64_t nwaves = (int64_t)gridDim.x * (kBlock / 64);
+	unsigned long long local_max = 0, local_sum = 0;
+	for (int64_t s = wave0; s < g.nslices; s += nwaves) {
+		int64_t row0;
+		int nvalid;
+		slice_rows(g, s, row0, nvalid);
+		if (nvalid == 0) continue;
+		const bool valid = lane < nvalid;
+		const int64_t row = row0 + (valid ? lane : 0);
+		const int64_t pbeg = rowptr[row];
+		int64_t q = valid ? pbeg : 0;
+		const int64_t end = valid ? rowptr[row + 1] : 0;
+		const int64_t p00 = rowptr[row0];
+		const int len0 = (int)(rowptr[row0 + 1] - p00);
+		const int64_t blk0 = (s / g.spb) * g.B, blk1 = blk0 + g.B;
+		const unsigned long long vmask = __ballot(valid);
+		int64_t wp = (FILL && valid) ? rrowptr[row] : 0;
+		int nd = 0;
+		for (int k = 0; k < len0; k++) {
+			const int32_t c0 = col[p00 + k];
+			const T v0 = val[p00 + k];
+			const int64_t off = (int64_t)c0 - row0;
+			const int64_t target = row + off;
+			while (q < end && (int64_t)col[q] < target) { // entries passed over stay with the row
+				if (FILL) {
+					rcol[wp] = col[q];
+					rval[wp] = val[q];
+					wp++;
+				}
+				q++;
+			}
+			bool ok = valid && q < end && (int64_t)col[q] == target;
+			if (ok) ok = same_bits<T>(val[q], v0);
+			const bool in_block = win && row0 + off >= blk0 && row0 + (nvalid - 1) + off < blk1;
+			if (__ballot(ok) == vmask && !in_block && nd < kDiaMax) { // shared by every valid row of the slice
+				if (FILL && lane == 0) {
+					dia_off[s * stride + nd] = (int32_t)off;
+					dia_val[s * stride + nd] = v0;
+				}
+				nd++;
+				q++;
+			}
+		}
+		if (FILL) {
+			while (q < end) {
+				rcol[wp] = col[q];
+				rval[wp] = val[q];
+				wp++;
+				q++;
+			}
+		} else {
+			if (valid) rest_len[row] = (end - pbeg) - nd;
+			local_max = max(local_max, (unsigned long long)nd);
+			local_sum += (unsigned long long)nd;
+		}
+	}
+	if (!FILL && lane == 0) {
+		atomicMax(&stats[0], local_max);
+		atomicAdd(&stats[1], local_sum);
+	}
+}
+
+// inverse (lpp_engine_get_csr): merge a row's rest entries with its slice's shared entries by column
+template <typename T>
+__global__ void k_dia_merge(SliceGeom g, const int64_t* __restrict__ rowptr, const int64_t* __restrict__ rrowptr,
+                            const int32_t* __restrict__ rcol, const T* __restrict__ rval, int stride,
+                            const int32_t* __restrict__ dia_off, const T* __restrict__ dia_val, int32_t* __restrict__ col_out,
+                            T* __restrict__ val_out)
+{
+	const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= g.nrows) return;
+	const int64_t blk = r / g.B;
+	const int64_t s = blk * g.spb + (r - blk * g.B) / 64;
+	int64_t i = rrowptr[r], iend = rrowptr[r + 1], d = s * stride, dend = d + stride, o = rowptr[r];
+	while (true) {
+		const bool hd = d < dend && dia_off[d] != kDiaNone, hi = i < iend;
+		if (!hd && !hi) break;
+		const int64_t cd = hd ? r + (int64_t)dia_off[d] : INT64_MAX;
+		const int64_t ci = hi ? (int64_t)rcol[i] : INT64_MAX;
+		if (cd < ci) {
+			col_out[o] = (int32_t)cd;
+			val_out[o] = dia_val[d];
+			d++;
+		} else {
+			col_out[o] = (int32_t)ci;
+			val_out[o] = rval[i];
+			i++;
+		}
+		o++;
+	}
+}
+
+// *outside = 1 when some entry's column lies outside its row block [blk*B, (blk+1)*B)
+static __global__ void k_cols_local(SliceGeom g, const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col, int* outside)
+{
+	const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= g.nrows) return;
+	const int64_t r0 = (r / g.B) * g.B, r1 = r0 + g.B;
+	bool bad = false;
+	for (int64_t p = rowptr[r]; p < rowptr[r + 1]; p++) bad |= col[p] < r0 || col[p] >= r1;
+	if (bad) *outside = 1;
 }
 
 // ---- value dictionary ---------------------------------------------------------------------------
