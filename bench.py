@@ -311,7 +311,11 @@ def main():
                          "kernel": ("k_spmv_kron_packed (matrix-free x += H y; bytes = vector-streaming model N*s*(3 + down-hops/row))"
                                     if args.engine == "onthefly" else "k_spmv_window/k_spmv_sliced (stored CSR x += H y, fused a_j partial)"),
                          "spmv_ms": spmv_ms_per_step,
-                         "algorithmic_bytes_per_launch": w1["spmv_bytes"], "launches_timed": launches},
+                         "algorithmic_bytes_per_launch": w1["spmv_bytes"], "launches_timed": launches,
+                         # bytes the kernel really moved (PMC) per second: the stored layout is a lossless compression
+                         # of the CSR (value dictionary, shared-offset entries, 16-bit local columns), so `achieved`,
+                         # which prices the plain-CSR bytes of SURVEY 8(d), can exceed the HBM peak; this rate cannot
+                         "moved_GBps": (traffic / 1e9) / (spmv_ms_per_step / 1e3) if (traffic and spmv_ms_per_step > 0) else None},
             "e0_after_steps": e0,
         }
         if world == 1 and not args.no_cpu_baseline:

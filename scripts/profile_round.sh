@@ -10,10 +10,10 @@ cd /tmp
 CMD="python3 $R/bench.py --steps 40 --warmup 5"
 $CMD > $O/bench.json 2> $O/bench.err
 CMDP="python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline"
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- $CMDP > $O/trace.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -- $CMDP > $O/fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -- $CMDP > $O/write.log 2>&1
-rocprofv3 --pmc TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum TCC_HIT_sum --output-format csv -d $O/ea -- $CMDP > $O/ea.log 2>&1
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- $CMDP > $O/trace.log 2>&1
+timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -- $CMDP > $O/fetch.log 2>&1
+timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -- $CMDP > $O/write.log 2>&1
+timeout -k 10 400 rocprofv3 --pmc TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum TCC_HIT_sum --output-format csv -d $O/ea -- $CMDP > $O/ea.log 2>&1
 python3 - <<PY
 import csv,glob,collections,json
 for f in glob.glob('$O/trace/*/*_kernel_stats.csv'):
