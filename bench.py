@@ -290,6 +290,12 @@ def main():
 
     if rank == 0:
         e0 = float(tridiag_lowest(a, b[:-1] if len(b) > 1 else b, 1)[0]) if len(a) else float("nan")
+        layout = None
+        if args.engine == "stored":
+            lay = eng.layout(0)
+            layout = {"kernel": {1: "rowgroup", 2: "sliced", 3: "window"}.get(lay["kernel"]), "value_codes": bool(lay["coded"]),
+                      "local16_columns": bool(lay["local16"]), "per_row_entries": lay["per_row_entries"],
+                      "shared_offset_entries": lay["shared_entries"], "resident_GB": round(lay["resident_bytes"] / 1e9, 2)}
         out = {
             "metric": METRIC,
             "value": args.steps / elapsed,
@@ -305,7 +311,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": name, "rows": nrows_g, "nnz": nnz_g, "parallelism": "1-D row partition x%d" % world,
                        "reortho": False, "assembly": "on-device", "assembly_s": round(t_asm, 3), "engine": args.engine,
-                       "exchange": (("transpose" if comm.xchg_chunk > 0 else "allgather") if comm is not None else None)},
+                       "exchange": (("transpose" if comm.xchg_chunk > 0 else "allgather") if comm is not None else None),
+                       "layout": layout},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": ("k_spmv_kron_packed (matrix-free x += H y; bytes = vector-streaming model N*s*(3 + down-hops/row))"

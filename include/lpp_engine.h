@@ -80,6 +80,19 @@ typedef struct lpp_stats {
 	double spmv_bytes; /* algorithmic bytes of one SpMV: Z(s+4) + (N+1)8 + 3Ns */
 } lpp_stats;
 
+/* How a stored matrix is laid out in HBM (introspection for tests, bench.py and DESIGN.md; no effect on results). */
+typedef struct lpp_layout {
+	int32_t kernel; /* LPP_SPMV_ROWGROUP / _SLICED / _WINDOW actually selected */
+	int32_t coded; /* 1: values stored as 8-bit dictionary codes */
+	int32_t local16; /* 1: per-row columns stored as 16-bit block-local indices */
+	int32_t shared_stride; /* places per 64-row slice for shared-offset entries (0: none) */
+	int64_t nnz; /* entries of the CSR this layout represents */
+	int64_t per_row_entries; /* entries kept per row */
+	int64_t shared_entries; /* entries stored once per slice, summed over slices */
+	int64_t rows_per_block; /* row block of the sliced layout */
+	int64_t resident_bytes; /* device bytes held for this matrix */
+} lpp_layout;
+
 /* Communicator for the 1-D row-partitioned multi-GPU path.  The engine never
  * opens sockets itself: the host (torch.distributed over RCCL in bench.py) supplies the
  * collectives and owns the exchange buffers.
@@ -119,6 +132,12 @@ lpp_status lpp_engine_create(lpp_engine** out, const lpp_config* cfg);
 lpp_status lpp_engine_destroy(lpp_engine* e);
 
 /* ---- the stored Hamiltonian (replaces DefaultSymmetry::matrixStored_, DefaultSymmetry.h:120) ---- */
+
+/* Optional layout hint for the NEXT lpp_engine_set_csr / _set_csr_partition: the basis index is blocked in runs of
+ * `rows_per_block` consecutive states whose in-block couplings dominate -- N_up for the Hubbard product basis
+ * index = i_up + i_down * N_up (BasisHubbardLanczos.h:59-63).  The engine then stages one block of the source vector
+ * in LDS per workgroup.  0 = unknown (default).  Results do not depend on it. */
+lpp_status lpp_engine_set_row_block(lpp_engine* e, int64_t rows_per_block);
 
 /* Upload a host CSR (copied).  rowptr[nrows+1], colind[nnz], values[nnz] of the engine dtype. */
 lpp_status lpp_engine_set_csr(lpp_engine* e, int64_t nrows, const int64_t* rowptr, const int32_t* colind,
@@ -188,6 +207,8 @@ lpp_status lpp_engine_sync(lpp_engine* e);
 /* copy out the coefficients produced so far (after a sync): a[steps], b[steps] */
 lpp_status lpp_engine_lanczos_coeffs(lpp_engine* e, int32_t* steps, double* a, double* b);
 lpp_status lpp_engine_get_stats(lpp_engine* e, lpp_stats* stats);
+/* which: 0 = local part (or the whole matrix on one GPU), 1 = remote part of a partitioned matrix */
+lpp_status lpp_engine_get_layout(lpp_engine* e, int32_t which, lpp_layout* layout);
 
 /* Time `iters` back-to-back SpMV launches (x += H y on resident vectors) with HIP events on the
  * engine stream; returns the average milliseconds per launch. */

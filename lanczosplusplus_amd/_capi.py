@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "liblpp_engine.so")
 LPP_ABI_VERSION = 1
 LPP_OK, LPP_ERR_INVALID, LPP_ERR_HIP, LPP_ERR_NOMEM, LPP_ERR_NOCONV, LPP_ERR_STATE, LPP_ERR_COMM = range(7)
 LPP_F64, LPP_C128 = 0, 1
-LPP_SPMV_AUTO, LPP_SPMV_ROWGROUP, LPP_SPMV_SLICED = 0, 1, 2
+LPP_SPMV_AUTO, LPP_SPMV_ROWGROUP, LPP_SPMV_SLICED, LPP_SPMV_WINDOW = 0, 1, 2, 3
 
 STATUS_NAMES = {0: "LPP_OK", 1: "LPP_ERR_INVALID", 2: "LPP_ERR_HIP", 3: "LPP_ERR_NOMEM", 4: "LPP_ERR_NOCONV",
                 5: "LPP_ERR_STATE", 6: "LPP_ERR_COMM"}
@@ -42,6 +42,15 @@ class Stats(C.Structure):
         return {name: getattr(self, name) for name, _ in self._fields_}
 
 
+class Layout(C.Structure):
+    _fields_ = [("kernel", C.c_int32), ("coded", C.c_int32), ("local16", C.c_int32), ("shared_stride", C.c_int32),
+                ("nnz", C.c_int64), ("per_row_entries", C.c_int64), ("shared_entries", C.c_int64),
+                ("rows_per_block", C.c_int64), ("resident_bytes", C.c_int64)]
+
+    def as_dict(self):
+        return {name: getattr(self, name) for name, _ in self._fields_}
+
+
 CB_VOID = C.CFUNCTYPE(C.c_int32, C.c_void_p)
 CB_REDUCE = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_int32, C.c_int32)
 CB_XCHG = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_int32)
@@ -63,6 +72,7 @@ SYMBOLS = {
     "lpp_config_default": (None, [C.POINTER(Config)]),
     "lpp_engine_create": (C.c_int32, [C.POINTER(_P), C.POINTER(Config)]),
     "lpp_engine_destroy": (C.c_int32, [_P]),
+    "lpp_engine_set_row_block": (C.c_int32, [_P, C.c_int64]),
     "lpp_engine_set_csr": (C.c_int32, [_P, C.c_int64, _P, _P, _P]),
     "lpp_engine_set_csr_partition": (C.c_int32, [_P, C.POINTER(Comm), C.c_int64, _P, _P, _P, _P]),
     "lpp_engine_assemble_hubbard": (C.c_int32, [_P, C.POINTER(Comm), C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P]),
@@ -78,6 +88,7 @@ SYMBOLS = {
     "lpp_engine_sync": (C.c_int32, [_P]),
     "lpp_engine_lanczos_coeffs": (C.c_int32, [_P, C.POINTER(C.c_int32), _P, _P]),
     "lpp_engine_get_stats": (C.c_int32, [_P, C.POINTER(Stats)]),
+    "lpp_engine_get_layout": (C.c_int32, [_P, C.c_int32, C.POINTER(Layout)]),
     "lpp_engine_bench_spmv": (C.c_int32, [_P, C.c_int32, C.c_int32, C.POINTER(C.c_double)]),
     "lpp_partition_rows": (C.c_int32, [C.c_int64, C.c_int32, C.c_int64, _P]),
     "lpp_split_csr": (C.c_int32, [C.c_int32, C.c_int32, _P, C.c_int64, C.c_int64, _P, _P, _P, C.c_int32,

@@ -570,11 +570,13 @@ lpp_status lpp_engine_destroy(lpp_engine* e)
 	return LPP_OK;
 }
 
-static lpp_status upload_csr(lpp_engine* e, DevCsr& A, int64_t nrows, const int64_t* rowptr, const int32_t* colind, const void* values)
+static lpp_status upload_csr(lpp_engine* e, DevCsr& A, int64_t nrows, const int64_t* rowptr, const int32_t* colind, const void* values,
+                             int64_t hint_block = 0)
 {
 	const int64_t keep_src = A.src_elems;
 	free_csr(A);
 	A.src_elems = keep_src;
+	A.hint_block = hint_block;
 	A.nrows = nrows;
 	A.nnz = rowptr ? rowptr[nrows] : 0;
 	A.owned = true;
@@ -601,6 +603,13 @@ static lpp_status check_csr_host(int64_t nrows, int64_t ncols, const int64_t* ro
 	return LPP_OK;
 }
 
+lpp_status lpp_engine_set_row_block(lpp_engine* e, int64_t rows_per_block)
+{
+	if (!e || rows_per_block < 0) return fail(LPP_ERR_INVALID, "lpp_engine_set_row_block: bad argument");
+	e->row_block_hint = rows_per_block;
+	return LPP_OK;
+}
+
 lpp_status lpp_engine_set_csr(lpp_engine* e, int64_t nrows, const int64_t* rowptr, const int32_t* colind, const void* values)
 {
 	if (!e || nrows < 0 || !rowptr) return fail(LPP_ERR_INVALID, "lpp_engine_set_csr: bad argument");
@@ -613,7 +622,7 @@ lpp_status lpp_engine_set_csr(lpp_engine* e, int64_t nrows, const int64_t* rowpt
 	e->bind_scalars(e->scal_own);
 	free_csr(e->A_rem);
 	drop_product(e);
-	st = upload_csr(e, e->A_loc, nrows, rowptr, colind, values);
+	st = upload_csr(e, e->A_loc, nrows, rowptr, colind, values, e->row_block_hint);
 	if (st != LPP_OK) return st;
 	e->n_local = e->n_global = nrows;
 	e->row_start = 0;
@@ -645,7 +654,9 @@ lpp_status lpp_engine_set_csr_partition(lpp_engine* e, const lpp_comm* comm, int
 	                   cl.data(), vl.data(), rpr.data(), cr.data(), vr.data());
 	if (st != LPP_OK) return st;
 	drop_product(e);
-	st = upload_csr(e, e->A_loc, local, rpl.data(), cl.data(), vl.data());
+	// the hint survives the partition when this rank's rows start on a block boundary (columns of A_loc are local)
+	const int64_t hint = (e->row_block_hint > 0 && shard_starts[r] % e->row_block_hint == 0) ? e->row_block_hint : 0;
+	st = upload_csr(e, e->A_loc, local, rpl.data(), cl.data(), vl.data(), hint);
 	if (st != LPP_OK) return st;
 	e->A_rem.src_elems = (int64_t)comm->nranks * comm->shard_stride;
 	st = upload_csr(e, e->A_rem, local, rpr.data(), cr.data(), vr.data());
@@ -799,6 +810,39 @@ lpp_status lpp_engine_sync(lpp_engine* e)
 	if (!e) return fail(LPP_ERR_INVALID, "lpp_engine_sync: null engine");
 	HIP_TRY(hipSetDevice(e->cfg.device));
 	HIP_TRY(hipStreamSynchronize(e->stream));
+	return LPP_OK;
+}
+
+lpp_status lpp_engine_get_layout(lpp_engine* e, int32_t which, lpp_layout* out)
+{
+	if (!e || !out || which < 0 || which > 1) return fail(LPP_ERR_INVALID, "lpp_engine_get_layout: bad argument");
+	if (e->kron.active) return fail(LPP_ERR_STATE, "lpp_engine_get_layout: the matrix-free engine stores no CSR");
+	const DevCsr& A = which == 0 ? e->A_loc : e->A_rem;
+	const size_t s = e->esz;
+	lpp_layout L {};
+	L.kernel = A.sliced ? (A.window ? LPP_SPMV_WINDOW : LPP_SPMV_SLICED) : LPP_SPMV_ROWGROUP;
+	L.coded = A.coded ? 1 : 0;
+	L.local16 = A.local16 ? 1 : 0;
+	L.shared_stride = A.dia_stride;
+	L.nnz = A.nnz;
+	L.per_row_entries = A.rrowptr ? A.rnnz : A.nnz;
+	L.shared_entries = A.ndia;
+	L.rows_per_block = A.sliced ? A.geom.B : 0;
+	size_t bytes = A.rowptr ? sizeof(int64_t) * (size_t)(A.nrows + 1) : 0;
+	if (A.col) bytes += sizeof(int32_t) * (size_t)A.nnz;
+	if (A.val) bytes += s * (size_t)A.nnz;
+	if (A.sliced) {
+		const size_t nz = (size_t)L.per_row_entries;
+		bytes += sizeof(int64_t) * (size_t)(A.geom.nslices + 1) + sizeof(int32_t) * (size_t)A.nrows; // slice_ptr, row_len
+		bytes += (A.local16 ? sizeof(uint16_t) : sizeof(int32_t)) * (nz + 64);
+		if (A.coded)
+			bytes += sizeof(int64_t) * (size_t)(A.geom.nslices + 1) + 256 * sizeof(double) + (size_t)(nz * s / 8); // code_ptr, dict, ~1 B per real component (before padding)
+		else
+			bytes += s * (nz + 64);
+		if (A.rrowptr) bytes += sizeof(int64_t) * (size_t)(A.nrows + 1) + (size_t)A.geom.nslices * (size_t)A.dia_stride * (sizeof(int32_t) + s);
+	}
+	L.resident_bytes = (int64_t)bytes;
+	*out = L;
 	return LPP_OK;
 }
 

@@ -88,6 +88,7 @@ struct lpp_engine {
 	hipStream_t stream = nullptr;
 	bool own_stream = false;
 	int spmv_max_blocks = 4096;
+	int64_t row_block_hint = 0; // lpp_engine_set_row_block
 	int k2_variant = 4; // bit1: XCD-contiguous map, bit2: 8 slots per batch (set in lpp_engine_create)
 	int num_cus = 256;
 

@@ -70,6 +70,10 @@ class LanczosEngine:
         self.close()
 
     # ---- the stored Hamiltonian --------------------------------------------------------------
+    def set_row_block(self, rows_per_block):
+        """Layout hint for the next set_csr: rows_per_block = N_up of the Hubbard product basis (0 = unknown)."""
+        check(self._lib.lpp_engine_set_row_block(self._h, int(rows_per_block)))
+
     def set_csr(self, rowptr, colind, values):
         rowptr = np.ascontiguousarray(rowptr, np.int64)
         colind = np.ascontiguousarray(colind, np.int32)
@@ -199,6 +203,12 @@ class LanczosEngine:
         st = Stats()
         check(self._lib.lpp_engine_get_stats(self._h, C.byref(st)))
         return st.as_dict()
+
+    def layout(self, which=0):
+        """HBM layout of the stored matrix (lpp_layout as a dict)."""
+        lay = _capi.Layout()
+        check(self._lib.lpp_engine_get_layout(self._h, which, C.byref(lay)))
+        return lay.as_dict()
 
     def bench_spmv(self, warmup=3, iters=20):
         ms = C.c_double()

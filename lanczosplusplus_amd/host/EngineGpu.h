@@ -110,22 +110,22 @@ public:
 	InternalProductStored(const ModelType& model, SpecialSymmetryType& rs) : rs_(rs), engine_(defaultConfig()), rows_(0)
 	{
 		rs_.init(model, model.basis());
-		upload();
+		upload(model.basis());
 	}
 	InternalProductStored(const ModelType& model, const BasisType& basis, SpecialSymmetryType& rs) : rs_(rs), engine_(defaultConfig()), rows_(0)
 	{
 		rs_.init(model, basis);
-		upload();
+		upload(basis);
 	}
 	InternalProductStored(const ModelType& model, SpecialSymmetryType& rs, const lpp_config& cfg) : rs_(rs), engine_(cfg), rows_(0)
 	{
 		rs_.init(model, model.basis());
-		upload();
+		upload(model.basis());
 	}
 	InternalProductStored(const ModelType& model, const BasisType& basis, SpecialSymmetryType& rs, const lpp_config& cfg) : rs_(rs), engine_(cfg), rows_(0)
 	{
 		rs_.init(model, basis);
-		upload();
+		upload(basis);
 	}
 	SizeType rows() const { return rows_; }
 	void matrixVectorProduct(VectorType& x, const VectorType& y) const
@@ -137,10 +137,13 @@ public:
 	lpp_engine* engine() const { return engine_.get(); }
 
 private:
-	void upload()
+	void upload(const BasisType& basis)
 	{
 		const SparseMatrixType& m = rs_.storedMatrix();
 		rows_ = m.rows();
+		// layout hint only: the Hubbard product basis is blocked in runs of N_up states (BasisHubbardLanczos.h:59-63)
+		const BasisHubbardLanczos* hb = dynamic_cast<const BasisHubbardLanczos*>(&basis);
+		lppCheck(lpp_engine_set_row_block(engine_.get(), hb ? (int64_t)hb->sizeUp() : 0));
 		lppCheck(lpp_engine_set_csr(engine_.get(), (int64_t)m.rows(), m.rowptr().data(), m.colind().data(), m.values().data()));
 		rs_.releaseHostMatrix(); // the device copy is the resident one
 	}

@@ -330,3 +330,70 @@ def test_matrix_free_with_reortho_and_excited_states():
     # variational upper bounds of the exact levels, already close
     lev = np.unique(np.round(dense, 8))  # a single start vector sees each degenerate level once
     assert np.all(eg[1:] >= lev[1:3] - 1e-7) and np.abs(eg[1:] - lev[1:3]).max() < 5e-2
+
+
+def _bits(a):
+    return np.ascontiguousarray(a).view(np.uint64)
+
+
+@pytest.mark.parametrize("case", ["hubbard_window", "hubbard_sliced", "hubbard_complex_window", "tj_sliced"])
+def test_shared_offset_layout_is_lossless(case):
+    """Entries shared by all rows of a slice are stored once per slice (and, in the window kernel, per-row columns as
+    16-bit block-local indices): SpMV parity and a bit-exact get_csr round trip through the compressed layout."""
+    if case.startswith("hubbard"):
+        L, nu, nd = 10, 5, 4
+        cplx = "complex" in case
+        hop = chain(L, -1.0, True).astype(complex if cplx else float)
+        if cplx:
+            hop[0, 1] = -1.0 * np.exp(0.3j)
+            hop[1, 0] = np.conj(hop[0, 1])
+        A = oracle.hubbard_csr(L, nu, nd, hop, np.linspace(1.0, 4.0, L), np.linspace(-0.3, 0.3, 2 * L))
+        block = 252  # N_up = C(10,5)
+    else:
+        L = 10
+        A = oracle.tj_csr(L, 4, 3, chain(L, -1.0), chain(L, 0.4), chain(L, 0.4), chain(L, -0.1), force_complex=True)
+        block = 0
+    kernel = 3 if case.endswith("window") else 2
+    with LanczosEngine(dtype="c128" if A.is_complex else "f64", spmv_kernel=kernel) as e:
+        e.set_row_block(block)
+        e.set_csr(A.rowptr, A.colind, A.values)
+        lay = e.layout()
+        assert lay["nnz"] == A.rowptr[-1]
+        assert lay["kernel"] == kernel
+        if case.startswith("hubbard"):
+            # every down-hop is shared; with the window kernel the per-row rest is block-local
+            assert lay["shared_entries"] > 0 and lay["per_row_entries"] < 0.7 * lay["nnz"]
+            assert lay["local16"] == (1 if kernel == 3 else 0)
+            if kernel == 3:
+                assert lay["rows_per_block"] == block
+        x0 = oracle.fill_random(A.nrows, 7, A.is_complex)
+        y = oracle.fill_random(A.nrows, 8, A.is_complex)
+        assert rel(e.matrixVectorProduct(x0.copy(), y), oracle.spmv_acc(A, x0.copy(), y)) < SPMV_TOL
+        rp, ci, va = e.get_csr()
+        assert np.array_equal(rp, A.rowptr) and np.array_equal(ci, A.colind)
+        assert np.array_equal(_bits(va), _bits(A.values))
+        eg = e.computeAllStatesBelow(1, want_vectors=False)[0][0]
+    eo = oracle.lanczos_solve(A, oracle.fill_random(A.nrows, 1234, A.is_complex), 1, want_vectors=False)[0][0]
+    assert abs(eg - eo) <= E_TOL * abs(eo)
+
+
+def test_unsorted_rows_keep_their_order():
+    """The shared-offset split needs sorted rows; an unsorted CSR must still multiply correctly and come back from
+    get_csr in exactly the order it was given."""
+    A = oracle.hubbard_csr(8, 4, 4, chain(8, -1.0), np.full(8, 4.0))
+    rng = np.random.default_rng(5)
+    ci = A.colind.copy()
+    va = A.values.copy()
+    for r in range(A.nrows):
+        p0, p1 = A.rowptr[r], A.rowptr[r + 1]
+        perm = rng.permutation(p1 - p0)
+        ci[p0:p1] = ci[p0:p1][perm]
+        va[p0:p1] = va[p0:p1][perm]
+    with LanczosEngine(spmv_kernel=2) as e:
+        e.set_csr(A.rowptr, ci, va)
+        assert e.layout()["shared_entries"] == 0
+        x0 = oracle.fill_random(A.nrows, 7)
+        y = oracle.fill_random(A.nrows, 8)
+        assert rel(e.matrixVectorProduct(x0.copy(), y), oracle.spmv_acc(A, x0.copy(), y)) < SPMV_TOL
+        rp, c2, v2 = e.get_csr()
+        assert np.array_equal(c2, ci) and np.array_equal(_bits(v2), _bits(va))
