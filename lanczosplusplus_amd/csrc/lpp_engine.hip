@@ -26,14 +26,6 @@ namespace lpp {
 // ---------------------------------------------------------------------------------------------
 // small helpers
 // ---------------------------------------------------------------------------------------------
-static int blas_blocks(int64_t n2)
-{
-	int64_t b = (n2 + kBlock - 1) / kBlock;
-	if (b < 1) b = 1;
-	// 256 CUs x 8 blocks of 256 threads: enough waves to cover HBM latency, few enough partials
-	return (int)std::min<int64_t>(b, 2048);
-}
-
 void free_csr(DevCsr& A)
 {
 	if (A.owned) {

@@ -397,3 +397,31 @@ def test_unsorted_rows_keep_their_order():
         assert rel(e.matrixVectorProduct(x0.copy(), y), oracle.spmv_acc(A, x0.copy(), y)) < SPMV_TOL
         rp, c2, v2 = e.get_csr()
         assert np.array_equal(c2, ci) and np.array_equal(_bits(v2), _bits(va))
+
+
+@pytest.mark.parametrize("cplx", [False, True])
+def test_shared_offsets_beyond_the_per_slice_capacity(cplx):
+    """A Toeplitz band with 81 diagonals: every entry is shared by all rows of a slice, but a slice holds at most 64
+    shared entries; the rest must stay per-row entries.  Rows near the edges are shorter (ragged slices), the last
+    slice is partial."""
+    n, hb = 1000, 40
+    rng = np.random.default_rng(11)
+    dv = rng.standard_normal(2 * hb + 1) + (1j * rng.standard_normal(2 * hb + 1) if cplx else 0)
+    rowptr, ci, va = [0], [], []
+    for r in range(n):
+        for d in range(-hb, hb + 1):
+            c = r + d
+            if 0 <= c < n:
+                ci.append(c)
+                va.append(dv[d + hb])
+        rowptr.append(len(ci))
+    A = oracle.Csr(np.array(rowptr, np.int64), np.array(ci, np.int32), np.array(va, complex if cplx else float))
+    with LanczosEngine(dtype="c128" if cplx else "f64", spmv_kernel=2) as e:
+        e.set_csr(A.rowptr, A.colind, A.values)
+        lay = e.layout()
+        assert lay["shared_stride"] == 64 and 0 < lay["per_row_entries"] < lay["nnz"]
+        x0 = oracle.fill_random(n, 7, cplx)
+        y = oracle.fill_random(n, 8, cplx)
+        assert rel(e.matrixVectorProduct(x0.copy(), y), oracle.spmv_acc(A, x0.copy(), y)) < SPMV_TOL
+        rp, c2, v2 = e.get_csr()
+        assert np.array_equal(rp, A.rowptr) and np.array_equal(c2, A.colind) and np.array_equal(_bits(v2), _bits(A.values))
