@@ -754,6 +754,7 @@ template <typename T> static int kron_launch_t(lpp_engine* e, const void* ywin, 
 	a.up.dia_stride = 0;
 	a.up.dia_off = nullptr;
 	a.up.dia_val = nullptr;
+	a.up.tmpl = 0;
 	a.n_up = K.n_up;
 	a.id0 = K.id0;
 	a.nid = K.nid;

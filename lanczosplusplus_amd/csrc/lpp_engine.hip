@@ -99,6 +99,7 @@ template <typename T> static int spmv_launch_t(lpp_engine* e, const DevCsr& A, c
 		a.dia_stride = A.dia_stride;
 		a.dia_off = A.dia_off;
 		a.dia_val = (const T*)A.dia_val;
+		a.tmpl = A.tmpl ? 1 : 0;
 		const bool dot = partial != nullptr;
 		const bool u8 = (e->k2_variant & 4) != 0;
 		const int sel = (dot ? 4 : 0) | (A.coded ? 2 : 0) | (u8 ? 1 : 0);
@@ -368,6 +369,7 @@ template <typename T> static lpp_status build_sliced_t(lpp_engine* e, DevCsr& A,
 		int64_t nwords = 0;
 		lpp_status st = scan_exclusive(e, A.code_ptr, g.nslices + 1, &nwords);
 		if (st != LPP_OK) return st;
+		A.code_words = nwords;
 		HIP_TRY_MEM(hipMalloc(&A.codes, sizeof(uint32_t) * (size_t)(nwords + 64 * 16)));
 		HIP_TRY(hipMemsetAsync(A.codes + nwords, 0, sizeof(uint32_t) * 64 * 16, e->stream));
 		if (l16)
@@ -387,6 +389,42 @@ template <typename T> static lpp_status build_sliced_t(lpp_engine* e, DevCsr& A,
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipStreamSynchronize(e->stream));
 	A.sliced = true;
+	// Block-periodic structure: when every row block repeats block 0's row lengths and local columns (the in-block
+	// part of a product basis is the same one-species matrix in every block) only block 0's copy is kept; it stays
+	// in L2 instead of streaming 2 bytes per entry + 4 per row from HBM.  Values (codes) remain per block.
+	if (l16 && coded && g.nblocks >= 2 && g.nrows == g.nblocks * g.B && !(getenv("LPP_BLOCK_TEMPLATE") && atoi(getenv("LPP_BLOCK_TEMPLATE")) == 0)) {
+		int* differs = nullptr;
+		HIP_TRY_MEM(hipMalloc(&differs, sizeof(int)));
+		(void)hipMemsetAsync(differs, 0, sizeof(int), e->stream);
+		k_tmpl_check<<<nb2, kBlock, 0, e->stream>>>(g, A.slice_ptr, A.row_len, (const uint16_t*)A.scol, differs);
+		int bad = 1;
+		hipError_t e1 = hipMemcpyAsync(&bad, differs, sizeof(int), hipMemcpyDeviceToHost, e->stream);
+		hipError_t e2 = hipStreamSynchronize(e->stream);
+		(void)hipFree(differs);
+		if (e1 != hipSuccess || e2 != hipSuccess) return fail(LPP_ERR_HIP, "block-template check failed");
+		if (!bad) {
+			int64_t n0 = 0; // entries of block 0
+			HIP_TRY(hipMemcpy(&n0, A.slice_ptr + g.spb, sizeof(int64_t), hipMemcpyDeviceToHost));
+			int64_t* sp = nullptr;
+			int32_t* rl = nullptr;
+			int32_t* sc = nullptr;
+			HIP_TRY_MEM(hipMalloc(&sp, sizeof(int64_t) * (size_t)(g.spb + 1)));
+			HIP_TRY_MEM(hipMalloc(&rl, sizeof(int32_t) * (size_t)g.B));
+			HIP_TRY_MEM(hipMalloc(&sc, sizeof(uint16_t) * (size_t)(n0 + 64)));
+			HIP_TRY(hipMemcpyAsync(sp, A.slice_ptr, sizeof(int64_t) * (size_t)(g.spb + 1), hipMemcpyDeviceToDevice, e->stream));
+			HIP_TRY(hipMemcpyAsync(rl, A.row_len, sizeof(int32_t) * (size_t)g.B, hipMemcpyDeviceToDevice, e->stream));
+			HIP_TRY(hipMemcpyAsync(sc, A.scol, sizeof(uint16_t) * (size_t)n0, hipMemcpyDeviceToDevice, e->stream));
+			HIP_TRY(hipMemsetAsync((char*)sc + sizeof(uint16_t) * (size_t)n0, 0, sizeof(uint16_t) * 64, e->stream));
+			HIP_TRY(hipStreamSynchronize(e->stream));
+			(void)hipFree(A.slice_ptr);
+			(void)hipFree(A.row_len);
+			(void)hipFree(A.scol);
+			A.slice_ptr = sp;
+			A.row_len = rl;
+			A.scol = sc;
+			A.tmpl = true;
+		}
+	}
 	return LPP_OK;
 }
 
@@ -691,13 +729,13 @@ lpp_status lpp_engine_get_csr(lpp_engine* e, int32_t which, int64_t* nrows, int6
 			const int nb2 = (int)std::max<int64_t>(1, std::min<int64_t>((A.geom.nslices + 3) / 4, 8192));
 			if (e->is_complex) {
 				if (A.local16)
-					k_slice_fill<cplx, true, true><<<nb2, kBlock, 0, e->stream>>>(A.geom, rp, A.scol, (const cplx*)A.sval, tcol, A.coded ? nullptr : (cplx*)tval);
+					k_slice_fill<cplx, true, true><<<nb2, kBlock, 0, e->stream>>>(A.geom, rp, A.scol, (const cplx*)A.sval, tcol, A.coded ? nullptr : (cplx*)tval, A.tmpl ? 1 : 0);
 				else
 					k_slice_fill<cplx, true><<<nb2, kBlock, 0, e->stream>>>(A.geom, rp, A.scol, (const cplx*)A.sval, tcol, A.coded ? nullptr : (cplx*)tval);
 				if (A.coded) k_slice_decode<cplx><<<nb2, kBlock, 0, e->stream>>>(A.geom, rp, A.codes, A.code_ptr, A.dict, (cplx*)tval);
 			} else {
 				if (A.local16)
-					k_slice_fill<double, true, true><<<nb2, kBlock, 0, e->stream>>>(A.geom, rp, A.scol, (const double*)A.sval, tcol, A.coded ? nullptr : (double*)tval);
+					k_slice_fill<double, true, true><<<nb2, kBlock, 0, e->stream>>>(A.geom, rp, A.scol, (const double*)A.sval, tcol, A.coded ? nullptr : (double*)tval, A.tmpl ? 1 : 0);
 				else
 					k_slice_fill<double, true><<<nb2, kBlock, 0, e->stream>>>(A.geom, rp, A.scol, (const double*)A.sval, tcol, A.coded ? nullptr : (double*)tval);
 				if (A.coded) k_slice_decode<double><<<nb2, kBlock, 0, e->stream>>>(A.geom, rp, A.codes, A.code_ptr, A.dict, (double*)tval);
@@ -815,6 +853,7 @@ lpp_status lpp_engine_get_layout(lpp_engine* e, int32_t which, lpp_layout* out)
 	L.kernel = A.sliced ? (A.window ? LPP_SPMV_WINDOW : LPP_SPMV_SLICED) : LPP_SPMV_ROWGROUP;
 	L.coded = A.coded ? 1 : 0;
 	L.local16 = A.local16 ? 1 : 0;
+	L.block_template = A.tmpl ? 1 : 0;
 	L.shared_stride = A.dia_stride;
 	L.nnz = A.nnz;
 	L.per_row_entries = A.rrowptr ? A.rnnz : A.nnz;
@@ -825,10 +864,13 @@ lpp_status lpp_engine_get_layout(lpp_engine* e, int32_t which, lpp_layout* out)
 	if (A.val) bytes += s * (size_t)A.nnz;
 	if (A.sliced) {
 		const size_t nz = (size_t)L.per_row_entries;
-		bytes += sizeof(int64_t) * (size_t)(A.geom.nslices + 1) + sizeof(int32_t) * (size_t)A.nrows; // slice_ptr, row_len
-		bytes += (A.local16 ? sizeof(uint16_t) : sizeof(int32_t)) * (nz + 64);
+		const size_t struct_slices = A.tmpl ? (size_t)A.geom.spb : (size_t)A.geom.nslices; // block-periodic: block 0 only
+		const size_t struct_rows = A.tmpl ? (size_t)A.geom.B : (size_t)A.nrows;
+		const size_t struct_nz = A.tmpl ? nz / (size_t)A.geom.nblocks : nz;
+		bytes += sizeof(int64_t) * (struct_slices + 1) + sizeof(int32_t) * struct_rows; // slice_ptr, row_len
+		bytes += (A.local16 ? sizeof(uint16_t) : sizeof(int32_t)) * (struct_nz + 64);
 		if (A.coded)
-			bytes += sizeof(int64_t) * (size_t)(A.geom.nslices + 1) + 256 * sizeof(double) + (size_t)(nz * s / 8); // code_ptr, dict, ~1 B per real component (before padding)
+			bytes += sizeof(int64_t) * (size_t)(A.geom.nslices + 1) + 256 * sizeof(double) + sizeof(uint32_t) * (size_t)A.code_words;
 		else
 			bytes += s * (nz + 64);
 		if (A.rrowptr) bytes += sizeof(int64_t) * (size_t)(A.nrows + 1) + (size_t)A.geom.nslices * (size_t)A.dia_stride * (sizeof(int32_t) + s);

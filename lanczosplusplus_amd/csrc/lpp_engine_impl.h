@@ -36,6 +36,8 @@ struct DevCsr {
 	int G = 16; // lanes per row of the row-group kernel
 	bool sliced = false;
 	bool window = false; // LDS-window kernel (K3)
+	bool tmpl = false; // block-periodic structure: slice_ptr / row_len / scol describe block 0 only (see k_tmpl_check)
+	int64_t code_words = 0; // 32-bit words in `codes`
 	bool local16 = false; // scol holds 16-bit window-local columns (window kernel, every per-row entry inside its block)
 	int64_t hint_block = 0; // natural row block of the basis (N_up), 0 = unknown
 	int64_t src_elems = 0; // length of the vector the columns index (0 = nrows)

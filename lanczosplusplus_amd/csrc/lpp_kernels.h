@@ -249,6 +249,9 @@ template <typename T> struct SlicedArgs {
 	int dia_stride;
 	const int32_t* dia_off; // column - row, the same for every row of the slice
 	const T* dia_val;
+	// 1: block-periodic structure -- every row block has the row lengths and block-local columns of block 0, so
+	// slice_ptr / row_len / col describe ONE block (values/codes stay per block); see k_tmpl_check
+	int tmpl;
 };
 
 constexpr int32_t kDiaNone = INT32_MIN;
@@ -495,9 +498,11 @@ __device__ __forceinline__ void slice_meta(const SlicedArgs<T>& a, int64_t s, in
 	const int lane = threadIdx.x & 63;
 	slice_rows(a.g, s, row0, nvalid);
 	const int64_t r = (lane < nvalid) ? row0 + lane : min(row0, a.g.nrows - 1);
-	const int l = a.row_len[r];
+	// block-periodic structure: lengths and column stream of the same slice of block 0 (L2-resident)
+	const int64_t blk = a.tmpl ? s / a.g.spb : 0;
+	const int l = a.row_len[r - blk * a.g.B];
 	len = (lane < nvalid) ? l : 0;
-	base = a.slice_ptr[s];
+	base = a.slice_ptr[s - blk * a.g.spb];
 	cbase = CODED ? a.code_ptr[s] : 0;
 }
 
@@ -674,11 +679,12 @@ static __global__ void k_slice_meta(SliceGeom g, const int64_t* __restrict__ row
 
 // one wave per slice: scatter CSR entries into slot-major compact order (INVERSE: back to CSR order)
 // L16: the sliced side holds 16-bit window-local columns (column - first row of the row block)
+// tmpl (INVERSE only): the sliced column stream holds block 0 only (block-periodic structure)
 template <typename T, bool INVERSE, bool L16 = false>
 __global__ __launch_bounds__(kBlock) void k_slice_fill(SliceGeom g, const int64_t* __restrict__ rowptr,
                                                         const int32_t* __restrict__ col_in,
                                                         const T* __restrict__ val_in, int32_t* __restrict__ col_out,
-                                                        T* __restrict__ val_out)
+                                                        T* __restrict__ val_out, int tmpl = 0)
 {
 	const int lane = threadIdx.x & 63;
 	const int64_t wave0 = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
@@ -694,6 +700,9 @@ __global__ __launch_bounds__(kBlock) void k_slice_fill(SliceGeom g, const int64_
 			len = (int)(rowptr[row0 + lane + 1] - p0);
 		}
 		int64_t base = rowptr[nvalid > 0 ? row0 : g.nrows];
+		// position of this slice's columns in the sliced stream (block 0's copy when the structure is block-periodic)
+		int64_t cshift = 0;
+		if (INVERSE && tmpl && nvalid > 0) cshift = rowptr[row0 - (s / g.spb) * g.B] - base;
 		int maxlen = len;
 #pragma unroll
 		for (int off = 32; off > 0; off >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, off, 64));
@@ -704,7 +713,7 @@ __global__ __launch_bounds__(kBlock) void k_slice_fill(SliceGeom g, const int64_
 			if (on) {
 				const int32_t r0 = L16 ? (int32_t)((s / g.spb) * g.B) : 0;
 				if (INVERSE) {
-					col_out[p0 + k] = L16 ? (int32_t)((const uint16_t*)col_in)[base + pos] + r0 : col_in[base + pos];
+					col_out[p0 + k] = L16 ? (int32_t)((const uint16_t*)col_in)[base + cshift + pos] + r0 : col_in[base + cshift + pos];
 					if (val_out) val_out[p0 + k] = val_in[base + pos];
 				} else {
 					if (L16)
@@ -850,6 +859,30 @@ __global__ void k_dia_merge(SliceGeom g, const int64_t* __restrict__ rowptr, con
 		}
 		o++;
 	}
+}
+
+// Block-periodic structure (16-bit block-local columns only): *differs = 1 unless every row block has the row lengths
+// and the local column stream of block 0.  One wave per slice of blocks 1..nblocks-1.
+static __global__ __launch_bounds__(kBlock) void k_tmpl_check(SliceGeom g, const int64_t* __restrict__ slice_ptr,
+                                                               const int32_t* __restrict__ row_len, const uint16_t* __restrict__ col16,
+                                                               int* differs)
+{
+	const int lane = threadIdx.x & 63;
+	const int64_t wave0 = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+	const int64_t nwaves = (int64_t)gridDim.x * (kBlock / 64);
+	bool bad = false;
+	for (int64_t s = g.spb + wave0; s < g.nslices; s += nwaves) {
+		const int64_t blk = s / g.spb, j = s - blk * g.spb;
+		const int64_t b0 = slice_ptr[j], n0 = slice_ptr[j + 1] - b0, b1 = slice_ptr[s], n1 = slice_ptr[s + 1] - b1;
+		if (n0 != n1) {
+			bad = true;
+			continue;
+		}
+		const int64_t r = j * 64 + lane;
+		if (r < g.B) bad |= row_len[blk * g.B + r] != row_len[r];
+		for (int64_t i = lane; i < n0; i += 64) bad |= col16[b1 + i] != col16[b0 + i];
+	}
+	if (bad) *differs = 1;
 }
 
 // *outside = 1 when some entry's column lies outside its row block [blk*B, (blk+1)*B)

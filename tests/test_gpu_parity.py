@@ -336,7 +336,7 @@ def _bits(a):
     return np.ascontiguousarray(a).view(np.uint64)
 
 
-@pytest.mark.parametrize("case", ["hubbard_window", "hubbard_sliced", "hubbard_complex_window", "tj_sliced"])
+@pytest.mark.parametrize("case", ["hubbard_window", "hubbard_uniform_window", "hubbard_sliced", "hubbard_complex_window", "tj_sliced"])
 def test_shared_offset_layout_is_lossless(case):
     """Entries shared by all rows of a slice are stored once per slice (and, in the window kernel, per-row columns as
     16-bit block-local indices): SpMV parity and a bit-exact get_csr round trip through the compressed layout."""
@@ -347,7 +347,10 @@ def test_shared_offset_layout_is_lossless(case):
         if cplx:
             hop[0, 1] = -1.0 * np.exp(0.3j)
             hop[1, 0] = np.conj(hop[0, 1])
-        A = oracle.hubbard_csr(L, nu, nd, hop, np.linspace(1.0, 4.0, L), np.linspace(-0.3, 0.3, 2 * L))
+        if "uniform" in case:  # few distinct values: dictionary codes, and with them the block-periodic column template
+            A = oracle.hubbard_csr(L, nu, nd, hop, np.full(L, 4.0))
+        else:
+            A = oracle.hubbard_csr(L, nu, nd, hop, np.linspace(1.0, 4.0, L), np.linspace(-0.3, 0.3, 2 * L))
         block = 252  # N_up = C(10,5)
     else:
         L = 10
@@ -366,6 +369,10 @@ def test_shared_offset_layout_is_lossless(case):
             assert lay["local16"] == (1 if kernel == 3 else 0)
             if kernel == 3:
                 assert lay["rows_per_block"] == block
+                # every block of the product basis repeats block 0's in-block structure (it is H_up); the template
+                # needs the value codes (site-dependent U and V give more than 256 distinct diagonal values)
+                assert lay["block_template"] == lay["coded"]
+                assert lay["coded"] == (1 if "uniform" in case else 0)
         x0 = oracle.fill_random(A.nrows, 7, A.is_complex)
         y = oracle.fill_random(A.nrows, 8, A.is_complex)
         assert rel(e.matrixVectorProduct(x0.copy(), y), oracle.spmv_acc(A, x0.copy(), y)) < SPMV_TOL
