@@ -294,7 +294,7 @@ def main():
         if args.engine == "stored":
             lay = eng.layout(0)
             layout = {"kernel": {1: "rowgroup", 2: "sliced", 3: "window"}.get(lay["kernel"]), "value_codes": bool(lay["coded"]),
-                      "local16_columns": bool(lay["local16"]), "block_template": bool(lay["block_template"]), "per_row_entries": lay["per_row_entries"],
+                      "local16_columns": bool(lay["local16"]), "block_template": lay["block_template"], "diagonal_codes": bool(lay["diagonal_codes"]), "per_row_entries": lay["per_row_entries"],
                       "shared_offset_entries": lay["shared_entries"], "resident_GB": round(lay["resident_bytes"] / 1e9, 2)}
         out = {
             "metric": METRIC,

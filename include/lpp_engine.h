@@ -86,8 +86,8 @@ typedef struct lpp_layout {
 	int32_t coded; /* 1: values stored as 8-bit dictionary codes */
 	int32_t local16; /* 1: per-row columns stored as 16-bit block-local indices */
 	int32_t shared_stride; /* places per 64-row slice for shared-offset entries (0: none) */
-	int32_t block_template; /* 1: row lengths and local columns stored once for all row blocks (block-periodic structure) */
-	int32_t reserved;
+	int32_t block_template; /* block-periodic structure: 1 = row lengths and local columns stored once for all row blocks, 2 = value codes too */
+	int32_t diagonal_codes; /* 1: the diagonal travels as one dictionary code per row, apart from the per-row entries */
 	int64_t nnz; /* entries of the CSR this layout represents */
 	int64_t per_row_entries; /* entries kept per row */
 	int64_t shared_entries; /* entries stored once per slice, summed over slices */

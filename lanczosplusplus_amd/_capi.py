@@ -44,7 +44,7 @@ class Stats(C.Structure):
 
 class Layout(C.Structure):
     _fields_ = [("kernel", C.c_int32), ("coded", C.c_int32), ("local16", C.c_int32), ("shared_stride", C.c_int32),
-                ("block_template", C.c_int32), ("reserved", C.c_int32),
+                ("block_template", C.c_int32), ("diagonal_codes", C.c_int32),
                 ("nnz", C.c_int64), ("per_row_entries", C.c_int64), ("shared_entries", C.c_int64),
                 ("rows_per_block", C.c_int64), ("resident_bytes", C.c_int64)]
 

@@ -43,6 +43,7 @@ void free_csr(DevCsr& A)
 	if (A.rrowptr) (void)hipFree(A.rrowptr);
 	if (A.dia_off) (void)hipFree(A.dia_off);
 	if (A.dia_val) (void)hipFree(A.dia_val);
+	if (A.dcode) (void)hipFree(A.dcode);
 	A = DevCsr();
 }
 
@@ -99,7 +100,8 @@ template <typename T> static int spmv_launch_t(lpp_engine* e, const DevCsr& A, c
 		a.dia_stride = A.dia_stride;
 		a.dia_off = A.dia_off;
 		a.dia_val = (const T*)A.dia_val;
-		a.tmpl = A.tmpl ? 1 : 0;
+		a.tmpl = A.tmpl;
+		a.dcode = A.dcode;
 		const bool dot = partial != nullptr;
 		const bool u8 = (e->k2_variant & 4) != 0;
 		const int sel = (dot ? 4 : 0) | (A.coded ? 2 : 0) | (u8 ? 1 : 0);
@@ -230,9 +232,10 @@ static lpp_status scan_exclusive(lpp_engine* e, int64_t* arr, int64_t n, int64_t
 
 static void drop_dia(DevCsr& A)
 {
-	for (void* p : { (void*)A.rrowptr, (void*)A.dia_off, A.dia_val })
+	for (void* p : { (void*)A.rrowptr, (void*)A.dia_off, A.dia_val, (void*)A.dcode })
 		if (p) (void)hipFree(p);
 	A.rrowptr = nullptr;
+	A.dcode = nullptr;
 	A.dia_off = nullptr;
 	A.dia_val = nullptr;
 	A.rnnz = A.ndia = 0;
@@ -242,19 +245,20 @@ static void drop_dia(DevCsr& A)
 // Split the shared-offset entries off the plain CSR of A (see k_dia_split).  On success with A.rrowptr != nullptr the
 // rest CSR is (A.rrowptr, *rcol, *rval) -- the caller frees rcol / rval -- and A.dia_* hold the shared lists.
 // Leaves A untouched (rrowptr == nullptr) when rows are unsorted or fewer than 10 % of the entries are shared.
-template <typename T> static lpp_status split_dia_t(lpp_engine* e, DevCsr& A, const SliceGeom& g, bool for_window, int32_t** rcol, T** rval)
+// xdiag: also split the diagonal off (needs the value dictionary: its codes go to A.dcode, one per real component and row)
+template <typename T> static lpp_status split_dia_t(lpp_engine* e, DevCsr& A, const SliceGeom& g, bool for_window, bool xdiag, int32_t** rcol, T** rval)
 {
 	*rcol = nullptr;
 	*rval = nullptr;
-	unsigned long long* flags = nullptr; // [0] unsorted, [1] max shared per slice, [2] total shared
-	HIP_TRY_MEM(hipMalloc(&flags, sizeof(unsigned long long) * 3));
+	unsigned long long* flags = nullptr; // [0] unsorted, [1] max shared per slice, [2] total shared, [3] rows without a diagonal
+	HIP_TRY_MEM(hipMalloc(&flags, sizeof(unsigned long long) * 4));
 	struct Free {
 		void* p;
 		~Free() { (void)hipFree(p); }
 	} free_flags { flags };
-	HIP_TRY(hipMemsetAsync(flags, 0, sizeof(unsigned long long) * 3, e->stream));
+	HIP_TRY(hipMemsetAsync(flags, 0, sizeof(unsigned long long) * 4, e->stream));
 	k_rows_sorted<<<(int)((A.nrows + 255) / 256), 256, 0, e->stream>>>(A.nrows, A.rowptr, A.col, (int*)flags);
-	unsigned long long h[3] = { 0, 0, 0 };
+	unsigned long long h[4] = { 0, 0, 0, 0 };
 	HIP_TRY(hipMemcpyAsync(h, flags, sizeof(unsigned long long), hipMemcpyDeviceToHost, e->stream));
 	HIP_TRY(hipStreamSynchronize(e->stream));
 	if (h[0] != 0) return LPP_OK;
@@ -262,23 +266,35 @@ template <typename T> static lpp_status split_dia_t(lpp_engine* e, DevCsr& A, co
 	HIP_TRY(hipMemsetAsync(A.rrowptr, 0, sizeof(int64_t) * (size_t)(A.nrows + 1), e->stream));
 	const int nbw = (int)std::max<int64_t>(1, std::min<int64_t>((g.nslices + 3) / 4, 16384));
 	const int win = for_window ? 1 : 0;
-	k_dia_split<T, false><<<nbw, kBlock, 0, e->stream>>>(g, A.rowptr, A.col, (const T*)A.val, win, 0, A.rrowptr, flags + 1, nullptr, nullptr,
-	                                                    nullptr, nullptr, nullptr);
-	HIP_TRY(hipGetLastError());
+	int xd = xdiag ? 1 : 0;
+	for (;;) {
+		k_dia_split<T, false><<<nbw, kBlock, 0, e->stream>>>(g, A.rowptr, A.col, (const T*)A.val, win, 0, A.rrowptr, flags + 1, nullptr, nullptr,
+		                                                    nullptr, nullptr, nullptr, xd, nullptr, 0, nullptr);
+		HIP_TRY(hipGetLastError());
+		HIP_TRY(hipMemcpyAsync(h, flags, sizeof(unsigned long long) * 4, hipMemcpyDeviceToHost, e->stream));
+		HIP_TRY(hipStreamSynchronize(e->stream));
+		if (!xd || h[3] == 0) break;
+		// some row has no diagonal entry: count again with the diagonal left where it is
+		xd = 0;
+		HIP_TRY(hipMemsetAsync(A.rrowptr, 0, sizeof(int64_t) * (size_t)(A.nrows + 1), e->stream));
+		HIP_TRY(hipMemsetAsync(flags + 1, 0, sizeof(unsigned long long) * 3, e->stream));
+	}
 	lpp_status st = scan_exclusive(e, A.rrowptr, A.nrows + 1, &A.rnnz);
 	if (st != LPP_OK) return st;
-	HIP_TRY(hipMemcpyAsync(h, flags, sizeof(unsigned long long) * 3, hipMemcpyDeviceToHost, e->stream));
-	HIP_TRY(hipStreamSynchronize(e->stream));
 	A.ndia = (int64_t)h[2];
 	A.dia_stride = (int)((h[1] + 3) & ~3ull);
 	if (getenv("LPP_VERBOSE"))
-		fprintf(stderr, "lpp: shared-offset split: nnz %lld -> per-row %lld + %lld per-slice entries (%lld slices, <= %d per slice)\n",
-		        (long long)A.nnz, (long long)A.rnnz, (long long)A.ndia, (long long)g.nslices, (int)h[1]);
-	if ((double)(A.nnz - A.rnnz) < 0.10 * (double)A.nnz || A.dia_stride == 0) {
+		fprintf(stderr, "lpp: shared-offset split: nnz %lld -> per-row %lld + %lld per-slice entries (%lld slices, <= %d per slice)%s\n",
+		        (long long)A.nnz, (long long)A.rnnz, (long long)A.ndia, (long long)g.nslices, (int)h[1], xd ? " + diagonal codes" : "");
+	if ((double)(A.nnz - A.rnnz) < 0.10 * (double)A.nnz || (A.dia_stride == 0 && !xd)) {
 		drop_dia(A);
 		return LPP_OK;
 	}
-	const size_t places = (size_t)g.nslices * (size_t)A.dia_stride;
+	if (xd) {
+		HIP_TRY_MEM(hipMalloc(&A.dcode, (size_t)A.nrows * (sizeof(T) / sizeof(double))));
+		HIP_TRY(hipMemsetAsync(A.dcode, 0, (size_t)A.nrows * (sizeof(T) / sizeof(double)), e->stream));
+	}
+	const size_t places = std::max<size_t>((size_t)g.nslices * (size_t)A.dia_stride, 1);
 	HIP_TRY_MEM(hipMalloc(rcol, sizeof(int32_t) * (size_t)std::max<int64_t>(A.rnnz, 1)));
 	HIP_TRY_MEM(hipMalloc(rval, sizeof(T) * (size_t)std::max<int64_t>(A.rnnz, 1)));
 	HIP_TRY_MEM(hipMalloc(&A.dia_off, sizeof(int32_t) * places));
@@ -286,7 +302,7 @@ template <typename T> static lpp_status split_dia_t(lpp_engine* e, DevCsr& A, co
 	HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)A.dia_off, (int)kDiaNone, places, e->stream));
 	HIP_TRY(hipMemsetAsync(A.dia_val, 0, sizeof(T) * places, e->stream));
 	k_dia_split<T, true><<<nbw, kBlock, 0, e->stream>>>(g, A.rowptr, A.col, (const T*)A.val, win, A.dia_stride, nullptr, nullptr, A.rrowptr,
-	                                                   *rcol, *rval, A.dia_off, (T*)A.dia_val);
+	                                                   *rcol, *rval, A.dia_off, (T*)A.dia_val, xd, A.dict, A.ndict, A.dcode);
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipStreamSynchronize(e->stream));
 	return LPP_OK;
@@ -318,10 +334,19 @@ template <typename T> static lpp_status build_sliced_t(lpp_engine* e, DevCsr& A,
 			if (v) (void)hipFree(v);
 		}
 	} scratch { rcol, rval };
+	// the value dictionary is built from the whole matrix first: the diagonal codes below need it
+	int want = e->cfg.compress_values;
+	if (const char* s = getenv("LPP_COMPRESS_VALUES")) want = atoi(s);
+	bool coded = false;
+	if (want != 0) {
+		lpp_status st = try_build_dict<T>(e, A, vv, nz, &coded);
+		if (st != LPP_OK) return st;
+	}
 	int want_dia = A.no_dia ? 0 : 1;
 	if (const char* s = getenv("LPP_SHARED_OFFSETS")) want_dia = A.no_dia ? 0 : atoi(s);
+	const bool xdiag = for_window && coded && !(getenv("LPP_DIAG_CODES") && atoi(getenv("LPP_DIAG_CODES")) == 0);
 	if (want_dia && A.nnz > 0) {
-		lpp_status st = split_dia_t<T>(e, A, g, for_window, &rcol, &rval);
+		lpp_status st = split_dia_t<T>(e, A, g, for_window, xdiag, &rcol, &rval);
 		if (st != LPP_OK) return st;
 		if (A.rrowptr) {
 			rp = A.rrowptr;
@@ -329,13 +354,6 @@ template <typename T> static lpp_status build_sliced_t(lpp_engine* e, DevCsr& A,
 			vv = rval;
 			nz = A.rnnz;
 		}
-	}
-	int want = e->cfg.compress_values;
-	if (const char* s = getenv("LPP_COMPRESS_VALUES")) want = atoi(s);
-	bool coded = false;
-	if (want != 0) {
-		lpp_status st = try_build_dict<T>(e, A, vv, nz, &coded);
-		if (st != LPP_OK) return st;
 	}
 	// window kernel: 16-bit window-local columns when every per-row entry stays inside its row block
 	bool l16 = false;
@@ -394,14 +412,33 @@ template <typename T> static lpp_status build_sliced_t(lpp_engine* e, DevCsr& A,
 	// in L2 instead of streaming 2 bytes per entry + 4 per row from HBM.  Values (codes) remain per block.
 	if (l16 && coded && g.nblocks >= 2 && g.nrows == g.nblocks * g.B && !(getenv("LPP_BLOCK_TEMPLATE") && atoi(getenv("LPP_BLOCK_TEMPLATE")) == 0)) {
 		int* differs = nullptr;
-		HIP_TRY_MEM(hipMalloc(&differs, sizeof(int)));
-		(void)hipMemsetAsync(differs, 0, sizeof(int), e->stream);
-		k_tmpl_check<<<nb2, kBlock, 0, e->stream>>>(g, A.slice_ptr, A.row_len, (const uint16_t*)A.scol, differs);
-		int bad = 1;
-		hipError_t e1 = hipMemcpyAsync(&bad, differs, sizeof(int), hipMemcpyDeviceToHost, e->stream);
+		HIP_TRY_MEM(hipMalloc(&differs, sizeof(int) * 2));
+		(void)hipMemsetAsync(differs, 0, sizeof(int) * 2, e->stream);
+		k_tmpl_check<<<nb2, kBlock, 0, e->stream>>>(g, A.slice_ptr, A.row_len, (const uint16_t*)A.scol, A.code_ptr, A.codes, differs);
+		int hd[2] = { 1, 1 };
+		hipError_t e1 = hipMemcpyAsync(hd, differs, sizeof(int) * 2, hipMemcpyDeviceToHost, e->stream);
 		hipError_t e2 = hipStreamSynchronize(e->stream);
 		(void)hipFree(differs);
 		if (e1 != hipSuccess || e2 != hipSuccess) return fail(LPP_ERR_HIP, "block-template check failed");
+		const int bad = hd[0];
+		if (!bad && !hd[1]) {
+			// the value codes repeat as well (the diagonal travels apart): keep block 0's code words only
+			int64_t w0 = 0;
+			HIP_TRY(hipMemcpy(&w0, A.code_ptr + g.spb, sizeof(int64_t), hipMemcpyDeviceToHost));
+			int64_t* cp = nullptr;
+			uint32_t* cw = nullptr;
+			HIP_TRY_MEM(hipMalloc(&cp, sizeof(int64_t) * (size_t)(g.spb + 1)));
+			HIP_TRY_MEM(hipMalloc(&cw, sizeof(uint32_t) * (size_t)(w0 + 64 * 16)));
+			HIP_TRY(hipMemcpyAsync(cp, A.code_ptr, sizeof(int64_t) * (size_t)(g.spb + 1), hipMemcpyDeviceToDevice, e->stream));
+			HIP_TRY(hipMemcpyAsync(cw, A.codes, sizeof(uint32_t) * (size_t)w0, hipMemcpyDeviceToDevice, e->stream));
+			HIP_TRY(hipMemsetAsync(cw + w0, 0, sizeof(uint32_t) * 64 * 16, e->stream));
+			HIP_TRY(hipStreamSynchronize(e->stream));
+			(void)hipFree(A.code_ptr);
+			(void)hipFree(A.codes);
+			A.code_ptr = cp;
+			A.codes = cw;
+			A.code_words = w0;
+		}
 		if (!bad) {
 			int64_t n0 = 0; // entries of block 0
 			HIP_TRY(hipMemcpy(&n0, A.slice_ptr + g.spb, sizeof(int64_t), hipMemcpyDeviceToHost));
@@ -422,7 +459,7 @@ template <typename T> static lpp_status build_sliced_t(lpp_engine* e, DevCsr& A,
 			A.slice_ptr = sp;
 			A.row_len = rl;
 			A.scol = sc;
-			A.tmpl = true;
+			A.tmpl = hd[1] ? 1 : 2;
 		}
 	}
 	return LPP_OK;
@@ -732,13 +769,13 @@ lpp_status lpp_engine_get_csr(lpp_engine* e, int32_t which, int64_t* nrows, int6
 					k_slice_fill<cplx, true, true><<<nb2, kBlock, 0, e->stream>>>(A.geom, rp, A.scol, (const cplx*)A.sval, tcol, A.coded ? nullptr : (cplx*)tval, A.tmpl ? 1 : 0);
 				else
 					k_slice_fill<cplx, true><<<nb2, kBlock, 0, e->stream>>>(A.geom, rp, A.scol, (const cplx*)A.sval, tcol, A.coded ? nullptr : (cplx*)tval);
-				if (A.coded) k_slice_decode<cplx><<<nb2, kBlock, 0, e->stream>>>(A.geom, rp, A.codes, A.code_ptr, A.dict, (cplx*)tval);
+				if (A.coded) k_slice_decode<cplx><<<nb2, kBlock, 0, e->stream>>>(A.geom, rp, A.codes, A.code_ptr, A.dict, (cplx*)tval, A.tmpl == 2 ? 1 : 0);
 			} else {
 				if (A.local16)
 					k_slice_fill<double, true, true><<<nb2, kBlock, 0, e->stream>>>(A.geom, rp, A.scol, (const double*)A.sval, tcol, A.coded ? nullptr : (double*)tval, A.tmpl ? 1 : 0);
 				else
 					k_slice_fill<double, true><<<nb2, kBlock, 0, e->stream>>>(A.geom, rp, A.scol, (const double*)A.sval, tcol, A.coded ? nullptr : (double*)tval);
-				if (A.coded) k_slice_decode<double><<<nb2, kBlock, 0, e->stream>>>(A.geom, rp, A.codes, A.code_ptr, A.dict, (double*)tval);
+				if (A.coded) k_slice_decode<double><<<nb2, kBlock, 0, e->stream>>>(A.geom, rp, A.codes, A.code_ptr, A.dict, (double*)tval, A.tmpl == 2 ? 1 : 0);
 			}
 			if (A.rrowptr) {
 				// merge the shared-offset entries back into every row
@@ -752,9 +789,9 @@ lpp_status lpp_engine_get_csr(lpp_engine* e, int32_t which, int64_t* nrows, int6
 				}
 				const int nbm = (int)((A.nrows + 255) / 256);
 				if (e->is_complex)
-					k_dia_merge<cplx><<<nbm, 256, 0, e->stream>>>(A.geom, A.rowptr, rp, tcol, (const cplx*)tval, A.dia_stride, A.dia_off, (const cplx*)A.dia_val, fcol, (cplx*)fval);
+					k_dia_merge<cplx><<<nbm, 256, 0, e->stream>>>(A.geom, A.rowptr, rp, tcol, (const cplx*)tval, A.dia_stride, A.dia_off, (const cplx*)A.dia_val, fcol, (cplx*)fval, A.dcode, A.dict);
 				else
-					k_dia_merge<double><<<nbm, 256, 0, e->stream>>>(A.geom, A.rowptr, rp, tcol, (const double*)tval, A.dia_stride, A.dia_off, (const double*)A.dia_val, fcol, (double*)fval);
+					k_dia_merge<double><<<nbm, 256, 0, e->stream>>>(A.geom, A.rowptr, rp, tcol, (const double*)tval, A.dia_stride, A.dia_off, (const double*)A.dia_val, fcol, (double*)fval, A.dcode, A.dict);
 				(void)hipStreamSynchronize(e->stream);
 				(void)hipFree(tcol);
 				(void)hipFree(tval);
@@ -853,7 +890,8 @@ lpp_status lpp_engine_get_layout(lpp_engine* e, int32_t which, lpp_layout* out)
 	L.kernel = A.sliced ? (A.window ? LPP_SPMV_WINDOW : LPP_SPMV_SLICED) : LPP_SPMV_ROWGROUP;
 	L.coded = A.coded ? 1 : 0;
 	L.local16 = A.local16 ? 1 : 0;
-	L.block_template = A.tmpl ? 1 : 0;
+	L.block_template = A.tmpl;
+	L.diagonal_codes = A.dcode ? 1 : 0;
 	L.shared_stride = A.dia_stride;
 	L.nnz = A.nnz;
 	L.per_row_entries = A.rrowptr ? A.rnnz : A.nnz;
@@ -870,10 +908,11 @@ lpp_status lpp_engine_get_layout(lpp_engine* e, int32_t which, lpp_layout* out)
 		bytes += sizeof(int64_t) * (struct_slices + 1) + sizeof(int32_t) * struct_rows; // slice_ptr, row_len
 		bytes += (A.local16 ? sizeof(uint16_t) : sizeof(int32_t)) * (struct_nz + 64);
 		if (A.coded)
-			bytes += sizeof(int64_t) * (size_t)(A.geom.nslices + 1) + 256 * sizeof(double) + sizeof(uint32_t) * (size_t)A.code_words;
+			bytes += sizeof(int64_t) * ((A.tmpl == 2 ? (size_t)A.geom.spb : (size_t)A.geom.nslices) + 1) + 256 * sizeof(double) + sizeof(uint32_t) * (size_t)A.code_words;
 		else
 			bytes += s * (nz + 64);
 		if (A.rrowptr) bytes += sizeof(int64_t) * (size_t)(A.nrows + 1) + (size_t)A.geom.nslices * (size_t)A.dia_stride * (sizeof(int32_t) + s);
+		if (A.dcode) bytes += (size_t)A.nrows * (s / 8);
 	}
 	L.resident_bytes = (int64_t)bytes;
 	*out = L;

@@ -36,7 +36,8 @@ struct DevCsr {
 	int G = 16; // lanes per row of the row-group kernel
 	bool sliced = false;
 	bool window = false; // LDS-window kernel (K3)
-	bool tmpl = false; // block-periodic structure: slice_ptr / row_len / scol describe block 0 only (see k_tmpl_check)
+	int tmpl = 0; // block-periodic structure (k_tmpl_check): 1 = slice_ptr / row_len / scol describe block 0 only, 2 = codes / code_ptr too
+	uint8_t* dcode = nullptr; // diagonal split off the per-row entries: dictionary code(s) per row
 	int64_t code_words = 0; // 32-bit words in `codes`
 	bool local16 = false; // scol holds 16-bit window-local columns (window kernel, every per-row entry inside its block)
 	int64_t hint_block = 0; // natural row block of the basis (N_up), 0 = unknown

@@ -249,9 +249,12 @@ template <typename T> struct SlicedArgs {
 	int dia_stride;
 	const int32_t* dia_off; // column - row, the same for every row of the slice
 	const T* dia_val;
-	// 1: block-periodic structure -- every row block has the row lengths and block-local columns of block 0, so
-	// slice_ptr / row_len / col describe ONE block (values/codes stay per block); see k_tmpl_check
+	// block-periodic structure (see k_tmpl_check): 1 = every row block has the row lengths and block-local columns of
+	// block 0, so slice_ptr / row_len / col describe ONE block; 2 = the value codes repeat as well (codes / code_ptr
+	// describe one block too; the diagonal, which does differ, travels in dcode)
 	int tmpl;
+	// diagonal split off the per-row entries: one dictionary code per real component and row (null: not split off)
+	const uint8_t* dcode;
 };
 
 constexpr int32_t kDiaNone = INT32_MIN;
@@ -476,11 +479,17 @@ __device__ __forceinline__ double sliced_one(const SlicedArgs<T>& a, int64_t row
 	const T xold = a.x[row];
 	T yv = VT<T>::zero();
 	if (DOT) yv = a.ydot[row];
+	uint32_t dc = 0; // code(s) of the diagonal value, when it travels apart from the per-row entries
+	if (CODED && a.dcode) dc = sizeof(T) == 16 ? (uint32_t)((const uint16_t*)a.dcode)[row] : (uint32_t)a.dcode[row];
 	DiaPre<T> pre;
 	const int dcnt = __popcll(__ballot(dm.off != kDiaNone)); // wave-uniform
 	dia_request<T>(a, dm, dcnt, (uint32_t)row, pre);
 	T acc = sliced_accumulate<T, WINDOW, CODED, U, LOCAL16>(a, len, base, cbase, lds, r0, wlen, dict, (int32_t)row);
 	dia_consume<T>(a, dm, dcnt, (uint32_t)row, pre, acc);
+	if (CODED && a.dcode) {
+		const T ys = WINDOW ? lds[(uint32_t)((int32_t)row - r0)] : ld_off32(a.src, (uint32_t)row);
+		VT<T>::mac(acc, CodeTraits<T>::decode(dc, 0, dict), ys);
+	}
 	double d = 0.0;
 	if (valid) {
 		const T xv = epi_lin(beta, xold, alpha, acc);
@@ -503,7 +512,7 @@ __device__ __forceinline__ void slice_meta(const SlicedArgs<T>& a, int64_t s, in
 	const int l = a.row_len[r - blk * a.g.B];
 	len = (lane < nvalid) ? l : 0;
 	base = a.slice_ptr[s - blk * a.g.spb];
-	cbase = CODED ? a.code_ptr[s] : 0;
+	cbase = CODED ? a.code_ptr[a.tmpl == 2 ? s - blk * a.g.spb : s] : 0;
 }
 
 // the dictionary lives in LDS (2 KB); decode reads are mostly broadcasts (few distinct values)
@@ -755,22 +764,47 @@ static __global__ void k_rows_sorted(int64_t nrows, const int64_t* __restrict__ 
 	if (bad) *unsorted = 1;
 }
 
+__device__ __forceinline__ uint32_t dict_code(const double* dict, int ndict, double v);
+
 // One wave per slice.  FILL == false: rest_len[row] = entries the row keeps; stats[0] = max shared entries of any slice,
 // stats[1] = shared entries summed over slices.  FILL == true (after the scan of rest_len): writes the rest CSR
 // (rcol/rval at rrowptr) and the shared lists at dia_off/dia_val[s*stride ..] (pre-filled with kDiaNone / 0).
 // win != 0: the matrix is built for the LDS-window kernel; entries whose whole 64-row run lies inside the row block stay
 // per-row entries (served from LDS, 3 bytes each) instead of becoming global gathers.
+// xdiag != 0: the diagonal entry of every row is taken out of the per-row entries as well (FILL: its dictionary code(s)
+// go to dcode[row]); stats[2] counts rows WITHOUT a diagonal entry (the caller then repeats the count with xdiag = 0).
 template <typename T, bool FILL>
 __global__ __launch_bounds__(kBlock) void k_dia_split(SliceGeom g, const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
                                                        const T* __restrict__ val, int win, int stride, int64_t* __restrict__ rest_len,
                                                        unsigned long long* __restrict__ stats, const int64_t* __restrict__ rrowptr,
                                                        int32_t* __restrict__ rcol, T* __restrict__ rval, int32_t* __restrict__ dia_off,
-                                                       T* __restrict__ dia_val)
+                                                       T* __restrict__ dia_val, int xdiag, const double* __restrict__ dict, int ndict,
+                                                       uint8_t* __restrict__ dcode)
 {
 	const int lane = threadIdx.x & 63;
 	const int64_t wave0 = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
 	const int64_t nwaves = (int64_t)gridDim.x * (kBlock / 64);
-	unsigned long long local_max = 0, local_sum = 0;
+	unsigned long long local_max = 0, local_sum = 0, local_nodiag = 0;
+	// a per-row entry that stays: emitted to the rest CSR, or -- the diagonal, when it is split off -- to dcode
+#define LPP_KEEP_ENTRY(Q)                                                                                             \
+	do {                                                                                                              \
+		if (xdiag && (int64_t)col[Q] == row) {                                                                        \
+			ndg++;                                                                                                    \
+			if (FILL) {                                                                                               \
+				const double* pv_ = (const double*)(val + (Q));                                                       \
+				if (sizeof(T) == 16) {                                                                                \
+					dcode[2 * row] = (uint8_t)dict_code(dict, ndict, pv_[0]);                                         \
+					dcode[2 * row + 1] = (uint8_t)dict_code(dict, ndict, pv_[1]);                                     \
+				} else {                                                                                              \
+					dcode[row] = (uint8_t)dict_code(dict, ndict, pv_[0]);                                             \
+				}                                                                                                     \
+			}                                                                                                         \
+		} else if (FILL) {                                                                                            \
+			rcol[wp] = col[Q];                                                                                        \
+			rval[wp] = val[Q];                                                                                        \
+			wp++;                                                                                                     \
+		}                                                                                                             \
+	} while (0)
 	for (int64_t s = wave0; s < g.nslices; s += nwaves) {
 		int64_t row0;
 		int nvalid;
@@ -778,6 +812,7 @@ __global__ __launch_bounds__(kBlock) void k_dia_split(SliceGeom g, const int64_t
 		if (nvalid == 0) continue;
 		const bool valid = lane < nvalid;
 		const int64_t row = row0 + (valid ? lane : 0);
+		int ndg = 0; // diagonal entries of this row that were split off (0 or 1)
 		const int64_t pbeg = rowptr[row];
 		int64_t q = valid ? pbeg : 0;
 		const int64_t end = valid ? rowptr[row + 1] : 0;
@@ -793,11 +828,7 @@ __global__ __launch_bounds__(kBlock) void k_dia_split(SliceGeom g, const int64_t
 			const int64_t off = (int64_t)c0 - row0;
 			const int64_t target = row + off;
 			while (q < end && (int64_t)col[q] < target) { // entries passed over stay with the row
-				if (FILL) {
-					rcol[wp] = col[q];
-					rval[wp] = val[q];
-					wp++;
-				}
+				LPP_KEEP_ENTRY(q);
 				q++;
 			}
 			bool ok = valid && q < end && (int64_t)col[q] == target;
@@ -812,22 +843,24 @@ __global__ __launch_bounds__(kBlock) void k_dia_split(SliceGeom g, const int64_t
 				q++;
 			}
 		}
-		if (FILL) {
-			while (q < end) {
-				rcol[wp] = col[q];
-				rval[wp] = val[q];
-				wp++;
-				q++;
-			}
-		} else {
-			if (valid) rest_len[row] = (end - pbeg) - nd;
+		while (q < end) {
+			LPP_KEEP_ENTRY(q);
+			q++;
+		}
+		if (!FILL) {
+			if (valid) rest_len[row] = (end - pbeg) - nd - ndg;
+			if (valid && xdiag && ndg == 0) local_nodiag++;
 			local_max = max(local_max, (unsigned long long)nd);
 			local_sum += (unsigned long long)nd;
 		}
 	}
-	if (!FILL && lane == 0) {
-		atomicMax(&stats[0], local_max);
-		atomicAdd(&stats[1], local_sum);
+#undef LPP_KEEP_ENTRY
+	if (!FILL) {
+		if (lane == 0) {
+			atomicMax(&stats[0], local_max);
+			atomicAdd(&stats[1], local_sum);
+		}
+		if (local_nodiag) atomicAdd(&stats[2], local_nodiag);
 	}
 }
 
@@ -836,19 +869,25 @@ template <typename T>
 __global__ void k_dia_merge(SliceGeom g, const int64_t* __restrict__ rowptr, const int64_t* __restrict__ rrowptr,
                             const int32_t* __restrict__ rcol, const T* __restrict__ rval, int stride,
                             const int32_t* __restrict__ dia_off, const T* __restrict__ dia_val, int32_t* __restrict__ col_out,
-                            T* __restrict__ val_out)
+                            T* __restrict__ val_out, const uint8_t* __restrict__ dcode, const double* __restrict__ dict)
 {
 	const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (r >= g.nrows) return;
 	const int64_t blk = r / g.B;
 	const int64_t s = blk * g.spb + (r - blk * g.B) / 64;
 	int64_t i = rrowptr[r], iend = rrowptr[r + 1], d = s * stride, dend = d + stride, o = rowptr[r];
+	bool hg = dcode != nullptr; // the row's diagonal, when it was split off
 	while (true) {
 		const bool hd = d < dend && dia_off[d] != kDiaNone, hi = i < iend;
-		if (!hd && !hi) break;
+		if (!hd && !hi && !hg) break;
 		const int64_t cd = hd ? r + (int64_t)dia_off[d] : INT64_MAX;
 		const int64_t ci = hi ? (int64_t)rcol[i] : INT64_MAX;
-		if (cd < ci) {
+		if (hg && r < cd && r < ci) {
+			col_out[o] = (int32_t)r;
+			const uint32_t c = sizeof(T) == 16 ? (uint32_t)((const uint16_t*)dcode)[r] : (uint32_t)dcode[r];
+			val_out[o] = CodeTraits<T>::decode(c, 0, dict);
+			hg = false;
+		} else if (cd < ci) {
 			col_out[o] = (int32_t)cd;
 			val_out[o] = dia_val[d];
 			d++;
@@ -863,14 +902,16 @@ __global__ void k_dia_merge(SliceGeom g, const int64_t* __restrict__ rowptr, con
 
 // Block-periodic structure (16-bit block-local columns only): *differs = 1 unless every row block has the row lengths
 // and the local column stream of block 0.  One wave per slice of blocks 1..nblocks-1.
+// differs[1] = 1 unless the code words repeat too.
 static __global__ __launch_bounds__(kBlock) void k_tmpl_check(SliceGeom g, const int64_t* __restrict__ slice_ptr,
                                                                const int32_t* __restrict__ row_len, const uint16_t* __restrict__ col16,
+                                                               const int64_t* __restrict__ code_ptr, const uint32_t* __restrict__ codes,
                                                                int* differs)
 {
 	const int lane = threadIdx.x & 63;
 	const int64_t wave0 = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
 	const int64_t nwaves = (int64_t)gridDim.x * (kBlock / 64);
-	bool bad = false;
+	bool bad = false, badc = false;
 	for (int64_t s = g.spb + wave0; s < g.nslices; s += nwaves) {
 		const int64_t blk = s / g.spb, j = s - blk * g.spb;
 		const int64_t b0 = slice_ptr[j], n0 = slice_ptr[j + 1] - b0, b1 = slice_ptr[s], n1 = slice_ptr[s + 1] - b1;
@@ -881,8 +922,15 @@ static __global__ __launch_bounds__(kBlock) void k_tmpl_check(SliceGeom g, const
 		const int64_t r = j * 64 + lane;
 		if (r < g.B) bad |= row_len[blk * g.B + r] != row_len[r];
 		for (int64_t i = lane; i < n0; i += 64) bad |= col16[b1 + i] != col16[b0 + i];
+		const int64_t c0 = code_ptr[j], m0 = code_ptr[j + 1] - c0, c1 = code_ptr[s], m1 = code_ptr[s + 1] - c1;
+		if (m0 != m1) {
+			badc = true;
+			continue;
+		}
+		for (int64_t i = lane; i < m0; i += 64) badc |= codes[c1 + i] != codes[c0 + i];
 	}
-	if (bad) *differs = 1;
+	if (bad) differs[0] = 1;
+	if (badc) differs[1] = 1;
 }
 
 // *outside = 1 when some entry's column lies outside its row block [blk*B, (blk+1)*B)
@@ -995,7 +1043,7 @@ __global__ __launch_bounds__(kBlock) void k_slice_codes(SliceGeom g, const int64
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_slice_decode(SliceGeom g, const int64_t* __restrict__ rowptr,
                                                           const uint32_t* __restrict__ codes, const int64_t* __restrict__ code_ptr,
-                                                          const double* __restrict__ dict, T* __restrict__ val_out)
+                                                          const double* __restrict__ dict, T* __restrict__ val_out, int tmpl_codes = 0)
 {
 	constexpr int SPW = CodeTraits<T>::kSlotsPerWord;
 	const int lane = threadIdx.x & 63;
@@ -1008,7 +1056,7 @@ __global__ __launch_bounds__(kBlock) void k_slice_decode(SliceGeom g, const int6
 		if (lane >= nvalid) continue;
 		const int64_t p0 = rowptr[row0 + lane];
 		const int len = (int)(rowptr[row0 + lane + 1] - p0);
-		const int64_t cbase = code_ptr[s];
+		const int64_t cbase = code_ptr[tmpl_codes ? s % g.spb : s];
 		for (int k = 0; k < len; k++) val_out[p0 + k] = CodeTraits<T>::decode(codes[cbase + ((int64_t)(k / SPW) << 6) + lane], k % SPW, dict);
 	}
 }

@@ -371,7 +371,7 @@ def test_shared_offset_layout_is_lossless(case):
                 assert lay["rows_per_block"] == block
                 # every block of the product basis repeats block 0's in-block structure (it is H_up); the template
                 # needs the value codes (site-dependent U and V give more than 256 distinct diagonal values)
-                assert lay["block_template"] == lay["coded"]
+                assert lay["block_template"] == 2 * lay["coded"] and lay["diagonal_codes"] == lay["coded"]
                 assert lay["coded"] == (1 if "uniform" in case else 0)
         x0 = oracle.fill_random(A.nrows, 7, A.is_complex)
         y = oracle.fill_random(A.nrows, 8, A.is_complex)
