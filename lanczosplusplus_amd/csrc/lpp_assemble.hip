@@ -755,6 +755,10 @@ template <typename T> static int kron_launch_t(lpp_engine* e, const void* ywin, 
 	a.up.dia_off = nullptr;
 	a.up.dia_val = nullptr;
 	a.up.tmpl = 0;
+	a.up.dcode = nullptr;
+	a.up.tw = nullptr;
+	a.up.tw_off = nullptr;
+	a.up.tw_len = nullptr;
 	a.n_up = K.n_up;
 	a.id0 = K.id0;
 	a.nid = K.nid;

@@ -44,6 +44,9 @@ void free_csr(DevCsr& A)
 	if (A.dia_off) (void)hipFree(A.dia_off);
 	if (A.dia_val) (void)hipFree(A.dia_val);
 	if (A.dcode) (void)hipFree(A.dcode);
+	if (A.tw) (void)hipFree(A.tw);
+	if (A.tw_off) (void)hipFree(A.tw_off);
+	if (A.tw_len) (void)hipFree(A.tw_len);
 	A = DevCsr();
 }
 
@@ -102,6 +105,9 @@ template <typename T> static int spmv_launch_t(lpp_engine* e, const DevCsr& A, c
 		a.dia_val = (const T*)A.dia_val;
 		a.tmpl = A.tmpl;
 		a.dcode = A.dcode;
+		a.tw = A.tw;
+		a.tw_off = A.tw_off;
+		a.tw_len = A.tw_len;
 		const bool dot = partial != nullptr;
 		const bool u8 = (e->k2_variant & 4) != 0;
 		const int sel = (dot ? 4 : 0) | (A.coded ? 2 : 0) | (u8 ? 1 : 0);
@@ -460,6 +466,30 @@ template <typename T> static lpp_status build_sliced_t(lpp_engine* e, DevCsr& A,
 			A.row_len = rl;
 			A.scol = sc;
 			A.tmpl = hd[1] ? 1 : 2;
+			if (A.tmpl == 2 && !(getenv("LPP_TEMPLATE_PACK") && atoi(getenv("LPP_TEMPLATE_PACK")) == 0)) {
+				// packed padded copy of the template for the inner loop (the compact copy stays for get_csr)
+				HIP_TRY_MEM(hipMalloc(&A.tw_len, sizeof(int32_t) * (size_t)g.spb));
+				HIP_TRY_MEM(hipMalloc(&A.tw_off, sizeof(int32_t) * (size_t)g.spb));
+				const int nbp = (int)std::max<int64_t>(1, (g.spb + 3) / 4);
+				k_tmpl_pack<T, 0><<<nbp, kBlock, 0, e->stream>>>(g, A.slice_ptr, A.row_len, (const uint16_t*)A.scol, A.code_ptr, A.codes, A.tw_len,
+				                                                 nullptr, nullptr);
+				std::vector<int32_t> hl((size_t)g.spb), ho((size_t)g.spb);
+				HIP_TRY(hipMemcpyAsync(hl.data(), A.tw_len, sizeof(int32_t) * (size_t)g.spb, hipMemcpyDeviceToHost, e->stream));
+				HIP_TRY(hipStreamSynchronize(e->stream));
+				int64_t tot = 0;
+				for (int32_t j2 = 0; j2 < g.spb; j2++) {
+					ho[(size_t)j2] = (int32_t)tot;
+					tot += (int64_t)hl[(size_t)j2] * 64;
+				}
+				if (tot < ((int64_t)1 << 30)) {
+					HIP_TRY_MEM(hipMalloc(&A.tw, sizeof(uint32_t) * (size_t)std::max<int64_t>(tot, 1)));
+					HIP_TRY(hipMemcpyAsync(A.tw_off, ho.data(), sizeof(int32_t) * (size_t)g.spb, hipMemcpyHostToDevice, e->stream));
+					k_tmpl_pack<T, 1><<<nbp, kBlock, 0, e->stream>>>(g, A.slice_ptr, A.row_len, (const uint16_t*)A.scol, A.code_ptr, A.codes, A.tw_len,
+					                                                 A.tw_off, A.tw);
+					HIP_TRY(hipGetLastError());
+					HIP_TRY(hipStreamSynchronize(e->stream));
+				}
+			}
 		}
 	}
 	return LPP_OK;

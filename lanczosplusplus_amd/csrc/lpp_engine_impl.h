@@ -37,6 +37,8 @@ struct DevCsr {
 	bool sliced = false;
 	bool window = false; // LDS-window kernel (K3)
 	int tmpl = 0; // block-periodic structure (k_tmpl_check): 1 = slice_ptr / row_len / scol describe block 0 only, 2 = codes / code_ptr too
+	uint32_t* tw = nullptr; // packed padded copy of a level-2 template (k_tmpl_pack), with tw_off / tw_len per template slice
+	int32_t *tw_off = nullptr, *tw_len = nullptr;
 	uint8_t* dcode = nullptr; // diagonal split off the per-row entries: dictionary code(s) per row
 	int64_t code_words = 0; // 32-bit words in `codes`
 	bool local16 = false; // scol holds 16-bit window-local columns (window kernel, every per-row entry inside its block)

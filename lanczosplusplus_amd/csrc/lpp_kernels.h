@@ -255,6 +255,14 @@ template <typename T> struct SlicedArgs {
 	int tmpl;
 	// diagonal split off the per-row entries: one dictionary code per real component and row (null: not split off)
 	const uint8_t* dcode;
+	// packed copy of a level-2 template (k_tmpl_pack): one 32-bit word per entry = 16-bit local column | code(s) << 16,
+	// slot-major [slot][lane] per slice, every slice padded to a multiple of 8 slots with (own row, code 0 = +0.0).
+	// The inner loop is then one coalesced 4-byte load, two LDS reads and an FMA per entry: no row lengths, ballots or
+	// lane prefixes (measured on the compact walk: 15 VALU instructions per entry, and the 2-byte column loads cost the
+	// L1 as many tag accesses as 8-byte ones).  null: walk the compact layout.
+	const uint32_t* tw;
+	const int32_t* tw_off; // first word of template slice j
+	const int32_t* tw_len; // its padded slots
 };
 
 constexpr int32_t kDiaNone = INT32_MIN;
@@ -464,6 +472,32 @@ __device__ __forceinline__ void dia_consume(const SlicedArgs<T>& a, const DiaMet
 	}
 }
 
+// x += sum over the packed template entries of slice j (window kernel, see SlicedArgs::tw)
+template <typename T>
+__device__ __forceinline__ T tmpl_accumulate(const SlicedArgs<T>& a, int j, const T* lds, const double* dict)
+{
+	const int lane = threadIdx.x & 63;
+	const uint32_t* wp = a.tw + a.tw_off[j] + lane;
+	const int ml = a.tw_len[j]; // multiple of 8
+	T acc = VT<T>::zero();
+	uint32_t w0[8], w1[8];
+	if (ml > 0) {
+#pragma unroll
+		for (int q = 0; q < 8; q++) w0[q] = wp[q * 64];
+	}
+	for (int k = 0; k < ml; k += 8) {
+		if (k + 8 < ml) {
+#pragma unroll
+			for (int q = 0; q < 8; q++) w1[q] = wp[(k + 8 + q) * 64];
+		}
+#pragma unroll
+		for (int q = 0; q < 8; q++) VT<T>::mac(acc, CodeTraits<T>::decode(w0[q] >> 16, 0, dict), lds[w0[q] & 0xffffu]);
+#pragma unroll
+		for (int q = 0; q < 8; q++) w0[q] = w1[q];
+	}
+	return acc;
+}
+
 // process one slice with one wave (x[row] += acc); returns this lane's contribution to Re<ydot|x>.
 template <typename T, bool DOT, bool WINDOW, bool CODED, int U, bool LOCAL16 = false>
 __device__ __forceinline__ double sliced_one(const SlicedArgs<T>& a, int64_t row0, int nvalid, int len, int64_t base, int64_t cbase,
@@ -484,7 +518,11 @@ __device__ __forceinline__ double sliced_one(const SlicedArgs<T>& a, int64_t row
 	DiaPre<T> pre;
 	const int dcnt = __popcll(__ballot(dm.off != kDiaNone)); // wave-uniform
 	dia_request<T>(a, dm, dcnt, (uint32_t)row, pre);
-	T acc = sliced_accumulate<T, WINDOW, CODED, U, LOCAL16>(a, len, base, cbase, lds, r0, wlen, dict, (int32_t)row);
+	T acc;
+	if (LOCAL16 && CODED && a.tw) // wave-uniform
+		acc = tmpl_accumulate<T>(a, (int)((row0 - r0) >> 6), lds, dict);
+	else
+		acc = sliced_accumulate<T, WINDOW, CODED, U, LOCAL16>(a, len, base, cbase, lds, r0, wlen, dict, (int32_t)row);
 	dia_consume<T>(a, dm, dcnt, (uint32_t)row, pre, acc);
 	if (CODED && a.dcode) {
 		const T ys = WINDOW ? lds[(uint32_t)((int32_t)row - r0)] : ld_off32(a.src, (uint32_t)row);
@@ -931,6 +969,49 @@ static __global__ __launch_bounds__(kBlock) void k_tmpl_check(SliceGeom g, const
 	}
 	if (bad) differs[0] = 1;
 	if (badc) differs[1] = 1;
+}
+
+// Packed padded copy of a level-2 template (see SlicedArgs::tw).  One wave per slice of block 0.
+// PASS 0: tw_len[j] = padded slots of slice j;  PASS 1 (after the scan of 64*tw_len into tw_off): the words.
+template <typename T, int PASS>
+__global__ __launch_bounds__(kBlock) void k_tmpl_pack(SliceGeom g, const int64_t* __restrict__ slice_ptr, const int32_t* __restrict__ row_len,
+                                                       const uint16_t* __restrict__ col16, const int64_t* __restrict__ code_ptr,
+                                                       const uint32_t* __restrict__ codes, int32_t* __restrict__ tw_len,
+                                                       const int32_t* __restrict__ tw_off, uint32_t* __restrict__ tw)
+{
+	constexpr int SPW = CodeTraits<T>::kSlotsPerWord, BITS = CodeTraits<T>::kBits;
+	const int lane = threadIdx.x & 63;
+	const int64_t wave0 = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+	const int64_t nwaves = (int64_t)gridDim.x * (kBlock / 64);
+	for (int64_t j = wave0; j < g.spb; j += nwaves) {
+		const int64_t r = j * 64 + lane;
+		const int len = r < g.B ? row_len[r] : 0;
+		int maxlen = len;
+#pragma unroll
+		for (int off = 32; off > 0; off >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, off, 64));
+		const int ml = (maxlen + 7) & ~7;
+		if (PASS == 0) {
+			if (lane == 0) tw_len[j] = ml;
+			continue;
+		}
+		int64_t base = slice_ptr[j];
+		const int64_t cbase = code_ptr[j];
+		uint32_t* out = tw + tw_off[j];
+		const uint32_t own = (uint32_t)min(r, g.B - 1); // padding gathers the row's own window element (times +0.0)
+		for (int k = 0; k < ml; k++) {
+			const bool on = len > k;
+			const unsigned long long m = __ballot(on);
+			const int pos = __popcll(m & ((1ull << lane) - 1ull));
+			uint32_t w = own;
+			if (on) {
+				const uint32_t cw = codes[cbase + ((int64_t)(k / SPW) << 6) + lane];
+				const uint32_t c = (cw >> (BITS * (k % SPW))) & ((1u << BITS) - 1u);
+				w = (uint32_t)col16[base + pos] | (c << 16);
+			}
+			out[(int64_t)k * 64 + lane] = w;
+			base += __popcll(m);
+		}
+	}
 }
 
 // *outside = 1 when some entry's column lies outside its row block [blk*B, (blk+1)*B)
