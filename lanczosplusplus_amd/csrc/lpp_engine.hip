@@ -510,18 +510,17 @@ lpp_status finalize_csr(lpp_engine* e, DevCsr& A, bool allow_drop_plain, int for
 	const int64_t lds_cap_elems = (int64_t)((156 * 1024) / e->esz);
 	int64_t win_rows = 0;
 	if (A.hint_block > 0 && A.hint_block <= lds_cap_elems) {
-		// whole basis blocks per window, but keep >= ~4 row blocks per CU so every CU has work
-		const int64_t total_blocks = (A.nrows + A.hint_block - 1) / A.hint_block;
-		const int64_t k = std::max<int64_t>(1, std::min<int64_t>(lds_cap_elems / A.hint_block, total_blocks / (4 * (int64_t)e->num_cus)));
+		// one basis block per window whenever it gives the 16 waves of a workgroup something to do: only then do all
+		// row blocks repeat the same in-block structure (block template); tiny basis blocks are grouped
+		const int64_t k = A.hint_block >= 512 ? 1 : std::max<int64_t>(1, std::min<int64_t>(lds_cap_elems / A.hint_block, (1024 + A.hint_block - 1) / A.hint_block));
 		win_rows = A.hint_block * k;
 	}
 	if (mode == LPP_SPMV_AUTO) {
-		// the LDS window pays when in-block gathers dominate (Hubbard up-hops), the matrix is large enough to
-		// give every CU several blocks, and a window element is 8 bytes (measured: complex t-J windows lose)
-		// ... and the source vector exceeds the 256 MiB Infinity Cache (below that, random gathers are served
-		// on-die and the plain sliced kernel is faster: measured at L=12/14 Hubbard chains)
-		const bool window_ok = win_rows > 0 && !e->is_complex && (A.nrows + win_rows - 1) / win_rows >= 2 * (int64_t)e->num_cus
-		    && (size_t)A.nrows * e->esz > ((size_t)256 << 20);
+		// the LDS window pays when in-block gathers dominate (Hubbard up-hops), the matrix is large enough to give every
+		// CU several blocks, and a window element is 8 bytes (measured: complex t-J windows lose).  With the block
+		// template and 16-bit local columns it also wins when the whole vector fits the Infinity Cache
+		// (Hubbard chains L=12: 31.6 vs 33.1 us, L=14: 0.306 vs 0.372 ms).
+		const bool window_ok = win_rows > 0 && !e->is_complex && (A.nrows + win_rows - 1) / win_rows >= 2 * (int64_t)e->num_cus;
 		mode = window_ok ? LPP_SPMV_WINDOW : LPP_SPMV_SLICED;
 	}
 	if (mode == LPP_SPMV_WINDOW && win_rows == 0) {
