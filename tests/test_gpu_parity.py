@@ -341,7 +341,7 @@ def test_shared_offset_layout_is_lossless(case):
     """Entries shared by all rows of a slice are stored once per slice (and, in the window kernel, per-row columns as
     16-bit block-local indices): SpMV parity and a bit-exact get_csr round trip through the compressed layout."""
     if case.startswith("hubbard"):
-        L, nu, nd = 10, 5, 4
+        L, nu, nd = 12, 6, 3
         cplx = "complex" in case
         hop = chain(L, -1.0, True).astype(complex if cplx else float)
         if cplx:
@@ -351,7 +351,7 @@ def test_shared_offset_layout_is_lossless(case):
             A = oracle.hubbard_csr(L, nu, nd, hop, np.full(L, 4.0))
         else:
             A = oracle.hubbard_csr(L, nu, nd, hop, np.linspace(1.0, 4.0, L), np.linspace(-0.3, 0.3, 2 * L))
-        block = 252  # N_up = C(10,5)
+        block = 924  # N_up = C(12,6): >= 512 rows, so the window kernel takes one basis block per window
     else:
         L = 10
         A = oracle.tj_csr(L, 4, 3, chain(L, -1.0), chain(L, 0.4), chain(L, 0.4), chain(L, -0.1), force_complex=True)
