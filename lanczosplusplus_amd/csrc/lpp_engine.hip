@@ -520,7 +520,27 @@ lpp_status finalize_csr(lpp_engine* e, DevCsr& A, bool allow_drop_plain, int for
 		// CU several blocks, and a window element is 8 bytes (measured: complex t-J windows lose).  With the block
 		// template and 16-bit local columns it also wins when the whole vector fits the Infinity Cache
 		// (Hubbard chains L=12: 31.6 vs 33.1 us, L=14: 0.306 vs 0.372 ms).
-		const bool window_ok = win_rows > 0 && !e->is_complex && (A.nrows + win_rows - 1) / win_rows >= 2 * (int64_t)e->num_cus;
+		bool window_ok = win_rows > 0 && !e->is_complex && (A.nrows + win_rows - 1) / win_rows >= 2 * (int64_t)e->num_cus;
+		if (!window_ok && win_rows == 0 && !e->is_complex && fits32 && A.col && A.nnz > 0) {
+			// no natural block: a plain diagonal window of 16384 rows pays when enough gathers land inside it (bases in
+			// ascending word order couple mostly nearby ranks: Heisenberg L=28 0.95 vs 1.22 ms); measured here
+			const int64_t gw = std::min<int64_t>(lds_cap_elems, 16384);
+			if ((A.nrows + gw - 1) / gw >= 2 * (int64_t)e->num_cus) {
+				unsigned long long* inside = nullptr;
+				HIP_TRY_MEM(hipMalloc(&inside, sizeof(unsigned long long)));
+				(void)hipMemsetAsync(inside, 0, sizeof(unsigned long long), e->stream);
+				k_count_local<<<(int)((A.nrows + 255) / 256), 256, 0, e->stream>>>(A.nrows, gw, A.rowptr, A.col, inside);
+				unsigned long long h = 0;
+				hipError_t e1 = hipMemcpyAsync(&h, inside, sizeof(h), hipMemcpyDeviceToHost, e->stream);
+				hipError_t e2 = hipStreamSynchronize(e->stream);
+				(void)hipFree(inside);
+				if (e1 != hipSuccess || e2 != hipSuccess) return fail(LPP_ERR_HIP, "window locality count failed");
+				if ((double)h >= 0.35 * (double)A.nnz) {
+					window_ok = true;
+					win_rows = gw;
+				}
+			}
+		}
 		mode = window_ok ? LPP_SPMV_WINDOW : LPP_SPMV_SLICED;
 	}
 	if (mode == LPP_SPMV_WINDOW && win_rows == 0) {

@@ -1014,6 +1014,21 @@ __global__ __launch_bounds__(kBlock) void k_tmpl_pack(SliceGeom g, const int64_t
 	}
 }
 
+// *inside += number of entries whose column lies inside the row's own block of B rows (is an LDS window worth it?)
+static __global__ void k_count_local(int64_t nrows, int64_t B, const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                     unsigned long long* inside)
+{
+	const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	unsigned long long n = 0;
+	if (r < nrows) {
+		const int64_t r0 = (r / B) * B, r1 = r0 + B;
+		for (int64_t p = rowptr[r]; p < rowptr[r + 1]; p++) n += (col[p] >= r0 && col[p] < r1) ? 1u : 0u;
+	}
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1) n += __shfl_xor(n, off, 64);
+	if ((threadIdx.x & 63) == 0 && n) atomicAdd(inside, n);
+}
+
 // *outside = 1 when some entry's column lies outside its row block [blk*B, (blk+1)*B)
 static __global__ void k_cols_local(SliceGeom g, const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col, int* outside)
 {
