@@ -58,8 +58,10 @@ def test_host_assembly_bit_exact(name, tmp_path):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", ["input0.inp", "hubbard_ladder_2x4.inp", "hubbard_ladder_2x4_onthefly.inp", "heisenberg_chain_L12.inp",
-                                  "tj_chain_L8_complex.inp"])
+                                  "tj_chain_L8_complex.inp", "hubbard_chain_L12.inp"])
 def test_lanczos_driver_prints_reference_energy_line(name):
+    # hubbard_chain_L12.inp is BASELINE config 1 (853,776 states): host assembly, upload with the N_up = 924 row-block
+    # hint, i.e. the LDS-window kernel with the block template on an UPLOADED matrix
     exe = os.path.join(HOST, "lanczos")
     assert os.path.exists(exe)
     res = subprocess.run([exe, "-f", os.path.join(GOLD, name), "-p", "12"], capture_output=True, text=True, timeout=300)
