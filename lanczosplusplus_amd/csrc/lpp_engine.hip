@@ -601,6 +601,58 @@ lpp_status alloc_work(lpp_engine* e)
 
 } // namespace lpp
 
+// device scratch released on scope exit
+struct DevScratch {
+	void* p = nullptr;
+	DevScratch() = default;
+	DevScratch(const DevScratch&) = delete;
+	DevScratch& operator=(const DevScratch&) = delete;
+	~DevScratch()
+	{
+		if (p) (void)hipFree(p);
+	}
+	hipError_t alloc(size_t bytes) { return hipMalloc(&p, std::max<size_t>(bytes, 8)); }
+	void take(DevScratch& o)
+	{
+		if (p) (void)hipFree(p);
+		p = o.p;
+		o.p = nullptr;
+	}
+};
+
+// Plain CSR order (columns, values) of a matrix whose only resident form is the sliced layout: undo the slot-major
+// order (template-aware), decode the value codes, then merge the per-slice shared entries and the diagonal codes back.
+template <typename T> static lpp_status rebuild_csr_t(lpp_engine* e, const DevCsr& A, DevScratch& col_out, DevScratch& val_out)
+{
+	const int64_t* rp = A.rrowptr ? A.rrowptr : A.rowptr; // the sliced arrays hold the rest CSR when entries were split off
+	const int64_t nz = A.rrowptr ? A.rnnz : A.nnz;
+	DevScratch tcol, tval;
+	if (tcol.alloc(sizeof(int32_t) * (size_t)nz) != hipSuccess || tval.alloc(sizeof(T) * (size_t)nz) != hipSuccess)
+		return fail(LPP_ERR_NOMEM, "lpp_engine_get_csr: scratch allocation failed");
+	const int nb2 = (int)std::max<int64_t>(1, std::min<int64_t>((A.geom.nslices + 3) / 4, 8192));
+	T* plain_vals = A.coded ? nullptr : (T*)tval.p;
+	if (A.local16)
+		k_slice_fill<T, true, true><<<nb2, kBlock, 0, e->stream>>>(A.geom, rp, A.scol, (const T*)A.sval, (int32_t*)tcol.p, plain_vals, A.tmpl ? 1 : 0);
+	else
+		k_slice_fill<T, true><<<nb2, kBlock, 0, e->stream>>>(A.geom, rp, A.scol, (const T*)A.sval, (int32_t*)tcol.p, plain_vals);
+	if (A.coded) k_slice_decode<T><<<nb2, kBlock, 0, e->stream>>>(A.geom, rp, A.codes, A.code_ptr, A.dict, (T*)tval.p, A.tmpl == 2 ? 1 : 0);
+	if (A.rrowptr) {
+		DevScratch fcol, fval;
+		if (fcol.alloc(sizeof(int32_t) * (size_t)A.nnz) != hipSuccess || fval.alloc(sizeof(T) * (size_t)A.nnz) != hipSuccess)
+			return fail(LPP_ERR_NOMEM, "lpp_engine_get_csr: scratch allocation failed");
+		k_dia_merge<T><<<(int)((A.nrows + 255) / 256), 256, 0, e->stream>>>(A.geom, A.rowptr, rp, (const int32_t*)tcol.p, (const T*)tval.p, A.dia_stride,
+		                                                                   A.dia_off, (const T*)A.dia_val, (int32_t*)fcol.p, (T*)fval.p, A.dcode, A.dict);
+		HIP_TRY(hipStreamSynchronize(e->stream)); // the merge reads tcol / tval, which are released next
+		tcol.take(fcol);
+		tval.take(fval);
+	}
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipStreamSynchronize(e->stream));
+	col_out.take(tcol);
+	val_out.take(tval);
+	return LPP_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------------------------
@@ -798,70 +850,19 @@ lpp_status lpp_engine_get_csr(lpp_engine* e, int32_t which, int64_t* nrows, int6
 	HIP_TRY(hipStreamSynchronize(e->stream));
 	if (rowptr) HIP_TRY(hipMemcpy(rowptr, A.rowptr, sizeof(int64_t) * (size_t)(A.nrows + 1), hipMemcpyDeviceToHost));
 	if ((colind || values) && A.nnz) {
-		int32_t* dcol = A.col;
-		void* dval = A.val;
-		int32_t* tcol = nullptr;
-		void* tval = nullptr;
+		const int32_t* dcol = A.col;
+		const void* dval = A.val;
+		DevScratch scol, sval;
 		if (!dcol || !dval) {
 			// only the sliced layout is resident: rebuild CSR order in scratch buffers
 			if (!A.sliced) return fail(LPP_ERR_STATE, "lpp_engine_get_csr: matrix arrays missing");
-			const int64_t* rp = A.rrowptr ? A.rrowptr : A.rowptr; // the sliced arrays hold the rest CSR when entries were split off
-			const int64_t nz = A.rrowptr ? A.rnnz : A.nnz;
-			HIP_TRY_MEM(hipMalloc(&tcol, sizeof(int32_t) * (size_t)std::max<int64_t>(nz, 1)));
-			if (hipMalloc(&tval, e->esz * (size_t)std::max<int64_t>(nz, 1)) != hipSuccess) {
-				(void)hipFree(tcol);
-				return fail(LPP_ERR_NOMEM, "lpp_engine_get_csr: scratch allocation failed");
-			}
-			const int nb2 = (int)std::max<int64_t>(1, std::min<int64_t>((A.geom.nslices + 3) / 4, 8192));
-			if (e->is_complex) {
-				if (A.local16)
-					k_slice_fill<cplx, true, true><<<nb2, kBlock, 0, e->stream>>>(A.geom, rp, A.scol, (const cplx*)A.sval, tcol, A.coded ? nullptr : (cplx*)tval, A.tmpl ? 1 : 0);
-				else
-					k_slice_fill<cplx, true><<<nb2, kBlock, 0, e->stream>>>(A.geom, rp, A.scol, (const cplx*)A.sval, tcol, A.coded ? nullptr : (cplx*)tval);
-				if (A.coded) k_slice_decode<cplx><<<nb2, kBlock, 0, e->stream>>>(A.geom, rp, A.codes, A.code_ptr, A.dict, (cplx*)tval, A.tmpl == 2 ? 1 : 0);
-			} else {
-				if (A.local16)
-					k_slice_fill<double, true, true><<<nb2, kBlock, 0, e->stream>>>(A.geom, rp, A.scol, (const double*)A.sval, tcol, A.coded ? nullptr : (double*)tval, A.tmpl ? 1 : 0);
-				else
-					k_slice_fill<double, true><<<nb2, kBlock, 0, e->stream>>>(A.geom, rp, A.scol, (const double*)A.sval, tcol, A.coded ? nullptr : (double*)tval);
-				if (A.coded) k_slice_decode<double><<<nb2, kBlock, 0, e->stream>>>(A.geom, rp, A.codes, A.code_ptr, A.dict, (double*)tval, A.tmpl == 2 ? 1 : 0);
-			}
-			if (A.rrowptr) {
-				// merge the shared-offset entries back into every row
-				int32_t* fcol = nullptr;
-				void* fval = nullptr;
-				if (hipMalloc(&fcol, sizeof(int32_t) * (size_t)A.nnz) != hipSuccess || hipMalloc(&fval, e->esz * (size_t)A.nnz) != hipSuccess) {
-					(void)hipFree(tcol);
-					(void)hipFree(tval);
-					if (fcol) (void)hipFree(fcol);
-					return fail(LPP_ERR_NOMEM, "lpp_engine_get_csr: scratch allocation failed");
-				}
-				const int nbm = (int)((A.nrows + 255) / 256);
-				if (e->is_complex)
-					k_dia_merge<cplx><<<nbm, 256, 0, e->stream>>>(A.geom, A.rowptr, rp, tcol, (const cplx*)tval, A.dia_stride, A.dia_off, (const cplx*)A.dia_val, fcol, (cplx*)fval, A.dcode, A.dict);
-				else
-					k_dia_merge<double><<<nbm, 256, 0, e->stream>>>(A.geom, A.rowptr, rp, tcol, (const double*)tval, A.dia_stride, A.dia_off, (const double*)A.dia_val, fcol, (double*)fval, A.dcode, A.dict);
-				(void)hipStreamSynchronize(e->stream);
-				(void)hipFree(tcol);
-				(void)hipFree(tval);
-				tcol = fcol;
-				tval = fval;
-			}
-			hipError_t err = hipStreamSynchronize(e->stream);
-			if (err == hipSuccess) err = hipGetLastError();
-			if (err != hipSuccess) {
-				(void)hipFree(tcol);
-				(void)hipFree(tval);
-				return fail(LPP_ERR_HIP, std::string("lpp_engine_get_csr: ") + hipGetErrorString(err));
-			}
-			dcol = tcol;
-			dval = tval;
+			lpp_status st = e->is_complex ? rebuild_csr_t<cplx>(e, A, scol, sval) : rebuild_csr_t<double>(e, A, scol, sval);
+			if (st != LPP_OK) return st;
+			dcol = (const int32_t*)scol.p;
+			dval = sval.p;
 		}
-		hipError_t e1 = colind ? hipMemcpy(colind, dcol, sizeof(int32_t) * (size_t)A.nnz, hipMemcpyDeviceToHost) : hipSuccess;
-		hipError_t e2 = values ? hipMemcpy(values, dval, e->esz * (size_t)A.nnz, hipMemcpyDeviceToHost) : hipSuccess;
-		if (tcol) (void)hipFree(tcol);
-		if (tval) (void)hipFree(tval);
-		if (e1 != hipSuccess || e2 != hipSuccess) return fail(LPP_ERR_HIP, "lpp_engine_get_csr: copy failed");
+		if (colind) HIP_TRY(hipMemcpy(colind, dcol, sizeof(int32_t) * (size_t)A.nnz, hipMemcpyDeviceToHost));
+		if (values) HIP_TRY(hipMemcpy(values, dval, e->esz * (size_t)A.nnz, hipMemcpyDeviceToHost));
 	}
 	return LPP_OK;
 }
