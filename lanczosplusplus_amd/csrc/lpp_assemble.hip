@@ -500,32 +500,50 @@ template <typename T> lpp_status build_kron_up(lpp_engine* e, int64_t n_up)
 		return 0;
 	};
 	const int spb = (int)((n_up + 63) / 64);
-	std::vector<int32_t> off(spb + 1, 0), len(spb, 0);
-	for (int s = 0; s < spb; s++) {
-		int64_t mx = 0;
-		for (int64_t r = (int64_t)s * 64; r < std::min<int64_t>(n_up, (int64_t)(s + 1) * 64); r++) mx = std::max(mx, rp[r + 1] - rp[r]);
-		len[s] = (int32_t)((mx + 7) / 8 * 8);
-		off[s + 1] = off[s] + len[s] * 64;
-	}
-	std::vector<uint32_t> words((size_t)off[spb] + 64, 0);
-	for (int s = 0; s < spb; s++) {
-		for (int lane = 0; lane < 64; lane++) {
-			const int64_t r = std::min<int64_t>((int64_t)s * 64 + lane, n_up - 1);
-			const bool valid = (int64_t)s * 64 + lane < n_up;
-			const int64_t l = valid ? rp[r + 1] - rp[r] : 0;
-			for (int k = 0; k < len[s]; k++) {
-				uint32_t w = (uint32_t)r; // padding: own column, value 0.0 (code 0)
-				if (k < l) {
-					const int64_t p = rp[r] + k;
+	// one packing per LDS window piece: the whole row when N_up fits LDS (nchunk = 1), otherwise nchunk pieces of cw
+	// columns, each holding the entries whose column lies in the piece, with columns relative to it
+	const int64_t cap = (int64_t)((156 * 1024) / sizeof(T));
+	const int nchunk = (int)std::max<int64_t>(1, (n_up + cap - 1) / cap);
+	const int64_t cw = nchunk == 1 ? std::max<int64_t>(n_up, 64) : (((n_up + nchunk - 1) / nchunk + 63) / 64) * 64;
+	std::vector<int32_t> off((size_t)nchunk * (spb + 1), 0), len((size_t)nchunk * spb, 0);
+	std::vector<uint32_t> words;
+	std::vector<int64_t> cnt(64);
+	for (int c = 0; c < nchunk; c++) {
+		const int64_t c0 = (int64_t)c * cw, c1 = std::min<int64_t>(c0 + cw, n_up);
+		int32_t* offc = off.data() + (size_t)c * (spb + 1);
+		int32_t* lenc = len.data() + (size_t)c * spb;
+		for (int s2 = 0; s2 < spb; s2++) {
+			int64_t mx = 0;
+			for (int64_t r = (int64_t)s2 * 64; r < std::min<int64_t>(n_up, (int64_t)(s2 + 1) * 64); r++) {
+				int64_t n = 0;
+				for (int64_t p = rp[r]; p < rp[r + 1]; p++) n += (ci[p] >= c0 && ci[p] < c1) ? 1 : 0;
+				mx = std::max(mx, n);
+			}
+			lenc[s2] = (int32_t)((mx + 7) / 8 * 8);
+			offc[s2] = (int32_t)words.size();
+			words.resize(words.size() + (size_t)lenc[s2] * 64, 0u); // padding: column 0 of the piece, value 0.0 (code 0)
+			for (int lane = 0; lane < 64; lane++) {
+				const int64_t r = (int64_t)s2 * 64 + lane;
+				if (r >= n_up) continue;
+				int k = 0;
+				for (int64_t p = rp[r]; p < rp[r + 1]; p++) {
+					if (ci[p] < c0 || ci[p] >= c1) continue;
+					uint32_t w;
 					if (ncomp == 2)
-						w = (uint32_t)ci[p] | (code_of(va[(size_t)p * 2]) << 16) | (code_of(va[(size_t)p * 2 + 1]) << 24);
+						w = (uint32_t)(ci[p] - c0) | (code_of(va[(size_t)p * 2]) << 16) | (code_of(va[(size_t)p * 2 + 1]) << 24);
 					else
-						w = (uint32_t)ci[p] | (code_of(va[p]) << 24);
+						w = (uint32_t)(ci[p] - c0) | (code_of(va[p]) << 24);
+					words[(size_t)offc[s2] + (size_t)k * 64 + lane] = w;
+					k++;
 				}
-				words[(size_t)off[s] + (size_t)k * 64 + lane] = w;
 			}
 		}
+		offc[spb] = (int32_t)words.size();
+		if (words.size() > ((size_t)1 << 30)) return fail(LPP_ERR_INVALID, "setup_hubbard_onthefly: packed H_up too large");
 	}
+	words.resize(words.size() + 64, 0u);
+	K.pk_nchunk = nchunk;
+	K.pk_cw = (int)cw;
 	dict.resize(256, 0.0);
 	HIP_TRY_MEM(hipMalloc(&K.pk_words, sizeof(uint32_t) * words.size()));
 	HIP_TRY_MEM(hipMalloc(&K.pk_off, sizeof(int32_t) * off.size()));
@@ -639,7 +657,7 @@ lpp_status lpp_engine_setup_hubbard_onthefly(lpp_engine* e, const lpp_comm* comm
 	K.equiv_nnz = (double)nid * ((double)n_up + off_up) + (double)n_up * off_dn_total * ((double)nid / (double)n_dn);
 	if (multi && comm->exchange_begin && comm->exchange_end && comm->xchg_chunk > 0) {
 		const int64_t per = (n_dn + comm->nranks - 1) / comm->nranks, peru = (n_up + comm->nranks - 1) / comm->nranks;
-		if (!K.packed) return fail(LPP_ERR_INVALID, "setup_hubbard_onthefly: the transposition exchange needs the packed H_up layout");
+		if (!K.packed || K.pk_nchunk > 1) return fail(LPP_ERR_INVALID, "setup_hubbard_onthefly: the transposition exchange needs the packed H_up layout with N_up inside the LDS window");
 		if (!comm->send2_buf || !comm->recv2_buf || comm->xchg_chunk != per * peru)
 			return fail(LPP_ERR_INVALID, "setup_hubbard_onthefly: transposition exchange needs send2/recv2 buffers and xchg_chunk == ceil(N_down/P)*ceil(N_up/P)");
 		e->tx = true;
@@ -724,6 +742,23 @@ template <typename T> static int kron_launch_t(lpp_engine* e, const void* ywin, 
 		int nbp = (int)std::max<int64_t>(1, std::min<int64_t>(pa.nid, (int64_t)e->num_cus * pcu));
 		if (nbp >= 8) nbp &= ~7;
 		const bool dotp = partial != nullptr;
+		if (K.pk_nchunk > 1) { // N_up exceeds LDS: staged in pieces (single exchange-free product only)
+			if (part != 0) return -1;
+			KronChunkArgs<T> ca;
+			ca.k = pa;
+			ca.nchunk = K.pk_nchunk;
+			ca.cw = K.pk_cw;
+			const size_t ldsc = sizeof(T) * (size_t)K.pk_cw;
+			const int nbc = (int)std::max<int64_t>(1, std::min<int64_t>(pa.nid, (int64_t)e->num_cus));
+			if (dotp) {
+				(void)hipFuncSetAttribute((const void*)k_spmv_kron_chunked<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsc);
+				k_spmv_kron_chunked<T, true><<<nbc, kWinThreads, ldsc, e->stream>>>(ca);
+			} else {
+				(void)hipFuncSetAttribute((const void*)k_spmv_kron_chunked<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsc);
+				k_spmv_kron_chunked<T, false><<<nbc, kWinThreads, ldsc, e->stream>>>(ca);
+			}
+			return dotp ? nbc : 0;
+		}
 #define LPP_KP(DOT_, WIN_)                                                                                            \
 	do {                                                                                                              \
 		(void)hipFuncSetAttribute((const void*)k_spmv_kron_packed<T, DOT_, WIN_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb); \

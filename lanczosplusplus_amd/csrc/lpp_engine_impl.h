@@ -82,6 +82,7 @@ struct KronState {
 	int32_t *pk_off = nullptr, *pk_len = nullptr;
 	double* pk_dict = nullptr;
 	int pk_spb = 0;
+	int pk_nchunk = 1, pk_cw = 0; // LDS window pieces of the packed H_up (N_up beyond LDS: see k_spmv_kron_chunked)
 };
 
 } // namespace lpp

@@ -342,6 +342,132 @@ __global__ __launch_bounds__(kWinThreads) void k_spmv_kron_packed(KronPackedArgs
 	}
 }
 
+// ---------------------------------------------------------------------------------------------
+// Chunked-window variant for one-species spaces that exceed LDS (3x6 lattice: N_up = 48620 doubles = 389 KB).
+// Without a window every up-hop is a scattered 8-byte global gather, i.e. 64 L1 tag accesses per wave instruction
+// (measured: the L1, not L2 or HBM, bounds that shape), 80 of the 131 ms of a 2.36e9-state product.  Here the block's
+// source row y[id][:] is staged in nchunk pieces of `cw` columns; H_up is packed once per piece (entries whose column
+// lies in the piece, columns relative to it), and pass c adds the piece's contribution to x: pass 0 also applies the
+// down-hops, the U diagonal and beta*x_old.  x is re-read between passes, but one block of x (389 KB) stays in L2.
+// ---------------------------------------------------------------------------------------------
+template <typename T> struct KronChunkArgs {
+	KronPackedArgs<T> k; // words / slice_off / slice_len hold nchunk consecutive packings: off[c*(spb+1)+j], len[c*spb+j]
+	int nchunk;
+	int cw; // columns per piece (multiple of 64)
+};
+
+template <typename T, bool DOT>
+__global__ __launch_bounds__(kWinThreads) void k_spmv_kron_chunked(KronChunkArgs<T> ca)
+{
+	const KronPackedArgs<T>& a = ca.k;
+	extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+	T* lds = (T*)lds_raw;
+	__shared__ double smem[kWinThreads / 64];
+	__shared__ double dict_s[256];
+	__shared__ double U_s[32];
+	__shared__ long long doff_s[kKronDownCap];
+	__shared__ T dval_s[kKronDownCap];
+	__shared__ int next_slice;
+	for (int i = threadIdx.x; i < 256; i += kWinThreads) dict_s[i] = a.dict[i];
+	double alpha, beta;
+	epi_coeffs(a.sc, alpha, beta);
+	if (threadIdx.x < 32) U_s[threadIdx.x] = (int)threadIdx.x < a.L ? a.U[threadIdx.x] : 0.0;
+	const int lane = threadIdx.x & 63;
+	double dot = 0.0;
+	for (int64_t blk = blockIdx.x; blk < a.nid; blk += gridDim.x) {
+		const int64_t gid = a.id0 + blk;
+		const T* yblk = a.ywin + blk * a.n_up;
+		T* xblk = a.x + blk * a.n_up;
+		const int64_t p0 = a.dn_rowptr[gid];
+		const int ndn = (int)(a.dn_rowptr[gid + 1] - p0);
+		const uint32_t dnw = a.dn_words[gid];
+		for (int c = 0; c < ca.nchunk; c++) {
+			const int64_t c0 = (int64_t)c * ca.cw, c1 = min(c0 + ca.cw, a.n_up);
+			__syncthreads(); // previous pass fully consumed (window piece, H_down row)
+			if (threadIdx.x == 0) next_slice = 0;
+			for (int64_t i0 = c0 + threadIdx.x; i0 < c1; i0 += 8 * kWinThreads) {
+				T t[8];
+#pragma unroll
+				for (int q = 0; q < 8; q++) t[q] = yblk[min(i0 + (int64_t)q * kWinThreads, c1 - 1)];
+#pragma unroll
+				for (int q = 0; q < 8; q++)
+					if (i0 + (int64_t)q * kWinThreads < c1) lds[i0 - c0 + (int64_t)q * kWinThreads] = t[q];
+			}
+			if (c == 0 && (int)threadIdx.x < kKronDownCap) {
+				const bool in = (int)threadIdx.x < ndn;
+				doff_s[threadIdx.x] = (long long)(in ? a.dn_col[p0 + threadIdx.x] : (int32_t)gid) * a.n_up;
+				dval_s[threadIdx.x] = in ? a.dn_val[p0 + threadIdx.x] : VT<T>::zero();
+			}
+			__syncthreads();
+			const int ngroups = c == 0 ? ((min(ndn, kKronDownCap) + 7) >> 3) : 0;
+			const int32_t* offc = a.slice_off + (int64_t)c * (a.spb + 1);
+			const int32_t* lenc = a.slice_len + (int64_t)c * a.spb;
+			for (int j = next_slice_claim(&next_slice); j < a.spb; j = next_slice_claim(&next_slice)) {
+				const int iu_raw = j * 64 + lane;
+				const bool valid = iu_raw < a.n_up;
+				const int iu = valid ? iu_raw : (int)a.n_up - 1;
+				const T xold = xblk[iu];
+				const uint32_t* wp = a.words + offc[j] + lane;
+				const int ml = lenc[j]; // multiple of 8
+				uint32_t w0[8], w1[8];
+				if (ml > 0) {
+#pragma unroll
+					for (int q = 0; q < 8; q++) w0[q] = wp[q * 64];
+				}
+				T acc = VT<T>::zero();
+				T yc = VT<T>::zero();
+				if (c == 0 || (DOT && c == ca.nchunk - 1)) yc = yblk[iu];
+				if (c == 0) {
+					T g0[8], g1[8];
+					const T* yd = a.ydown + iu;
+					if (ngroups > 0) {
+#pragma unroll
+						for (int q = 0; q < 8; q++) g0[q] = yd[doff_s[q]];
+					}
+					for (int gk = 0; gk < ngroups; gk++) {
+						if (gk + 1 < ngroups) {
+#pragma unroll
+							for (int q = 0; q < 8; q++) g1[q] = yd[doff_s[(gk + 1) * 8 + q]];
+						}
+#pragma unroll
+						for (int q = 0; q < 8; q++) VT<T>::mac(acc, dval_s[gk * 8 + q], g0[q]);
+#pragma unroll
+						for (int q = 0; q < 8; q++) g0[q] = g1[q];
+					}
+					for (int p = kKronDownCap; p < ndn; p++) VT<T>::mac(acc, a.dn_val[p0 + p], yd[(int64_t)a.dn_col[p0 + p] * a.n_up]);
+					// Hubbard U on the doubly occupied sites
+					double ud = 0.0;
+					for (uint32_t m = a.up_words[iu] & dnw; m; m &= m - 1) ud += U_s[__ffs((int)m) - 1];
+					T t = yc;
+					double* td = (double*)&t;
+					td[0] *= ud;
+					if (sizeof(T) == 16) td[1] *= ud;
+					acc = VT<T>::add(acc, t);
+				}
+				for (int k = 0; k < ml; k += 8) {
+					if (k + 8 < ml) {
+#pragma unroll
+						for (int q = 0; q < 8; q++) w1[q] = wp[(k + 8 + q) * 64];
+					}
+#pragma unroll
+					for (int q = 0; q < 8; q++) VT<T>::mac(acc, kron_decode<T>(w0[q], dict_s), lds[kron_col<T>(w0[q])]);
+#pragma unroll
+					for (int q = 0; q < 8; q++) w0[q] = w1[q];
+				}
+				if (valid) {
+					const T xv = epi_lin(c == 0 ? beta : 1.0, xold, alpha, acc);
+					xblk[iu] = xv;
+					if (DOT && c == ca.nchunk - 1) dot += VT<T>::dot_re(yc, xv);
+				}
+			}
+		}
+	}
+	if (DOT) {
+		const double r = block_sum_n<kWinThreads / 64>(dot, smem);
+		if (threadIdx.x == 0) a.partial[blockIdx.x] = r;
+	}
+}
+
 // basis words of one species: word(i) = i-th L-bit word with n set bits, ascending
 static __global__ void k_basis_words(const uint64_t* __restrict__ comb, int combdim, int64_t count, int nbits, int L,
                                      uint32_t* __restrict__ out)
