@@ -5,6 +5,8 @@
 
 #include <algorithm>
 #include <cmath>
+#include <chrono>
+#include <cstdio>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -77,6 +79,7 @@ template <int MODEL, typename T>
 lpp_status run_assembly(lpp_engine* e, AsmParams P, DevCsr& A, int force_mode = 0, int64_t force_block = 0)
 {
 	hipStream_t st = e->stream;
+	const auto t_asm0 = std::chrono::steady_clock::now();
 	const int64_t keep_src = A.src_elems;
 	free_csr(A);
 	A.src_elems = keep_src;
@@ -106,6 +109,8 @@ lpp_status run_assembly(lpp_engine* e, AsmParams P, DevCsr& A, int force_mode = 
 	if (P.nloc > 0) k_asm_fill<MODEL, T><<<nb, kBlock, 0, st>>>(P, A.rowptr, A.col, (T*)A.val);
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipStreamSynchronize(st));
+	if (getenv("LPP_VERBOSE"))
+		fprintf(stderr, "lpp: %-28s %8.1f ms\n", "assembly (count, scan, fill)", 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t_asm0).count());
 	return finalize_csr(e, A, true, force_mode, force_block);
 }
 

@@ -215,6 +215,18 @@ template <typename T> static lpp_status try_build_dict(lpp_engine* e, DevCsr& A,
 	return LPP_OK;
 }
 
+// LPP_VERBOSE=1: wall-clock of the one-off layout stages on stderr
+struct StageTimer {
+	const char* what;
+	bool on;
+	std::chrono::steady_clock::time_point t0;
+	explicit StageTimer(const char* w) : what(w), on(getenv("LPP_VERBOSE") != nullptr), t0(std::chrono::steady_clock::now()) { }
+	~StageTimer()
+	{
+		if (on) fprintf(stderr, "lpp: %-28s %8.1f ms\n", what, 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+	}
+};
+
 // in-place exclusive scan of arr[0..n) (arr[n-1] must be 0 on entry and receives the total, also returned)
 static lpp_status scan_exclusive(lpp_engine* e, int64_t* arr, int64_t n, int64_t* total_out)
 {
@@ -345,6 +357,7 @@ template <typename T> static lpp_status build_sliced_t(lpp_engine* e, DevCsr& A,
 	if (const char* s = getenv("LPP_COMPRESS_VALUES")) want = atoi(s);
 	bool coded = false;
 	if (want != 0) {
+		StageTimer tm("value dictionary");
 		lpp_status st = try_build_dict<T>(e, A, vv, nz, &coded);
 		if (st != LPP_OK) return st;
 	}
@@ -352,6 +365,7 @@ template <typename T> static lpp_status build_sliced_t(lpp_engine* e, DevCsr& A,
 	if (const char* s = getenv("LPP_SHARED_OFFSETS")) want_dia = A.no_dia ? 0 : atoi(s);
 	const bool xdiag = for_window && coded && !(getenv("LPP_DIAG_CODES") && atoi(getenv("LPP_DIAG_CODES")) == 0);
 	if (want_dia && A.nnz > 0) {
+		StageTimer tm("shared-offset split");
 		lpp_status st = split_dia_t<T>(e, A, g, for_window, xdiag, &rcol, &rval);
 		if (st != LPP_OK) return st;
 		if (A.rrowptr) {
@@ -553,10 +567,12 @@ lpp_status finalize_csr(lpp_engine* e, DevCsr& A, bool allow_drop_plain, int for
 	if ((mode == LPP_SPMV_SLICED || mode == LPP_SPMV_WINDOW) && A.nrows > 0) {
 		const int64_t B = force_block > 0 ? force_block : ((mode == LPP_SPMV_WINDOW) ? win_rows : A.nrows);
 		const bool win = (mode == LPP_SPMV_WINDOW);
+		StageTimer tm("sliced layout (total)");
 		lpp_status st = e->is_complex ? build_sliced_t<cplx>(e, A, B, win) : build_sliced_t<double>(e, A, B, win);
 		if (st != LPP_OK) return st;
 		A.window = (mode == LPP_SPMV_WINDOW);
 		if (allow_drop_plain && getenv("LPP_KEEP_PLAIN_CSR") == nullptr && A.owned) {
+			StageTimer tm("release plain CSR");
 			// the sliced copy is the resident one; release the plain arrays (frees ~12 B/nnz)
 			(void)hipFree(A.col);
 			(void)hipFree(A.val);
