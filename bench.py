@@ -65,6 +65,8 @@ WORKLOADS = {
     "hubbard_3x6_half_filling_pbc_U4": ("hubbard", dict(L=18, nup=9, ndown=9, hop=lambda: square_lattice(3, 6, -1.0), U=4.0)),
     "hubbard_chain_L12_half_filling_U4": ("hubbard", dict(L=12, nup=6, ndown=6, hop=lambda: chain(12, -1.0), U=4.0)),
     "hubbard_chain_L14_half_filling_U4": ("hubbard", dict(L=14, nup=7, ndown=7, hop=lambda: chain(14, -1.0), U=4.0)),
+    # complex hoppings (Peierls phase on every bond): the reference's SolverOptions=useComplex path
+    "hubbard_chain_L14_complex_U4": ("hubbard", dict(L=14, nup=7, ndown=7, hop=lambda: chain(14, -1.0) * np.where(np.triu(np.ones((14, 14)), 1) > 0, np.exp(0.2j), np.exp(-0.2j)), U=4.0)),
     "heisenberg_chain_L28_sz0_obc": ("heisenberg", dict(L=28, sz=14, j=1.0, pbc=False)),
     "heisenberg_chain_L24_sz0_obc": ("heisenberg", dict(L=24, sz=12, j=1.0, pbc=False)),
     "tj_4x5_9up9down_complex": ("tj", dict(L=20, nup=9, ndown=9, lx=5, ly=4, t=-1.0, j=0.4)),
@@ -179,7 +181,7 @@ def main():
     torch.cuda.set_device(local_rank)
     name = args.workload
     model, p = WORKLOADS[name]
-    is_complex = model == "tj"
+    is_complex = model == "tj" or "complex" in name
     max_steps = args.steps + args.warmup + 2
 
     comm = None
