@@ -445,3 +445,40 @@ def test_shared_offsets_beyond_the_per_slice_capacity(cplx):
         assert rel(e.matrixVectorProduct(x0.copy(), y), oracle.spmv_acc(A, x0.copy(), y)) < SPMV_TOL
         rp, c2, v2 = e.get_csr()
         assert np.array_equal(rp, A.rowptr) and np.array_equal(c2, A.colind) and np.array_equal(_bits(v2), _bits(A.values))
+
+
+def test_engine_reuse_across_matrices_and_engines():
+    """One engine takes a sequence of different matrices (device-assembled, uploaded with and without a row-block hint,
+    matrix-free) and every product / solve is right; a second engine alive at the same time does not disturb it."""
+    L = 10
+    hop = chain(L, -1.0, True)
+    H1 = oracle.hubbard_csr(L, 5, 5, hop, np.full(L, 4.0))          # N_up = 252
+    H2 = oracle.heis_csr(14, 1, 7, chain(14, 1.0), chain(14, 1.0))  # other size, no block structure
+    H3 = oracle.hubbard_csr(8, 4, 3, chain(8, -1.0), np.linspace(1, 3, 8))
+
+    def check(e, A):
+        x0, y = oracle.fill_random(A.nrows, 3), oracle.fill_random(A.nrows, 4)
+        assert rel(e.matrixVectorProduct(x0.copy(), y), oracle.spmv_acc(A, x0.copy(), y)) < SPMV_TOL
+        eo = oracle.lanczos_solve(A, oracle.fill_random(A.nrows, 1234), want_vectors=False)[0][0]
+        eg = e.computeAllStatesBelow(1, want_vectors=False)[0][0]
+        assert abs(eg - eo) <= E_TOL * abs(eo)
+
+    with LanczosEngine(max_steps=300) as e, LanczosEngine(max_steps=300) as other:
+        other.assemble_heisenberg(12, 6, chain(12, 1.0, True), chain(12, 1.0, True))
+        e.assemble_hubbard(L, 5, 5, hop, np.full(L, 4.0))
+        check(e, H1)
+        e.set_csr(H2.rowptr, H2.colind, H2.values)                  # smaller matrix, hint still 0
+        check(e, H2)
+        e.set_row_block(252)
+        e.set_csr(H1.rowptr, H1.colind, H1.values)                  # uploaded with the basis block
+        check(e, H1)
+        e.setup_hubbard_onthefly(L, 5, 5, hop, np.full(L, 4.0))     # matrix-free on the same engine
+        check(e, H1)
+        e.set_row_block(0)
+        e.set_csr(H3.rowptr, H3.colind, H3.values)
+        check(e, H3)
+        a, b, st = e.decomposition()
+        assert st["steps"] >= 4 and len(a) == len(b) == st["steps"]
+        rp, ci, va = other.get_csr()
+        O = oracle.heis_csr(12, 1, 6, chain(12, 1.0, True), chain(12, 1.0, True), literal_index=True)
+        assert np.array_equal(rp, O.rowptr) and np.array_equal(ci, O.colind) and np.array_equal(_bits(va), _bits(O.values))
