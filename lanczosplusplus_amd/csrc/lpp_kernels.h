@@ -544,6 +544,10 @@ __device__ __forceinline__ void slice_meta(const SlicedArgs<T>& a, int64_t s, in
 {
 	const int lane = threadIdx.x & 63;
 	slice_rows(a.g, s, row0, nvalid);
+	len = 0;
+	base = 0;
+	cbase = 0;
+	if (CODED && a.tw) return; // the packed template is walked instead (tmpl_accumulate): no per-row metadata needed
 	const int64_t r = (lane < nvalid) ? row0 + lane : min(row0, a.g.nrows - 1);
 	// block-periodic structure: lengths and column stream of the same slice of block 0 (L2-resident)
 	const int64_t blk = a.tmpl ? s / a.g.spb : 0;
