@@ -516,7 +516,11 @@ __device__ __forceinline__ double sliced_one(const SlicedArgs<T>& a, int64_t row
 	uint32_t dc = 0; // code(s) of the diagonal value, when it travels apart from the per-row entries
 	if (CODED && a.dcode) dc = sizeof(T) == 16 ? (uint32_t)((const uint16_t*)a.dcode)[row] : (uint32_t)a.dcode[row];
 	DiaPre<T> pre;
-	const int dcnt = __popcll(__ballot(dm.off != kDiaNone)); // wave-uniform
+	// shared entries of the slice: a leading run of places (global gathers) and a trailing run (inside the LDS window)
+	const unsigned long long dmask = __ballot(dm.off != kDiaNone);
+	const int dcnt = dmask == ~0ull ? 64 : __ffsll((long long)~dmask) - 1; // wave-uniform
+	int wcnt = 0;
+	if (WINDOW && a.dia_stride > 0) wcnt = __clzll((long long)~(dmask << (64 - a.dia_stride)));
 	dia_request<T>(a, dm, dcnt, (uint32_t)row, pre);
 	T acc;
 	if (LOCAL16 && CODED && a.tw) // wave-uniform
@@ -524,6 +528,13 @@ __device__ __forceinline__ double sliced_one(const SlicedArgs<T>& a, int64_t row
 	else
 		acc = sliced_accumulate<T, WINDOW, CODED, U, LOCAL16>(a, len, base, cbase, lds, r0, wlen, dict, (int32_t)row);
 	dia_consume<T>(a, dm, dcnt, (uint32_t)row, pre, acc);
+	if (WINDOW) {
+		for (int i = 0; i < wcnt; i++) { // contiguous 64-element runs of the window: conflict-free LDS reads, scalar offset/value
+			const int place = a.dia_stride - 1 - i;
+			const int32_t o = __builtin_amdgcn_readlane(dm.off, place);
+			VT<T>::mac(acc, readlane_t(dm.val, place), lds[(uint32_t)((int32_t)row - r0 + o)]);
+		}
+	}
 	if (CODED && a.dcode) {
 		const T ys = WINDOW ? lds[(uint32_t)((int32_t)row - r0)] : ld_off32(a.src, (uint32_t)row);
 		VT<T>::mac(acc, CodeTraits<T>::decode(dc, 0, dict), ys);
@@ -811,8 +822,9 @@ __device__ __forceinline__ uint32_t dict_code(const double* dict, int ndict, dou
 // One wave per slice.  FILL == false: rest_len[row] = entries the row keeps; stats[0] = max shared entries of any slice,
 // stats[1] = shared entries summed over slices.  FILL == true (after the scan of rest_len): writes the rest CSR
 // (rcol/rval at rrowptr) and the shared lists at dia_off/dia_val[s*stride ..] (pre-filled with kDiaNone / 0).
-// win != 0: the matrix is built for the LDS-window kernel; entries whose whole 64-row run lies inside the row block stay
-// per-row entries (served from LDS, 3 bytes each) instead of becoming global gathers.
+// win != 0: the matrix is built for the LDS-window kernel; shared entries whose whole 64-row run lies inside the row block
+// are listed from the END of the slice's places (stride-1 downwards) and are read from the LDS window, the others from
+// place 0 upwards and are gathered from global memory; at least one empty place separates the two groups.
 // xdiag != 0: the diagonal entry of every row is taken out of the per-row entries as well (FILL: its dictionary code(s)
 // go to dcode[row]); stats[2] counts rows WITHOUT a diagonal entry (the caller then repeats the count with xdiag = 0).
 template <typename T, bool FILL>
@@ -863,7 +875,8 @@ __global__ __launch_bounds__(kBlock) void k_dia_split(SliceGeom g, const int64_t
 		const int64_t blk0 = (s / g.spb) * g.B, blk1 = blk0 + g.B;
 		const unsigned long long vmask = __ballot(valid);
 		int64_t wp = (FILL && valid) ? rrowptr[row] : 0;
-		int nd = 0;
+		int nd = 0; // shared entries gathered from global memory: places 0, 1, ... of the slice's list
+		int nw = 0; // shared entries whose whole run lies inside the LDS window: places stride-1, stride-2, ...
 		for (int k = 0; k < len0; k++) {
 			const int32_t c0 = col[p00 + k];
 			const T v0 = val[p00 + k];
@@ -876,12 +889,18 @@ __global__ __launch_bounds__(kBlock) void k_dia_split(SliceGeom g, const int64_t
 			bool ok = valid && q < end && (int64_t)col[q] == target;
 			if (ok) ok = same_bits<T>(val[q], v0);
 			const bool in_block = win && row0 + off >= blk0 && row0 + (nvalid - 1) + off < blk1;
-			if (__ballot(ok) == vmask && !in_block && nd < kDiaMax) { // shared by every valid row of the slice
+			// shared by every valid row of the slice (the diagonal, when it is split off, has its own stream); one place
+			// of the list always stays empty between the two groups
+			if (__ballot(ok) == vmask && !(xdiag && off == 0) && nd + nw < kDiaMax - 2) {
 				if (FILL && lane == 0) {
-					dia_off[s * stride + nd] = (int32_t)off;
-					dia_val[s * stride + nd] = v0;
+					const int64_t place = in_block ? s * stride + (stride - 1 - nw) : s * stride + nd;
+					dia_off[place] = (int32_t)off;
+					dia_val[place] = v0;
 				}
-				nd++;
+				if (in_block)
+					nw++;
+				else
+					nd++;
 				q++;
 			}
 		}
@@ -890,10 +909,10 @@ __global__ __launch_bounds__(kBlock) void k_dia_split(SliceGeom g, const int64_t
 			q++;
 		}
 		if (!FILL) {
-			if (valid) rest_len[row] = (end - pbeg) - nd - ndg;
+			if (valid) rest_len[row] = (end - pbeg) - nd - nw - ndg;
 			if (valid && xdiag && ndg == 0) local_nodiag++;
-			local_max = max(local_max, (unsigned long long)nd);
-			local_sum += (unsigned long long)nd;
+			local_max = max(local_max, (unsigned long long)(nd + nw + 1));
+			local_sum += (unsigned long long)(nd + nw);
 		}
 	}
 #undef LPP_KEEP_ENTRY
@@ -906,7 +925,8 @@ __global__ __launch_bounds__(kBlock) void k_dia_split(SliceGeom g, const int64_t
 	}
 }
 
-// inverse (lpp_engine_get_csr): merge a row's rest entries with its slice's shared entries by column
+// inverse (lpp_engine_get_csr): merge a row's rest entries with its slice's shared entries (both groups) and its
+// diagonal code by column
 template <typename T>
 __global__ void k_dia_merge(SliceGeom g, const int64_t* __restrict__ rowptr, const int64_t* __restrict__ rrowptr,
                             const int32_t* __restrict__ rcol, const T* __restrict__ rval, int stride,
@@ -917,24 +937,30 @@ __global__ void k_dia_merge(SliceGeom g, const int64_t* __restrict__ rowptr, con
 	if (r >= g.nrows) return;
 	const int64_t blk = r / g.B;
 	const int64_t s = blk * g.spb + (r - blk * g.B) / 64;
-	int64_t i = rrowptr[r], iend = rrowptr[r + 1], d = s * stride, dend = d + stride, o = rowptr[r];
+	int64_t i = rrowptr[r], iend = rrowptr[r + 1], o = rowptr[r];
+	int64_t d = s * stride, w = s * stride + stride - 1; // global group ascends from the front, window group from the back
+	const int64_t dlim = s * stride + stride, wlim = s * stride;
 	bool hg = dcode != nullptr; // the row's diagonal, when it was split off
 	while (true) {
-		const bool hd = d < dend && dia_off[d] != kDiaNone, hi = i < iend;
-		if (!hd && !hi && !hg) break;
+		const bool hd = d < dlim && dia_off[d] != kDiaNone, hw = stride > 0 && w >= wlim && w >= d && dia_off[w] != kDiaNone, hi = i < iend;
+		if (!hd && !hw && !hi && !hg) break;
 		const int64_t cd = hd ? r + (int64_t)dia_off[d] : INT64_MAX;
+		const int64_t cw = hw ? r + (int64_t)dia_off[w] : INT64_MAX;
 		const int64_t ci = hi ? (int64_t)rcol[i] : INT64_MAX;
-		if (hg && r < cd && r < ci) {
-			col_out[o] = (int32_t)r;
-			const uint32_t c = sizeof(T) == 16 ? (uint32_t)((const uint16_t*)dcode)[r] : (uint32_t)dcode[r];
-			val_out[o] = CodeTraits<T>::decode(c, 0, dict);
+		const int64_t cg = hg ? r : INT64_MAX;
+		const int64_t c = min(min(cd, cw), min(ci, cg));
+		col_out[o] = (int32_t)c;
+		if (c == cg) {
+			const uint32_t cc = sizeof(T) == 16 ? (uint32_t)((const uint16_t*)dcode)[r] : (uint32_t)dcode[r];
+			val_out[o] = CodeTraits<T>::decode(cc, 0, dict);
 			hg = false;
-		} else if (cd < ci) {
-			col_out[o] = (int32_t)cd;
+		} else if (c == cd) {
 			val_out[o] = dia_val[d];
 			d++;
+		} else if (c == cw) {
+			val_out[o] = dia_val[w];
+			w--;
 		} else {
-			col_out[o] = (int32_t)ci;
 			val_out[o] = rval[i];
 			i++;
 		}
