@@ -482,3 +482,81 @@ def test_engine_reuse_across_matrices_and_engines():
         rp, ci, va = other.get_csr()
         O = oracle.heis_csr(12, 1, 6, chain(12, 1.0, True), chain(12, 1.0, True), literal_index=True)
         assert np.array_equal(rp, O.rowptr) and np.array_equal(ci, O.colind) and np.array_equal(_bits(va), _bits(O.values))
+
+
+def _random_structured_csr(rng, cplx, product_like=False):
+    """Random matrices that exercise the layout machinery: a block-periodic in-block pattern (sometimes perturbed in one
+    block), block-shifted couplings shared by all rows of a block (sometimes broken in one row), a diagonal that is
+    present / absent / few-valued / many-valued, values from a small or a large set, last block possibly partial."""
+    B = int(rng.choice([520, 576, 700])) if product_like else int(rng.choice([64, 70, 128, 200, 520, 700]))
+    nblocks = int(rng.integers(2, 9))
+    n = B * nblocks - (int(rng.integers(0, B // 2)) if (rng.random() < 0.3 and not product_like) else 0)
+    few = True if product_like else rng.random() < 0.7
+    pool = rng.standard_normal(4) if few else None
+
+    def value():
+        v = rng.choice(pool) if few else rng.standard_normal()
+        if cplx:
+            v = v + 1j * (rng.choice(pool) if few else rng.standard_normal())
+        return v
+
+    local = {}  # block-periodic pattern: local row -> {local col: value}
+    for r in range(B):
+        cols = rng.choice(B, size=int(rng.integers(0, 7)), replace=False)
+        local[r] = {int(c): value() for c in cols if c != r}
+    shifts = {int(k): value() for k in rng.choice(np.arange(-3, 4), size=int(rng.integers(0, 5)), replace=False) if k != 0}
+    diag_mode = rng.choice(["all_few", "all_few", "some", "none"]) if product_like else rng.choice(["all_few", "all_many", "some", "none"])
+    rows = []
+    for r in range(n):
+        b, l = divmod(r, B)
+        ent = {b * B + c: v for c, v in local[l].items() if b * B + c < n}
+        for k, v in shifts.items():
+            c = r + k * B
+            if 0 <= c < n:
+                ent[c] = v
+        if diag_mode == "all_few":
+            ent[r] = (rng.choice(pool) if few else float(rng.integers(0, 3))) + (0j if cplx else 0.0)
+        elif diag_mode == "all_many":
+            ent[r] = rng.standard_normal() + (0j if cplx else 0.0)
+        elif diag_mode == "some" and rng.random() < 0.5:
+            ent[r] = value()
+        rows.append(ent)
+    if rng.random() < (0.25 if product_like else 0.3):  # break the block periodicity / a shared run in one place
+        r = int(rng.integers(0, n))
+        c = int(rng.integers(0, n))
+        rows[r][c] = value()
+    if product_like and rng.random() < 0.3:  # same structure everywhere, but one in-block value differs in one block
+        r = int(rng.integers(B, n))
+        inblock = [c for c in rows[r] if c // B == r // B and c != r]
+        if inblock:
+            rows[r][inblock[0]] = rows[r][inblock[0]] * 2 + (pool[0] if few else 1.0)
+    rowptr, ci, va = [0], [], []
+    for ent in rows:
+        for c in sorted(ent):
+            ci.append(c)
+            va.append(ent[c])
+        rowptr.append(len(ci))
+    A = oracle.Csr(np.array(rowptr, np.int64), np.array(ci, np.int32), np.array(va, complex if cplx else float))
+    return A, B
+
+
+@pytest.mark.parametrize("seed", range(36))
+def test_layout_fuzz_spmv_and_roundtrip(seed):
+    rng = np.random.default_rng(1000 + seed)
+    cplx = bool(seed % 3 == 2)
+    product_like = seed >= 12  # block-periodic with a basis block >= 512 rows and few values: template, diagonal codes
+    A, B = _random_structured_csr(rng, cplx, product_like)
+    if A.nnz == 0:
+        pytest.skip("empty draw")
+    kernel = 3 if product_like else [2, 3, 3][seed % 3]
+    hint = B if (kernel == 3 and (product_like or rng.random() < 0.8)) else 0
+    with LanczosEngine(dtype="c128" if cplx else "f64", spmv_kernel=kernel) as e:
+        e.set_row_block(hint)
+        e.set_csr(A.rowptr, A.colind, A.values)
+        x0 = oracle.fill_random(A.nrows, 7, cplx)
+        y = oracle.fill_random(A.nrows, 8, cplx)
+        xo = oracle.spmv_acc(A, x0.copy(), y)
+        xg = e.matrixVectorProduct(x0.copy(), y)
+        assert np.max(np.abs(xg - xo)) <= 1e-12 * max(1.0, np.max(np.abs(xo))), e.layout()
+        rp, c2, v2 = e.get_csr()
+        assert np.array_equal(rp, A.rowptr) and np.array_equal(c2, A.colind) and np.array_equal(_bits(v2), _bits(A.values)), e.layout()
