@@ -55,3 +55,30 @@ def test_config2_shape_matrix_free_equals_stored_energy_with_U():
     # literature cross-check: the 4x4 periodic Hubbard cluster at U=4t, half filling, has E0 = -13.6219 t
     # (E0/N = -0.8514, exact diagonalisation results quoted since Fano, Ortolani & Parola 1990)
     assert abs(e2[0] - (-13.62185)) < 2e-4
+
+
+def test_config2_shape_products_agree_and_are_hermitian():
+    """x += H y at config 2's full size: the stored engine (compressed layout: shared offsets, block template, diagonal
+    codes) and the matrix-free engine give the same vector, the product is linear, and <u|H v> = <H u|v>."""
+    L = 16
+    hop, U = square(4, 4, -1.0, pbc=True), np.full(L, 4.0)
+    n = 12870 * 12870
+    rng = np.random.default_rng(42)
+    u = rng.standard_normal(n)
+    v = rng.standard_normal(n)
+    with LanczosEngine(save_vectors=0) as e:
+        e.assemble_hubbard(L, 8, 8, hop, U)
+        lay = e.layout()
+        assert lay["block_template"] == 2 and lay["diagonal_codes"] == 1 and lay["local16"] == 1
+        assert lay["resident_bytes"] < 6e9  # 71 GB as a plain CSR
+        hv = e.matrixVectorProduct(np.zeros(n), v)
+        hu = e.matrixVectorProduct(np.zeros(n), u)
+        acc = e.matrixVectorProduct(u.copy(), v)           # accumulate form
+        lin = e.matrixVectorProduct(np.zeros(n), 2.0 * u - 0.5 * v)
+    assert np.max(np.abs(acc - (u + hv))) <= 1e-12 * np.max(np.abs(hv))
+    assert np.max(np.abs(lin - (2.0 * hu - 0.5 * hv))) <= 1e-12 * np.max(np.abs(hv))
+    assert abs(np.dot(u, hv) - np.dot(hu, v)) <= 1e-11 * abs(np.dot(u, hv))
+    with LanczosEngine(save_vectors=0) as e:
+        e.setup_hubbard_onthefly(L, 8, 8, hop, U)
+        hv2 = e.matrixVectorProduct(np.zeros(n), v)
+    assert np.max(np.abs(hv2 - hv)) <= 1e-13 * np.max(np.abs(hv))
