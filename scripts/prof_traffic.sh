@@ -1,9 +1,9 @@
 #!/bin/bash
-# kernel times + HBM read requests of the split product (LPP_SPLIT=1)
+# kernel times (rocprofv3 --kernel-trace --stats) + L2-miss read requests (separate --pmc pass) of one bench configuration:
+#   BENCH_ARGS="--workload ... --engine ..." bash scripts/prof_traffic.sh <tag>
 R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=$(pwd)
 export TMPDIR=/tmp
-export LPP_SPLIT=${LPP_SPLIT:-1}
-TAG=${1:-split}
+TAG=${1:-traffic}
 O=$R/gpurun_out/prof_$TAG
 mkdir -p $O; cd /tmp
 B="python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline $BENCH_ARGS"
