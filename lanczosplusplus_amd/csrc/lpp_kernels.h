@@ -1194,6 +1194,21 @@ __global__ __launch_bounds__(kBlock) void k_slice_decode(SliceGeom g, const int6
 // x -= g*y ;  partial[b] = sum |x|^2     (scalars read from device memory: no host round trip)
 // g = *a_ptr (normalised recurrence) or *a_ptr / *b2_prev (scale-free recurrence: raw dot <r_j|w> over b_{j-1}^2).
 // `send` (optional) receives a copy of the new x: the slice handed to the next all-gather.
+// streamed 16-byte accesses (read once / written once per pass: keep them out of the way of the SpMV's L2 contents)
+typedef double lpp_d2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double2 nt_load2(const double2* p)
+{
+	const lpp_d2 v = __builtin_nontemporal_load((const lpp_d2*)p);
+	return double2 { v.x, v.y };
+}
+__device__ __forceinline__ void nt_store2(double2 v, double2* p)
+{
+	lpp_d2 w;
+	w.x = v.x;
+	w.y = v.y;
+	__builtin_nontemporal_store(w, (lpp_d2*)p);
+}
+
 template <bool NRM>
 __global__ __launch_bounds__(kBlock) void k_axpy_nrm(double2* __restrict__ x, const double2* __restrict__ y,
                                                       const double* __restrict__ a_ptr, const double* __restrict__ b2_prev,
@@ -1213,14 +1228,14 @@ __global__ __launch_bounds__(kBlock) void k_axpy_nrm(double2* __restrict__ x, co
 	for (; i + 3 * stride < n2; i += 4 * stride) {
 		double2 xv[4], yv[4];
 #pragma unroll
-		for (int k = 0; k < 4; k++) xv[k] = x[i + k * stride];
+		for (int k = 0; k < 4; k++) xv[k] = nt_load2(&x[i + k * stride]);
 #pragma unroll
-		for (int k = 0; k < 4; k++) yv[k] = y[i + k * stride];
+		for (int k = 0; k < 4; k++) yv[k] = nt_load2(&y[i + k * stride]);
 #pragma unroll
 		for (int k = 0; k < 4; k++) {
 			xv[k].x -= a * yv[k].x;
 			xv[k].y -= a * yv[k].y;
-			x[i + k * stride] = xv[k];
+			nt_store2(xv[k], &x[i + k * stride]);
 			if (send) send[i + k * stride] = xv[k];
 			if (NRM) s += xv[k].x * xv[k].x + xv[k].y * xv[k].y;
 		}
