@@ -1212,7 +1212,7 @@ __device__ __forceinline__ void nt_store2(double2 v, double2* p)
 template <bool NRM>
 __global__ __launch_bounds__(kBlock) void k_axpy_nrm(double2* __restrict__ x, const double2* __restrict__ y,
                                                       const double* __restrict__ a_ptr, const double* __restrict__ b2_prev,
-                                                      double2* __restrict__ send, int64_t n2, double* __restrict__ partial)
+                                                      double2* __restrict__ send, int64_t n2, double* __restrict__ partial, int stream = 0)
 {
 	__shared__ double smem[kBlock / 64];
 	double a = *a_ptr;
@@ -1228,14 +1228,17 @@ __global__ __launch_bounds__(kBlock) void k_axpy_nrm(double2* __restrict__ x, co
 	for (; i + 3 * stride < n2; i += 4 * stride) {
 		double2 xv[4], yv[4];
 #pragma unroll
-		for (int k = 0; k < 4; k++) xv[k] = nt_load2(&x[i + k * stride]);
+		for (int k = 0; k < 4; k++) xv[k] = stream ? nt_load2(&x[i + k * stride]) : x[i + k * stride];
 #pragma unroll
-		for (int k = 0; k < 4; k++) yv[k] = nt_load2(&y[i + k * stride]);
+		for (int k = 0; k < 4; k++) yv[k] = stream ? nt_load2(&y[i + k * stride]) : y[i + k * stride];
 #pragma unroll
 		for (int k = 0; k < 4; k++) {
 			xv[k].x -= a * yv[k].x;
 			xv[k].y -= a * yv[k].y;
-			nt_store2(xv[k], &x[i + k * stride]);
+			if (stream) // vectors beyond the Infinity Cache: nothing of this pass is re-read before it is evicted anyway
+				nt_store2(xv[k], &x[i + k * stride]);
+			else
+				x[i + k * stride] = xv[k];
 			if (send) send[i + k * stride] = xv[k];
 			if (NRM) s += xv[k].x * xv[k].x + xv[k].y * xv[k].y;
 		}

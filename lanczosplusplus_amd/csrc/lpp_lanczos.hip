@@ -225,8 +225,10 @@ lpp_status one_step(lpp_engine* e, const double* ritz, int nst)
 	lpp_status rc = comm_allreduce(e, e->ab_off + 2 * j, 1);
 	if (rc != LPP_OK) return rc;
 	if (e->scalefree) {
+		// streamed accesses once the two vectors no longer fit the 256 MiB Infinity Cache (measured: +4 % there, -7 % below)
+		const int stream_axpy = (size_t)e->n2 * 32 > ((size_t)256 << 20) ? 1 : 0;
 		k_axpy_nrm<true><<<nb, kBlock, 0, st>>>((double2*)xcur, (const double2*)ycur, a_ptr, b2_prev,
-		                                       (multi(e) && !e->tx) ? (double2*)e->comm.send_buf : nullptr, e->n2, e->partial);
+		                                       (multi(e) && !e->tx) ? (double2*)e->comm.send_buf : nullptr, e->n2, e->partial, stream_axpy);
 	} else if (e->cfg.reortho) {
 		k_axpy_nrm<false><<<nb, kBlock, 0, st>>>((double2*)xcur, (const double2*)ycur, a_ptr, nullptr, nullptr, e->n2, nullptr);
 		rc = cgs2(e, j + 1);
