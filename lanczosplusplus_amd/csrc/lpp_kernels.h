@@ -10,1454 +10,7 @@
 //   x += H y                         Engine/InternalProductStored.h:77,121-124
 //   a = Re<y|x>; x -= a y; b = |x|;  (y,x) <- (x/b, -b y)     LanczosSolver [PsimagLite], SURVEY 3.1
 #pragma once
-#include <hip/hip_runtime.h>
-#include <stdint.h>
-
-namespace lpp {
-
-struct __attribute__((aligned(16))) cplx {
-	double re, im;
-};
-
-constexpr int kBlock = 256; // 4 waves
-constexpr int kMaxPartials = 4096; // upper bound on blocks of any reducing kernel
-constexpr int kPanel = 8; // Gram-Schmidt panel width
-
-// ---------------------------------------------------------------------------------------------
-// wave / block reductions (wave64: hard-coded 64)
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ double wave_sum(double v)
-{
-#pragma unroll
-	for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-	return v;
-}
-
-// result valid in thread 0
-__device__ __forceinline__ double block_sum(double v, double* smem)
-{
-	v = wave_sum(v);
-	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-	__syncthreads(); // protect smem reuse across consecutive calls
-	if (lane == 0) smem[w] = v;
-	__syncthreads();
-	double r = 0;
-	if (threadIdx.x == 0) {
-#pragma unroll
-		for (int i = 0; i < kBlock / 64; i++) r += smem[i];
-	}
-	return r;
-}
-
-// ---------------------------------------------------------------------------------------------
-// value traits
-// ---------------------------------------------------------------------------------------------
-template <typename T> struct VT;
-template <> struct VT<double> {
-	static __device__ __forceinline__ double zero() { return 0.0; }
-	static __device__ __forceinline__ void mac(double& acc, double v, double y) { acc += v * y; }
-	static __device__ __forceinline__ double add(double a, double b) { return a + b; }
-	static __device__ __forceinline__ double dot_re(double y, double x) { return y * x; } // Re(y conj x)
-	static __device__ __forceinline__ double shfl_down(double v, int off, int w) { return __shfl_down(v, off, w); }
-};
-template <> struct VT<cplx> {
-	static __device__ __forceinline__ cplx zero() { return cplx { 0.0, 0.0 }; }
-	static __device__ __forceinline__ void mac(cplx& acc, cplx v, cplx y)
-	{
-		acc.re += v.re * y.re - v.im * y.im;
-		acc.im += v.re * y.im + v.im * y.re;
-	}
-	static __device__ __forceinline__ cplx add(cplx a, cplx b) { return cplx { a.re + b.re, a.im + b.im }; }
-	static __device__ __forceinline__ double dot_re(cplx y, cplx x) { return y.re * x.re + y.im * x.im; }
-	static __device__ __forceinline__ cplx shfl_down(cplx v, int off, int w)
-	{
-		return cplx { __shfl_down(v.re, off, w), __shfl_down(v.im, off, w) };
-	}
-};
-
-// Epilogue scaling of the SpMV kernels:  x_new = beta * x_old + alpha * (H y)_row.
-// Plain products use alpha = beta = 1 (x += H y).  The scale-free Lanczos recurrence keeps the Lanczos
-// vectors unnormalised (r_j = b_{j-1} y_j) and folds the scalings into this epilogue:
-// alpha = 1/b_{j-1}, beta = -b_{j-1}/b_{j-2}, both derived in-kernel from b^2 values in device memory,
-// which removes the separate swap/scale pass (4 N s bytes per step).
-struct EpiScale {
-	const double* b2_prev; // b_{j-1}^2 (null: alpha = 1)
-	const double* b2_prev2; // b_{j-2}^2 (null: beta = 0 when b2_prev is set)
-	int beta_one; // 1: beta = 1 regardless (second kernel of a split product)
-};
-
-__device__ __forceinline__ void epi_coeffs(const EpiScale& sc, double& alpha, double& beta)
-{
-	alpha = 1.0;
-	beta = 1.0;
-	if (sc.b2_prev) {
-		const double b1 = sqrt(*sc.b2_prev);
-		alpha = (fabs(b1) < 1e-10) ? 1.0 : 1.0 / b1;
-		if (!sc.beta_one) {
-			beta = 0.0;
-			if (sc.b2_prev2) {
-				const double b2 = sqrt(*sc.b2_prev2);
-				beta = (fabs(b2) < 1e-10) ? -b1 : -b1 / b2;
-			}
-		}
-	}
-}
-
-__device__ __forceinline__ double epi_lin(double beta, double xold, double alpha, double acc) { return beta * xold + alpha * acc; }
-__device__ __forceinline__ cplx epi_lin(double beta, cplx xold, double alpha, cplx acc)
-{
-	return cplx { beta * xold.re + alpha * acc.re, beta * xold.im + alpha * acc.im };
-}
-
-// ---------------------------------------------------------------------------------------------
-// K1: row-group CSR SpMV   x[row] += sum_k val[k] * src[col[k]]   (+ fused partial of Re<ydot|x>)
-//
-// G lanes cooperate on one row (G = 4..64, chosen from nnz/row); the 64/G rows of a wave are
-// consecutive, so the wave's val/col reads cover one contiguous CSR range.  Up to 4 strided
-// chunks are issued per lane before the dependent gathers to keep >= 4 loads in flight.
-// Row owners write x (race-free by construction, like the reference's per-row threads,
-// HubbardHelper.h:119-129).  Grid-stride over rows, so consecutive blocks work on neighbouring
-// rows at the same time (x-gather locality in L2 / Infinity Cache).
-// ---------------------------------------------------------------------------------------------
-template <typename T, int G, bool DOT>
-__global__ __launch_bounds__(kBlock) void k_spmv_rowgroup(int64_t nrows, const int64_t* __restrict__ rowptr,
-                                                           const int32_t* __restrict__ col,
-                                                           const T* __restrict__ val, const T* __restrict__ src,
-                                                           T* __restrict__ x, const T* __restrict__ ydot,
-                                                           double* __restrict__ partial, EpiScale sc)
-{
-	__shared__ double smem[kBlock / 64];
-	double alpha, beta;
-	epi_coeffs(sc, alpha, beta);
-	const int lig = threadIdx.x % G;
-	const int64_t ngroups = (int64_t)gridDim.x * (kBlock / G);
-	double dot = 0.0;
-	for (int64_t row = (int64_t)blockIdx.x * (kBlock / G) + threadIdx.x / G; row < nrows; row += ngroups) {
-		const int64_t p0 = rowptr[row], p1 = rowptr[row + 1];
-		T acc = VT<T>::zero();
-		for (int64_t p = p0 + lig; p < p1; p += 4 * G) {
-			int32_t c[4];
-			T v[4];
-			bool ok[4];
-#pragma unroll
-			for (int k = 0; k < 4; k++) { // unconditional loads (clamped index), products selected afterwards
-				const int64_t pk = p + (int64_t)k * G;
-				ok[k] = pk < p1;
-				const int64_t q = ok[k] ? pk : p;
-				c[k] = col[q];
-				v[k] = val[q];
-			}
-			T g[4];
-#pragma unroll
-			for (int k = 0; k < 4; k++) g[k] = src[c[k]];
-#pragma unroll
-			for (int k = 0; k < 4; k++) {
-				T t = VT<T>::zero();
-				VT<T>::mac(t, v[k], g[k]);
-				acc = VT<T>::add(acc, ok[k] ? t : VT<T>::zero());
-			}
-		}
-#pragma unroll
-		for (int off = G / 2; off > 0; off >>= 1) acc = VT<T>::add(acc, VT<T>::shfl_down(acc, off, G));
-		if (lig == 0) {
-			const T xv = epi_lin(beta, x[row], alpha, acc);
-			x[row] = xv;
-			if (DOT) dot += VT<T>::dot_re(ydot[row], xv);
-		}
-	}
-	if (DOT) {
-		const double r = block_sum(dot, smem);
-		if (threadIdx.x == 0) partial[blockIdx.x] = r;
-	}
-}
-
-// ---------------------------------------------------------------------------------------------
-// K2/K3: sliced ("wave-interleaved") CSR SpMV, optionally with an LDS-staged source window.
-//
-// Device-internal layout built once from the CSR (k_slice_*): rows are grouped in row blocks of B
-// rows (B = N_up for the Hubbard product basis, i.e. one down-configuration; a generic power of
-// two otherwise) and every block in slices of 64 rows (one wave; the last slice of a block may be
-// short).  Inside a slice the entries are stored slot-major and COMPACT: all first entries of
-// the rows that have one, then all second entries, ... -- the same bytes as CSR, no padding, no
-// row permutation.  Lane r owns one row; at slot k the active lanes (len > k) read a dense,
-// coalesced run of val/col, a lane's position in the run being the popcount of the active mask
-// below it (ballot).  The gather src[col] has lanes = consecutive rows, which for product bases
-// (Hubbard down-hops: col = row + const*N_up) is itself a coalesced 512-byte read.
-//
-// WINDOW (K3): a 1024-thread workgroup owns one row block at a time and stages the source
-// entries of the block's own column range [r0, r0+B) in LDS (<= 156 KB of the CU's 160 KB);
-// gathers that fall in the window (Hubbard: the diagonal and every up-hop) are served by
-// ds_read_b64 instead of random 8-byte global loads, which removes their L2 misses (each one
-// pulls a 128-byte line) -- measured 147 GB -> ~106 GB of fabric reads per SpMV at 4x4 Hubbard.
-//
-// The slot loop is software-pipelined: the col/val loads of batch b+1 are issued right after the
-// gathers of batch b, so one dependent round trip per batch is exposed instead of two, and every
-// load is UNCONDITIONAL (an inactive lane reads the slot's first entry and its product is
-// discarded by a select): predicated loads made hipcc emit a branch and s_waitcnt vmcnt(0) per
-// load, i.e. a single load in flight per wave.
-// ---------------------------------------------------------------------------------------------
-struct SliceGeom {
-	int64_t nrows;
-	int64_t B; // rows per block
-	int32_t spb; // slices per block = ceil(B/64)
-	int64_t nblocks;
-	int64_t nslices; // nblocks * spb
-};
-
-__device__ __forceinline__ void slice_rows(const SliceGeom& g, int64_t s, int64_t& row0, int& nvalid)
-{
-	const int64_t blk = s / g.spb;
-	const int j = (int)(s - blk * g.spb);
-	row0 = blk * g.B + (int64_t)j * 64;
-	const int64_t end = min((blk + 1) * g.B, g.nrows);
-	const int64_t nv = end - row0;
-	nvalid = nv < 0 ? 0 : (nv > 64 ? 64 : (int)nv);
-}
-
-template <int NW> __device__ __forceinline__ double block_sum_n(double v, double* smem)
-{
-	v = wave_sum(v);
-	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-	__syncthreads();
-	if (lane == 0) smem[w] = v;
-	__syncthreads();
-	double r = 0;
-	if (threadIdx.x == 0) {
-#pragma unroll
-		for (int i = 0; i < NW; i++) r += smem[i];
-	}
-	return r;
-}
-
-template <typename T> struct SlicedArgs {
-	SliceGeom g;
-	const int64_t* slice_ptr;
-	const int32_t* row_len;
-	const int32_t* col;
-	const T* val; // plain values (null when the value dictionary is used)
-	const uint32_t* codes; // packed dictionary codes, [slice][slot group][lane]
-	const int64_t* code_ptr; // first code word of each slice
-	const double* dict; // <= 256 distinct doubles
-	const T* src;
-	T* x;
-	const T* ydot;
-	double* partial;
-	int xcd_map;
-	EpiScale sc;
-	// shared-offset entries ("diagonals", see k_dia_split): slice s owns dia_off/dia_val[s*dia_stride .. +dia_stride),
-	// unused places hold kDiaNone; dia_stride == 0: none
-	int dia_stride;
-	const int32_t* dia_off; // column - row, the same for every row of the slice
-	const T* dia_val;
-	// block-periodic structure (see k_tmpl_check): 1 = every row block has the row lengths and block-local columns of
-	// block 0, so slice_ptr / row_len / col describe ONE block; 2 = the value codes repeat as well (codes / code_ptr
-	// describe one block too; the diagonal, which does differ, travels in dcode)
-	int tmpl;
-	// diagonal split off the per-row entries: one dictionary code per real component and row (null: not split off)
-	const uint8_t* dcode;
-	// packed copy of a level-2 template (k_tmpl_pack): one 32-bit word per entry = 16-bit local column | code(s) << 16,
-	// slot-major [slot][lane] per slice, every slice padded to a multiple of 8 slots with (own row, code 0 = +0.0).
-	// The inner loop is then one coalesced 4-byte load, two LDS reads and an FMA per entry: no row lengths, ballots or
-	// lane prefixes (measured on the compact walk: 15 VALU instructions per entry, and the 2-byte column loads cost the
-	// L1 as many tag accesses as 8-byte ones).  null: walk the compact layout.
-	const uint32_t* tw;
-	const int32_t* tw_off; // first word of template slice j
-	const int32_t* tw_len; // its padded slots
-};
-
-constexpr int32_t kDiaNone = INT32_MIN;
-constexpr int kDiaMax = 64; // shared entries per slice (one per lane of the metadata load)
-
-// Value dictionary ("coded" layout): the Hamiltonians of this path take very few distinct values
-// (+-t, J/2, U*k, ...), so when a matrix has <= 256 distinct doubles the 8-byte value of an entry is
-// replaced by an 8-bit code per real component (lossless).  Codes are packed 4 slots (real) / 2 slots
-// (complex, 8+8 bits) per 32-bit word, one word per lane and slot group, padded to the slice's longest
-// row so a wave reads one dense 256-byte run per slot group.
-template <typename T> struct CodeTraits;
-template <> struct CodeTraits<double> {
-	static constexpr int kBits = 8, kSlotsPerWord = 4;
-	static __device__ __forceinline__ double decode(uint32_t word, int slot_in_word, const double* dict)
-	{
-		return dict[(word >> (8 * slot_in_word)) & 0xffu];
-	}
-};
-template <> struct CodeTraits<cplx> {
-	static constexpr int kBits = 16, kSlotsPerWord = 2;
-	static __device__ __forceinline__ cplx decode(uint32_t word, int slot_in_word, const double* dict)
-	{
-		const uint32_t c = (word >> (16 * slot_in_word)) & 0xffffu;
-		return cplx { dict[c & 0xffu], dict[c >> 8] };
-	}
-};
-
-// 32-bit-offset load relative to a wave-uniform base pointer: lets hipcc use the scalar-base addressing
-// form instead of building a 64-bit vector address per load
-template <typename V> __device__ __forceinline__ V ld_off32(const V* base, uint32_t index)
-{
-	return *(const V*)((const char*)base + (size_t)(index * (uint32_t)sizeof(V)));
-}
-
-__device__ __forceinline__ uint32_t lane_prefix(unsigned long long m)
-{ // number of set bits of m below this lane (v_mbcnt_lo + v_mbcnt_hi)
-	return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-}
-
-// Accumulate one slice with one wave: returns sum_k val_k * src[col_k] of this lane's row.
-// (len, base, cbase) = this lane's row length, the slice's first entry and first code word, prefetched by
-// the caller; `safe` is a valid source index used by lanes whose gather is served from the LDS window.
-// Gathers use 32-bit byte offsets (the engine only selects these kernels for vectors < 4 GiB).
-// Per-entry instruction count matters here (measured: ~31 VALU instructions per entry made the kernel
-// issue-bound for 25-50 % of its time): mbcnt for the lane prefix, scalar base pointers, wave-uniform
-// skips of the global gather when a whole slot is inside the window (and of the LDS read when none is),
-// and -- coded layout -- no select at all: inactive lanes decode code 0 == +0.0.
-// LOCAL16 (window kernel only): every entry's column lies in the row block's own window and columns are stored as
-// 16-bit window-local indices -- 2 bytes per entry and no in-window test, select or global gather in the loop.
-template <typename T, bool WINDOW, bool CODED, int U, bool LOCAL16 = false>
-__device__ __forceinline__ T sliced_accumulate(const SlicedArgs<T>& a, int len, int64_t base, int64_t cbase, const T* lds,
-                                               int32_t r0, uint32_t wlen, const double* dict, int32_t safe)
-{
-	constexpr int SPW = CodeTraits<T>::kSlotsPerWord;
-	constexpr int NW = (U + SPW - 1) / SPW; // code words per batch
-	const int lane = threadIdx.x & 63;
-	int maxlen = len;
-#pragma unroll
-	for (int off = 32; off > 0; off >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, off, 64));
-	const int nb = (maxlen + U - 1) / U;
-	// base / cbase are the same in every lane: move them to SGPRs so that every stream address is
-	// (scalar base pointer + 32-bit lane offset) instead of 64-bit vector arithmetic per load
-	const int64_t base_u = ((int64_t)__builtin_amdgcn_readfirstlane((int)(base >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-	const int64_t cbase_u = ((int64_t)__builtin_amdgcn_readfirstlane((int)(cbase >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)cbase);
-	const int32_t* colp = LOCAL16 ? nullptr : a.col + base_u;
-	const uint16_t* colp16 = LOCAL16 ? (const uint16_t*)a.col + base_u : nullptr;
-	const T* valp = CODED ? nullptr : a.val + base_u;
-	const uint32_t* codep = CODED ? a.codes + cbase_u : nullptr;
-	uint32_t run = 0; // entries of this slice consumed so far (wave-uniform)
-	T acc = VT<T>::zero();
-	int32_t c0[U], c1[U];
-	T v0[CODED ? 1 : U], v1[CODED ? 1 : U];
-	uint32_t w0[CODED ? NW : 1], w1[CODED ? NW : 1];
-#define LPP_LOAD_BATCH(K0, C, V, W)                                                                                   \
-	_Pragma("unroll") for (int u = 0; u < U; u++)                                                                     \
-	{                                                                                                                 \
-		const bool on_ = len > (K0) + u;                                                                              \
-		const unsigned long long m_ = __ballot(on_);                                                                  \
-		const uint32_t p_ = run + (on_ ? lane_prefix(m_) : 0u);                                                       \
-		C[u] = LOCAL16 ? (int32_t)ld_off32(colp16, p_) : ld_off32(colp, p_);                                          \
-		if (!CODED) {                                                                                                 \
-			const T t_ = ld_off32(valp, p_);                                                                          \
-			V[u] = on_ ? t_ : VT<T>::zero();                                                                          \
-		}                                                                                                             \
-		run += (uint32_t)__popcll(m_);                                                                                \
-	}                                                                                                                 \
-	if (CODED) {                                                                                                      \
-		_Pragma("unroll") for (int q = 0; q < NW; q++) W[q] = ld_off32(codep, (uint32_t)(((K0) / SPW + q) << 6) + (uint32_t)lane); \
-	}
-	if (nb > 0) { LPP_LOAD_BATCH(0, c0, v0, w0) }
-	for (int b = 0; b < nb; b++) {
-		T g[U];
-#pragma unroll
-		for (int u = 0; u < U; u++) {
-			if (LOCAL16) {
-				g[u] = lds[c0[u]];
-			} else if (WINDOW) {
-				const uint32_t d = (uint32_t)(c0[u] - r0);
-				const bool inw = d < wlen;
-				const unsigned long long min_ = __ballot(inw);
-				T gl = VT<T>::zero(), gg = VT<T>::zero();
-				if (min_ != 0ull) gl = lds[inw ? d : (uint32_t)lane]; // wave-uniform branches
-				if (min_ != ~0ull) gg = ld_off32(a.src, (uint32_t)(inw ? safe : c0[u]));
-				g[u] = inw ? gl : gg;
-			} else {
-				g[u] = ld_off32(a.src, (uint32_t)c0[u]);
-			}
-		}
-		if (b + 1 < nb) { LPP_LOAD_BATCH((b + 1) * U, c1, v1, w1) }
-#pragma unroll
-		for (int u = 0; u < U; u++) {
-			// inactive lanes carry a zero value (plain: selected at load; coded: code 0 decodes to +0.0)
-			const T vv = CODED ? CodeTraits<T>::decode(w0[u / SPW], u % SPW, dict) : v0[u];
-			VT<T>::mac(acc, vv, g[u]);
-		}
-#pragma unroll
-		for (int u = 0; u < U; u++) c0[u] = c1[u];
-		if (CODED) {
-#pragma unroll
-			for (int q = 0; q < NW; q++) w0[q] = w1[q];
-		} else {
-#pragma unroll
-			for (int u = 0; u < U; u++) v0[u] = v1[u];
-		}
-	}
-#undef LPP_LOAD_BATCH
-	return acc;
-}
-
-// Shared-offset entries of a slice: entry d contributes val_d * src[row + off_d] to EVERY row of the slice, so the gather
-// is one contiguous 64-element run and needs no column load.  The slice's (off, val) list is fetched by ONE vector load
-// (lane l takes entry l, a slice ahead, together with the other slice metadata) and handed out with v_readlane, i.e.
-// offsets and values are scalar operands.  The first 8*kChunks gathers are requested before the slice's per-row
-// entries are walked and consumed after them.
-template <typename T> struct DiaMeta {
-	int32_t off; // lane l: offset of shared entry l, kDiaNone past the end
-	T val;
-};
-
-__device__ __forceinline__ double readlane_t(double v, int l)
-{
-	const long long b = __double_as_longlong(v);
-	const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)b, l);
-	const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(b >> 32), l);
-	return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
-}
-__device__ __forceinline__ cplx readlane_t(cplx v, int l) { return cplx { readlane_t(v.re, l), readlane_t(v.im, l) }; }
-
-template <typename T> __device__ __forceinline__ void dia_meta(const SlicedArgs<T>& a, int64_t s, DiaMeta<T>& m)
-{
-	m.off = kDiaNone;
-	m.val = VT<T>::zero();
-	if (a.dia_stride > 0) { // wave-uniform
-		const int lane = threadIdx.x & 63;
-		const int64_t i = s * a.dia_stride + min(lane, a.dia_stride - 1);
-		const int32_t o = a.dia_off[i];
-		m.val = a.dia_val[i];
-		m.off = lane < a.dia_stride ? o : kDiaNone;
-	}
-}
-
-template <typename T> struct DiaPre {
-	static constexpr int kChunks = sizeof(T) == 8 ? 2 : 1; // chunks of 8 gathers kept in flight
-	T g[8 * kChunks];
-};
-
-template <typename T>
-__device__ __forceinline__ void dia_request(const SlicedArgs<T>& a, const DiaMeta<T>& m, int dcnt, uint32_t row, DiaPre<T>& pre)
-{
-#pragma unroll
-	for (int ch = 0; ch < DiaPre<T>::kChunks; ch++) {
-		if (ch * 8 < dcnt) { // wave-uniform
-#pragma unroll
-			for (int q = 0; q < 8; q++) {
-				// clamped: the tail of a chunk repeats the last entry (its value is selected to 0 in dia_consume)
-				const int32_t o = __builtin_amdgcn_readlane(m.off, min(ch * 8 + q, dcnt - 1));
-				pre.g[ch * 8 + q] = ld_off32(a.src, row + (uint32_t)o);
-			}
-		}
-	}
-}
-
-template <typename T>
-__device__ __forceinline__ void dia_consume(const SlicedArgs<T>& a, const DiaMeta<T>& m, int dcnt, uint32_t row, const DiaPre<T>& pre, T& acc)
-{
-	constexpr int NPRE = 8 * DiaPre<T>::kChunks;
-	for (int d0 = NPRE; d0 < dcnt; d0 += 8) { // rare: more shared entries than prefetch places
-		T g[8];
-#pragma unroll
-		for (int q = 0; q < 8; q++) g[q] = ld_off32(a.src, row + (uint32_t)__builtin_amdgcn_readlane(m.off, min(d0 + q, dcnt - 1)));
-#pragma unroll
-		for (int q = 0; q < 8; q++) {
-			const T v = d0 + q < dcnt ? readlane_t(m.val, min(d0 + q, dcnt - 1)) : VT<T>::zero();
-			VT<T>::mac(acc, v, g[q]);
-		}
-	}
-#pragma unroll
-	for (int ch = 0; ch < DiaPre<T>::kChunks; ch++) {
-		if (ch * 8 < dcnt) {
-#pragma unroll
-			for (int q = 0; q < 8; q++) {
-				const int d = ch * 8 + q;
-				const T v = d < dcnt ? readlane_t(m.val, min(d, dcnt - 1)) : VT<T>::zero();
-				VT<T>::mac(acc, v, pre.g[d]);
-			}
-		}
-	}
-}
-
-// x += sum over the packed template entries of slice j (window kernel, see SlicedArgs::tw)
-template <typename T>
-__device__ __forceinline__ T tmpl_accumulate(const SlicedArgs<T>& a, int j, const T* lds, const double* dict)
-{
-	const int lane = threadIdx.x & 63;
-	const uint32_t* wp = a.tw + a.tw_off[j] + lane;
-	const int ml = a.tw_len[j]; // multiple of 8
-	T acc = VT<T>::zero();
-	uint32_t w0[8], w1[8];
-	if (ml > 0) {
-#pragma unroll
-		for (int q = 0; q < 8; q++) w0[q] = wp[q * 64];
-	}
-	for (int k = 0; k < ml; k += 8) {
-		if (k + 8 < ml) {
-#pragma unroll
-			for (int q = 0; q < 8; q++) w1[q] = wp[(k + 8 + q) * 64];
-		}
-#pragma unroll
-		for (int q = 0; q < 8; q++) VT<T>::mac(acc, CodeTraits<T>::decode(w0[q] >> 16, 0, dict), lds[w0[q] & 0xffffu]);
-#pragma unroll
-		for (int q = 0; q < 8; q++) w0[q] = w1[q];
-	}
-	return acc;
-}
-
-// process one slice with one wave (x[row] += acc); returns this lane's contribution to Re<ydot|x>.
-template <typename T, bool DOT, bool WINDOW, bool CODED, int U, bool LOCAL16 = false>
-__device__ __forceinline__ double sliced_one(const SlicedArgs<T>& a, int64_t row0, int nvalid, int len, int64_t base, int64_t cbase,
-                                             const T* lds, int32_t r0, uint32_t wlen, const double* dict, double alpha, double beta,
-                                             const DiaMeta<T>& dm)
-{
-	if (nvalid == 0) return 0.0; // wave-uniform
-	const int lane = threadIdx.x & 63;
-	const bool valid = lane < nvalid;
-	const int64_t row = row0 + (valid ? lane : 0);
-	// the row's old x and y are requested first: they are the oldest loads in flight and have landed
-	// long before the epilogue needs them
-	const T xold = a.x[row];
-	T yv = VT<T>::zero();
-	if (DOT) yv = a.ydot[row];
-	uint32_t dc = 0; // code(s) of the diagonal value, when it travels apart from the per-row entries
-	if (CODED && a.dcode) dc = sizeof(T) == 16 ? (uint32_t)((const uint16_t*)a.dcode)[row] : (uint32_t)a.dcode[row];
-	DiaPre<T> pre;
-	// shared entries of the slice: a leading run of places (global gathers) and a trailing run (inside the LDS window)
-	const unsigned long long dmask = __ballot(dm.off != kDiaNone);
-	const int dcnt = dmask == ~0ull ? 64 : __ffsll((long long)~dmask) - 1; // wave-uniform
-	int wcnt = 0;
-	if (WINDOW && a.dia_stride > 0) wcnt = __clzll((long long)~(dmask << (64 - a.dia_stride)));
-	dia_request<T>(a, dm, dcnt, (uint32_t)row, pre);
-	T acc;
-	if (LOCAL16 && CODED && a.tw) // wave-uniform
-		acc = tmpl_accumulate<T>(a, (int)((row0 - r0) >> 6), lds, dict);
-	else
-		acc = sliced_accumulate<T, WINDOW, CODED, U, LOCAL16>(a, len, base, cbase, lds, r0, wlen, dict, (int32_t)row);
-	dia_consume<T>(a, dm, dcnt, (uint32_t)row, pre, acc);
-	if (WINDOW) {
-		for (int i = 0; i < wcnt; i++) { // contiguous 64-element runs of the window: conflict-free LDS reads, scalar offset/value
-			const int place = a.dia_stride - 1 - i;
-			const int32_t o = __builtin_amdgcn_readlane(dm.off, place);
-			VT<T>::mac(acc, readlane_t(dm.val, place), lds[(uint32_t)((int32_t)row - r0 + o)]);
-		}
-	}
-	if (CODED && a.dcode) {
-		const T ys = WINDOW ? lds[(uint32_t)((int32_t)row - r0)] : ld_off32(a.src, (uint32_t)row);
-		VT<T>::mac(acc, CodeTraits<T>::decode(dc, 0, dict), ys);
-	}
-	double d = 0.0;
-	if (valid) {
-		const T xv = epi_lin(beta, xold, alpha, acc);
-		a.x[row] = xv;
-		if (DOT) d = VT<T>::dot_re(yv, xv);
-	}
-	return d;
-}
-
-// metadata of slice s for this lane (row_len is read unconditionally from a clamped row)
-template <typename T, bool CODED>
-__device__ __forceinline__ void slice_meta(const SlicedArgs<T>& a, int64_t s, int64_t& row0, int& nvalid, int& len, int64_t& base,
-                                           int64_t& cbase)
-{
-	const int lane = threadIdx.x & 63;
-	slice_rows(a.g, s, row0, nvalid);
-	len = 0;
-	base = 0;
-	cbase = 0;
-	if (CODED && a.tw) return; // the packed template is walked instead (tmpl_accumulate): no per-row metadata needed
-	const int64_t r = (lane < nvalid) ? row0 + lane : min(row0, a.g.nrows - 1);
-	// block-periodic structure: lengths and column stream of the same slice of block 0 (L2-resident)
-	const int64_t blk = a.tmpl ? s / a.g.spb : 0;
-	const int l = a.row_len[r - blk * a.g.B];
-	len = (lane < nvalid) ? l : 0;
-	base = a.slice_ptr[s - blk * a.g.spb];
-	cbase = CODED ? a.code_ptr[a.tmpl == 2 ? s - blk * a.g.spb : s] : 0;
-}
-
-// the dictionary lives in LDS (2 KB); decode reads are mostly broadcasts (few distinct values)
-template <bool CODED> __device__ __forceinline__ void load_dict(double* dict_s, const double* dict)
-{
-	if (CODED) {
-		for (int i = threadIdx.x; i < 256; i += blockDim.x) dict_s[i] = dict[i];
-		__syncthreads();
-	}
-}
-
-// K2: no window, 256-thread blocks, waves walk slices (grid-stride, or one contiguous eighth of
-// the slices per XCD: blocks b and b+8 share an XCD under round-robin dispatch -- speed only).
-template <typename T, bool DOT, bool CODED, int U>
-__global__ __launch_bounds__(kBlock) void k_spmv_sliced(SlicedArgs<T> a)
-{
-	__shared__ double smem[kBlock / 64];
-	__shared__ double dict_s[CODED ? 256 : 1];
-	load_dict<CODED>(dict_s, a.dict);
-	double alpha, beta;
-	epi_coeffs(a.sc, alpha, beta);
-	int64_t s_begin, s_end, s_stride;
-	if (a.xcd_map && (gridDim.x & 7) == 0) {
-		const int64_t chunk = (a.g.nslices + 7) / 8;
-		const int xcd = blockIdx.x & 7;
-		s_begin = xcd * chunk + (int64_t)(blockIdx.x >> 3) * (kBlock / 64) + (threadIdx.x >> 6);
-		s_end = min((int64_t)(xcd + 1) * chunk, a.g.nslices);
-		s_stride = (int64_t)(gridDim.x >> 3) * (kBlock / 64);
-	} else {
-		s_begin = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
-		s_end = a.g.nslices;
-		s_stride = (int64_t)gridDim.x * (kBlock / 64);
-	}
-	double dot = 0.0;
-	int64_t row0 = 0, base = 0, cbase = 0;
-	int nvalid = 0, len = 0;
-	DiaMeta<T> dm { kDiaNone, VT<T>::zero() };
-	if (s_begin < s_end) {
-		slice_meta<T, CODED>(a, s_begin, row0, nvalid, len, base, cbase);
-		dia_meta<T>(a, s_begin, dm);
-	}
-	for (int64_t s = s_begin; s < s_end; s += s_stride) {
-		// prefetch the next slice's metadata before working on this one
-		int64_t row0n = 0, basen = 0, cbasen = 0;
-		int nvalidn = 0, lenn = 0;
-		DiaMeta<T> dmn { kDiaNone, VT<T>::zero() };
-		if (s + s_stride < s_end) {
-			slice_meta<T, CODED>(a, s + s_stride, row0n, nvalidn, lenn, basen, cbasen);
-			dia_meta<T>(a, s + s_stride, dmn);
-		}
-		dot += sliced_one<T, DOT, false, CODED, U>(a, row0, nvalid, len, base, cbase, nullptr, 0, 0, dict_s, alpha, beta, dm);
-		row0 = row0n;
-		base = basen;
-		cbase = cbasen;
-		nvalid = nvalidn;
-		len = lenn;
-		dm = dmn;
-	}
-	if (DOT) {
-		const double r = block_sum(dot, smem);
-		if (threadIdx.x == 0) a.partial[blockIdx.x] = r;
-	}
-}
-
-// one lane takes the next slice index from the workgroup's LDS counter and broadcasts it to its wave
-__device__ __forceinline__ int next_slice_claim(int* counter)
-{
-	int v = 0;
-	if ((threadIdx.x & 63) == 0) v = atomicAdd(counter, 1);
-	return __builtin_amdgcn_readfirstlane(v);
-}
-
-// K3: LDS window.  One 1024-thread workgroup per CU walks row blocks; dynamic LDS = B elements.
-constexpr int kWinThreads = 1024;
-template <typename T, bool DOT, bool CODED, int U, bool LOCAL16>
-__global__ __launch_bounds__(kWinThreads) void k_spmv_window(SlicedArgs<T> a)
-{
-	extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-	T* lds = (T*)lds_raw;
-	__shared__ double smem[kWinThreads / 64];
-	__shared__ double dict_s[CODED ? 256 : 1];
-	__shared__ int next_slice;
-	load_dict<CODED>(dict_s, a.dict);
-	double alpha, beta;
-	epi_coeffs(a.sc, alpha, beta);
-	int64_t b_begin, b_end, b_stride;
-	if (a.xcd_map && (gridDim.x & 7) == 0) {
-		const int64_t chunk = (a.g.nblocks + 7) / 8;
-		const int xcd = blockIdx.x & 7;
-		b_begin = xcd * chunk + (blockIdx.x >> 3);
-		b_end = min((int64_t)(xcd + 1) * chunk, a.g.nblocks);
-		b_stride = gridDim.x >> 3;
-	} else {
-		b_begin = blockIdx.x;
-		b_end = a.g.nblocks;
-		b_stride = gridDim.x;
-	}
-	double dot = 0.0;
-	for (int64_t blk = b_begin; blk < b_end; blk += b_stride) {
-		const int64_t r0 = blk * a.g.B;
-		const int64_t wl = min(a.g.B, a.g.nrows - r0);
-		__syncthreads(); // everyone is done reading the previous window
-		if (threadIdx.x == 0) next_slice = 0;
-		// stage the window: 8 independent loads per thread in flight (a load-wait-store loop exposed
-		// one HBM round trip per element and kept all 16 waves idle for ~25 us per block)
-		for (int64_t i0 = threadIdx.x; i0 < wl; i0 += 8 * kWinThreads) {
-			T t[8];
-#pragma unroll
-			for (int q = 0; q < 8; q++) t[q] = a.src[r0 + min(i0 + (int64_t)q * kWinThreads, wl - 1)];
-#pragma unroll
-			for (int q = 0; q < 8; q++)
-				if (i0 + (int64_t)q * kWinThreads < wl) lds[i0 + (int64_t)q * kWinThreads] = t[q];
-		}
-		__syncthreads();
-		// slices are handed out dynamically (LDS counter): with 201 slices on 16 waves a static split leaves
-		// the waves that got 12 instead of 13 slices idle at the block's closing barrier (~8 % of the time)
-		int64_t row0 = 0, base = 0, cbase = 0;
-		int nvalid = 0, len = 0;
-		DiaMeta<T> dm { kDiaNone, VT<T>::zero() };
-		int j = next_slice_claim(&next_slice);
-		if (j < a.g.spb) {
-			slice_meta<T, CODED>(a, blk * a.g.spb + j, row0, nvalid, len, base, cbase);
-			dia_meta<T>(a, blk * a.g.spb + j, dm);
-		}
-		while (j < a.g.spb) {
-			const int jn = next_slice_claim(&next_slice);
-			int64_t row0n = 0, basen = 0, cbasen = 0;
-			int nvalidn = 0, lenn = 0;
-			DiaMeta<T> dmn { kDiaNone, VT<T>::zero() };
-			if (jn < a.g.spb) {
-				slice_meta<T, CODED>(a, blk * a.g.spb + jn, row0n, nvalidn, lenn, basen, cbasen);
-				dia_meta<T>(a, blk * a.g.spb + jn, dmn);
-			}
-			dot += sliced_one<T, DOT, true, CODED, U, LOCAL16>(a, row0, nvalid, len, base, cbase, lds, (int32_t)r0, (uint32_t)wl, dict_s, alpha, beta, dm);
-			row0 = row0n;
-			base = basen;
-			cbase = cbasen;
-			nvalid = nvalidn;
-			len = lenn;
-			dm = dmn;
-			j = jn;
-		}
-	}
-	if (DOT) {
-		const double r = block_sum_n<kWinThreads / 64>(dot, smem);
-		if (threadIdx.x == 0) a.partial[blockIdx.x] = r;
-	}
-}
-
-// CSR -> sliced layout.  Slices cover consecutive row ranges, so a slice's entries are the CSR range
-// rowptr[row0] .. rowptr[row0+nvalid).  words[s] (optional) = code words of slice s = 64*ceil(maxlen/spw).
-static __global__ void k_slice_meta(SliceGeom g, const int64_t* __restrict__ rowptr, int64_t* __restrict__ slice_ptr,
-                                    int32_t* __restrict__ row_len, int64_t* __restrict__ words, int spw)
-{
-	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (i < g.nrows) row_len[i] = (int32_t)(rowptr[i + 1] - rowptr[i]);
-	if (i < g.nslices) {
-		int64_t row0;
-		int nvalid;
-		slice_rows(g, i, row0, nvalid);
-		slice_ptr[i] = rowptr[nvalid > 0 ? row0 : g.nrows];
-		if (words) {
-			int64_t mx = 0;
-			for (int r = 0; r < nvalid; r++) mx = max(mx, rowptr[row0 + r + 1] - rowptr[row0 + r]);
-			words[i] = 64 * ((mx + 7) / 8) * (8 / spw); // padded to whole batches of 8 slots: trailing codes are 0
-		}
-	}
-	if (i == g.nslices) {
-		slice_ptr[i] = rowptr[g.nrows];
-		if (words) words[i] = 0;
-	}
-}
-
-// one wave per slice: scatter CSR entries into slot-major compact order (INVERSE: back to CSR order)
-// L16: the sliced side holds 16-bit window-local columns (column - first row of the row block)
-// tmpl (INVERSE only): the sliced column stream holds block 0 only (block-periodic structure)
-template <typename T, bool INVERSE, bool L16 = false>
-__global__ __launch_bounds__(kBlock) void k_slice_fill(SliceGeom g, const int64_t* __restrict__ rowptr,
-                                                        const int32_t* __restrict__ col_in,
-                                                        const T* __restrict__ val_in, int32_t* __restrict__ col_out,
-                                                        T* __restrict__ val_out, int tmpl = 0)
-{
-	const int lane = threadIdx.x & 63;
-	const int64_t wave0 = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
-	const int64_t nwaves = (int64_t)gridDim.x * (kBlock / 64);
-	for (int64_t s = wave0; s < g.nslices; s += nwaves) {
-		int64_t row0;
-		int nvalid;
-		slice_rows(g, s, row0, nvalid);
-		int64_t p0 = 0;
-		int len = 0;
-		if (lane < nvalid) {
-			p0 = rowptr[row0 + lane];
-			len = (int)(rowptr[row0 + lane + 1] - p0);
-		}
-		int64_t base = rowptr[nvalid > 0 ? row0 : g.nrows];
-		// position of this slice's columns in the sliced stream (block 0's copy when the structure is block-periodic)
-		int64_t cshift = 0;
-		if (INVERSE && tmpl && nvalid > 0) cshift = rowptr[row0 - (s / g.spb) * g.B] - base;
-		int maxlen = len;
-#pragma unroll
-		for (int off = 32; off > 0; off >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, off, 64));
-		for (int k = 0; k < maxlen; k++) {
-			const bool on = len > k;
-			const unsigned long long m = __ballot(on);
-			const int pos = __popcll(m & ((1ull << lane) - 1ull));
-			if (on) {
-				const int32_t r0 = L16 ? (int32_t)((s / g.spb) * g.B) : 0;
-				if (INVERSE) {
-					col_out[p0 + k] = L16 ? (int32_t)((const uint16_t*)col_in)[base + cshift + pos] + r0 : col_in[base + cshift + pos];
-					if (val_out) val_out[p0 + k] = val_in[base + pos];
-				} else {
-					if (L16)
-						((uint16_t*)col_out)[base + pos] = (uint16_t)(col_in[p0 + k] - r0);
-					else
-						col_out[base + pos] = col_in[p0 + k];
-					if (val_out) val_out[base + pos] = val_in[p0 + k];
-				}
-			}
-			base += __popcll(m);
-		}
-	}
-}
-
-// ---- shared-offset ("diagonal") entries -----------------------------------------------------------
-// Product-basis Hamiltonians repeat themselves: in the Hubbard basis every row of one down-configuration block has
-// the same down-hops, i.e. the entries (column - row, value) are identical for all 64 rows of a slice.  Such an entry
-// is stored once per slice (12 or 20 bytes) instead of once per row, its gather needs no column load at all, and
-// offset and value live in scalar registers.  The split is structural (no model knowledge) and lossless:
-//   CSR = per-row "rest" entries (sliced layout as before) + per-slice shared entries, merged back by k_dia_merge.
-// An entry of the slice's first row is shared when every other valid row holds an entry with the same offset and
-// bit-identical value.  Rows must be strictly sorted by column (checked by k_rows_sorted; otherwise disabled).
-template <typename T> __device__ __forceinline__ bool same_bits(const T& x, const T& y);
-template <> __device__ __forceinline__ bool same_bits<double>(const double& x, const double& y)
-{
-	return __double_as_longlong(x) == __double_as_longlong(y);
-}
-template <> __device__ __forceinline__ bool same_bits<cplx>(const cplx& x, const cplx& y)
-{
-	return __double_as_longlong(x.re) == __double_as_longlong(y.re) && __double_as_longlong(x.im) == __double_as_longlong(y.im);
-}
-
-static __global__ void k_rows_sorted(int64_t nrows, const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col, int* unsorted)
-{
-	const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (r >= nrows) return;
-	bool bad = false;
-	for (int64_t p = rowptr[r] + 1; p < rowptr[r + 1]; p++) bad |= col[p] <= col[p - 1];
-	if (bad) *unsorted = 1;
-}
-
-__device__ __forceinline__ uint32_t dict_code(const double* dict, int ndict, double v);
-
-// One wave per slice.  FILL == false: rest_len[row] = entries the row keeps; stats[0] = max shared entries of any slice,
-// stats[1] = shared entries summed over slices.  FILL == true (after the scan of rest_len): writes the rest CSR
-// (rcol/rval at rrowptr) and the shared lists at dia_off/dia_val[s*stride ..] (pre-filled with kDiaNone / 0).
-// win != 0: the matrix is built for the LDS-window kernel; shared entries whose whole 64-row run lies inside the row block
-// are listed from the END of the slice's places (stride-1 downwards) and are read from the LDS window, the others from
-// place 0 upwards and are gathered from global memory; at least one empty place separates the two groups.
-// xdiag != 0: the diagonal entry of every row is taken out of the per-row entries as well (FILL: its dictionary code(s)
-// go to dcode[row]); stats[2] counts rows WITHOUT a diagonal entry (the caller then repeats the count with xdiag = 0).
-template <typename T, bool FILL>
-__global__ __launch_bounds__(kBlock) void k_dia_split(SliceGeom g, const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
-                                                       const T* __restrict__ val, int win, int stride, int64_t* __restrict__ rest_len,
-                                                       unsigned long long* __restrict__ stats, const int64_t* __restrict__ rrowptr,
-                                                       int32_t* __restrict__ rcol, T* __restrict__ rval, int32_t* __restrict__ dia_off,
-                                                       T* __restrict__ dia_val, int xdiag, const double* __restrict__ dict, int ndict,
-                                                       uint8_t* __restrict__ dcode)
-{
-	const int lane = threadIdx.x & 63;
-	const int64_t wave0 = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
-	const int64_t nwaves = (int64_t)gridDim.x * (kBlock / 64);
-	unsigned long long local_max = 0, local_sum = 0, local_nodiag = 0;
-	// a per-row entry that stays: emitted to the rest CSR, or -- the diagonal, when it is split off -- to dcode
-#define LPP_KEEP_ENTRY(Q)                                                                                             \
-	do {                                                                                                              \
-		if (xdiag && (int64_t)col[Q] == row) {                                                                        \
-			ndg++;                                                                                                    \
-			if (FILL) {                                                                                               \
-				const double* pv_ = (const double*)(val + (Q));                                                       \
-				if (sizeof(T) == 16) {                                                                                \
-					dcode[2 * row] = (uint8_t)dict_code(dict, ndict, pv_[0]);                                         \
-					dcode[2 * row + 1] = (uint8_t)dict_code(dict, ndict, pv_[1]);                                     \
-				} else {                                                                                              \
-					dcode[row] = (uint8_t)dict_code(dict, ndict, pv_[0]);                                             \
-				}                                                                                                     \
-			}                                                                                                         \
-		} else if (FILL) {                                                                                            \
-			rcol[wp] = col[Q];                                                                                        \
-			rval[wp] = val[Q];                                                                                        \
-			wp++;                                                                                                     \
-		}                                                                                                             \
-	} while (0)
-	for (int64_t s = wave0; s < g.nslices; s += nwaves) {
-		int64_t row0;
-		int nvalid;
-		slice_rows(g, s, row0, nvalid);
-		if (nvalid == 0) continue;
-		const bool valid = lane < nvalid;
-		const int64_t row = row0 + (valid ? lane : 0);
-		int ndg = 0; // diagonal entries of this row that were split off (0 or 1)
-		const int64_t pbeg = rowptr[row];
-		int64_t q = valid ? pbeg : 0;
-		const int64_t end = valid ? rowptr[row + 1] : 0;
-		const int64_t p00 = rowptr[row0];
-		const int len0 = (int)(rowptr[row0 + 1] - p00);
-		const int64_t blk0 = (s / g.spb) * g.B, blk1 = blk0 + g.B;
-		const unsigned long long vmask = __ballot(valid);
-		int64_t wp = (FILL && valid) ? rrowptr[row] : 0;
-		int nd = 0; // shared entries gathered from global memory: places 0, 1, ... of the slice's list
-		int nw = 0; // shared entries whose whole run lies inside the LDS window: places stride-1, stride-2, ...
-		for (int k = 0; k < len0; k++) {
-			const int32_t c0 = col[p00 + k];
-			const T v0 = val[p00 + k];
-			const int64_t off = (int64_t)c0 - row0;
-			const int64_t target = row + off;
-			while (q < end && (int64_t)col[q] < target) { // entries passed over stay with the row
-				LPP_KEEP_ENTRY(q);
-				q++;
-			}
-			bool ok = valid && q < end && (int64_t)col[q] == target;
-			if (ok) ok = same_bits<T>(val[q], v0);
-			const bool in_block = win && row0 + off >= blk0 && row0 + (nvalid - 1) + off < blk1;
-			// shared by every valid row of the slice (the diagonal, when it is split off, has its own stream); one place
-			// of the list always stays empty between the two groups
-			if (__ballot(ok) == vmask && !(xdiag && off == 0) && nd + nw < kDiaMax - 2) {
-				if (FILL && lane == 0) {
-					const int64_t place = in_block ? s * stride + (stride - 1 - nw) : s * stride + nd;
-					dia_off[place] = (int32_t)off;
-					dia_val[place] = v0;
-				}
-				if (in_block)
-					nw++;
-				else
-					nd++;
-				q++;
-			}
-		}
-		while (q < end) {
-			LPP_KEEP_ENTRY(q);
-			q++;
-		}
-		if (!FILL) {
-			if (valid) rest_len[row] = (end - pbeg) - nd - nw - ndg;
-			if (valid && xdiag && ndg == 0) local_nodiag++;
-			local_max = max(local_max, (unsigned long long)(nd + nw + 1));
-			local_sum += (unsigned long long)(nd + nw);
-		}
-	}
-#undef LPP_KEEP_ENTRY
-	if (!FILL) {
-		if (lane == 0) {
-			atomicMax(&stats[0], local_max);
-			atomicAdd(&stats[1], local_sum);
-		}
-		if (local_nodiag) atomicAdd(&stats[2], local_nodiag);
-	}
-}
-
-// inverse (lpp_engine_get_csr): merge a row's rest entries with its slice's shared entries (both groups) and its
-// diagonal code by column
-template <typename T>
-__global__ void k_dia_merge(SliceGeom g, const int64_t* __restrict__ rowptr, const int64_t* __restrict__ rrowptr,
-                            const int32_t* __restrict__ rcol, const T* __restrict__ rval, int stride,
-                            const int32_t* __restrict__ dia_off, const T* __restrict__ dia_val, int32_t* __restrict__ col_out,
-                            T* __restrict__ val_out, const uint8_t* __restrict__ dcode, const double* __restrict__ dict)
-{
-	const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (r >= g.nrows) return;
-	const int64_t blk = r / g.B;
-	const int64_t s = blk * g.spb + (r - blk * g.B) / 64;
-	int64_t i = rrowptr[r], iend = rrowptr[r + 1], o = rowptr[r];
-	int64_t d = s * stride, w = s * stride + stride - 1; // global group ascends from the front, window group from the back
-	const int64_t dlim = s * stride + stride, wlim = s * stride;
-	bool hg = dcode != nullptr; // the row's diagonal, when it was split off
-	while (true) {
-		const bool hd = d < dlim && dia_off[d] != kDiaNone, hw = stride > 0 && w >= wlim && w >= d && dia_off[w] != kDiaNone, hi = i < iend;
-		if (!hd && !hw && !hi && !hg) break;
-		const int64_t cd = hd ? r + (int64_t)dia_off[d] : INT64_MAX;
-		const int64_t cw = hw ? r + (int64_t)dia_off[w] : INT64_MAX;
-		const int64_t ci = hi ? (int64_t)rcol[i] : INT64_MAX;
-		const int64_t cg = hg ? r : INT64_MAX;
-		const int64_t c = min(min(cd, cw), min(ci, cg));
-		col_out[o] = (int32_t)c;
-		if (c == cg) {
-			const uint32_t cc = sizeof(T) == 16 ? (uint32_t)((const uint16_t*)dcode)[r] : (uint32_t)dcode[r];
-			val_out[o] = CodeTraits<T>::decode(cc, 0, dict);
-			hg = false;
-		} else if (c == cd) {
-			val_out[o] = dia_val[d];
-			d++;
-		} else if (c == cw) {
-			val_out[o] = dia_val[w];
-			w--;
-		} else {
-			val_out[o] = rval[i];
-			i++;
-		}
-		o++;
-	}
-}
-
-// Block-periodic structure (16-bit block-local columns only): *differs = 1 unless every row block has the row lengths
-// and the local column stream of block 0.  One wave per slice of blocks 1..nblocks-1.
-// differs[1] = 1 unless the code words repeat too.
-static __global__ __launch_bounds__(kBlock) void k_tmpl_check(SliceGeom g, const int64_t* __restrict__ slice_ptr,
-                                                               const int32_t* __restrict__ row_len, const uint16_t* __restrict__ col16,
-                                                               const int64_t* __restrict__ code_ptr, const uint32_t* __restrict__ codes,
-                                                               int* differs)
-{
-	const int lane = threadIdx.x & 63;
-	const int64_t wave0 = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
-	const int64_t nwaves = (int64_t)gridDim.x * (kBlock / 64);
-	bool bad = false, badc = false;
-	for (int64_t s = g.spb + wave0; s < g.nslices; s += nwaves) {
-		const int64_t blk = s / g.spb, j = s - blk * g.spb;
-		const int64_t b0 = slice_ptr[j], n0 = slice_ptr[j + 1] - b0, b1 = slice_ptr[s], n1 = slice_ptr[s + 1] - b1;
-		if (n0 != n1) {
-			bad = true;
-			continue;
-		}
-		const int64_t r = j * 64 + lane;
-		if (r < g.B) bad |= row_len[blk * g.B + r] != row_len[r];
-		for (int64_t i = lane; i < n0; i += 64) bad |= col16[b1 + i] != col16[b0 + i];
-		const int64_t c0 = code_ptr[j], m0 = code_ptr[j + 1] - c0, c1 = code_ptr[s], m1 = code_ptr[s + 1] - c1;
-		if (m0 != m1) {
-			badc = true;
-			continue;
-		}
-		for (int64_t i = lane; i < m0; i += 64) badc |= codes[c1 + i] != codes[c0 + i];
-	}
-	if (bad) differs[0] = 1;
-	if (badc) differs[1] = 1;
-}
-
-// Packed padded copy of a level-2 template (see SlicedArgs::tw).  One wave per slice of block 0.
-// PASS 0: tw_len[j] = padded slots of slice j;  PASS 1 (after the scan of 64*tw_len into tw_off): the words.
-template <typename T, int PASS>
-__global__ __launch_bounds__(kBlock) void k_tmpl_pack(SliceGeom g, const int64_t* __restrict__ slice_ptr, const int32_t* __restrict__ row_len,
-                                                       const uint16_t* __restrict__ col16, const int64_t* __restrict__ code_ptr,
-                                                       const uint32_t* __restrict__ codes, int32_t* __restrict__ tw_len,
-                                                       const int32_t* __restrict__ tw_off, uint32_t* __restrict__ tw)
-{
-	constexpr int SPW = CodeTraits<T>::kSlotsPerWord, BITS = CodeTraits<T>::kBits;
-	const int lane = threadIdx.x & 63;
-	const int64_t wave0 = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
-	const int64_t nwaves = (int64_t)gridDim.x * (kBlock / 64);
-	for (int64_t j = wave0; j < g.spb; j += nwaves) {
-		const int64_t r = j * 64 + lane;
-		const int len = r < g.B ? row_len[r] : 0;
-		int maxlen = len;
-#pragma unroll
-		for (int off = 32; off > 0; off >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, off, 64));
-		const int ml = (maxlen + 7) & ~7;
-		if (PASS == 0) {
-			if (lane == 0) tw_len[j] = ml;
-			continue;
-		}
-		int64_t base = slice_ptr[j];
-		const int64_t cbase = code_ptr[j];
-		uint32_t* out = tw + tw_off[j];
-		const uint32_t own = (uint32_t)min(r, g.B - 1); // padding gathers the row's own window element (times +0.0)
-		for (int k = 0; k < ml; k++) {
-			const bool on = len > k;
-			const unsigned long long m = __ballot(on);
-			const int pos = __popcll(m & ((1ull << lane) - 1ull));
-			uint32_t w = own;
-			if (on) {
-				const uint32_t cw = codes[cbase + ((int64_t)(k / SPW) << 6) + lane];
-				const uint32_t c = (cw >> (BITS * (k % SPW))) & ((1u << BITS) - 1u);
-				w = (uint32_t)col16[base + pos] | (c << 16);
-			}
-			out[(int64_t)k * 64 + lane] = w;
-			base += __popcll(m);
-		}
-	}
-}
-
-// *inside += number of entries whose column lies inside the row's own block of B rows (is an LDS window worth it?)
-static __global__ void k_count_local(int64_t nrows, int64_t B, const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
-                                     unsigned long long* inside)
-{
-	const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	unsigned long long n = 0;
-	if (r < nrows) {
-		const int64_t r0 = (r / B) * B, r1 = r0 + B;
-		for (int64_t p = rowptr[r]; p < rowptr[r + 1]; p++) n += (col[p] >= r0 && col[p] < r1) ? 1u : 0u;
-	}
-#pragma unroll
-	for (int off = 32; off > 0; off >>= 1) n += __shfl_xor(n, off, 64);
-	if ((threadIdx.x & 63) == 0 && n) atomicAdd(inside, n);
-}
-
-// *outside = 1 when some entry's column lies outside its row block [blk*B, (blk+1)*B)
-static __global__ void k_cols_local(SliceGeom g, const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col, int* outside)
-{
-	const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (r >= g.nrows) return;
-	const int64_t r0 = (r / g.B) * g.B, r1 = r0 + g.B;
-	bool bad = false;
-	for (int64_t p = rowptr[r]; p < rowptr[r + 1]; p++) bad |= col[p] < r0 || col[p] >= r1;
-	if (bad) *outside = 1;
-}
-
-// ---- value dictionary ---------------------------------------------------------------------------
-constexpr int kDictTable = 4096; // open-addressing table of distinct 64-bit patterns
-constexpr unsigned long long kDictEmpty = ~0ull;
-
-__device__ __forceinline__ unsigned dict_hash(unsigned long long k)
-{
-	k ^= k >> 33;
-	k *= 0xff51afd7ed558ccdULL;
-	k ^= k >> 33;
-	return (unsigned)k & (kDictTable - 1);
-}
-
-// collect the distinct doubles of vals[0..n) into table (pre-filled with kDictEmpty); *overflow != 0 when full
-static __global__ __launch_bounds__(kBlock) void k_dict_collect(const double* __restrict__ vals, int64_t n,
-                                                                 unsigned long long* table, int* overflow)
-{
-	unsigned long long last = kDictEmpty;
-	for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
-		const unsigned long long key = (unsigned long long)__double_as_longlong(vals[i]);
-		if (key == last) continue; // runs of equal values are the common case
-		last = key;
-		unsigned h = dict_hash(key);
-		int probes = 0;
-		for (; probes < kDictTable; probes++) {
-			const unsigned long long cur = table[h];
-			if (cur == key) break;
-			if (cur == kDictEmpty) {
-				const unsigned long long old = atomicCAS(&table[h], kDictEmpty, key);
-				if (old == kDictEmpty || old == key) break;
-			}
-			h = (h + 1) & (kDictTable - 1);
-		}
-		if (probes == kDictTable) *overflow = 1;
-	}
-}
-
-// code of v in the sorted dictionary (bit patterns compared as unsigned integers)
-__device__ __forceinline__ uint32_t dict_code(const double* dict, int ndict, double v)
-{
-	const unsigned long long key = (unsigned long long)__double_as_longlong(v);
-	int lo = 0, hi = ndict - 1;
-	while (lo < hi) {
-		const int mid = (lo + hi) >> 1;
-		if ((unsigned long long)__double_as_longlong(dict[mid]) < key)
-			lo = mid + 1;
-		else
-			hi = mid;
-	}
-	return (uint32_t)lo;
-}
-
-// one wave per slice: pack the codes of the slice's values (read in CSR order) into the padded word layout
-template <typename T>
-__global__ __launch_bounds__(kBlock) void k_slice_codes(SliceGeom g, const int64_t* __restrict__ rowptr,
-                                                         const T* __restrict__ val_in, const int64_t* __restrict__ code_ptr,
-                                                         const double* __restrict__ dict, int ndict,
-                                                         uint32_t* __restrict__ codes)
-{
-	constexpr int SPW = CodeTraits<T>::kSlotsPerWord;
-	constexpr int BITS = CodeTraits<T>::kBits;
-	const int lane = threadIdx.x & 63;
-	const int64_t wave0 = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
-	const int64_t nwaves = (int64_t)gridDim.x * (kBlock / 64);
-	for (int64_t s = wave0; s < g.nslices; s += nwaves) {
-		int64_t row0;
-		int nvalid;
-		slice_rows(g, s, row0, nvalid);
-		int64_t p0 = 0;
-		int len = 0;
-		if (lane < nvalid) {
-			p0 = rowptr[row0 + lane];
-			len = (int)(rowptr[row0 + lane + 1] - p0);
-		}
-		int maxlen = len;
-#pragma unroll
-		for (int off = 32; off > 0; off >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, off, 64));
-		const int nwords = ((maxlen + 7) / 8) * (8 / SPW);
-		const int64_t cbase = code_ptr[s];
-		for (int w = 0; w < nwords; w++) {
-			uint32_t word = 0;
-#pragma unroll
-			for (int q = 0; q < SPW; q++) {
-				const int k = w * SPW + q;
-				if (k < len) {
-					const double* pv = (const double*)(val_in + p0 + k);
-					uint32_t c = dict_code(dict, ndict, pv[0]);
-					if (sizeof(T) == 16) c |= dict_code(dict, ndict, pv[1]) << 8;
-					word |= c << (BITS * q);
-				}
-			}
-			codes[cbase + ((int64_t)w << 6) + lane] = word;
-		}
-	}
-}
-
-// decode back to CSR order (for lpp_engine_get_csr)
-template <typename T>
-__global__ __launch_bounds__(kBlock) void k_slice_decode(SliceGeom g, const int64_t* __restrict__ rowptr,
-                                                          const uint32_t* __restrict__ codes, const int64_t* __restrict__ code_ptr,
-                                                          const double* __restrict__ dict, T* __restrict__ val_out, int tmpl_codes = 0)
-{
-	constexpr int SPW = CodeTraits<T>::kSlotsPerWord;
-	const int lane = threadIdx.x & 63;
-	const int64_t wave0 = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
-	const int64_t nwaves = (int64_t)gridDim.x * (kBlock / 64);
-	for (int64_t s = wave0; s < g.nslices; s += nwaves) {
-		int64_t row0;
-		int nvalid;
-		slice_rows(g, s, row0, nvalid);
-		if (lane >= nvalid) continue;
-		const int64_t p0 = rowptr[row0 + lane];
-		const int len = (int)(rowptr[row0 + lane + 1] - p0);
-		const int64_t cbase = code_ptr[tmpl_codes ? s % g.spb : s];
-		for (int k = 0; k < len; k++) val_out[p0 + k] = CodeTraits<T>::decode(codes[cbase + ((int64_t)(k / SPW) << 6) + lane], k % SPW, dict);
-	}
-}
-
-// ---------------------------------------------------------------------------------------------
-// fused BLAS-1 of the three-term recurrence (double2 = 16 B per lane)
-// ---------------------------------------------------------------------------------------------
-
-// x -= g*y ;  partial[b] = sum |x|^2     (scalars read from device memory: no host round trip)
-// g = *a_ptr (normalised recurrence) or *a_ptr / *b2_prev (scale-free recurrence: raw dot <r_j|w> over b_{j-1}^2).
-// `send` (optional) receives a copy of the new x: the slice handed to the next all-gather.
-// streamed 16-byte accesses (read once / written once per pass: keep them out of the way of the SpMV's L2 contents)
-typedef double lpp_d2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ double2 nt_load2(const double2* p)
-{
-	const lpp_d2 v = __builtin_nontemporal_load((const lpp_d2*)p);
-	return double2 { v.x, v.y };
-}
-__device__ __forceinline__ void nt_store2(double2 v, double2* p)
-{
-	lpp_d2 w;
-	w.x = v.x;
-	w.y = v.y;
-	__builtin_nontemporal_store(w, (lpp_d2*)p);
-}
-
-template <bool NRM>
-__global__ __launch_bounds__(kBlock) void k_axpy_nrm(double2* __restrict__ x, const double2* __restrict__ y,
-                                                      const double* __restrict__ a_ptr, const double* __restrict__ b2_prev,
-                                                      double2* __restrict__ send, int64_t n2, double* __restrict__ partial, int stream = 0)
-{
-	__shared__ double smem[kBlock / 64];
-	double a = *a_ptr;
-	if (b2_prev) {
-		const double b2 = *b2_prev;
-		if (sqrt(b2) >= 1e-10) a /= b2;
-	}
-	double s = 0.0;
-	const int64_t stride = (int64_t)gridDim.x * kBlock;
-	int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-	// four independent 16-byte loads of x and of y in flight per lane (a one-element loop body left the kernel at
-	// 4.5 TB/s: the loads of the next iteration were not issued before the store of this one)
-	for (; i + 3 * stride < n2; i += 4 * stride) {
-		double2 xv[4], yv[4];
-#pragma unroll
-		for (int k = 0; k < 4; k++) xv[k] = stream ? nt_load2(&x[i + k * stride]) : x[i + k * stride];
-#pragma unroll
-		for (int k = 0; k < 4; k++) yv[k] = stream ? nt_load2(&y[i + k * stride]) : y[i + k * stride];
-#pragma unroll
-		for (int k = 0; k < 4; k++) {
-			xv[k].x -= a * yv[k].x;
-			xv[k].y -= a * yv[k].y;
-			if (stream) // vectors beyond the Infinity Cache: nothing of this pass is re-read before it is evicted anyway
-				nt_store2(xv[k], &x[i + k * stride]);
-			else
-				x[i + k * stride] = xv[k];
-			if (send) send[i + k * stride] = xv[k];
-			if (NRM) s += xv[k].x * xv[k].x + xv[k].y * xv[k].y;
-		}
-	}
-	for (; i < n2; i += stride) {
-		double2 xv = x[i];
-		const double2 yv = y[i];
-		xv.x -= a * yv.x;
-		xv.y -= a * yv.y;
-		x[i] = xv;
-		if (send) send[i] = xv;
-		if (NRM) s += xv.x * xv.x + xv.y * xv.y;
-	}
-	if (NRM) {
-		const double r = block_sum(s, smem);
-		if (threadIdx.x == 0) partial[blockIdx.x] = r;
-	}
-}
-
-static __global__ __launch_bounds__(kBlock) void k_dot(const double2* __restrict__ x, const double2* __restrict__ y,
-                                                 int64_t n2, double* __restrict__ partial)
-{
-	__shared__ double smem[kBlock / 64];
-	double s = 0.0;
-	for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n2; i += (int64_t)gridDim.x * kBlock) {
-		const double2 xv = x[i], yv = y[i];
-		s += xv.x * yv.x + xv.y * yv.y;
-	}
-	const double r = block_sum(s, smem);
-	if (threadIdx.x == 0) partial[blockIdx.x] = r;
-}
-
-// (y_next, x) <- (x / b, -b * y)  with b = sqrt(*b2_ptr);  |b| < 1e-10 leaves x unscaled
-// (the reference's guard in LanczosSolver::oneStepDecomposition [PsimagLite]).
-// `send` (optional) receives a second copy of y_next: the slice handed to the all-gather.
-// y and ynext may alias (in-place swap when the Lanczos vectors are not kept), hence no __restrict__.
-static __global__ __launch_bounds__(kBlock) void k_swap_scale(double2* __restrict__ x, const double2* y,
-                                                        double2* ynext, double2* __restrict__ send,
-                                                        const double* __restrict__ b2_ptr, int64_t n2)
-{
-	const double b = sqrt(*b2_ptr);
-	const double inv = (fabs(b) < 1e-10) ? 1.0 : 1.0 / b;
-	for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n2; i += (int64_t)gridDim.x * kBlock) {
-		const double2 xv = x[i];
-		const double2 yv = y[i];
-		double2 yn, xn;
-		yn.x = xv.x * inv;
-		yn.y = xv.y * inv;
-		xn.x = -b * yv.x;
-		xn.y = -b * yv.y;
-		ynext[i] = yn;
-		x[i] = xn;
-		if (send) send[i] = yn;
-	}
-}
-
-// dst = src / sqrt(*n2_ptr)   (normalise the start vector); optional second copy
-static __global__ __launch_bounds__(kBlock) void k_scale_copy(double2* __restrict__ dst, double2* __restrict__ send,
-                                                        const double2* __restrict__ src,
-                                                        const double* __restrict__ nrm2_ptr, int64_t n2)
-{
-	const double inv = 1.0 / sqrt(*nrm2_ptr);
-	for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n2; i += (int64_t)gridDim.x * kBlock) {
-		double2 v = src[i];
-		v.x *= inv;
-		v.y *= inv;
-		dst[i] = v;
-		if (send) send[i] = v;
-	}
-}
-
-// z += s * y   (two-pass Ritz accumulation; s passed by value)
-static __global__ __launch_bounds__(kBlock) void k_axpy_const(double2* __restrict__ z, const double2* __restrict__ y,
-                                                        double s, int64_t n2)
-{
-	for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n2; i += (int64_t)gridDim.x * kBlock) {
-		double2 zv = z[i];
-		const double2 yv = y[i];
-		zv.x += s * yv.x;
-		zv.y += s * yv.y;
-		z[i] = zv;
-	}
-}
-
-// ---------------------------------------------------------------------------------------------
-// Transposition exchange (multi-GPU Hubbard): the rank's slice y[(id-id0)*N_up + iu] is re-cut by UP index.
-// Chunk p of the send buffer holds the sub-block iu in [p*peru, (p+1)*peru) of every local down index:
-//   send[p*C + id_l*peru + iu_lp],  C = per*peru (padded, padding never written and pre-zeroed).
-// After the all-to-all, chunk q of the receive buffer holds the rank's own UP range for rank q's down indices,
-// i.e. the transposed slice yT[id*peru + iu_l] with id running over ALL down indices.
-// ---------------------------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(kBlock) void k_pack_transpose(const T* __restrict__ y, T* __restrict__ send, int64_t nid,
-                                                            int64_t n_up, int64_t peru, int64_t chunk)
-{
-	const int64_t n = nid * n_up;
-	for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
-		const int64_t idl = i / n_up, iu = i - idl * n_up;
-		const int64_t p = iu / peru, iul = iu - p * peru;
-		send[p * chunk + idl * peru + iul] = y[i];
-	}
-}
-
-// x[i] += recv[...] (the down-hop part computed on the UP-partitioned layout and sent back), fused Re<y|x> partial
-template <typename T, bool DOT>
-__global__ __launch_bounds__(kBlock) void k_unpack_add_dot(T* __restrict__ x, const T* __restrict__ recv,
-                                                            const T* __restrict__ y, int64_t nid, int64_t n_up,
-                                                            int64_t peru, int64_t chunk, double* __restrict__ partial)
-{
-	__shared__ double smem[kBlock / 64];
-	const int64_t n = nid * n_up;
-	double dot = 0.0;
-	for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
-		const int64_t idl = i / n_up, iu = i - idl * n_up;
-		const int64_t p = iu / peru, iul = iu - p * peru;
-		const T xv = VT<T>::add(x[i], recv[p * chunk + idl * peru + iul]);
-		x[i] = xv;
-		if (DOT) dot += VT<T>::dot_re(y[i], xv);
-	}
-	if (DOT) {
-		const double r = block_sum(dot, smem);
-		if (threadIdx.x == 0) partial[blockIdx.x] = r;
-	}
-}
-
-// splitmix64 start vector; the test-suite checks it is bit-identical to the CPU checker's stream
-__device__ __forceinline__ uint64_t splitmix64(uint64_t z)
-{
-	z += 0x9E3779B97F4A7C15ULL;
-	z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
-	z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
-	return z ^ (z >> 31);
-}
-static __global__ void k_fill_random(double* __restrict__ v, int64_t nd, int64_t offset, uint64_t seed)
-{
-	for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nd; k += (int64_t)gridDim.x * blockDim.x) {
-		const uint64_t r = splitmix64(seed * 0x2545F4914F6CDD1DULL + (uint64_t)(k + offset));
-		v[k] = (double)(r >> 11) * (1.0 / 9007199254740992.0) - 0.5;
-	}
-}
-
-// out[c] = sum_p partial[p*stride + c], c < count  (single block; fixed summation order)
-static __global__ __launch_bounds__(kBlock) void k_reduce_final(const double* __restrict__ partial, int np, int stride,
-                                                          int count, double* __restrict__ out)
-{
-	__shared__ double smem[kBlock / 64];
-	for (int c = 0; c < count; c++) {
-		double s = 0.0;
-		for (int p = threadIdx.x; p < np; p += kBlock) s += partial[(int64_t)p * stride + c];
-		const double r = block_sum(s, smem);
-		if (threadIdx.x == 0) out[c] = r;
-	}
-}
-
-// ---------------------------------------------------------------------------------------------
-// blocked Gram-Schmidt against the on-device Krylov basis (panels of kPanel columns)
-//   coef_p = <v_p | x> = sum conj(v_p) x        k_multi_dot   (reads x once per panel)
-//   x     -= sum_p coef_p v_p                   k_multi_axpy
-// V column p of the panel starts at v0 + p*ldv (ldv in double2 units).
-// ---------------------------------------------------------------------------------------------
-template <bool CPLX>
-__global__ __launch_bounds__(kBlock) void k_multi_dot(const double2* __restrict__ x, const double2* __restrict__ v0,
-                                                       int64_t ldv, int np, int64_t n2,
-                                                       double* __restrict__ partial)
-{
-	__shared__ double smem[kBlock / 64];
-	double re[kPanel], im[kPanel];
-#pragma unroll
-	for (int p = 0; p < kPanel; p++) re[p] = im[p] = 0.0;
-	for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n2; i += (int64_t)gridDim.x * kBlock) {
-		const double2 xv = x[i];
-#pragma unroll
-		for (int p = 0; p < kPanel; p++) {
-			if (p < np) {
-				const double2 vv = v0[(int64_t)p * ldv + i];
-				re[p] += vv.x * xv.x + vv.y * xv.y;
-				if (CPLX) im[p] += vv.x * xv.y - vv.y * xv.x;
-			}
-		}
-	}
-#pragma unroll
-	for (int p = 0; p < kPanel; p++) {
-		const double r = block_sum(re[p], smem);
-		if (threadIdx.x == 0) partial[(int64_t)blockIdx.x * (2 * kPanel) + 2 * p] = r;
-		const double q = CPLX ? block_sum(im[p], smem) : 0.0;
-		if (threadIdx.x == 0) partial[(int64_t)blockIdx.x * (2 * kPanel) + 2 * p + 1] = q;
-	}
-}
-
-// coef: 2 doubles (re,im) per panel column in device memory; sign = -1 for orthogonalisation,
-// +1 to accumulate Ritz vectors (z += sum S_jk v_j).
-template <bool CPLX>
-__global__ __launch_bounds__(kBlock) void k_multi_axpy(double2* __restrict__ x, const double2* __restrict__ v0,
-                                                        int64_t ldv, int np, const double* __restrict__ coef,
-                                                        double sign, int64_t n2)
-{
-	double cr[kPanel], ci[kPanel];
-#pragma unroll
-	for (int p = 0; p < kPanel; p++) {
-		cr[p] = (p < np) ? sign * coef[2 * p] : 0.0;
-		ci[p] = (p < np && CPLX) ? sign * coef[2 * p + 1] : 0.0;
-	}
-	for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n2; i += (int64_t)gridDim.x * kBlock) {
-		double2 xv = x[i];
-#pragma unroll
-		for (int p = 0; p < kPanel; p++) {
-			if (p < np) {
-				const double2 vv = v0[(int64_t)p * ldv + i];
-				if (CPLX) {
-					xv.x += cr[p] * vv.x - ci[p] * vv.y;
-					xv.y += cr[p] * vv.y + ci[p] * vv.x;
-				} else {
-					xv.x += cr[p] * vv.x;
-					xv.y += cr[p] * vv.y;
-				}
-			}
-		}
-		x[i] = xv;
-	}
-}
-
-} // namespace lpp
+#include "lpp_common.h"
+#include "lpp_spmv_kernels.h"
+#include "lpp_layout_kernels.h"
+#include "lpp_blas_kernels.h"
