@@ -144,6 +144,10 @@ lpp_status lpp_engine_set_row_block(lpp_engine* e, int64_t rows_per_block);
 /* Upload a host CSR (copied).  rowptr[nrows+1], colind[nnz], values[nnz] of the engine dtype. */
 lpp_status lpp_engine_set_csr(lpp_engine* e, int64_t nrows, const int64_t* rowptr, const int32_t* colind,
                               const void* values);
+/* The same from DEVICE pointers of the engine's GPU (copied device-to-device, validated on the device): for hosts that
+ * assemble on the GPU themselves (SURVEY 8(b) `_set_csr_device`).  Honours lpp_engine_set_row_block. */
+lpp_status lpp_engine_set_csr_device(lpp_engine* e, int64_t nrows, const int64_t* d_rowptr, const int32_t* d_colind,
+                                     const void* d_values);
 
 /* Row-partitioned upload for rank `comm->rank`: rows [row_start, row_start+local_rows) of a
  * global_rows x global_rows matrix, colind holding GLOBAL column indices, rowptr relative to the

@@ -75,6 +75,7 @@ SYMBOLS = {
     "lpp_engine_destroy": (C.c_int32, [_P]),
     "lpp_engine_set_row_block": (C.c_int32, [_P, C.c_int64]),
     "lpp_engine_set_csr": (C.c_int32, [_P, C.c_int64, _P, _P, _P]),
+    "lpp_engine_set_csr_device": (C.c_int32, [_P, C.c_int64, _P, _P, _P]),
     "lpp_engine_set_csr_partition": (C.c_int32, [_P, C.POINTER(Comm), C.c_int64, _P, _P, _P, _P]),
     "lpp_engine_assemble_hubbard": (C.c_int32, [_P, C.POINTER(Comm), C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P]),
     "lpp_engine_setup_hubbard_onthefly": (C.c_int32, [_P, C.POINTER(Comm), C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P]),

@@ -815,6 +815,54 @@ lpp_status lpp_engine_set_csr(lpp_engine* e, int64_t nrows, const int64_t* rowpt
 	return alloc_work(e);
 }
 
+lpp_status lpp_engine_set_csr_device(lpp_engine* e, int64_t nrows, const int64_t* d_rowptr, const int32_t* d_colind, const void* d_values)
+{
+	if (!e || nrows < 0 || !d_rowptr) return fail(LPP_ERR_INVALID, "lpp_engine_set_csr_device: bad argument");
+	if (nrows > (int64_t)INT32_MAX) return fail(LPP_ERR_INVALID, "lpp_engine_set_csr_device: nrows exceeds 32-bit column range");
+	HIP_TRY(hipSetDevice(e->cfg.device));
+	int64_t nnz = 0;
+	HIP_TRY(hipMemcpy(&nnz, d_rowptr + nrows, sizeof(int64_t), hipMemcpyDeviceToHost));
+	if (nnz < 0) return fail(LPP_ERR_INVALID, "lpp_engine_set_csr_device: negative rowptr[nrows]");
+	if (nnz > 0 && (!d_colind || !d_values)) return fail(LPP_ERR_INVALID, "lpp_engine_set_csr_device: null colind/values");
+	// the same structural checks as the host entry point, on the device
+	int* bad = nullptr;
+	HIP_TRY_MEM(hipMalloc(&bad, sizeof(int)));
+	(void)hipMemsetAsync(bad, 0, sizeof(int), e->stream);
+	k_check_csr<<<(int)((std::max<int64_t>(nrows, 1) + 255) / 256), 256, 0, e->stream>>>(nrows, nrows, d_rowptr, d_colind, bad);
+	int hbad = 0;
+	hipError_t e1 = hipMemcpyAsync(&hbad, bad, sizeof(int), hipMemcpyDeviceToHost, e->stream);
+	hipError_t e2 = hipStreamSynchronize(e->stream);
+	(void)hipFree(bad);
+	if (e1 != hipSuccess || e2 != hipSuccess) return fail(LPP_ERR_HIP, "lpp_engine_set_csr_device: validation failed to run");
+	if (hbad) return fail(LPP_ERR_INVALID, "CSR: rowptr not monotone from 0 or column index out of range");
+	e->has_comm = false;
+	e->bind_scalars(e->scal_own);
+	free_csr(e->A_rem);
+	drop_product(e);
+	DevCsr& A = e->A_loc;
+	free_csr(A);
+	A.hint_block = e->row_block_hint;
+	A.nrows = nrows;
+	A.nnz = nnz;
+	A.owned = true;
+	HIP_TRY_MEM(hipMalloc(&A.rowptr, sizeof(int64_t) * (size_t)(nrows + 1)));
+	HIP_TRY_MEM(hipMalloc(&A.col, sizeof(int32_t) * (size_t)std::max<int64_t>(nnz, 1)));
+	HIP_TRY_MEM(hipMalloc(&A.val, e->esz * (size_t)std::max<int64_t>(nnz, 1)));
+	HIP_TRY(hipMemcpyAsync(A.rowptr, d_rowptr, sizeof(int64_t) * (size_t)(nrows + 1), hipMemcpyDeviceToDevice, e->stream));
+	if (nnz > 0) {
+		HIP_TRY(hipMemcpyAsync(A.col, d_colind, sizeof(int32_t) * (size_t)nnz, hipMemcpyDeviceToDevice, e->stream));
+		HIP_TRY(hipMemcpyAsync(A.val, d_values, e->esz * (size_t)nnz, hipMemcpyDeviceToDevice, e->stream));
+	}
+	HIP_TRY(hipStreamSynchronize(e->stream));
+	lpp_status st = finalize_csr(e, A, true);
+	if (st != LPP_OK) return st;
+	e->n_local = e->n_global = nrows;
+	e->row_start = 0;
+	e->active = false;
+	set_spmv_bytes(e);
+	return alloc_work(e);
+}
+
 lpp_status lpp_engine_set_csr_partition(lpp_engine* e, const lpp_comm* comm, int64_t global_rows, const int64_t* shard_starts,
                                         const int64_t* rowptr, const int32_t* colind, const void* values)
 {

@@ -98,6 +98,22 @@ template <> __device__ __forceinline__ bool same_bits<cplx>(const cplx& x, const
 	return __double_as_longlong(x.re) == __double_as_longlong(y.re) && __double_as_longlong(x.im) == __double_as_longlong(y.im);
 }
 
+// device-side counterpart of the host CSR validation (lpp_engine_set_csr_device)
+static __global__ void k_check_csr(int64_t nrows, int64_t ncols, const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col, int* bad)
+{
+	const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (r == 0 && rowptr[0] != 0) *bad = 1;
+	if (r >= nrows) return;
+	const int64_t p0 = rowptr[r], p1 = rowptr[r + 1];
+	if (p1 < p0) {
+		*bad = 1;
+		return;
+	}
+	bool b = false;
+	for (int64_t p = p0; p < p1; p++) b |= col[p] < 0 || (int64_t)col[p] >= ncols;
+	if (b) *bad = 1;
+}
+
 static __global__ void k_rows_sorted(int64_t nrows, const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col, int* unsorted)
 {
 	const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -83,6 +83,10 @@ class LanczosEngine:
             raise ValueError("inconsistent CSR arrays")
         check(self._lib.lpp_engine_set_csr(self._h, n, _vp(rowptr), _vp(colind), _vp(values)))
 
+    def set_csr_device(self, nrows, d_rowptr, d_colind, d_values):
+        """CSR already resident on the engine's GPU: raw device addresses (e.g. torch tensor .data_ptr())."""
+        check(self._lib.lpp_engine_set_csr_device(self._h, int(nrows), C.c_void_p(d_rowptr), C.c_void_p(d_colind), C.c_void_p(d_values)))
+
     def set_csr_partition(self, comm, global_rows, shard_starts, rowptr, colind, values):
         shard_starts = np.ascontiguousarray(shard_starts, np.int64)
         rowptr = np.ascontiguousarray(rowptr, np.int64)

@@ -560,3 +560,53 @@ def test_layout_fuzz_spmv_and_roundtrip(seed):
         assert np.max(np.abs(xg - xo)) <= 1e-12 * max(1.0, np.max(np.abs(xo))), e.layout()
         rp, c2, v2 = e.get_csr()
         assert np.array_equal(rp, A.rowptr) and np.array_equal(c2, A.colind) and np.array_equal(_bits(v2), _bits(A.values)), e.layout()
+
+
+def _hip_runtime():
+    """The HIP runtime instance the engine itself is linked against (found in this process' maps once the engine library is
+    loaded): torch would bring its own copy of the runtime, and two of them in one process do not share a device."""
+    import ctypes as C
+    from lanczosplusplus_amd import _capi
+    _capi.lib()
+    for line in open("/proc/self/maps"):
+        if "libamdhip64" in line:
+            return C.CDLL(line.split()[-1])
+    raise RuntimeError("libamdhip64 is not mapped")
+
+
+def test_set_csr_from_device_pointers():
+    """lpp_engine_set_csr_device: a CSR that already lives on the GPU gives the same layout, product and round trip as the
+    host upload; a malformed one is refused."""
+    import ctypes as C
+    A = oracle.hubbard_csr(10, 5, 4, chain(10, -1.0, True), np.full(10, 4.0))
+    with LanczosEngine(spmv_kernel=3) as e, LanczosEngine(spmv_kernel=3) as h:
+        hip = _hip_runtime()
+        hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+        hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        hip.hipFree.argtypes = [C.c_void_p]
+
+        def to_device(a):
+            p = C.c_void_p()
+            assert hip.hipMalloc(C.byref(p), a.nbytes) == 0
+            assert hip.hipMemcpy(p, a.ctypes.data_as(C.c_void_p), a.nbytes, 1) == 0  # hipMemcpyHostToDevice
+            return p
+
+        rp, ci, va = to_device(A.rowptr), to_device(A.colind), to_device(A.values)
+        bad_ci = A.colind.copy()
+        bad_ci[5] = A.nrows  # column out of range
+        bad = to_device(bad_ci)
+        try:
+            e.set_row_block(252)
+            e.set_csr_device(A.nrows, rp.value, ci.value, va.value)
+            h.set_row_block(252)
+            h.set_csr(A.rowptr, A.colind, A.values)
+            assert e.layout() == h.layout()
+            x0, y = oracle.fill_random(A.nrows, 3), oracle.fill_random(A.nrows, 4)
+            assert rel(e.matrixVectorProduct(x0.copy(), y), oracle.spmv_acc(A, x0.copy(), y)) < SPMV_TOL
+            r2, c2, v2 = e.get_csr()
+            assert np.array_equal(r2, A.rowptr) and np.array_equal(c2, A.colind) and np.array_equal(_bits(v2), _bits(A.values))
+            with pytest.raises(LppError):
+                e.set_csr_device(A.nrows, rp.value, bad.value, va.value)
+        finally:
+            for p in (rp, ci, va, bad):
+                hip.hipFree(p)
