@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstdio>
 #include <cstring>
+#include <numeric>
 #include <string>
 #include <vector>
 
@@ -509,6 +510,72 @@ template <typename T> static lpp_status build_sliced_t(lpp_engine* e, DevCsr& A,
 	return LPP_OK;
 }
 
+// Basis block of an uploaded matrix nobody described (lpp_engine_set_row_block not called): product bases show up as
+// couplings at offsets k*B that are identical for 64 consecutive rows.  A sample of 64-row slices is copied to the
+// host; per slice the largest offset shared by all its rows (same value in every row) is a block shift, B = the gcd of
+// those over the sample.  Accepted only when every sampled entry is then either inside its row's block or a whole
+// number of blocks away, and B fits the LDS window.  Returns 0 when no such structure is found.
+template <typename T> static int64_t detect_row_block_t(lpp_engine* e, const DevCsr& A, int64_t lds_cap_elems)
+{
+	const int64_t nsl = A.nrows / 64;
+	if (nsl < 64 || !A.col || !A.val || A.nnz == 0) return 0;
+	const int samples = 48;
+	std::vector<int64_t> rp(65);
+	std::vector<int32_t> ci;
+	std::vector<T> va;
+	struct Slice {
+		int64_t row0;
+		std::vector<int64_t> rp;
+		std::vector<int32_t> ci;
+	};
+	std::vector<Slice> kept;
+	int64_t G = 0;
+	for (int sidx = 0; sidx < samples; sidx++) {
+		const int64_t row0 = ((nsl * (2 * sidx + 1)) / (2 * samples)) * 64;
+		if (hipMemcpy(rp.data(), A.rowptr + row0, sizeof(int64_t) * 65, hipMemcpyDeviceToHost) != hipSuccess) return 0;
+		const int64_t p0 = rp[0], n = rp[64] - rp[0];
+		if (n <= 0 || n > (int64_t)1 << 20) continue;
+		ci.resize((size_t)n);
+		va.resize((size_t)n);
+		if (hipMemcpy(ci.data(), A.col + p0, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost) != hipSuccess) return 0;
+		if (hipMemcpy(va.data(), (const T*)A.val + p0, sizeof(T) * (size_t)n, hipMemcpyDeviceToHost) != hipSuccess) return 0;
+		int64_t best = 0; // largest |offset| shared by all 64 rows with the same value
+		for (int64_t q = rp[0]; q < rp[1]; q++) {
+			const int64_t off = (int64_t)ci[(size_t)(q - p0)] - row0;
+			if (std::llabs(off) < 64 || std::llabs(off) <= best) continue;
+			bool all = true;
+			for (int r = 1; r < 64 && all; r++) {
+				bool found = false;
+				for (int64_t t = rp[r]; t < rp[r + 1]; t++)
+					if ((int64_t)ci[(size_t)(t - p0)] - (row0 + r) == off) {
+						found = std::memcmp(&va[(size_t)(t - p0)], &va[(size_t)(q - p0)], sizeof(T)) == 0;
+						break;
+					}
+				all = found;
+			}
+			if (all) best = std::llabs(off);
+		}
+		if (best > 0) G = G == 0 ? best : std::gcd(G, best);
+		Slice sl;
+		sl.row0 = row0;
+		sl.rp.assign(rp.begin(), rp.end());
+		sl.ci = ci;
+		kept.push_back(std::move(sl));
+	}
+	if (G < 64 || G > lds_cap_elems || kept.empty()) return 0;
+	for (const Slice& sl : kept) {
+		const int64_t p0 = sl.rp[0];
+		for (int r = 0; r < 64; r++) {
+			const int64_t row = sl.row0 + r, b0 = (row / G) * G;
+			for (int64_t t = sl.rp[r]; t < sl.rp[r + 1]; t++) {
+				const int64_t c = sl.ci[(size_t)(t - p0)];
+				if (!((c >= b0 && c < b0 + G) || (c - row) % G == 0)) return 0;
+			}
+		}
+	}
+	return G;
+}
+
 // Choose the SpMV kernel and build its layout.  hint_block (rows) is the basis' natural block
 // (N_up for the Hubbard product basis): when a whole number of such blocks fits the LDS window,
 // the window kernel serves every in-block gather (diagonal + up-hops) from LDS.
@@ -523,6 +590,12 @@ lpp_status finalize_csr(lpp_engine* e, DevCsr& A, bool allow_drop_plain, int for
 	const bool fits32 = src_elems * e->esz < ((size_t)1 << 32);
 	const int64_t lds_cap_elems = (int64_t)((156 * 1024) / e->esz);
 	int64_t win_rows = 0;
+	if (A.hint_block == 0 && mode == LPP_SPMV_AUTO && !e->is_complex && fits32 && A.src_elems == 0
+	    && !(getenv("LPP_DETECT_BLOCK") && atoi(getenv("LPP_DETECT_BLOCK")) == 0)) {
+		StageTimer tm("basis block detection");
+		A.hint_block = detect_row_block_t<double>(e, A, lds_cap_elems);
+		if (A.hint_block && getenv("LPP_VERBOSE")) fprintf(stderr, "lpp: detected a basis block of %lld rows\n", (long long)A.hint_block);
+	}
 	if (A.hint_block > 0 && A.hint_block <= lds_cap_elems) {
 		// one basis block per window whenever it gives the 16 waves of a workgroup something to do: only then do all
 		// row blocks repeat the same in-block structure (block template); tiny basis blocks are grouped

@@ -610,3 +610,25 @@ def test_set_csr_from_device_pointers():
         finally:
             for p in (rp, ci, va, bad):
                 hip.hipFree(p)
+
+
+def test_basis_block_is_detected_without_a_hint():
+    """An uploaded product-basis matrix that nobody described gets the same layout as a hinted one: the basis block is
+    read off the structure (couplings at multiples of N_up shared by 64 consecutive rows).  Matrices without such a
+    structure are left alone."""
+    L = 12
+    A = oracle.hubbard_csr(L, 6, 5, chain(L, -1.0, True), np.full(L, 4.0))  # N_up = 924, N = 731,808
+    with LanczosEngine() as auto, LanczosEngine() as hinted:
+        auto.set_csr(A.rowptr, A.colind, A.values)
+        hinted.set_row_block(924)
+        hinted.set_csr(A.rowptr, A.colind, A.values)
+        la, lh = auto.layout(), hinted.layout()
+        assert la["rows_per_block"] == 924 and la == lh and la["block_template"] == 2
+        x0, y = oracle.fill_random(A.nrows, 3), oracle.fill_random(A.nrows, 4)
+        assert rel(auto.matrixVectorProduct(x0.copy(), y), oracle.spmv_acc(A, x0.copy(), y)) < SPMV_TOL
+    H = oracle.heis_csr(22, 1, 11, chain(22, 1.0), chain(22, 1.0))  # 705,432 states, no uniform block
+    with LanczosEngine() as e:
+        e.set_csr(H.rowptr, H.colind, H.values)
+        assert e.layout()["rows_per_block"] != 924 and e.layout()["block_template"] == 0
+        x0, y = oracle.fill_random(H.nrows, 3), oracle.fill_random(H.nrows, 4)
+        assert rel(e.matrixVectorProduct(x0.copy(), y), oracle.spmv_acc(H, x0.copy(), y)) < SPMV_TOL
