@@ -1,15 +1,15 @@
 #!/bin/bash
 # Round profile: the default bench line + rocprofv3 kernel trace and PMC passes of the SAME command.
-# usage: bash scripts/profile_round.sh r01   (outputs under gpurun_out/profile_<tag>/)
+# usage: [BENCH_ARGS="--workload ... --engine ..."] bash scripts/profile_round.sh r01   (outputs under gpurun_out/profile_<tag>/)
 R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=$(pwd)
 TAG=${1:-r01}
 export TMPDIR=/tmp
 O=$R/gpurun_out/profile_$TAG
 mkdir -p $O
 cd /tmp
-CMD="python3 $R/bench.py --steps 40 --warmup 5"
+CMD="python3 $R/bench.py --steps 40 --warmup 5 $BENCH_ARGS"
 $CMD > $O/bench.json 2> $O/bench.err
-CMDP="python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline"
+CMDP="python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline $BENCH_ARGS"
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- $CMDP > $O/trace.log 2>&1
 timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -- $CMDP > $O/fetch.log 2>&1
 timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -- $CMDP > $O/write.log 2>&1
