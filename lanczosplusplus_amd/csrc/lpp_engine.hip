@@ -286,6 +286,7 @@ template <typename T> static lpp_status split_dia_t(lpp_engine* e, DevCsr& A, co
 	const int nbw = (int)std::max<int64_t>(1, std::min<int64_t>((g.nslices + 3) / 4, 16384));
 	const int win = for_window ? 1 : 0;
 	int xd = xdiag ? 1 : 0;
+	StageTimer* t_count = new StageTimer("  split: count pass");
 	for (;;) {
 		k_dia_split<T, false><<<nbw, kBlock, 0, e->stream>>>(g, A.rowptr, A.col, (const T*)A.val, win, 0, A.rrowptr, flags + 1, nullptr, nullptr,
 		                                                    nullptr, nullptr, nullptr, xd, nullptr, 0, nullptr);
@@ -298,6 +299,7 @@ template <typename T> static lpp_status split_dia_t(lpp_engine* e, DevCsr& A, co
 		HIP_TRY(hipMemsetAsync(A.rrowptr, 0, sizeof(int64_t) * (size_t)(A.nrows + 1), e->stream));
 		HIP_TRY(hipMemsetAsync(flags + 1, 0, sizeof(unsigned long long) * 3, e->stream));
 	}
+	delete t_count;
 	lpp_status st = scan_exclusive(e, A.rrowptr, A.nrows + 1, &A.rnnz);
 	if (st != LPP_OK) return st;
 	A.ndia = (int64_t)h[2];
@@ -313,6 +315,7 @@ template <typename T> static lpp_status split_dia_t(lpp_engine* e, DevCsr& A, co
 		HIP_TRY_MEM(hipMalloc(&A.dcode, (size_t)A.nrows * (sizeof(T) / sizeof(double))));
 		HIP_TRY(hipMemsetAsync(A.dcode, 0, (size_t)A.nrows * (sizeof(T) / sizeof(double)), e->stream));
 	}
+	StageTimer* t_alloc = new StageTimer("  split: allocations");
 	const size_t places = std::max<size_t>((size_t)g.nslices * (size_t)A.dia_stride, 1);
 	HIP_TRY_MEM(hipMalloc(rcol, sizeof(int32_t) * (size_t)std::max<int64_t>(A.rnnz, 1)));
 	HIP_TRY_MEM(hipMalloc(rval, sizeof(T) * (size_t)std::max<int64_t>(A.rnnz, 1)));
@@ -320,6 +323,9 @@ template <typename T> static lpp_status split_dia_t(lpp_engine* e, DevCsr& A, co
 	HIP_TRY_MEM(hipMalloc(&A.dia_val, sizeof(T) * places));
 	HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)A.dia_off, (int)kDiaNone, places, e->stream));
 	HIP_TRY(hipMemsetAsync(A.dia_val, 0, sizeof(T) * places, e->stream));
+	HIP_TRY(hipStreamSynchronize(e->stream));
+	delete t_alloc;
+	StageTimer t_fill("  split: fill pass");
 	k_dia_split<T, true><<<nbw, kBlock, 0, e->stream>>>(g, A.rowptr, A.col, (const T*)A.val, win, A.dia_stride, nullptr, nullptr, A.rrowptr,
 	                                                   *rcol, *rval, A.dia_off, (T*)A.dia_val, xd, A.dict, A.ndict, A.dcode);
 	HIP_TRY(hipGetLastError());
