@@ -86,6 +86,7 @@ lpp_status run_assembly(lpp_engine* e, AsmParams P, DevCsr& A, int force_mode = 
 	A.hint_block = (MODEL == ASM_HUBBARD && P.part != 2) ? P.n_up : 0; // Hubbard product basis: one down configuration per block
 	A.nrows = P.nloc;
 	A.owned = true;
+	A.known_sorted = true; // rows come out of the delta-sorted term list in column order
 	HIP_TRY_MEM(hipMalloc(&A.rowptr, sizeof(int64_t) * (size_t)(P.nloc + 1)));
 	HIP_TRY(hipMemsetAsync(A.rowptr, 0, sizeof(int64_t) * (size_t)(P.nloc + 1), st));
 	const int nb = (int)std::max<int64_t>(1, std::min<int64_t>((P.nloc + kBlock - 1) / kBlock, 1 << 20));

@@ -276,11 +276,13 @@ template <typename T> static lpp_status split_dia_t(lpp_engine* e, DevCsr& A, co
 		~Free() { (void)hipFree(p); }
 	} free_flags { flags };
 	HIP_TRY(hipMemsetAsync(flags, 0, sizeof(unsigned long long) * 4, e->stream));
-	k_rows_sorted<<<(int)((A.nrows + 255) / 256), 256, 0, e->stream>>>(A.nrows, A.rowptr, A.col, (int*)flags);
 	unsigned long long h[4] = { 0, 0, 0, 0 };
-	HIP_TRY(hipMemcpyAsync(h, flags, sizeof(unsigned long long), hipMemcpyDeviceToHost, e->stream));
-	HIP_TRY(hipStreamSynchronize(e->stream));
-	if (h[0] != 0) return LPP_OK;
+	if (!A.known_sorted) {
+		k_rows_sorted<<<(int)((A.nrows + 255) / 256), 256, 0, e->stream>>>(A.nrows, A.rowptr, A.col, (int*)flags);
+		HIP_TRY(hipMemcpyAsync(h, flags, sizeof(unsigned long long), hipMemcpyDeviceToHost, e->stream));
+		HIP_TRY(hipStreamSynchronize(e->stream));
+		if (h[0] != 0) return LPP_OK;
+	}
 	HIP_TRY_MEM(hipMalloc(&A.rrowptr, sizeof(int64_t) * (size_t)(A.nrows + 1)));
 	HIP_TRY(hipMemsetAsync(A.rrowptr, 0, sizeof(int64_t) * (size_t)(A.nrows + 1), e->stream));
 	const int nbw = (int)std::max<int64_t>(1, std::min<int64_t>((g.nslices + 3) / 4, 16384));

@@ -57,6 +57,7 @@ struct DevCsr {
 	int ndict = 0;
 	// shared-offset entries (k_dia_split): the sliced arrays then hold the "rest" CSR described by rrowptr
 	bool no_dia = false;
+	bool known_sorted = false; // rows strictly sorted by column by construction (device assembler): skip the check
 	int64_t* rrowptr = nullptr; // row pointers of the rest CSR (null: nothing was split off)
 	int64_t rnnz = 0; // its entries
 	int64_t ndia = 0; // shared entries, summed over slices
