@@ -63,6 +63,8 @@ WORKLOADS = {
     "hubbard_4x4_7up7down_pbc_U4": ("hubbard", dict(L=16, nup=7, ndown=7, hop=lambda: square_lattice(4, 4, -1.0), U=4.0)),
     # 2.36e9 states: 14x more than fits one GPU as a stored CSR (would be ~1 TB); matrix-free engine only
     "hubbard_3x6_half_filling_pbc_U4": ("hubbard", dict(L=18, nup=9, ndown=9, hop=lambda: square_lattice(3, 6, -1.0), U=4.0)),
+    # 3.4e8 states, ~1.2e10 non-zeros (144 GB as a plain CSR): the largest 3x6 sector whose one-species space fits the LDS window
+    "hubbard_3x6_6up6down_pbc_U4": ("hubbard", dict(L=18, nup=6, ndown=6, hop=lambda: square_lattice(3, 6, -1.0), U=4.0)),
     "hubbard_chain_L12_half_filling_U4": ("hubbard", dict(L=12, nup=6, ndown=6, hop=lambda: chain(12, -1.0), U=4.0)),
     "hubbard_chain_L14_half_filling_U4": ("hubbard", dict(L=14, nup=7, ndown=7, hop=lambda: chain(14, -1.0), U=4.0)),
     # complex hoppings (Peierls phase on every bond): the reference's SolverOptions=useComplex path

@@ -82,3 +82,18 @@ def test_config2_shape_products_agree_and_are_hermitian():
         e.setup_hubbard_onthefly(L, 8, 8, hop, U)
         hv2 = e.matrixVectorProduct(np.zeros(n), v)
     assert np.max(np.abs(hv2 - hv)) <= 1e-13 * np.max(np.abs(hv))
+
+
+def test_3e8_states_stored_csr_free_fermions():
+    """Twice config 2: the 3x6 cluster with 6 up / 6 down electrons -- 344,622,096 states, 1.2e10 non-zeros, 144 GB as a plain
+    CSR while it is being assembled on the device, ~8 GB once it is in the compressed layout -- through the STORED engine."""
+    L = 18
+    hop = square(3, 6, -1.0, pbc=True)
+    exact = _exact(hop, 6)
+    with LanczosEngine(max_steps=300, eps=1e-11, save_vectors=0) as e:
+        e.assemble_hubbard(L, 6, 6, hop, np.zeros(L))
+        st0, lay = e.stats(), e.layout()
+        assert (st0["nrows"], st0["nnz"]) == (18564 * 18564, 12021229584)
+        assert lay["block_template"] == 2 and lay["resident_bytes"] < 12e9
+        eg, _, st = e.lanczos(1, want_vectors=False)
+    assert abs(eg[0] - exact) <= 1e-10 * abs(exact), (eg[0], exact, st["steps"])
