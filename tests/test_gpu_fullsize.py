@@ -97,3 +97,16 @@ def test_3e8_states_stored_csr_free_fermions():
         assert lay["block_template"] == 2 and lay["resident_bytes"] < 12e9
         eg, _, st = e.lanczos(1, want_vectors=False)
     assert abs(eg[0] - exact) <= 1e-10 * abs(exact), (eg[0], exact, st["steps"])
+
+
+def test_config5_lattice_sector_matrix_free_free_fermions():
+    """BASELINE config 5's lattice (4x5, periodic), the (6,6) sector of SURVEY 8(e): 1,502,337,600 states (0.67 TB as a CSR),
+    matrix-free on one GPU; exact free-fermion energy."""
+    L = 20
+    hop = square(4, 5, -1.0, pbc=True)
+    exact = _exact(hop, 6)
+    with LanczosEngine(max_steps=300, eps=1e-11, save_vectors=0) as e:
+        e.setup_hubbard_onthefly(L, 6, 6, hop, np.zeros(L))
+        assert e.rows() == 38760 * 38760 == 1502337600
+        eg, _, st = e.lanczos(1, want_vectors=False)
+    assert abs(eg[0] - exact) <= 1e-10 * abs(exact), (eg[0], exact, st["steps"])
