@@ -663,7 +663,7 @@ lpp_status lpp_engine_setup_hubbard_onthefly(lpp_engine* e, const lpp_comm* comm
 	K.equiv_nnz = (double)nid * ((double)n_up + off_up) + (double)n_up * off_dn_total * ((double)nid / (double)n_dn);
 	if (multi && comm->exchange_begin && comm->exchange_end && comm->xchg_chunk > 0) {
 		const int64_t per = (n_dn + comm->nranks - 1) / comm->nranks, peru = (n_up + comm->nranks - 1) / comm->nranks;
-		if (!K.packed || K.pk_nchunk > 1) return fail(LPP_ERR_INVALID, "setup_hubbard_onthefly: the transposition exchange needs the packed H_up layout with N_up inside the LDS window");
+		if (!K.packed) return fail(LPP_ERR_INVALID, "setup_hubbard_onthefly: the transposition exchange needs the packed H_up layout");
 		if (!comm->send2_buf || !comm->recv2_buf || comm->xchg_chunk != per * peru)
 			return fail(LPP_ERR_INVALID, "setup_hubbard_onthefly: transposition exchange needs send2/recv2 buffers and xchg_chunk == ceil(N_down/P)*ceil(N_up/P)");
 		e->tx = true;
@@ -748,8 +748,7 @@ template <typename T> static int kron_launch_t(lpp_engine* e, const void* ywin, 
 		int nbp = (int)std::max<int64_t>(1, std::min<int64_t>(pa.nid, (int64_t)e->num_cus * pcu));
 		if (nbp >= 8) nbp &= ~7;
 		const bool dotp = partial != nullptr;
-		if (K.pk_nchunk > 1) { // N_up exceeds LDS: staged in pieces (single exchange-free product only)
-			if (part != 0) return -1;
+		if (K.pk_nchunk > 1 && part != 2) { // N_up exceeds LDS: the source row is staged in pieces (part 2 has no up-hops)
 			KronChunkArgs<T> ca;
 			ca.k = pa;
 			ca.nchunk = K.pk_nchunk;

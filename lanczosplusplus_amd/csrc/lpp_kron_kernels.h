@@ -399,7 +399,8 @@ __global__ __launch_bounds__(kWinThreads) void k_spmv_kron_chunked(KronChunkArgs
 				dval_s[threadIdx.x] = in ? a.dn_val[p0 + threadIdx.x] : VT<T>::zero();
 			}
 			__syncthreads();
-			const int ngroups = c == 0 ? ((min(ndn, kKronDownCap) + 7) >> 3) : 0;
+			// part == 1 (transposition exchange): up-hops + U diagonal only, the down-hops act on the transposed slice elsewhere
+			const int ngroups = (c == 0 && a.part != 1) ? ((min(ndn, kKronDownCap) + 7) >> 3) : 0;
 			const int32_t* offc = a.slice_off + (int64_t)c * (a.spb + 1);
 			const int32_t* lenc = a.slice_len + (int64_t)c * a.spb;
 			for (int j = next_slice_claim(&next_slice); j < a.spb; j = next_slice_claim(&next_slice)) {
@@ -434,7 +435,8 @@ __global__ __launch_bounds__(kWinThreads) void k_spmv_kron_chunked(KronChunkArgs
 #pragma unroll
 						for (int q = 0; q < 8; q++) g0[q] = g1[q];
 					}
-					for (int p = kKronDownCap; p < ndn; p++) VT<T>::mac(acc, a.dn_val[p0 + p], yd[(int64_t)a.dn_col[p0 + p] * a.n_up]);
+					if (a.part != 1)
+						for (int p = kKronDownCap; p < ndn; p++) VT<T>::mac(acc, a.dn_val[p0 + p], yd[(int64_t)a.dn_col[p0 + p] * a.n_up]);
 					// Hubbard U on the doubly occupied sites
 					double ud = 0.0;
 					for (uint32_t m = a.up_words[iu] & dnw; m; m &= m - 1) ud += U_s[__ffs((int)m) - 1];

@@ -249,3 +249,53 @@ def test_four_ranks_uneven_shards():
     z = res[0]["z_tx"]
     r = oracle.spmv_acc(A, np.zeros_like(z), z) - res[0]["e_tx2"] * z
     assert np.linalg.norm(r) < 1e-5
+
+
+def _worker_beyond_lds(rank, world, port, q):
+    """2 ranks, matrix-free engine with N_up = C(18,9) = 48620 beyond the LDS window (source row staged in three pieces),
+    all-gather and transposition exchange."""
+    try:
+        import torch
+        import torch.distributed as dist
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import oracle
+        import lanczosplusplus_amd as lp
+        from helpers import square
+        from lanczosplusplus_amd.comm import TorchDistComm
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(dev)
+        L, nup, ndown = 18, 9, 1
+        hop, U = square(3, 6, -1.0, True), np.full(L, 4.0)
+        n_up, n_dn = 48620, 18
+        per, peru = -(-n_dn // world), -(-n_up // world)
+        out = {}
+        for name, chunk in (("allgather", 0), ("transpose", per * peru)):
+            comm = TorchDistComm(per * n_up, 300, False, device=dev, xchg_chunk=chunk)
+            with comm.stream_context():
+                e = lp.LanczosEngine(max_steps=300, stream=comm.stream_handle)
+                e.setup_hubbard_onthefly(L, nup, ndown, hop, U, comm=comm)
+                eg, _, st = e.lanczos(1, want_vectors=False)
+                out["e_" + name], out["steps_" + name] = float(eg[0]), st["steps"]
+                e.close()
+        if rank == 0:
+            A = oracle.hubbard_csr(L, nup, ndown, hop, U)
+            eo, _, so = oracle.lanczos_solve(A, oracle.fill_random(A.nrows, 1234), want_vectors=False, max_steps=300)
+            out["e_oracle"], out["steps_oracle"] = float(eo[0]), so
+        q.put((rank, out))
+        dist.destroy_process_group()
+    except Exception:
+        import traceback
+        q.put((rank, {"error": traceback.format_exc()}))
+
+
+def test_two_ranks_matrix_free_beyond_lds():
+    world = 2
+    res = _run_ranks(_worker_beyond_lds, world, timeout=400)
+    for r in range(world):
+        assert "error" not in res[r], res[r].get("error")
+    eo, so = res[0]["e_oracle"], res[0]["steps_oracle"]
+    for r in range(world):
+        for name in ("allgather", "transpose"):
+            assert abs(res[r]["e_" + name] - eo) <= 1e-10 * abs(eo), (name, res[r], eo)
+            assert abs(res[r]["steps_" + name] - so) <= 1
