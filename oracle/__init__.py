@@ -57,6 +57,14 @@ def lib():
     L.lppo_hubbard_setup.restype = C.c_void_p
     L.lppo_hubbard_setup.argtypes = [C.c_int] * 3 + [C.c_void_p] * 5 + [C.c_int]
     L.lppo_hubbard_otf_mvp.argtypes = [C.c_int] * 3 + [_f64p, _f64p, _f64p, _f64p, _f64p, C.c_int64, C.c_int64, C.c_int]
+    L.lppo_hubbard_otf_new.restype = C.c_void_p
+    L.lppo_hubbard_otf_new.argtypes = [C.c_int] * 3 + [_f64p, _f64p, _f64p, C.c_int]
+    L.lppo_hubbard_otf_free.argtypes = [C.c_void_p]
+    L.lppo_hubbard_otf_rows.restype = C.c_int64
+    L.lppo_hubbard_otf_rows.argtypes = [C.c_void_p]
+    L.lppo_hubbard_otf_apply.argtypes = [C.c_void_p, _f64p, _f64p, C.c_int64, C.c_int64]
+    L.lppo_hubbard_otf_lanczos.restype = C.c_int
+    L.lppo_hubbard_otf_lanczos.argtypes = [C.c_void_p, _f64p, C.POINTER(LanczosParams), _f64p, _f64p, _f64p]
     L.lppo_heis_bits.restype = C.c_int
     L.lppo_heis_bits.argtypes = [C.c_int]
     L.lppo_heis_basis.restype = C.c_int64
@@ -175,6 +183,38 @@ def hubbard_otf_mvp(L, nup, ndown, hop, U, V, x, y, row0=0, row1=0, nthreads=0):
     hr = _mat(np.asarray(hop).real, L)
     lib().lppo_hubbard_otf_mvp(L, nup, ndown, hr, np.ascontiguousarray(U, np.float64),
                                np.ascontiguousarray(np.asarray(V, np.float64)[:L]), x, y, row0, row1, nthreads)
+
+
+class HubbardOtf:
+    """Tabulated form of hubbard_otf_mvp (bit-identical results, see lpp_oracle.c) + the Lanczos loop over it:
+    the reference's SolverOptions=InternalProductOnTheFly run, fast enough for BASELINE config 2 on a few cores."""
+
+    def __init__(self, L, nup, ndown, hop, U, V=None, nthreads=0):
+        hr = _mat(np.asarray(hop).real, L)
+        U = np.ascontiguousarray(U, np.float64)
+        V = np.zeros(L) if V is None else np.ascontiguousarray(np.asarray(V, np.float64)[:L])
+        self._h = lib().lppo_hubbard_otf_new(L, nup, ndown, hr, U, V, nthreads)
+        self.nrows = lib().lppo_hubbard_otf_rows(self._h)
+
+    def close(self):
+        if self._h:
+            lib().lppo_hubbard_otf_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def apply(self, x, y, row0=0, row1=0):
+        """x += H y on rows [row0, row1) (0, 0 = all)."""
+        lib().lppo_hubbard_otf_apply(self._h, x, y, row0, row1)
+        return x
+
+    def lanczos(self, init, max_steps=200, min_steps=4, eps=1e-12):
+        prm = LanczosParams(max_steps, min_steps, eps, 0)
+        ms = min(max_steps, self.nrows)
+        a, b, hist = np.zeros(ms + 1), np.zeros(ms + 1), np.zeros(ms + 1)
+        steps = lib().lppo_hubbard_otf_lanczos(self._h, init, C.byref(prm), a, b, hist)
+        return steps, a[:steps], b[:steps], hist[:steps]
 
 
 def heis_basis(L, twiceS, szPlusConst):

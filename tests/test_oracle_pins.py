@@ -16,7 +16,7 @@ import numpy as np
 import pytest
 
 import oracle
-from helpers import chain, square
+from helpers import chain, rel, square
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 
@@ -307,3 +307,63 @@ def test_config1_sizes():
     """BASELINE config 1 (Hubbard chain L=12, 6 up 6 down): N and nnz as tabulated in BASELINE.md."""
     A = oracle.hubbard_csr(12, 6, 6, chain(12, -1.0), np.full(12, 4.0))
     assert (A.nrows, A.nnz) == (853776, 11099088)
+
+
+def test_tabulated_otf_product_is_bit_identical_to_the_literal_one():
+    """lppo_hubbard_otf_apply (tables of one-species hops) == lppo_hubbard_otf_mvp (literal HubbardHelper.h:105-134)
+    bit for bit -- same elements, same summation order -- on whole vectors and on row windows; the Lanczos loop over
+    it gives the tridiagonal matrix of the stored-CSR run.  This is what carries the config-2 golden fixture."""
+    rng = np.random.default_rng(11)
+    for (L, nu, nd, hop) in [(8, 4, 4, square(2, 4, -1.0)), (8, 3, 5, chain(8, -1.3, True)), (10, 5, 4, square(2, 5, -0.7)),
+                             (6, 0, 3, chain(6, -1.0)), (5, 5, 2, chain(5, -1.0, True))]:
+        U, V = rng.standard_normal(L), rng.standard_normal(L)
+        n = oracle.lib().lppo_hubbard_size(L, nu, nd)
+        y, x0 = oracle.fill_random(n, 3), oracle.fill_random(n, 4)
+        xa = x0.copy()
+        oracle.hubbard_otf_mvp(L, nu, nd, hop, U, V, xa, y, 0, 0, 3)
+        H = oracle.HubbardOtf(L, nu, nd, hop, U, V, nthreads=3)
+        assert H.nrows == n
+        assert np.array_equal(H.apply(x0.copy(), y), xa)
+        r0, r1 = n // 3, max(n // 3 + 1, (2 * n) // 3 + 1)
+        xb, xc = x0.copy(), x0.copy()
+        oracle.hubbard_otf_mvp(L, nu, nd, hop, U, V, xb, y, r0, r1, 2)
+        assert np.array_equal(H.apply(xc, y, r0, r1), xb)
+        if n > 100:
+            A = oracle.hubbard_csr(L, nu, nd, hop, U, V)
+            init = oracle.fill_random(n, 1234)
+            s1, a1, b1, _, h1 = oracle.lanczos_decomposition(A, init)
+            s2, a2, b2, h2 = H.lanczos(init)
+            assert s1 == s2 and rel(a2, a1) < 1e-10 and rel(b2, b1) < 1e-10 and abs(h1[-1] - h2[-1]) < 1e-11 * abs(h1[-1])
+
+
+def test_threaded_assembly_equals_one_chunk():
+    """The row-chunked (OpenMP) assemblers give the same CSR whatever the chunking: compare against a matrix small
+    enough for a single chunk built row by row through the dense ED cross-checks above, and a multi-chunk one against
+    its own transpose (hermiticity, isHermitian assert of Heisenberg.h:113) and the literal-index variant."""
+    A = oracle.heis_csr(16, 1, 8, chain(16, 1.0, True), chain(16, 0.8, True))  # 12870 rows: one chunk
+    B = oracle.heis_csr(20, 1, 10, chain(20, 1.0, True), chain(20, 0.8, True))  # 184756 rows: nine chunks
+    assert B.nrows == 184756 and np.all(np.diff(B.rowptr) > 0)
+    M = B.to_scipy()
+    assert abs(M - M.T).max() == 0
+    for rr in range(0, B.nrows, 997):  # rows are sorted by column and hold no duplicates (SparseRow::finalize)
+        c = B.colind[B.rowptr[rr]:B.rowptr[rr + 1]]
+        assert np.all(np.diff(c) > 0)
+    assert A.nrows == 12870
+    T1 = oracle.tj_csr(12, 4, 4, chain(12, -1.0), chain(12, 0.4), chain(12, 0.4), chain(12, -0.1))
+    T2 = oracle.tj_csr(12, 4, 4, chain(12, -1.0), chain(12, 0.4), chain(12, 0.4), chain(12, -0.1), literal_index=True)
+    assert np.array_equal(T1.rowptr, T2.rowptr) and np.array_equal(T1.colind, T2.colind) and np.array_equal(T1.values, T2.values)
+
+
+def test_config2_golden_fixture_is_self_consistent():
+    """tests/golden/c2_hubbard4x4_U4.json (made by make_c2_hubbard4x4_U4.py): E0 is the lowest eigenvalue of the
+    tridiagonal matrix of its own coefficients, the run stopped by the reference's rule, and the value is the
+    literature energy of the 4x4 periodic cluster at U = 4t (-13.6219 t)."""
+    import json
+    import os
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "c2_hubbard4x4_U4.json")))
+    a, b, h = np.array(g["a"]), np.array(g["b"]), np.array(g["e0_history"])
+    assert g["rows"] == 165636900 and len(a) == len(b) == len(h) == g["steps"] < g["max_steps"]
+    w = oracle.tridiag_eig(a, b[:-1])
+    assert abs(w[0] - g["e0"]) < 1e-12 * abs(g["e0"]) and h[-1] == g["e0"]
+    assert abs(h[-1] - h[-2]) < g["eps"] and abs(h[-2] - h[-3]) >= g["eps"]
+    assert abs(g["e0"] + 13.62185) < 2e-4
