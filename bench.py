@@ -25,6 +25,39 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured float4 copy is ~6290 GB/s
 METRIC = "Lanczos iterations/sec + SpMV achieved HBM GB/s vs roofline, 1/2/4/8 GPU"
+# environment switches that change the kernel or the layout: a committed PMC traffic figure only applies without them
+LAYOUT_ENV = ("LPP_COMPRESS_VALUES", "LPP_SHARED_OFFSETS", "LPP_LOCAL16", "LPP_DIAG_CODES", "LPP_BLOCK_TEMPLATE", "LPP_SPMV_KERNEL",
+              "LPP_WINDOW_ROWS", "LPP_K2_VARIANT", "LPP_KRON_NO_WINDOW", "LPP_KRON_NO_PACK", "LPP_TEMPLATE_PACK", "LPP_PRODUCT_LAYOUT")
+
+
+def csrc_hash():
+    """sha256 over the engine sources: profiles/traffic.json is stamped with it by scripts/traffic_stamp.py, so a
+    PMC byte count is only ever quoted for the code it was measured on."""
+    import hashlib
+    d = os.path.join(ROOT, "lanczosplusplus_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h", ".cpp")) or f == "Makefile":
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def committed_traffic(engine, name, world, spmv_kernel):
+    """per-launch HBM bytes of the dominant kernel from the committed rocprofv3 --pmc passes, or None when the figure
+    does not belong to this code / this configuration"""
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+    except Exception:
+        return None, "no profiles/traffic.json"
+    if tj.get("csrc_hash") != csrc_hash():
+        return None, "stale: profiles/traffic.json was measured on other engine sources"
+    if world != 1 or spmv_kernel != 0 or any(os.environ.get(k) is not None for k in LAYOUT_ENV):
+        return None, "not measured for this configuration"
+    ent = tj.get(engine, {}).get(name)
+    if not ent:
+        return None, "no PMC pass committed for this workload"
+    return float(ent["traffic_bytes_per_launch"]), ent.get("source", "profiles/")
 
 
 def square_lattice(lx, ly, v, pbc=True):
@@ -101,7 +134,7 @@ def assemble(engine, name, comm=None, onthefly=False):
         engine.assemble_tj(L, p["nup"], p["ndown"], lat(p["t"]), lat(p["j"]), lat(p["j"]), lat(-p["j"] / 4))
 
 
-def cpu_baseline(name, nrows, budget_s=15.0, engine=None):
+def cpu_baseline(name, nrows, budget_s=15.0):
     """Reference-style CPU path timed on this box's host cores on a bounded sample: the oracle's threaded
     on-the-fly Hubbard x += H y (HubbardHelper::matrixVectorProduct, the reference's only multi-core
     Hubbard path) over the first M rows, or the oracle's stored-CSR Lanczos iteration for the other models."""
@@ -128,17 +161,23 @@ def cpu_baseline(name, nrows, budget_s=15.0, engine=None):
         oracle.hubbard_otf_mvp(L, p["nup"], p["ndown"], hop, U, V, x, y, 0, m2, cores)
         dt = time.time() - t0
         its = (m2 / dt) / nrows
-        sample = "on-the-fly x+=Hy (oracle port of HubbardHelper::matrixVectorProduct) over the first %d of %d rows, %.1f s; SpMV part of an iteration only" % (m2, nrows, dt)
-        return {"value": its, "unit": "iterations/s", "cores": cores, "kind": "port", "sample": sample}
-    # other models: the reference's stored path (serial CrsMatrix::matrixVectorProduct) restated with OpenMP rows,
-    # timed on the very CSR the GPU holds (copied back once), plus the three BLAS-1 passes of an iteration
-    if engine is None:
-        return None
-    st = engine.stats()
-    if st["nnz"] * 20 > 40e9:
-        return None
-    rp, ci, va = engine.get_csr()
-    A = oracle.Csr(rp, ci, va)
+        # BASELINE.md section 3 single-thread leg (mirrors the reference's serial CrsMatrix loop), a tenth of the budget
+        m1 = int(min(nrows, max(100_000, rate / max(cores, 1) * budget_s / 10)))
+        t0 = time.time()
+        oracle.hubbard_otf_mvp(L, p["nup"], p["ndown"], hop, U, V, x, y, 0, m1, 1)
+        its1 = (m1 / max(time.time() - t0, 1e-9)) / nrows
+        sample = ("SpMV-only, extrapolated: on-the-fly x+=Hy (oracle port of HubbardHelper::matrixVectorProduct, HubbardHelper.h:105-134) "
+                  "timed over the first %d of %d rows (%.1f s) and scaled to all rows; the three BLAS-1 passes of an iteration are not included" % (m2, nrows, dt))
+        return {"value": its, "unit": "iterations/s", "cores": cores, "kind": "port", "sample": sample,
+                "what": "SpMV-only, extrapolated from a row sample", "single_thread_value": its1, "single_thread_rows": m1}
+    # other models: the reference's stored path (serial CrsMatrix::matrixVectorProduct) restated with OpenMP rows on the
+    # oracle's own assembly of the same Hamiltonian, plus the three BLAS-1 passes of an iteration
+    L = p["L"]
+    if model == "heisenberg":
+        A = oracle.heis_csr(L, 1, p["sz"], chain(L, p["j"], p["pbc"]), chain(L, p["j"], p["pbc"]))
+    else:
+        lat = (lambda v: square_lattice(p["lx"], p["ly"], v, pbc=True)) if p["ly"] > 1 else (lambda v: chain(L, v))
+        A = oracle.tj_csr(L, p["nup"], p["ndown"], lat(p["t"]), lat(p["j"]), lat(p["j"]), lat(-p["j"] / 4), force_complex=True)
     y = oracle.fill_random(A.nrows, 99, A.is_complex)
     x = np.zeros_like(y)
     oracle.spmv_acc(A, x, y, cores)  # warm-up
@@ -151,8 +190,64 @@ def cpu_baseline(name, nrows, budget_s=15.0, engine=None):
         x, y = -b * y, x / b
         reps += 1
     dt = time.time() - t0
-    return {"value": reps / dt, "unit": "iterations/s", "cores": cores, "kind": "port",
+    A1rows = A.nrows
+    t1 = time.time()
+    oracle.spmv_acc(A, x, y, 1)  # single-thread leg: one serial product
+    dt1 = time.time() - t1
+    return {"value": reps / dt, "unit": "iterations/s", "cores": cores, "kind": "port", "what": "full iterations on the whole matrix",
+            "single_thread_spmv_s": dt1, "single_thread_rows": A1rows,
             "sample": "%d full Lanczos iterations (OpenMP stored-CSR x+=Hy from the oracle + numpy BLAS-1) on the same %d x %d matrix, %.1f s" % (reps, A.nrows, A.nrows, dt)}
+
+
+GOLDEN = {"hubbard_4x4_half_filling_pbc_U4": "c2_hubbard4x4_U4.json"}
+
+
+def kernel_name(engine, layout):
+    if engine == "onthefly":
+        return "k_spmv_kron_packed / k_spmv_kron_chunked (matrix-free x += H y, fused a_j partial)"
+    k = (layout or {}).get("kernel")
+    return {"window": "k_spmv_window (stored matrix, LDS source window; x += H y, fused a_j partial)",
+            "sliced": "k_spmv_sliced (stored matrix, wave-interleaved slices; x += H y, fused a_j partial)",
+            "rowgroup": "k_spmv_rowgroup (plain CSR; x += H y, fused a_j partial)",
+            "product": "k_pb_up + k_pb_down (stored product-basis matrix: in-block part from the LDS window, block couplings panel-wise from L2)"}.get(k, str(k))
+
+
+def per_rank_bytes(eng, comm, st, esz, engine):
+    """device memory one rank holds: matrix + 2 work vectors (+ exchange buffers)"""
+    n = st["nrows"]
+    b = 2.0 * n * esz
+    if engine == "stored":
+        b += eng.layout(0)["resident_bytes"]
+        if comm is not None:
+            b += eng.layout(1)["resident_bytes"]
+    if comm is not None:
+        for t in (comm.send, comm.gath, comm.send2, comm.recv2):
+            if t is not None:
+                b += t.numel() * 8
+    return b
+
+
+def generic_csr_leg(name, is_complex, device, iters=10):
+    """x += H y with the plain 12-byte-per-entry layout (no value dictionary, no shared offsets): achieved = SURVEY 8(d)
+    algorithmic bytes / HIP-event time of back-to-back launches"""
+    from lanczosplusplus_amd import LanczosEngine
+    saved = {k: os.environ.get(k) for k in ("LPP_COMPRESS_VALUES", "LPP_SHARED_OFFSETS", "LPP_PRODUCT_LAYOUT")}
+    os.environ.update(LPP_COMPRESS_VALUES="0", LPP_SHARED_OFFSETS="0", LPP_PRODUCT_LAYOUT="0")
+    try:
+        with LanczosEngine(dtype="c128" if is_complex else "f64", device=device, max_steps=8, eps=0.0, save_vectors=0, compress_values=0) as e:
+            assemble(e, name)
+            lay, st = e.layout(0), e.stats()
+            ms = e.bench_spmv(warmup=2, iters=iters)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    gbs = (st["spmv_bytes"] / 1e9) / (ms / 1e3)
+    return {"kernel": {1: "k_spmv_rowgroup", 2: "k_spmv_sliced", 3: "k_spmv_window"}.get(lay["kernel"]), "layout": "plain values and 32-bit columns (12 B per f64 entry)",
+            "spmv_ms": ms, "algorithmic_bytes_per_launch": st["spmv_bytes"], "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": gbs / HBM_PEAK_GBS, "target_frac": 0.60, "resident_GB": round(lay["resident_bytes"] / 1e9, 2), "launches_timed": iters}
 
 
 def main():
@@ -165,6 +260,8 @@ def main():
     ap.add_argument("--engine", default=os.environ.get("LPP_BENCH_ENGINE", "stored"), choices=["stored", "onthefly"],
                     help="stored CSR (default, the BASELINE metric) or the matrix-free Hubbard product")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-generic-csr", action="store_true", help="skip the plain-CSR kernel leg (second roofline object)")
+    ap.add_argument("--no-e0-check", action="store_true", help="skip the converged solve against the CPU-oracle fixture")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     args = ap.parse_args()
 
@@ -286,24 +383,38 @@ def main():
     launches = (w1["spmv_launches"] - w0["spmv_launches"])
     # per-rank SpMV time per step (multi-GPU: local + remote kernel of this rank)
     spmv_ms_per_step = spmv_ms / max(args.steps, 1)
-    achieved = (w1["spmv_bytes"] / 1e9) / (spmv_ms_per_step / 1e3) if spmv_ms_per_step > 0 else 0.0
+    spmv_s = spmv_ms_per_step / 1e3
+    esz = 16 if is_complex else 8
+    csr_bytes = w1["spmv_bytes"]  # SURVEY 8(d) plain-CSR model of this rank's rows: Z(s+4) + (N+1)8 + 3Ns
 
-    traffic = None
-    try:  # per-launch HBM bytes of the SpMV kernel from the committed rocprofv3 PMC pass of this workload
-        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-        if world == 1 and name in tj.get(args.engine, {}) and os.environ.get("LPP_COMPRESS_VALUES", "-1") != "0":
-            traffic = tj[args.engine][name]["traffic_bytes_per_launch"]
-    except Exception:
-        traffic = None
+    traffic, traffic_note = committed_traffic(args.engine, name, world, args.spmv_kernel)
 
     if rank == 0:
         e0 = float(tridiag_lowest(a, b[:-1] if len(b) > 1 else b, 1)[0]) if len(a) else float("nan")
         layout = None
         if args.engine == "stored":
             lay = eng.layout(0)
-            layout = {"kernel": {1: "rowgroup", 2: "sliced", 3: "window"}.get(lay["kernel"]), "value_codes": bool(lay["coded"]),
+            layout = {"kernel": {1: "rowgroup", 2: "sliced", 3: "window", 4: "product"}.get(lay["kernel"]), "value_codes": bool(lay["coded"]),
                       "local16_columns": bool(lay["local16"]), "block_template": lay["block_template"], "diagonal_codes": bool(lay["diagonal_codes"]), "per_row_entries": lay["per_row_entries"],
                       "shared_offset_entries": lay["shared_entries"], "resident_GB": round(lay["resident_bytes"] / 1e9, 2)}
+            min_bytes = float(lay["stream_bytes"]) + 3.0 * st0["nrows"] * esz
+            if world > 1:
+                lay1 = eng.layout(1)
+                min_bytes += float(lay1["stream_bytes"])
+        else:
+            min_bytes = 3.0 * st0["nrows"] * esz  # matrix-free: x in/out and y once; H_up / H_down are L2-resident
+        # roofline of the dominant kernel (the SpMV): bytes that crossed the L2/fabric boundary per launch (rocprofv3 PMC
+        # passes of this very code, profiles/) over the live HIP-event time.  Never above 1: when no fresh PMC figure
+        # exists, the least traffic the resident layout allows (min_bytes) stands in, which can only under-state it.
+        moved = traffic if traffic else min_bytes
+        achieved = (moved / 1e9) / spmv_s if spmv_s > 0 else 0.0
+        roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                    "traffic": traffic, "achieved_basis": "pmc_traffic" if traffic else "min_bytes", "traffic_note": traffic_note,
+                    "min_bytes": min_bytes, "wasted": (traffic / min_bytes) if traffic else None,
+                    "kernel": kernel_name(args.engine, layout), "spmv_ms": spmv_ms_per_step, "launches_timed": launches,
+                    # the plain-CSR figure of SURVEY 8(d) (12 B per entry for f64): what a kernel streaming the reference's
+                    # CrsMatrix would have to sustain for this time -- a compression ratio times a bandwidth, NOT a roofline number
+                    "csr_equivalent_bytes": csr_bytes, "csr_equivalent_GBps": (csr_bytes / 1e9) / spmv_s if spmv_s > 0 else 0.0}
         out = {
             "metric": METRIC,
             "value": args.steps / elapsed,
@@ -320,24 +431,41 @@ def main():
             "config": {"workload": name, "rows": nrows_g, "nnz": nnz_g, "parallelism": "1-D row partition x%d" % world,
                        "reortho": False, "assembly": "on-device", "assembly_s": round(t_asm, 3), "engine": args.engine,
                        "exchange": (("transpose" if comm.xchg_chunk > 0 else "allgather") if comm is not None else None),
+                       "per_rank_memory_GB": round(per_rank_bytes(eng, comm, st0, esz, args.engine) / 1e9, 2),
                        "layout": layout},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": ("k_spmv_kron_packed (matrix-free x += H y; bytes = vector-streaming model N*s*(3 + down-hops/row))"
-                                    if args.engine == "onthefly" else "k_spmv_window/k_spmv_sliced (stored CSR x += H y, fused a_j partial)"),
-                         "spmv_ms": spmv_ms_per_step,
-                         "algorithmic_bytes_per_launch": w1["spmv_bytes"], "launches_timed": launches,
-                         # bytes the kernel really moved (PMC) per second: the stored layout is a lossless compression
-                         # of the CSR (value dictionary, shared-offset entries, 16-bit local columns), so `achieved`,
-                         # which prices the plain-CSR bytes of SURVEY 8(d), can exceed the HBM peak; this rate cannot
-                         "moved_GBps": (traffic / 1e9) / (spmv_ms_per_step / 1e3) if (traffic and spmv_ms_per_step > 0) else None},
+            "roofline": roofline,
             "e0_after_steps": e0,
         }
-        if world == 1 and not args.no_cpu_baseline:
+    if world == 1 and rank == 0:
+        # |E0(GPU) - E0(CPU)|: a converged solve against the CPU-oracle fixture of this workload, when one is committed
+        gold = os.path.join(ROOT, "tests", "golden", GOLDEN.get(name, ""))
+        if name in GOLDEN and os.path.exists(gold) and not args.no_e0_check:
+            g = json.load(open(gold))
+            eng.close()
+            with LanczosEngine(dtype="f64", device=local_rank, max_steps=g["max_steps"], min_steps=g["min_steps"], eps=g["eps"],
+                               save_vectors=0, seed=g["seed"], spmv_kernel=args.spmv_kernel) as e2:
+                assemble(e2, name, None, onthefly=(args.engine == "onthefly"))
+                t_s = time.time()
+                a2, b2, _ = e2.decomposition()
+                t_s = time.time() - t_s
+            eg = float(tridiag_lowest(a2, b2[:-1], 1)[0])
+            out["e0_check"] = {"e0_gpu": eg, "e0_cpu": g["e0"], "abs_diff": abs(eg - g["e0"]), "rel_diff": abs(eg - g["e0"]) / abs(g["e0"]),
+                               "steps_gpu": len(a2), "steps_cpu": g["steps"], "solve_s": round(t_s, 3),
+                               "cpu_source": "tests/golden/" + GOLDEN[name] + " (oracle on-the-fly Lanczos, " + g["generator"] + ")"}
+        # the generic (uncompressed, 12 B per entry) CSR kernel on the same matrix: the north_star's ">= 60 % of the HBM
+        # roofline on the CSR SpMV" is about THIS kernel; its algorithmic bytes are the SURVEY 8(d) figure
+        if args.engine == "stored" and not args.no_generic_csr:
+            eng.close()
             try:
-                out["cpu_baseline"] = cpu_baseline(name, nrows_g, args.cpu_budget, engine=(eng if args.engine == "stored" else None))
+                out["generic_csr"] = generic_csr_leg(name, is_complex, local_rank)
+            except Exception as ex:
+                out["generic_csr"] = {"error": repr(ex)}
+        if not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(name, nrows_g, args.cpu_budget)
             except Exception as ex:  # the baseline must never take the bench line down
                 out["cpu_baseline"] = {"error": repr(ex)}
+    if rank == 0:
         print(json.dumps(out))
     eng.close()
     if world > 1:

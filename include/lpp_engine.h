@@ -93,12 +93,15 @@ typedef struct lpp_layout {
 	int64_t shared_entries; /* entries stored once per slice, summed over slices */
 	int64_t rows_per_block; /* row block of the sliced layout */
 	int64_t resident_bytes; /* device bytes held for this matrix */
+	int64_t stream_bytes; /* bytes of matrix data ONE product has to read at least once (arrays kept only for
+	                         lpp_engine_get_csr and block-0 templates that stay in L2 are not streamed);
+	                         stream_bytes + 3*rows*sizeof(value) is the least HBM traffic of x += H y in this layout */
 } lpp_layout;
 
 /* Communicator for the 1-D row-partitioned multi-GPU path.  The engine never
  * opens sockets itself: the host (torch.distributed over RCCL in bench.py) supplies the
  * collectives and owns the exchange buffers.
- *   send_buf : device, shard_stride elements      (this rank's slice of the Lanczos vector, zero padded)
+ *   send_buf : device, shard_stride elements, 16-byte aligned (this rank's slice of the Lanczos vector, zero padded)
  *   gath_buf : device, nranks*shard_stride elems  (slice r at gath_buf + r*shard_stride)
  *   red_buf  : device doubles, red_len >= 6*(max_steps+2)   (a_j, b_j^2 and reortho coefficients)
  * allgather_begin may return before the gather completes (so the local-column SpMV overlaps
@@ -132,6 +135,13 @@ void lpp_config_default(lpp_config* cfg);
 
 lpp_status lpp_engine_create(lpp_engine** out, const lpp_config* cfg);
 lpp_status lpp_engine_destroy(lpp_engine* e);
+
+/* Solver parameters after creation: the reference builds its LanczosSolver(hamiltonian, params) AFTER the InternalProduct that
+ * owns the matrix (Engine.h:608-610), so the shim's LanczosSolver pushes ParametersForSolver (LanczosSteps=, LanczosMinSteps=,
+ * LanczosEps=, LanczosOptions=reortho, lotaMemory) into the engine here.  Not while a Lanczos run is active; with a
+ * communicator attached comm.red_len must cover the new max_steps.  The matrix stays resident. */
+lpp_status lpp_engine_set_solver(lpp_engine* e, int32_t max_steps, int32_t min_steps, double eps, int32_t reortho,
+                                 int32_t save_vectors);
 
 /* ---- the stored Hamiltonian (replaces DefaultSymmetry::matrixStored_, DefaultSymmetry.h:120) ---- */
 

@@ -46,7 +46,7 @@ class Layout(C.Structure):
     _fields_ = [("kernel", C.c_int32), ("coded", C.c_int32), ("local16", C.c_int32), ("shared_stride", C.c_int32),
                 ("block_template", C.c_int32), ("diagonal_codes", C.c_int32),
                 ("nnz", C.c_int64), ("per_row_entries", C.c_int64), ("shared_entries", C.c_int64),
-                ("rows_per_block", C.c_int64), ("resident_bytes", C.c_int64)]
+                ("rows_per_block", C.c_int64), ("resident_bytes", C.c_int64), ("stream_bytes", C.c_int64)]
 
     def as_dict(self):
         return {name: getattr(self, name) for name, _ in self._fields_}
@@ -73,6 +73,7 @@ SYMBOLS = {
     "lpp_config_default": (None, [C.POINTER(Config)]),
     "lpp_engine_create": (C.c_int32, [C.POINTER(_P), C.POINTER(Config)]),
     "lpp_engine_destroy": (C.c_int32, [_P]),
+    "lpp_engine_set_solver": (C.c_int32, [_P, C.c_int32, C.c_int32, C.c_double, C.c_int32, C.c_int32]),
     "lpp_engine_set_row_block": (C.c_int32, [_P, C.c_int64]),
     "lpp_engine_set_csr": (C.c_int32, [_P, C.c_int64, _P, _P, _P]),
     "lpp_engine_set_csr_device": (C.c_int32, [_P, C.c_int64, _P, _P, _P]),

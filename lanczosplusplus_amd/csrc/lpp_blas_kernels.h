@@ -27,10 +27,19 @@ __device__ __forceinline__ void nt_store2(double2 v, double2* p)
 	__builtin_nontemporal_store(w, (lpp_d2*)p);
 }
 
+// copy for the next exchange: the send buffer holds exactly nd doubles, so an odd tail element is stored as a scalar
+__device__ __forceinline__ void send_store(double2* send, int64_t i, double2 v, int64_t nd)
+{
+	if (2 * i + 2 <= nd)
+		send[i] = v;
+	else if (2 * i < nd)
+		((double*)send)[2 * i] = v.x;
+}
+
 template <bool NRM>
 __global__ __launch_bounds__(kBlock) void k_axpy_nrm(double2* __restrict__ x, const double2* __restrict__ y,
                                                       const double* __restrict__ a_ptr, const double* __restrict__ b2_prev,
-                                                      double2* __restrict__ send, int64_t n2, double* __restrict__ partial, int stream = 0)
+                                                      double2* __restrict__ send, int64_t n2, double* __restrict__ partial, int stream = 0, int64_t nd = 0)
 {
 	__shared__ double smem[kBlock / 64];
 	double a = *a_ptr;
@@ -57,7 +66,7 @@ __global__ __launch_bounds__(kBlock) void k_axpy_nrm(double2* __restrict__ x, co
 				nt_store2(xv[k], &x[i + k * stride]);
 			else
 				x[i + k * stride] = xv[k];
-			if (send) send[i + k * stride] = xv[k];
+			if (send) send_store(send, i + k * stride, xv[k], nd);
 			if (NRM) s += xv[k].x * xv[k].x + xv[k].y * xv[k].y;
 		}
 	}
@@ -67,7 +76,7 @@ __global__ __launch_bounds__(kBlock) void k_axpy_nrm(double2* __restrict__ x, co
 		xv.x -= a * yv.x;
 		xv.y -= a * yv.y;
 		x[i] = xv;
-		if (send) send[i] = xv;
+		if (send) send_store(send, i, xv, nd);
 		if (NRM) s += xv.x * xv.x + xv.y * xv.y;
 	}
 	if (NRM) {
@@ -95,7 +104,7 @@ static __global__ __launch_bounds__(kBlock) void k_dot(const double2* __restrict
 // y and ynext may alias (in-place swap when the Lanczos vectors are not kept), hence no __restrict__.
 static __global__ __launch_bounds__(kBlock) void k_swap_scale(double2* __restrict__ x, const double2* y,
                                                         double2* ynext, double2* __restrict__ send,
-                                                        const double* __restrict__ b2_ptr, int64_t n2)
+                                                        const double* __restrict__ b2_ptr, int64_t n2, int64_t nd = 0)
 {
 	const double b = sqrt(*b2_ptr);
 	const double inv = (fabs(b) < 1e-10) ? 1.0 : 1.0 / b;
@@ -109,14 +118,14 @@ static __global__ __launch_bounds__(kBlock) void k_swap_scale(double2* __restric
 		xn.y = -b * yv.y;
 		ynext[i] = yn;
 		x[i] = xn;
-		if (send) send[i] = yn;
+		if (send) send_store(send, i, yn, nd);
 	}
 }
 
 // dst = src / sqrt(*n2_ptr)   (normalise the start vector); optional second copy
 static __global__ __launch_bounds__(kBlock) void k_scale_copy(double2* __restrict__ dst, double2* __restrict__ send,
                                                         const double2* __restrict__ src,
-                                                        const double* __restrict__ nrm2_ptr, int64_t n2)
+                                                        const double* __restrict__ nrm2_ptr, int64_t n2, int64_t nd = 0)
 {
 	const double inv = 1.0 / sqrt(*nrm2_ptr);
 	for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n2; i += (int64_t)gridDim.x * kBlock) {
@@ -124,7 +133,7 @@ static __global__ __launch_bounds__(kBlock) void k_scale_copy(double2* __restric
 		v.x *= inv;
 		v.y *= inv;
 		dst[i] = v;
-		if (send) send[i] = v;
+		if (send) send_store(send, i, v, nd);
 	}
 }
 

@@ -1093,6 +1093,7 @@ lpp_status lpp_engine_get_layout(lpp_engine* e, int32_t which, lpp_layout* out)
 	L.shared_entries = A.ndia;
 	L.rows_per_block = A.sliced ? A.geom.B : 0;
 	size_t bytes = A.rowptr ? sizeof(int64_t) * (size_t)(A.nrows + 1) : 0;
+	size_t stream = 0; // what one product must read of the matrix (see lpp_layout::stream_bytes)
 	if (A.col) bytes += sizeof(int32_t) * (size_t)A.nnz;
 	if (A.val) bytes += s * (size_t)A.nnz;
 	if (A.sliced) {
@@ -1100,15 +1101,29 @@ lpp_status lpp_engine_get_layout(lpp_engine* e, int32_t which, lpp_layout* out)
 		const size_t struct_slices = A.tmpl ? (size_t)A.geom.spb : (size_t)A.geom.nslices; // block-periodic: block 0 only
 		const size_t struct_rows = A.tmpl ? (size_t)A.geom.B : (size_t)A.nrows;
 		const size_t struct_nz = A.tmpl ? nz / (size_t)A.geom.nblocks : nz;
-		bytes += sizeof(int64_t) * (struct_slices + 1) + sizeof(int32_t) * struct_rows; // slice_ptr, row_len
-		bytes += (A.local16 ? sizeof(uint16_t) : sizeof(int32_t)) * (struct_nz + 64);
+		const size_t b_struct = sizeof(int64_t) * (struct_slices + 1) + sizeof(int32_t) * struct_rows // slice_ptr, row_len
+		    + (A.local16 ? sizeof(uint16_t) : sizeof(int32_t)) * (struct_nz + 64);
+		bytes += b_struct;
+		size_t b_val;
 		if (A.coded)
-			bytes += sizeof(int64_t) * ((A.tmpl == 2 ? (size_t)A.geom.spb : (size_t)A.geom.nslices) + 1) + 256 * sizeof(double) + sizeof(uint32_t) * (size_t)A.code_words;
+			b_val = sizeof(int64_t) * ((A.tmpl == 2 ? (size_t)A.geom.spb : (size_t)A.geom.nslices) + 1) + 256 * sizeof(double) + sizeof(uint32_t) * (size_t)A.code_words;
 		else
-			bytes += s * (nz + 64);
-		if (A.rrowptr) bytes += sizeof(int64_t) * (size_t)(A.nrows + 1) + (size_t)A.geom.nslices * (size_t)A.dia_stride * (sizeof(int32_t) + s);
-		if (A.dcode) bytes += (size_t)A.nrows * (s / 8);
+			b_val = s * (nz + 64);
+		bytes += b_val;
+		stream += b_struct + b_val; // a template (block 0 only) is counted once: it stays in L2 after the first block
+		if (A.rrowptr) {
+			const size_t lists = (size_t)A.geom.nslices * (size_t)A.dia_stride * (sizeof(int32_t) + s);
+			bytes += sizeof(int64_t) * (size_t)(A.nrows + 1) + lists;
+			stream += lists;
+		}
+		if (A.dcode) {
+			bytes += (size_t)A.nrows * (s / 8);
+			stream += (size_t)A.nrows * (s / 8);
+		}
+	} else {
+		stream = bytes; // row-group kernel: row pointers, columns and values are all read
 	}
+	L.stream_bytes = (int64_t)stream;
 	L.resident_bytes = (int64_t)bytes;
 	*out = L;
 	return LPP_OK;

@@ -34,6 +34,9 @@ lpp_status lpp_engine::adopt_comm(const lpp_comm* c)
 			return fail(LPP_ERR_INVALID, "lpp_comm: missing buffer or callback");
 		if (c->red_len < 4 * M + 8) return fail(LPP_ERR_INVALID, "lpp_comm: red_len < 4*(max_steps+2)+8");
 		if (c->shard_stride <= 0) return fail(LPP_ERR_INVALID, "lpp_comm: shard_stride <= 0");
+		// the BLAS-1 kernels store the slice for the next exchange as 16-byte pairs (the odd tail element as a scalar)
+		if (((uintptr_t)c->send_buf & 15) != 0 || ((uintptr_t)c->gath_buf & 15) != 0)
+			return fail(LPP_ERR_INVALID, "lpp_comm: send_buf / gath_buf must be 16-byte aligned");
 	}
 	comm = *c;
 	has_comm = true;
@@ -228,7 +231,7 @@ lpp_status one_step(lpp_engine* e, const double* ritz, int nst)
 		// streamed accesses once the two vectors no longer fit the 256 MiB Infinity Cache (measured: +4 % there, -7 % below)
 		const int stream_axpy = (size_t)e->n2 * 32 > ((size_t)256 << 20) ? 1 : 0;
 		k_axpy_nrm<true><<<nb, kBlock, 0, st>>>((double2*)xcur, (const double2*)ycur, a_ptr, b2_prev,
-		                                       (multi(e) && !e->tx) ? (double2*)e->comm.send_buf : nullptr, e->n2, e->partial, stream_axpy);
+		                                       (multi(e) && !e->tx) ? (double2*)e->comm.send_buf : nullptr, e->n2, e->partial, stream_axpy, e->nd);
 	} else if (e->cfg.reortho) {
 		k_axpy_nrm<false><<<nb, kBlock, 0, st>>>((double2*)xcur, (const double2*)ycur, a_ptr, nullptr, nullptr, e->n2, nullptr);
 		rc = cgs2(e, j + 1);
@@ -247,7 +250,7 @@ lpp_status one_step(lpp_engine* e, const double* ritz, int nst)
 	} else {
 		double* ynext = e->saving ? e->V + (int64_t)(j + 1) * e->ldv : e->y;
 		k_swap_scale<<<nb, kBlock, 0, st>>>((double2*)xcur, (const double2*)ycur, (double2*)ynext,
-		                                   (multi(e) && !e->tx) ? (double2*)e->comm.send_buf : nullptr, b2_ptr, e->n2);
+		                                   (multi(e) && !e->tx) ? (double2*)e->comm.send_buf : nullptr, b2_ptr, e->n2, e->nd);
 		e->ycur = ynext;
 	}
 	HIP_TRY(hipGetLastError());
@@ -347,7 +350,7 @@ lpp_status begin_run(lpp_engine* e, const void* init, bool want_save)
 	} else {
 		e->ycur = e->saving ? e->V : e->y;
 		e->xcur = e->x;
-		k_scale_copy<<<nb, kBlock, 0, st>>>((double2*)e->ycur, (multi(e) && !e->tx) ? (double2*)e->comm.send_buf : nullptr, (const double2*)e->x, e->tmp_dev, e->n2);
+		k_scale_copy<<<nb, kBlock, 0, st>>>((double2*)e->ycur, (multi(e) && !e->tx) ? (double2*)e->comm.send_buf : nullptr, (const double2*)e->x, e->tmp_dev, e->n2, e->nd);
 		HIP_TRY(hipMemsetAsync(e->x, 0, sizeof(double) * (size_t)e->nd_pad, st));
 	}
 	HIP_TRY(hipGetLastError());
@@ -417,6 +420,36 @@ lpp_status run_recurrence(lpp_engine* e, SolveResult& res)
 } // namespace
 
 extern "C" {
+
+lpp_status lpp_engine_set_solver(lpp_engine* e, int32_t max_steps, int32_t min_steps, double eps, int32_t reortho, int32_t save_vectors)
+{
+	if (!e || max_steps < 1 || min_steps < 0) return fail(LPP_ERR_INVALID, "lpp_engine_set_solver: bad argument");
+	if (e->active) return fail(LPP_ERR_STATE, "lpp_engine_set_solver: a Lanczos run is active");
+	HIP_TRY(hipSetDevice(e->cfg.device));
+	const int M = max_steps + 2;
+	if (M != e->M) {
+		if (multi(e) && e->comm.red_len < 4 * M + 8) return fail(LPP_ERR_INVALID, "lpp_engine_set_solver: comm.red_len < 4*(max_steps+2)+8");
+		HIP_TRY(hipStreamSynchronize(e->stream));
+		double *scal = nullptr, *hs = nullptr;
+		HIP_TRY_MEM(hipMalloc(&scal, sizeof(double) * (size_t)(6 * M + 8)));
+		if (hipHostMalloc(&hs, sizeof(double) * (size_t)(2 * M + 2), hipHostMallocDefault) != hipSuccess) {
+			(void)hipFree(scal);
+			return fail(LPP_ERR_NOMEM, "lpp_engine_set_solver: pinned allocation failed");
+		}
+		if (e->scal_own) (void)hipFree(e->scal_own);
+		if (e->h_scal) (void)hipHostFree(e->h_scal);
+		e->scal_own = scal;
+		e->h_scal = hs;
+		e->M = M;
+		e->bind_scalars(multi(e) ? e->comm.red_buf : e->scal_own);
+	}
+	e->cfg.max_steps = max_steps;
+	e->cfg.min_steps = min_steps;
+	e->cfg.eps = eps;
+	e->cfg.reortho = reortho ? 1 : 0;
+	e->cfg.save_vectors = save_vectors;
+	return LPP_OK;
+}
 
 lpp_status lpp_engine_lanczos_begin(lpp_engine* e, const void* init)
 {

@@ -69,6 +69,11 @@ class LanczosEngine:
     def __exit__(self, *exc):
         self.close()
 
+    def set_solver(self, max_steps=200, min_steps=4, eps=1e-12, reortho=False, save_vectors=-1):
+        """ParametersForSolver after creation (the reference builds LanczosSolver after the InternalProduct, Engine.h:608-610)."""
+        check(self._lib.lpp_engine_set_solver(self._h, int(max_steps), int(min_steps), float(eps), int(bool(reortho)), int(save_vectors)))
+        self.max_steps = int(max_steps)
+
     # ---- the stored Hamiltonian --------------------------------------------------------------
     def set_row_block(self, rows_per_block):
         """Layout hint for the next set_csr: rows_per_block = N_up of the Hubbard product basis (0 = unknown)."""

@@ -63,27 +63,48 @@ template <typename RealType> struct ParametersForSolver {
 	LppHost::String options;
 };
 
+// rows above which the reference refuses a dense diagonalisation (DefaultSymmetry.h:82)
+enum { LPP_FULLDIAG_MAX_ROWS = 4900 };
+
 template <typename BasisType_, typename GeometryType_> class DefaultSymmetry {
 public:
 	typedef GeometryType_ GeometryType;
 	typedef typename GeometryType::ComplexOrRealType ComplexOrRealType;
+	typedef typename LppHost::Real<ComplexOrRealType>::Type RealType;
 	typedef LppHost::CrsMatrix<ComplexOrRealType> SparseMatrixType;
+	typedef LppHost::Matrix<ComplexOrRealType> MatrixType;
+	typedef std::vector<RealType> VectorRealType;
 	typedef std::vector<ComplexOrRealType> VectorType;
 	typedef std::vector<VectorType> VectorVectorType;
 	typedef BasisType_ BasisType;
 
 	DefaultSymmetry(const BasisType&, const GeometryType&, LppHost::String) { }
 	template <typename SomeModelType> void init(const SomeModelType& model, const BasisType& basis) { model.setupHamiltonian(matrixStored_, basis); }
+	// DefaultSymmetry.h:80-93: dense LAPACK diagonalisation of the stored matrix, refused above 4900 rows
+	void fullDiag(VectorRealType& eigs, MatrixType& fm) const
+	{
+		if (rows_ > LPP_FULLDIAG_MAX_ROWS) throw LppHost::RuntimeError("fullDiag too big\n");
+		if (matrixStored_.nonZeros() == 0 && rows_ > 0) throw LppHost::RuntimeError("fullDiag: the host matrix was released\n");
+		fm = LppHost::toDense(matrixStored_);
+		LppHost::diag(fm, eigs, 'V');
+	}
 	void transform(VectorVectorType&, SizeType) { }
 	SizeType sectors() const { return 1; }
 	void setPointer(SizeType) { }
 	LppHost::String name() const { return "default"; }
 	SizeType rows() const { return matrixStored_.rows(); }
+	// the matrix of the sector selected by setPointer: what InternalProductStored makes resident on the GPU
 	const SparseMatrixType& storedMatrix() const { return matrixStored_; }
-	void releaseHostMatrix() { matrixStored_.resize(matrixStored_.rows(), matrixStored_.cols()); }
+	// after the upload the device copy is the resident one; small matrices stay on the host for the fullDiag fallback (Engine.h:633)
+	void releaseHostMatrix()
+	{
+		rows_ = matrixStored_.rows();
+		if (rows_ > LPP_FULLDIAG_MAX_ROWS) matrixStored_.resize(matrixStored_.rows(), matrixStored_.cols());
+	}
 
 private:
 	SparseMatrixType matrixStored_;
+	SizeType rows_ = 0;
 };
 
 // x += H y with H resident on the GPU
@@ -96,6 +117,7 @@ public:
 	typedef typename ModelType::RealType RealType;
 	typedef typename ModelType::GeometryType GeometryType;
 	typedef typename GeometryType::ComplexOrRealType ComplexOrRealType;
+	typedef LppHost::Matrix<ComplexOrRealType> MatrixType;
 	typedef std::vector<RealType> VectorRealType;
 	typedef std::vector<ComplexOrRealType> VectorType;
 
@@ -107,25 +129,25 @@ public:
 		return cfg;
 	}
 	// the reference's two constructors (InternalProductStored.h:104-117) with the default solver configuration
-	InternalProductStored(const ModelType& model, SpecialSymmetryType& rs) : rs_(rs), engine_(defaultConfig()), rows_(0)
+	InternalProductStored(const ModelType& model, SpecialSymmetryType& rs) : rs_(rs), engine_(defaultConfig()), basis_(model.basis()), rows_(0), sector_(0)
 	{
 		rs_.init(model, model.basis());
-		upload(model.basis());
+		upload();
 	}
-	InternalProductStored(const ModelType& model, const BasisType& basis, SpecialSymmetryType& rs) : rs_(rs), engine_(defaultConfig()), rows_(0)
+	InternalProductStored(const ModelType& model, const BasisType& basis, SpecialSymmetryType& rs) : rs_(rs), engine_(defaultConfig()), basis_(basis), rows_(0), sector_(0)
 	{
 		rs_.init(model, basis);
-		upload(basis);
+		upload();
 	}
-	InternalProductStored(const ModelType& model, SpecialSymmetryType& rs, const lpp_config& cfg) : rs_(rs), engine_(cfg), rows_(0)
+	InternalProductStored(const ModelType& model, SpecialSymmetryType& rs, const lpp_config& cfg) : rs_(rs), engine_(cfg), basis_(model.basis()), rows_(0), sector_(0)
 	{
 		rs_.init(model, model.basis());
-		upload(model.basis());
+		upload();
 	}
-	InternalProductStored(const ModelType& model, const BasisType& basis, SpecialSymmetryType& rs, const lpp_config& cfg) : rs_(rs), engine_(cfg), rows_(0)
+	InternalProductStored(const ModelType& model, const BasisType& basis, SpecialSymmetryType& rs, const lpp_config& cfg) : rs_(rs), engine_(cfg), basis_(basis), rows_(0), sector_(0)
 	{
 		rs_.init(model, basis);
-		upload(basis);
+		upload();
 	}
 	SizeType rows() const { return rows_; }
 	void matrixVectorProduct(VectorType& x, const VectorType& y) const
@@ -133,23 +155,36 @@ public:
 		if (x.size() != rows_ || y.size() != rows_) throw std::runtime_error("InternalProductStored::matrixVectorProduct: size mismatch\n");
 		lppCheck(lpp_engine_spmv_acc(engine_.get(), x.data(), y.data()));
 	}
-	void specialSymmetrySector(SizeType p) { rs_.setPointer(p); }
+	// InternalProductStored.h:124: the matrix of symmetry sector p becomes THE matrix (ReflectionSymmetry.h:138-190 and
+	// TranslationSymmetry.h:245-268 hold one CSR per sector); here it is made resident on the GPU in place of the previous one
+	void specialSymmetrySector(SizeType p)
+	{
+		rs_.setPointer(p);
+		if (p == sector_) return;
+		sector_ = p;
+		upload();
+	}
+	// InternalProductStored.h:126-130
+	void fullDiag(VectorRealType& eigs, MatrixType& fm) const { rs_.fullDiag(eigs, fm); }
 	lpp_engine* engine() const { return engine_.get(); }
 
 private:
-	void upload(const BasisType& basis)
+	void upload()
 	{
 		const SparseMatrixType& m = rs_.storedMatrix();
 		rows_ = m.rows();
-		// layout hint only: the Hubbard product basis is blocked in runs of N_up states (BasisHubbardLanczos.h:59-63)
-		const BasisHubbardLanczos* hb = dynamic_cast<const BasisHubbardLanczos*>(&basis);
-		lppCheck(lpp_engine_set_row_block(engine_.get(), hb ? (int64_t)hb->sizeUp() : 0));
+		// layout hint only: the Hubbard product basis is blocked in runs of N_up states (BasisHubbardLanczos.h:59-63);
+		// it holds for the whole-space matrix of a one-sector symmetry, not for symmetry-adapted sector matrices
+		const BasisHubbardLanczos* hb = dynamic_cast<const BasisHubbardLanczos*>(&basis_);
+		const bool whole = rs_.sectors() == 1 && hb && (SizeType)hb->size() == rows_;
+		lppCheck(lpp_engine_set_row_block(engine_.get(), whole ? (int64_t)hb->sizeUp() : 0));
 		lppCheck(lpp_engine_set_csr(engine_.get(), (int64_t)m.rows(), m.rowptr().data(), m.colind().data(), m.values().data()));
-		rs_.releaseHostMatrix(); // the device copy is the resident one
+		rs_.releaseHostMatrix(); // the device copy is the resident one (matrices small enough for fullDiag stay)
 	}
 	SpecialSymmetryType& rs_;
 	EngineHandle engine_;
-	SizeType rows_;
+	const BasisType& basis_;
+	SizeType rows_, sector_;
 };
 
 // x += H y without a stored matrix: SolverOptions=InternalProductOnTheFly (src/Engine/InternalProductOnTheFly.h:93-133).
@@ -162,6 +197,8 @@ public:
 	typedef typename ModelType::RealType RealType;
 	typedef typename ModelType::GeometryType GeometryType;
 	typedef typename GeometryType::ComplexOrRealType ComplexOrRealType;
+	typedef LppHost::Matrix<ComplexOrRealType> MatrixType;
+	typedef std::vector<RealType> VectorRealType;
 	typedef std::vector<ComplexOrRealType> VectorType;
 
 	InternalProductOnTheFly(const ModelType& model, SpecialSymmetryType& rs, const lpp_config& cfg) : rs_(rs), engine_(cfg), rows_(model.size())
@@ -185,6 +222,11 @@ public:
 		lppCheck(lpp_engine_spmv_acc(engine_.get(), x.data(), y.data()));
 	}
 	void specialSymmetrySector(SizeType p) { rs_.setPointer(p); }
+	// InternalProductOnTheFly.h:125-130: no stored matrix, hence no dense fallback
+	template <typename VectorRealType, typename MatrixType> void fullDiag(VectorRealType&, MatrixType&) const
+	{
+		throw std::runtime_error("no fullDiag possible when on the fly\n");
+	}
 	lpp_engine* engine() const { return engine_.get(); }
 
 private:
@@ -215,7 +257,14 @@ public:
 	typedef std::vector<VectorType> VectorVectorType;
 	typedef TridiagonalMatrix TridiagonalMatrixType;
 
-	LanczosSolver(const MatrixType& mat, const SolverParametersType& params) : mat_(mat), params_(params) { }
+	// The reference hands (matrix, params) to the solver AFTER the matrix object exists (Engine.h:608-610): the parameters
+	// are pushed into the engine here, so both reference-style InternalProduct constructors honour LanczosSteps= etc.
+	LanczosSolver(const MatrixType& mat, const SolverParametersType& params) : mat_(mat), params_(params)
+	{
+		const bool reortho = params_.options.find("reortho") != LppHost::String::npos;
+		lppCheck(lpp_engine_set_solver(mat_.engine(), (int32_t)params_.steps, (int32_t)params_.minSteps, params_.tolerance, reortho ? 1 : 0,
+		                               params_.lotaMemory ? -1 : 0));
+	}
 
 	void computeAllStatesBelow(VectorRealType& eigs, VectorVectorType& zs, const VectorType& initial, SizeType nStates)
 	{
@@ -239,7 +288,7 @@ public:
 	}
 	void decomposition(const VectorType& initVector, TridiagonalMatrixType& ab)
 	{
-		ab.resize(params_.steps + 2);
+		ab.resize(params_.steps + 2); // the engine holds max_steps = params_.steps (set in the constructor) and writes at most that many
 		int32_t n = 0;
 		lppCheck(lpp_engine_decomposition(mat_.engine(), initVector.data(), &n, &ab.a(0), &ab.b(0), nullptr));
 		ab.a_.resize(n);
@@ -292,29 +341,61 @@ public:
 	RealType energies(SizeType ind) const { return energies_[ind]; }
 	const VectorType& eigenvector(SizeType ind) const { return vectors_[ind]; }
 	SizeType lanczosSteps() const { return steps_; }
+	SizeType sector() const { return sector_; } // the symmetry sector the returned states live in
+	bool usedFullDiag() const { return usedFullDiag_; }
 
 private:
 	void computeAllStatesBelow(SizeType excited)
-	{ // Engine.h:601-657 for sectors() == 1
+	{ // Engine.h:601-657
 		const SizeType excitedPlusOne = excited + 1;
+		energies_.assign(excitedPlusOne, 0);
+		vectors_.assign(excitedPlusOne, VectorType());
 		ParametersForSolverType params(io_, "Lanczos");
 		lpp_config cfg;
 		lpp_config_default(&cfg);
 		cfg.device = device_;
 		cfg.dtype = LppDtype<ComplexOrRealType>::value;
-		cfg.max_steps = (int32_t)params.steps;
-		cfg.min_steps = (int32_t)params.minSteps;
-		cfg.eps = params.tolerance;
-		cfg.reortho = params.options.find("reortho") != LppHost::String::npos;
-		cfg.save_vectors = params.lotaMemory ? -1 : 0;
 		SpecialSymmetryType rs(model_.basis(), model_.geometry(), "");
 		InternalProductType hamiltonian(model_, rs, cfg);
-		LanczosSolverType lanczosSolver(hamiltonian, params);
-		const SizeType n = hamiltonian.rows();
-		VectorType initial(n);
-		fillRandom(initial);
-		lanczosSolver.computeAllStatesBelow(energies_, vectors_, initial, excitedPlusOne);
-		steps_ = lanczosSolver.steps();
+		LanczosSolverType lanczosSolver(hamiltonian, params); // pushes params into the engine
+		SizeType offset = model_.size();
+		SizeType currentOffset = 0;
+		bool firstNonZeroSectorSeen = false;
+		for (SizeType i = 0; i < rs.sectors(); ++i) { // :616-652
+			hamiltonian.specialSymmetrySector(i);
+			const SizeType n = hamiltonian.rows();
+			if (n == 0) continue;
+			VectorType initial(n);
+			fillRandom(initial);
+			VectorVectorType zs(excitedPlusOne, VectorType(n));
+			VectorRealType eigs(excitedPlusOne);
+			try {
+				lanczosSolver.computeAllStatesBelow(eigs, zs, initial, excitedPlusOne);
+				steps_ = lanczosSolver.steps();
+			} catch (std::exception& ex) { // :627-639
+				std::cerr << "Engine: Lanczos Solver failed (" << ex.what() << ") trying exact diagonalization...\n";
+				typename InternalProductType::VectorRealType eigs2(n);
+				typename InternalProductType::MatrixType fm;
+				hamiltonian.fullDiag(eigs2, fm);
+				if (excitedPlusOne > n) throw std::runtime_error("Engine: more states requested than the sector holds\n");
+				for (SizeType k = 0; k < excitedPlusOne; ++k) {
+					for (SizeType j = 0; j < n; ++j) zs[k][j] = fm(j, k);
+					eigs[k] = eigs2[k];
+				}
+				usedFullDiag_ = true;
+			}
+			if (eigs[0] < energies_[0] || !firstNonZeroSectorSeen) { // :641-649
+				for (SizeType j = 0; j < excitedPlusOne; ++j) {
+					vectors_[j] = zs[j];
+					energies_[j] = eigs[j];
+				}
+				offset = currentOffset;
+				firstNonZeroSectorSeen = true;
+				sector_ = i;
+			}
+			currentOffset += zs[0].size();
+		}
+		rs.transform(vectors_, offset); // :654
 		for (SizeType i = 0; i < excitedPlusOne; i++) { // printEnergiesAndNorms, Engine.h:666-674
 			RealType nrm = 0;
 			for (const ComplexOrRealType& z : vectors_[i]) nrm += LppHost::real(z * LppHost::conj(z));
@@ -326,7 +407,8 @@ private:
 	int device_;
 	VectorRealType energies_;
 	VectorVectorType vectors_;
-	SizeType steps_ = 0;
+	SizeType steps_ = 0, sector_ = 0;
+	bool usedFullDiag_ = false;
 };
 
 } // namespace LanczosPlusPlus

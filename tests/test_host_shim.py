@@ -78,3 +78,74 @@ def test_lanczos_driver_prints_reference_energy_line(name):
     if name == "input0.inp":
         assert abs(e + 2 * np.sqrt(5)) < 1e-10
     assert re.search(r"^E\[0\]=\S+ norm=\S+$", res.stdout, re.M)
+
+
+def _with_lines(name, tmp_path, extra):
+    """copy of a golden input with extra `Label=value` lines appended"""
+    txt = open(os.path.join(GOLD, name)).read()
+    out = tmp_path / ("mod_" + name)
+    out.write_text(txt.rstrip("\n") + "\n" + "\n".join(extra) + "\n")
+    return str(out)
+
+
+def _boundary(path, mode):
+    exe = os.path.join(HOST, "test_boundary")
+    assert os.path.exists(exe), "run __graft_entry__.build()"
+    res = subprocess.run([exe, "-f", path, "-m", mode, "-p", "14"], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr
+    return res
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["hubbard_ladder_2x4.inp", "tj_chain_L8_complex.inp"])
+def test_engine_loops_over_symmetry_sectors(name):
+    """Engine.h:616-652 with a symmetry class of three sectors (H+3, H, empty): specialSymmetrySector(p) must make sector p's
+    matrix the resident one (InternalProductStored.h:124); the lowest sector wins and rs.transform embeds its vector."""
+    path = os.path.join(GOLD, name)
+    A = _oracle_csr(path)
+    e0 = np.linalg.eigvalsh(A.to_scipy().toarray())[0]
+    res = _boundary(path, "sectors")
+    e = float(re.search(r"^Energy=(\S+)$", res.stdout, re.M).group(1))
+    assert abs(e - e0) <= 1e-10 * abs(e0), (e, e0, "an engine stuck on sector 0 reports E0 + 3")
+    m = re.search(r"^Sector=(\d+) Length=(\d+) NormInside=(\S+) NormOutside=(\S+)$", res.stdout, re.M)
+    assert m and int(m.group(1)) == 1 and int(m.group(2)) == 2 * A.nrows
+    assert abs(float(m.group(3)) - 1) < 1e-8 and float(m.group(4)) == 0
+    # both non-empty sectors were solved: two E[0]= lines would be wrong (printEnergiesAndNorms runs once), one is right
+    assert len(re.findall(r"^E\[0\]=", res.stdout, re.M)) == 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["input0.inp", "tj_chain_L8_complex.inp"])
+def test_lanczos_failure_falls_back_to_full_diagonalisation(name, tmp_path):
+    """Engine.h:625-639: when the solver throws (here: Excited=2 but LanczosSteps=2, fewer steps than states) the engine
+    catches and calls hamiltonian.fullDiag (DefaultSymmetry.h:80-93); the levels are then the dense spectrum."""
+    path = _with_lines(name, tmp_path, ["LanczosSteps=2", "Excited=2"])
+    A = _oracle_csr(os.path.join(GOLD, name))
+    dense = np.linalg.eigvalsh(A.to_scipy().toarray())
+    res = _boundary(path, "fulldiag")
+    assert "trying exact diagonalization" in res.stderr
+    assert re.search(r"^UsedFullDiag=1$", res.stdout, re.M)
+    lev = [float(re.search(r"^Level%d=(\S+)$" % k, res.stdout, re.M).group(1)) for k in range(3)]
+    assert np.abs(np.array(lev) - dense[:3]).max() <= 1e-10 * np.abs(dense[:3]).max()
+    norms = [float(x) for x in re.findall(r"^E\[\d\]=\S+ norm=(\S+)$", res.stdout, re.M)]
+    assert len(norms) == 3 and all(abs(v - 1) < 1e-10 for v in norms)
+    # without the failure the same binary does not touch fullDiag
+    res = _boundary(os.path.join(GOLD, name), "fulldiag")
+    assert re.search(r"^UsedFullDiag=0$", res.stdout, re.M)
+
+
+@pytest.mark.gpu
+def test_reference_constructors_honour_the_solver_parameters(tmp_path):
+    """The reference's (model, rs) constructor + LanczosSolver(hamiltonian, params): LanczosSteps=20 must bound the
+    decomposition (the engine is created before the parameters are known: lpp_engine_set_solver), eps is honoured."""
+    name = "hubbard_ladder_2x4.inp"
+    A = _oracle_csr(os.path.join(GOLD, name))
+    init = oracle.fill_random(A.nrows, 1234)
+    for steps, eps in ((20, 0.0), (200, 1e-12)):
+        path = _with_lines(name, tmp_path, ["LanczosSteps=%d" % steps, "LanczosEps=%g" % eps])
+        res = _boundary(path, "decomp")
+        n = int(re.search(r"^Steps=(\d+)$", res.stdout, re.M).group(1))
+        ab = np.array([[float(x) for x in ln.split()[2:4]] for ln in res.stdout.splitlines() if ln.startswith("ab ")])
+        so, ao, bo, _, _ = oracle.lanczos_decomposition(A, init, max_steps=steps, eps=eps)
+        assert n == so == len(ab) and (n == 20 if eps == 0.0 else n < 200)
+        assert np.abs(ab[:, 0] - ao).max() < 1e-8 and np.abs(ab[:, 1] - bo).max() < 1e-8
