@@ -43,7 +43,8 @@ enum {
 enum { LPP_F64 = 0, LPP_C128 = 1 };
 
 /* SpMV kernel selection (0 = automatic) */
-enum { LPP_SPMV_AUTO = 0, LPP_SPMV_ROWGROUP = 1, LPP_SPMV_SLICED = 2, LPP_SPMV_WINDOW = 3 };
+enum { LPP_SPMV_AUTO = 0, LPP_SPMV_ROWGROUP = 1, LPP_SPMV_SLICED = 2, LPP_SPMV_WINDOW = 3,
+       LPP_SPMV_PRODUCT = 4 /* reported by lpp_engine_get_layout only: product-basis layout (device-assembled Hubbard) */ };
 
 typedef struct lpp_engine lpp_engine;
 
@@ -249,6 +250,14 @@ lpp_status lpp_split_csr(int32_t rank, int32_t nranks, const int64_t* shard_star
 /* Lowest `k` eigenvalues (and optionally eigenvectors, row-major z[j*n+i] = component j of vector i)
  * of the symmetric tridiagonal matrix (d[n], e[n-1]) -- the host part of the Lanczos loop. */
 lpp_status lpp_tridiag_lowest(int32_t n, const double* d, const double* e, int32_t k, double* w, double* z);
+
+/* Product-basis layout, host part (used by lpp_engine_assemble_hubbard; exposed for the CPU test-suite): packs the in-block
+ * matrix `rows` x `rows` (CSR, diagonal entries skipped) into per-slice, per-value-group streams of 16-bit LDS window indices with
+ * a bank-conflict-free slot assignment (two indices per 32-bit word, [pair][lane]).  pitch: multiple of 16, >= rows.  Two-call
+ * protocol: off/len/words NULL returns sizes only (ngroups, slices, nwords).  group_values holds 8 doubles. */
+lpp_status lpp_pb_pack_template(int64_t rows, int64_t pitch, const int64_t* rowptr, const int32_t* colind, const double* values,
+                                int32_t* ngroups, double* group_values, int32_t* slices, int64_t* nwords, int32_t* off, uint16_t* len,
+                                uint32_t* words, int64_t* entries, int64_t* slots);
 
 #ifdef __cplusplus
 }

@@ -176,6 +176,120 @@ lpp_status common_setup(lpp_engine* e, int64_t nrows, int is_complex_input)
 	return LPP_OK;
 }
 
+// plain host copy of a small device CSR
+lpp_status fetch_csr(const DevCsr& A, std::vector<int64_t>& rp, std::vector<int32_t>& ci, std::vector<double>& va)
+{
+	rp.resize((size_t)A.nrows + 1);
+	ci.resize((size_t)std::max<int64_t>(A.nnz, 1));
+	va.resize((size_t)std::max<int64_t>(A.nnz, 1));
+	HIP_TRY(hipMemcpy(rp.data(), A.rowptr, sizeof(int64_t) * (size_t)(A.nrows + 1), hipMemcpyDeviceToHost));
+	if (A.nnz) {
+		HIP_TRY(hipMemcpy(ci.data(), A.col, sizeof(int32_t) * (size_t)A.nnz, hipMemcpyDeviceToHost));
+		HIP_TRY(hipMemcpy(va.data(), A.val, sizeof(double) * (size_t)A.nnz, hipMemcpyDeviceToHost));
+	}
+	return LPP_OK;
+}
+
+// Hubbard straight into the product-basis layout (lpp_pb_kernels.h): the two one-species matrices (a few hundred KB, built
+// by the same assembler with the other species empty), the distinct diagonal values and one diagonal code per row.  The
+// N-row CSR (71 GB at BASELINE config 2) never exists.  *done stays false when the matrix does not qualify (the caller
+// then takes the general path); P carries the full-matrix parameters.
+lpp_status assemble_hubbard_pb(lpp_engine* e, AsmParams P, int nup, int ndown, int64_t n_up, int64_t n_dn, const double* zeroU_dev, bool* done)
+{
+	*done = false;
+	if (e->is_complex || n_up < 512) return LPP_OK;
+	if (const char* s = getenv("LPP_PRODUCT_LAYOUT")) {
+		if (atoi(s) == 0) return LPP_OK;
+	}
+	if (e->cfg.spmv_kernel != LPP_SPMV_AUTO || getenv("LPP_SPMV_KERNEL")) return LPP_OK;
+	int want = e->cfg.compress_values;
+	if (const char* s = getenv("LPP_COMPRESS_VALUES")) want = atoi(s);
+	if (want == 0) return LPP_OK;
+	for (const char* k : { "LPP_SHARED_OFFSETS", "LPP_LOCAL16", "LPP_DIAG_CODES", "LPP_BLOCK_TEMPLATE", "LPP_WINDOW_ROWS" })
+		if (getenv(k)) return LPP_OK; // switches of the general layout: measure that one
+	const int64_t pitch = pb_pitch_for(n_up);
+	if ((size_t)(pitch + kPbZeroSlots) * sizeof(double) > (size_t)156 * 1024) return LPP_OK;
+	if ((size_t)n_dn * (size_t)pitch * sizeof(double) >= ((size_t)1 << 32)) return LPP_OK;
+	hipStream_t st = e->stream;
+	// one-species matrices: hops of that species + its potential diagonal (ignored below; the true diagonal is per row)
+	DevCsr Tm, Cm;
+	struct Guard {
+		DevCsr &a, &b;
+		~Guard()
+		{
+			free_csr(a);
+			free_csr(b);
+		}
+	} guard { Tm, Cm };
+	AsmParams P1 = P;
+	P1.d0 = zeroU_dev;
+	P1.ndown = 0;
+	P1.part = 0;
+	P1.row0 = 0;
+	P1.nup = nup;
+	P1.n_up = n_up;
+	P1.nrows_global = P1.nloc = n_up;
+	lpp_status rc = dispatch<ASM_HUBBARD>(e, P1, Tm, LPP_SPMV_ROWGROUP, 0);
+	if (rc != LPP_OK) return rc;
+	P1.nup = ndown;
+	P1.n_up = n_dn;
+	P1.nrows_global = P1.nloc = n_dn;
+	rc = dispatch<ASM_HUBBARD>(e, P1, Cm, LPP_SPMV_ROWGROUP, 0);
+	if (rc != LPP_OK) return rc;
+	std::vector<int64_t> trp, crp;
+	std::vector<int32_t> tci, cci;
+	std::vector<double> tva, cva;
+	if ((rc = fetch_csr(Tm, trp, tci, tva)) != LPP_OK) return rc;
+	if ((rc = fetch_csr(Cm, crp, cci, cva)) != LPP_OK) return rc;
+	// distinct diagonal values over all rows
+	DevBuf table, overflow;
+	HIP_TRY_MEM(hipMalloc(&table.p, sizeof(unsigned long long) * kDictTable));
+	HIP_TRY_MEM(hipMalloc(&overflow.p, sizeof(int)));
+	HIP_TRY(hipMemsetAsync(table.p, 0xff, sizeof(unsigned long long) * kDictTable, st));
+	HIP_TRY(hipMemsetAsync(overflow.p, 0, sizeof(int), st));
+	AsmParams Pf = P;
+	Pf.row0 = 0;
+	Pf.nloc = P.nrows_global;
+	Pf.part = 0;
+	const int nb = (int)std::max<int64_t>(1, std::min<int64_t>((Pf.nloc + kBlock - 1) / kBlock, 1 << 16));
+	k_pb_diag_collect<ASM_HUBBARD><<<nb, kBlock, 0, st>>>(Pf, (unsigned long long*)table.p, (int*)overflow.p);
+	std::vector<unsigned long long> host(kDictTable);
+	int ov = 0;
+	HIP_TRY(hipMemcpyAsync(host.data(), table.p, sizeof(unsigned long long) * kDictTable, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipMemcpyAsync(&ov, overflow.p, sizeof(int), hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipStreamSynchronize(st));
+	if (ov) return LPP_OK;
+	std::vector<unsigned long long> keys;
+	keys.push_back(0ull); // code 0 = +0.0 (padding places of k_pb_down)
+	auto add_key = [&](unsigned long long k) {
+		if (std::find(keys.begin(), keys.end(), k) == keys.end()) keys.push_back(k);
+	};
+	for (unsigned long long k : host)
+		if (k != kDictEmpty) add_key(k);
+	for (int64_t b = 0; b < n_dn; b++)
+		for (int64_t p = crp[(size_t)b]; p < crp[(size_t)b + 1] && keys.size() <= 256; p++)
+			if (cci[(size_t)p] != b) {
+				unsigned long long k;
+				std::memcpy(&k, &cva[(size_t)p], 8);
+				add_key(k);
+			}
+	if (keys.size() > 256) return LPP_OK;
+	std::sort(keys.begin(), keys.end());
+	std::vector<double> dict(256);
+	for (size_t i = 0; i < 256; i++) std::memcpy(&dict[i], &keys[std::min(i, keys.size() - 1)], 8);
+	rc = pb_build(e, n_up, n_dn, trp.data(), tci.data(), tva.data(), crp.data(), cci.data(), cva.data(), dict.data(), (int)keys.size());
+	if (rc == LPP_ERR_INVALID) { // not representable (e.g. more than 8 distinct in-block values): general path
+		free_pb(e);
+		return LPP_OK;
+	}
+	if (rc != LPP_OK) return rc;
+	k_pb_diag_codes<ASM_HUBBARD><<<nb, kBlock, 0, st>>>(Pf, e->pb.pitch, e->pb.dict, e->pb.ndict, e->pb.dcode);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipStreamSynchronize(st));
+	*done = true;
+	return LPP_OK;
+}
+
 } // namespace
 
 extern "C" {
@@ -201,11 +315,13 @@ lpp_status lpp_engine_assemble_hubbard(lpp_engine* e, const lpp_comm* comm, int3
 	st = finish_procs(hp, procs, &nneg);
 	if (st != LPP_OK) return st;
 
-	DevBuf d_procs, d_comb, d_U, d_V;
+	DevBuf d_procs, d_comb, d_U, d_V, d_U0;
+	const std::vector<double> zeroU((size_t)L, 0.0);
 	if ((st = upload(e->stream, d_procs, procs.data(), sizeof(Proc) * procs.size())) != LPP_OK) return st;
 	if ((st = upload(e->stream, d_comb, comb.data(), sizeof(uint64_t) * comb.size())) != LPP_OK) return st;
 	if ((st = upload(e->stream, d_U, U, sizeof(double) * L)) != LPP_OK) return st;
 	if ((st = upload(e->stream, d_V, V, sizeof(double) * L)) != LPP_OK) return st;
+	if ((st = upload(e->stream, d_U0, zeroU.data(), sizeof(double) * L)) != LPP_OK) return st;
 
 	AsmParams P {};
 	P.model = ASM_HUBBARD;
@@ -230,8 +346,15 @@ lpp_status lpp_engine_assemble_hubbard(lpp_engine* e, const lpp_comm* comm, int3
 		P.row0 = 0;
 		P.nloc = nrows;
 		P.part = 0;
-		st = dispatch<ASM_HUBBARD>(e, P, e->A_loc);
+		bool as_product = false;
+		st = assemble_hubbard_pb(e, P, nup, ndown, n_up, n_dn, (const double*)d_U0.p, &as_product);
 		if (st != LPP_OK) return st;
+		if (as_product) {
+			free_csr(e->A_loc);
+		} else {
+			st = dispatch<ASM_HUBBARD>(e, P, e->A_loc);
+			if (st != LPP_OK) return st;
+		}
 		e->n_local = e->n_global = nrows;
 		e->row_start = 0;
 	} else {
@@ -687,6 +810,7 @@ namespace lpp {
 void drop_product(lpp_engine* e)
 {
 	free_kron(e);
+	free_pb(e);
 	e->tx = false;
 }
 

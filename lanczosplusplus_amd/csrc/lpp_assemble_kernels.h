@@ -274,6 +274,48 @@ __global__ __launch_bounds__(kBlock) void k_asm_fill(AsmParams P, const int64_t*
 }
 
 // ---------------------------------------------------------------------------------------------
+// Product-basis layout (lpp_pb_kernels.h): the diagonal of every row straight from the state, never through a CSR.
+// Pass 1 collects the distinct diagonal values (same open-addressing table as k_dict_collect), pass 2 writes one
+// dictionary code per row into the pitched code array.  diag_of adds in the reference's loop order, so the decoded
+// doubles are the ones HubbardHelper::calcDiagonalElements produces (HubbardHelper.h:138-189), bit for bit.
+// ---------------------------------------------------------------------------------------------
+template <int MODEL>
+__global__ __launch_bounds__(kBlock) void k_pb_diag_collect(AsmParams P, unsigned long long* table, int* overflow)
+{
+	unsigned long long last = kDictEmpty;
+	for (int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x; r < P.nloc; r += (int64_t)gridDim.x * kBlock) {
+		const uint64_t ket = state_of<MODEL>(P, P.row0 + r);
+		const unsigned long long key = (unsigned long long)__double_as_longlong(diag_of<MODEL>(P, ket));
+		if (key == last) continue;
+		last = key;
+		unsigned h = dict_hash(key);
+		int probes = 0;
+		for (; probes < kDictTable; probes++) {
+			const unsigned long long cur = table[h];
+			if (cur == key) break;
+			if (cur == kDictEmpty) {
+				const unsigned long long old = atomicCAS(&table[h], kDictEmpty, key);
+				if (old == kDictEmpty || old == key) break;
+			}
+			h = (h + 1) & (kDictTable - 1);
+		}
+		if (probes == kDictTable) *overflow = 1;
+	}
+}
+
+template <int MODEL>
+__global__ __launch_bounds__(kBlock) void k_pb_diag_codes(AsmParams P, int64_t pitch, const double* __restrict__ dict, int ndict,
+                                                           uint8_t* __restrict__ dcode)
+{
+	for (int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x; r < P.nloc; r += (int64_t)gridDim.x * kBlock) {
+		const int64_t row = P.row0 + r;
+		const uint64_t ket = state_of<MODEL>(P, row);
+		const int64_t b = row / P.n_up, i = row - b * P.n_up;
+		dcode[b * pitch + i] = (uint8_t)dict_code(dict, ndict, diag_of<MODEL>(P, ket));
+	}
+}
+
+// ---------------------------------------------------------------------------------------------
 // exclusive scan of int64 (three phases, chunk = 2048 elements per block)
 // ---------------------------------------------------------------------------------------------
 constexpr int kScanChunk = 2048;

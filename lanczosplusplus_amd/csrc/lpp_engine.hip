@@ -668,6 +668,10 @@ void set_spmv_bytes(lpp_engine* e)
 {
 	const double s = (double)e->esz;
 	const double N = (double)e->n_local;
+	if (e->pb.active) {
+		e->spmv_bytes = (double)e->pb.nnz * (s + 4.0) + (N + 1.0) * 8.0 + 3.0 * N * s; // the CSR this layout stands for
+		return;
+	}
 	if (e->kron.active) {
 		// matrix-free product: no matrix stream.  Vector-streaming model: x in/out and y once (3 N s) plus one
 		// coalesced pass over the source block of every connected down-configuration (H_down off-diagonals).
@@ -683,7 +687,8 @@ void set_spmv_bytes(lpp_engine* e)
 lpp_status alloc_work(lpp_engine* e)
 {
 	// vectors are padded to an even number of doubles so BLAS-1 kernels can move double2
-	const int64_t nd = e->n_local * (e->is_complex ? 2 : 1);
+	// product-basis matrices keep their vectors pitched (block b at element b*pitch, padding zero)
+	const int64_t nd = (e->pitch > 0 ? e->pitch * e->pitch_blocks : e->n_local) * (e->is_complex ? 2 : 1);
 	e->nd = nd;
 	e->nd_pad = (nd + 1) & ~(int64_t)1;
 	e->n2 = e->nd_pad / 2;
@@ -819,6 +824,7 @@ lpp_status lpp_engine_destroy(lpp_engine* e)
 	free_csr(e->A_loc);
 	free_csr(e->A_rem);
 	drop_product(e);
+	free_pb(e);
 	for (double* p : { e->x, e->y, e->V, e->partial, e->scal_own, e->zwork })
 		if (p) (void)hipFree(p);
 	if (e->h_scal) (void)hipHostFree(e->h_scal);
@@ -986,6 +992,14 @@ lpp_status lpp_engine_get_csr(lpp_engine* e, int32_t which, int64_t* nrows, int6
 {
 	if (!e) return fail(LPP_ERR_INVALID, "lpp_engine_get_csr: null engine");
 	DevCsr& A = which == 0 ? e->A_loc : e->A_rem;
+	if (e->pb.active) { // product-basis layout: the CSR is regenerated from T, C and the diagonal codes
+		if (nrows) *nrows = which == 0 ? e->n_local : 0;
+		if (nnz) *nnz = which == 0 ? e->pb.nnz : 0;
+		if (!rowptr && !colind && !values) return LPP_OK;
+		if (which != 0) return fail(LPP_ERR_STATE, "lpp_engine_get_csr: no remote part");
+		HIP_TRY(hipSetDevice(e->cfg.device));
+		return pb_get_csr(e, rowptr, colind, values);
+	}
 	if (nrows) *nrows = A.nrows;
 	if (nnz) *nnz = A.nnz;
 	if (!rowptr && !colind && !values) return LPP_OK;
@@ -1019,15 +1033,17 @@ lpp_status lpp_engine_spmv_acc(lpp_engine* e, void* x_inout, const void* y)
 	if (e->has_comm && e->comm.nranks > 1) return fail(LPP_ERR_STATE, "lpp_engine_spmv_acc: not available on a partitioned matrix");
 	if (e->active) return fail(LPP_ERR_STATE, "lpp_engine_spmv_acc: a Lanczos run is active");
 	HIP_TRY(hipSetDevice(e->cfg.device));
-	const size_t bytes = e->esz * (size_t)e->n_local;
-	HIP_TRY(hipMemcpyAsync(e->x, x_inout, bytes, hipMemcpyHostToDevice, e->stream));
-	HIP_TRY(hipMemcpyAsync(e->y, y, bytes, hipMemcpyHostToDevice, e->stream));
-	if (e->kron.active)
+	lpp_status st = vec_from_host(e, e->x, x_inout);
+	if (st != LPP_OK) return st;
+	if ((st = vec_from_host(e, e->y, y)) != LPP_OK) return st;
+	if (e->pb.active)
+		pb_launch(e, e->y, e->x, nullptr);
+	else if (e->kron.active)
 		kron_launch(e, e->y, e->y, e->x, nullptr);
 	else
 		spmv_launch(e, e->A_loc, e->y, e->x, nullptr, nullptr);
 	HIP_TRY(hipGetLastError());
-	HIP_TRY(hipMemcpyAsync(x_inout, e->x, bytes, hipMemcpyDeviceToHost, e->stream));
+	if ((st = vec_to_host(e, x_inout, e->x)) != LPP_OK) return st;
 	HIP_TRY(hipStreamSynchronize(e->stream));
 	return LPP_OK;
 }
@@ -1039,7 +1055,7 @@ lpp_status lpp_engine_bench_spmv(lpp_engine* e, int32_t warmup, int32_t iters, d
 	if (e->active) return fail(LPP_ERR_STATE, "lpp_engine_bench_spmv: a Lanczos run is active");
 	if (e->has_comm && e->comm.nranks > 1 && e->tx) return fail(LPP_ERR_STATE, "lpp_engine_bench_spmv: not available with the transposition exchange");
 	HIP_TRY(hipSetDevice(e->cfg.device));
-	k_fill_random<<<1024, 256, 0, e->stream>>>(e->y, e->nd, 0, 99);
+	vec_fill_random(e, e->y, 99);
 	HIP_TRY(hipMemsetAsync(e->x, 0, sizeof(double) * (size_t)e->nd_pad, e->stream));
 	const void* src = e->y;
 	if (e->has_comm && e->comm.nranks > 1) {
@@ -1048,6 +1064,10 @@ lpp_status lpp_engine_bench_spmv(lpp_engine* e, int32_t warmup, int32_t iters, d
 	}
 	for (int i = 0; i < warmup + iters; i++) {
 		if (i == warmup) HIP_TRY(hipEventRecord(e->ev_t0, e->stream));
+		if (e->pb.active) {
+			pb_launch(e, e->y, e->x, e->partial);
+			continue;
+		}
 		if (e->kron.active) {
 			kron_launch(e, e->y, (e->has_comm && e->comm.nranks > 1) ? e->comm.gath_buf : e->y, e->x, e->partial);
 			continue;
@@ -1082,6 +1102,26 @@ lpp_status lpp_engine_get_layout(lpp_engine* e, int32_t which, lpp_layout* out)
 	const DevCsr& A = which == 0 ? e->A_loc : e->A_rem;
 	const size_t s = e->esz;
 	lpp_layout L {};
+	if (e->pb.active && which == 0) {
+		const PbState& B = e->pb;
+		L.kernel = LPP_SPMV_PRODUCT;
+		L.coded = 1;
+		L.local16 = 1;
+		L.block_template = 2;
+		L.diagonal_codes = 1;
+		L.shared_stride = B.rowcap;
+		L.nnz = B.nnz;
+		L.per_row_entries = B.t_entries * B.n_blk; // in-block entries, stored once (the template)
+		L.shared_entries = B.c_nnz; // block couplings, stored once per block
+		L.rows_per_block = B.n_up;
+		const size_t small = sizeof(uint32_t) * (size_t)B.tw_words + (sizeof(int32_t) + sizeof(uint16_t)) * (size_t)B.spb * (size_t)B.G
+		    + (size_t)B.t_entries * 12 + sizeof(int64_t) * (size_t)(B.n_up + 1) + (size_t)B.c_nnz * 5 + sizeof(int64_t) * 2 * (size_t)(B.n_blk + 1) + 256 * sizeof(double);
+		L.resident_bytes = (int64_t)(small + (size_t)B.n_blk * (size_t)B.pitch);
+		// per product: one diagonal code per row; the template words and the couplings are re-read from L2 / LDS
+		L.stream_bytes = (int64_t)((size_t)B.n_blk * (size_t)B.pitch + sizeof(uint32_t) * (size_t)B.tw_words + (size_t)B.c_nnz * 5);
+		*out = L;
+		return LPP_OK;
+	}
 	L.kernel = A.sliced ? (A.window ? LPP_SPMV_WINDOW : LPP_SPMV_SLICED) : LPP_SPMV_ROWGROUP;
 	L.coded = A.coded ? 1 : 0;
 	L.local16 = A.local16 ? 1 : 0;
@@ -1135,7 +1175,7 @@ lpp_status lpp_engine_get_stats(lpp_engine* e, lpp_stats* s)
 	e->collect_spmv_times();
 	*s = e->stats;
 	s->nrows = e->n_local;
-	s->nnz = e->kron.active ? (int64_t)e->kron.equiv_nnz : e->A_loc.nnz + e->A_rem.nnz;
+	s->nnz = e->pb.active ? e->pb.nnz : (e->kron.active ? (int64_t)e->kron.equiv_nnz : e->A_loc.nnz + e->A_rem.nnz);
 	s->spmv_bytes = e->spmv_bytes;
 	return LPP_OK;
 }

@@ -8,6 +8,7 @@
 
 #include "lpp_host.h"
 #include "lpp_kernels.h"
+#include "lpp_pb_kernels.h"
 
 #define HIP_TRY(expr)                                                                                                  \
 	do {                                                                                                               \
@@ -86,6 +87,37 @@ struct KronState {
 	int pk_nchunk = 1, pk_cw = 0; // LDS window pieces of the packed H_up (N_up beyond LDS: see k_spmv_kron_chunked)
 };
 
+// product-basis stored matrix  H = 1 (x) T + C (x) 1 + D  (lpp_pb_kernels.h): everything the 5.8e9-entry CSR of BASELINE
+// config 2 needs is T, C, a 256-entry dictionary and one code per row
+struct PbState {
+	bool active = false;
+	int64_t n_up = 0, n_blk = 0, pitch = 0;
+	int64_t nnz = 0; // entries of the CSR this stands for
+	// in-block matrix T (off-diagonal part): packed for k_pb_up + plain CSR for lpp_engine_get_csr
+	int G = 0;
+	double gval[8] = { 0 };
+	int spb = 0;
+	uint32_t* tw = nullptr;
+	int32_t* tw_off = nullptr;
+	uint16_t* tw_len = nullptr;
+	int64_t tw_words = 0, t_entries = 0, t_slots = 0;
+	int64_t* t_ptr = nullptr;
+	int32_t* t_col = nullptr;
+	double* t_val = nullptr;
+	// block couplings C (off-diagonal)
+	int64_t* c_ptr = nullptr;
+	int32_t* c_col = nullptr;
+	uint8_t* c_code = nullptr;
+	int64_t c_nnz = 0;
+	int rowcap = 0, ids_per_wg = 0, down_grid = 0;
+	int* pace = nullptr;
+	// diagonal
+	double* dict = nullptr; // 256 doubles
+	int ndict = 0;
+	uint8_t* dcode = nullptr; // n_blk * pitch codes
+	int64_t* blockbase = nullptr; // first CSR entry of every block (n_blk + 1), for get_csr
+};
+
 } // namespace lpp
 
 struct lpp_engine {
@@ -102,12 +134,15 @@ struct lpp_engine {
 	// matrix: A_loc has columns inside this rank's slice, A_rem (multi-GPU only) indexes the gathered buffer
 	lpp::DevCsr A_loc, A_rem;
 	lpp::KronState kron;
+	lpp::PbState pb;
+	// pitched vector layout (product-basis matrices): block b of `pitch_rows` valid elements starts at element b*pitch; 0 = contiguous
+	int64_t pitch = 0, pitch_rows = 0, pitch_blocks = 0;
 	// transposition exchange (multi-GPU Hubbard): A_loc = diagonal + up-hops on the rank's slice, A_rem = down-hops
 	// on the UP-partitioned transposed slice; see lpp_assemble.hip / one_step
 	bool tx = false;
 	int64_t tx_per = 0, tx_peru = 0;
 	int64_t kron_n_up_tx = 1; // N_up of the transposition layout
-	bool has_matrix() const { return A_loc.rowptr != nullptr || kron.active; }
+	bool has_matrix() const { return A_loc.rowptr != nullptr || kron.active || pb.active; }
 	int64_t n_local = 0, n_global = 0, row_start = 0;
 	double spmv_bytes = 0;
 
@@ -168,4 +203,17 @@ int kron_launch(lpp_engine* e, const void* ywin, const void* ydown, void* x, dou
 void set_spmv_bytes(lpp_engine* e);
 lpp_status alloc_work(lpp_engine* e);
 int spmv_launch(lpp_engine* e, const DevCsr& A, const void* src, void* x, const void* ydot, double* partial, const EpiScale& sc = EpiScale { nullptr, nullptr, 0 });
+// product-basis layout (lpp_pb.hip)
+void free_pb(lpp_engine* e);
+// T and C as host CSRs over one species each (diagonal entries are ignored), sorted 256-entry dictionary holding every coupling
+// value; the caller fills pb.dcode (n_blk*pitch codes) afterwards
+lpp_status pb_build(lpp_engine* e, int64_t n_up, int64_t n_blk, const int64_t* t_rp, const int32_t* t_ci, const double* t_va,
+                    const int64_t* c_rp, const int32_t* c_ci, const double* c_va, const double* dict256, int ndict);
+int pb_launch(lpp_engine* e, const void* y, void* x, double* partial, const EpiScale& sc = EpiScale { nullptr, nullptr, 0 });
+lpp_status pb_get_csr(lpp_engine* e, int64_t* rowptr, int32_t* colind, void* values);
+int64_t pb_pitch_for(int64_t n_up);
+// host <-> device vector copies that know the pitched layout
+lpp_status vec_from_host(lpp_engine* e, double* dev, const void* host);
+lpp_status vec_to_host(lpp_engine* e, void* host, const double* dev);
+void vec_fill_random(lpp_engine* e, double* dev, uint64_t seed);
 } // namespace lpp

@@ -228,3 +228,174 @@ lpp_status lpp_tridiag_lowest(int32_t n, const double* d, const double* e, int32
 }
 
 } // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// product-basis layout: template packing with bank-conflict-free slot assignment
+// ---------------------------------------------------------------------------------------------
+namespace lpp {
+
+namespace {
+
+// Proper edge colouring of a bipartite multigraph (left: up to 32 rows, right: 32 LDS banks) with D = max degree colours
+// (Koenig's theorem; alternating-path recolouring).  edges[k] = (row, bank); returns the colour of every edge.
+int edge_colour(const std::vector<std::pair<int, int>>& edges, std::vector<int>& colour)
+{
+	int degL[32] = { 0 }, degR[32] = { 0 };
+	for (const auto& e : edges) {
+		degL[e.first]++;
+		degR[e.second]++;
+	}
+	int D = 0;
+	for (int i = 0; i < 32; i++) D = std::max(D, std::max(degL[i], degR[i]));
+	colour.assign(edges.size(), -1);
+	if (D == 0) return 0;
+	std::vector<int> atL(32 * (size_t)D, -1), atR(32 * (size_t)D, -1); // edge holding colour c at a vertex
+	for (size_t k = 0; k < edges.size(); k++) {
+		const int u = edges[k].first, v = edges[k].second;
+		int a = 0, b = 0;
+		while (atL[(size_t)u * D + a] >= 0) a++; // free at the row (exists: deg <= D)
+		while (atR[(size_t)v * D + b] >= 0) b++; // free at the bank
+		if (atR[(size_t)v * D + a] >= 0) {
+			// a is taken at v: flip the a/b alternating path that starts at v with colour a.  It cannot end in u
+			// (bipartite, a is free at u), afterwards a is free at v.
+			std::vector<int> path;
+			int x = v, col = a;
+			bool right = true;
+			for (;;) {
+				const int e2 = right ? atR[(size_t)x * D + col] : atL[(size_t)x * D + col];
+				if (e2 < 0) break;
+				path.push_back(e2);
+				x = right ? edges[(size_t)e2].first : edges[(size_t)e2].second;
+				right = !right;
+				col = (col == a) ? b : a;
+			}
+			for (int e2 : path) {
+				atL[(size_t)edges[(size_t)e2].first * D + colour[(size_t)e2]] = -1;
+				atR[(size_t)edges[(size_t)e2].second * D + colour[(size_t)e2]] = -1;
+			}
+			for (int e2 : path) {
+				const int nc = (colour[(size_t)e2] == a) ? b : a;
+				colour[(size_t)e2] = nc;
+				atL[(size_t)edges[(size_t)e2].first * D + nc] = e2;
+				atR[(size_t)edges[(size_t)e2].second * D + nc] = e2;
+			}
+		}
+		colour[k] = a;
+		atL[(size_t)u * D + a] = (int)k;
+		atR[(size_t)v * D + a] = (int)k;
+	}
+	return D;
+}
+
+} // namespace
+
+lpp_status pb_pack_template(int64_t rows, int64_t pitch, const int64_t* rp, const int32_t* ci, const double* va, PbTemplate& out)
+{
+	if (rows <= 0 || pitch < rows || (pitch & 15) != 0 || pitch + kPbZeroSlotsHost > 65536) return fail(LPP_ERR_INVALID, "pb_pack_template: bad shape");
+	out = PbTemplate();
+	// value groups (bit patterns, first-seen order then sorted for determinism)
+	std::vector<uint64_t> keys;
+	for (int64_t r = 0; r < rows; r++)
+		for (int64_t p = rp[r]; p < rp[r + 1]; p++) {
+			if (ci[p] == r) continue;
+			if (ci[p] < 0 || ci[p] >= rows) return fail(LPP_ERR_INVALID, "pb_pack_template: column out of range");
+			uint64_t k;
+			std::memcpy(&k, &va[p], 8);
+			if (std::find(keys.begin(), keys.end(), k) == keys.end()) {
+				keys.push_back(k);
+				if ((int)keys.size() > kPbGroupsMax) return fail(LPP_ERR_INVALID, "pb_pack_template: more than 8 distinct in-block values");
+			}
+		}
+	std::sort(keys.begin(), keys.end());
+	out.G = std::max<int>(1, (int)keys.size());
+	for (size_t g = 0; g < keys.size(); g++) std::memcpy(&out.gval[g], &keys[g], 8);
+	const int G = out.G;
+	out.spb = (int)((rows + 63) / 64);
+	out.off.assign((size_t)out.spb * G, 0);
+	out.len.assign((size_t)out.spb * G, 0);
+	std::vector<std::pair<int, int>> edges;
+	std::vector<int> ecol, colour;
+	std::vector<int> slot_idx; // [slot][lane] window index or -1
+	for (int j = 0; j < out.spb; j++) {
+		for (int g = 0; g < G; g++) {
+			int nslots = 0;
+			struct Ent {
+				int lane, col, slot;
+			};
+			std::vector<Ent> ents;
+			for (int h = 0; h < 2; h++) {
+				edges.clear();
+				ecol.clear();
+				for (int l = 0; l < 32; l++) {
+					const int64_t r = (int64_t)j * 64 + h * 32 + l;
+					if (r >= rows) break;
+					for (int64_t p = rp[r]; p < rp[r + 1]; p++) {
+						if (ci[p] == r) continue;
+						uint64_t k;
+						std::memcpy(&k, &va[p], 8);
+						if (!keys.empty() && k != keys[(size_t)g]) continue;
+						edges.emplace_back(l, (int)(ci[p] & 31));
+						ecol.push_back((int)ci[p]);
+					}
+				}
+				const int D = edge_colour(edges, colour);
+				nslots = std::max(nslots, D);
+				for (size_t k = 0; k < edges.size(); k++) ents.push_back(Ent { h * 32 + edges[k].first, ecol[k], colour[k] });
+				out.entries += (int64_t)edges.size();
+			}
+			const int npairs = (nslots + 1) / 2;
+			nslots = npairs * 2;
+			slot_idx.assign((size_t)nslots * 64, -1);
+			for (const Ent& e : ents) slot_idx[(size_t)e.slot * 64 + e.lane] = e.col;
+			// padding: a zero slot in a bank no real entry of this slot and half-wave uses
+			for (int s = 0; s < nslots; s++)
+				for (int h = 0; h < 2; h++) {
+					bool used[32] = { false };
+					bool any_pad = false;
+					for (int l = 0; l < 32; l++) {
+						const int c = slot_idx[(size_t)s * 64 + h * 32 + l];
+						if (c >= 0)
+							used[c & 31] = true;
+						else
+							any_pad = true;
+					}
+					if (!any_pad) continue;
+					int z = 0;
+					while (z < 31 && used[(pitch + z) & 31]) z++;
+					for (int l = 0; l < 32; l++)
+						if (slot_idx[(size_t)s * 64 + h * 32 + l] < 0) slot_idx[(size_t)s * 64 + h * 32 + l] = (int)(pitch + z);
+				}
+			out.off[(size_t)j * G + g] = (int32_t)out.words.size();
+			out.len[(size_t)j * G + g] = (uint16_t)npairs;
+			for (int p = 0; p < npairs; p++)
+				for (int l = 0; l < 64; l++)
+					out.words.push_back((uint32_t)slot_idx[(size_t)(2 * p) * 64 + l] | ((uint32_t)slot_idx[(size_t)(2 * p + 1) * 64 + l] << 16));
+			out.slots += (int64_t)nslots * 64;
+			if (out.words.size() > ((size_t)1 << 30)) return fail(LPP_ERR_INVALID, "pb_pack_template: template too large");
+		}
+	}
+	out.words.resize(out.words.size() + 64 * 8, (uint32_t)pitch | ((uint32_t)pitch << 16)); // slack for the pipelined word loads
+	return LPP_OK;
+}
+
+} // namespace lpp
+
+extern "C" lpp_status lpp_pb_pack_template(int64_t rows, int64_t pitch, const int64_t* rowptr, const int32_t* colind, const double* values,
+                                           int32_t* ngroups, double* group_values, int32_t* slices, int64_t* nwords, int32_t* off, uint16_t* len,
+                                           uint32_t* words, int64_t* entries, int64_t* slots)
+{
+	if (!rowptr || !ngroups || !nwords) return lpp::fail(LPP_ERR_INVALID, "lpp_pb_pack_template: null argument");
+	lpp::PbTemplate t;
+	lpp_status st = lpp::pb_pack_template(rows, pitch, rowptr, colind, values, t);
+	if (st != LPP_OK) return st;
+	*ngroups = t.G;
+	*nwords = (int64_t)t.words.size();
+	if (slices) *slices = t.spb;
+	if (entries) *entries = t.entries;
+	if (slots) *slots = t.slots;
+	if (group_values) std::memcpy(group_values, t.gval, sizeof(double) * lpp::kPbGroupsMax);
+	if (off) std::memcpy(off, t.off.data(), sizeof(int32_t) * t.off.size());
+	if (len) std::memcpy(len, t.len.data(), sizeof(uint16_t) * t.len.size());
+	if (words) std::memcpy(words, t.words.data(), sizeof(uint32_t) * t.words.size());
+	return LPP_OK;
+}

@@ -24,3 +24,32 @@ double tridiag_kth(int n, const double* d, const double* e, int k);
 bool tridiag_qr(int n, const double* d, const double* e, double* w, double* z);
 
 } // namespace lpp
+
+// ---------------------------------------------------------------------------------------------
+// Product-basis layout (lpp_pb_kernels.h), host part: the in-block matrix T as per-slice, per-value-group streams of
+// 16-bit LDS window indices.  Within a half-wave (32 lanes = 32 consecutive rows) the entries of a group are assigned to
+// slots by a bipartite edge colouring (rows x LDS banks), so the 32 lanes of a slot hit 32 different banks: a
+// ds_read_b64 gather then takes its conflict-free 2 cycles instead of ~3.7x that for the entries in column order.
+// ---------------------------------------------------------------------------------------------
+namespace lpp {
+
+constexpr int kPbGroupsMax = 8;
+constexpr int kPbZeroSlotsHost = 32;
+
+struct PbTemplate {
+	int G = 0; // value groups
+	double gval[kPbGroupsMax] = { 0 };
+	int spb = 0; // 64-row slices
+	std::vector<int32_t> off; // [spb*G] first word of (slice, group)
+	std::vector<uint16_t> len; // [spb*G] slot pairs
+	std::vector<uint32_t> words; // [pair][lane] per (slice, group): low half = slot 2p, high half = slot 2p+1
+	int64_t entries = 0; // real entries
+	int64_t slots = 0; // lane-slots incl. padding
+};
+
+// rows x rows CSR (rp, ci, va); entries with ci == row (the diagonal) are skipped.  pitch: the zero slots start at window
+// index `pitch` (a multiple of 16, >= rows; pitch + 32 <= 65536).  Fails (LPP_ERR_INVALID) when the off-diagonal part has more
+// than kPbGroupsMax distinct values.
+lpp_status pb_pack_template(int64_t rows, int64_t pitch, const int64_t* rp, const int32_t* ci, const double* va, PbTemplate& out);
+
+} // namespace lpp

@@ -194,6 +194,10 @@ lpp_status one_step(lpp_engine* e, const double* ritz, int nst)
 		else
 			k_unpack_add_dot<double, true><<<nbp, kBlock, 0, st>>>((double*)xcur, (const double*)e->comm.recv2_buf, (const double*)ycur, nid, n_up, e->tx_peru, chunk, e->partial);
 		np = nbp;
+	} else if (e->pb.active) {
+		SpmvTimer t(e);
+		np = pb_launch(e, ycur, xcur, e->partial, sc);
+		t.stop();
 	} else if (e->kron.active) {
 		// matrix-free product with the all-gather: the down part needs the whole vector, so the gather completes first
 		if (multi(e)) {
@@ -332,9 +336,10 @@ lpp_status begin_run(lpp_engine* e, const void* init, bool want_save)
 	// start vector -> x (scratch)
 	HIP_TRY(hipMemsetAsync(e->x, 0, sizeof(double) * (size_t)e->nd_pad, st));
 	if (init) {
-		HIP_TRY(hipMemcpyAsync(e->x, init, e->esz * (size_t)e->n_local, hipMemcpyHostToDevice, st));
-	} else if (e->nd > 0) {
-		k_fill_random<<<1024, 256, 0, st>>>(e->x, e->nd, e->row_start * (e->is_complex ? 2 : 1), e->cfg.seed);
+		lpp_status rc0 = vec_from_host(e, e->x, init);
+		if (rc0 != LPP_OK) return rc0;
+	} else {
+		vec_fill_random(e, e->x, e->cfg.seed);
 	}
 	k_dot<<<nb, kBlock, 0, st>>>((const double2*)e->x, (const double2*)e->x, e->n2, e->partial);
 	k_reduce_final<<<1, kBlock, 0, st>>>(e->partial, nb, 1, 1, e->tmp_dev);
@@ -530,8 +535,8 @@ lpp_status lpp_engine_lanczos(lpp_engine* e, const void* init, int32_t nstates, 
 						k_multi_axpy<false><<<nb, kBlock, 0, e->stream>>>((double2*)e->x, v0, e->ldv / 2, np, e->coef_dev + 2 * p0, 1.0, e->n2);
 				}
 				HIP_TRY(hipGetLastError());
-				HIP_TRY(hipMemcpyAsync((char*)ritz_vectors + (size_t)k * e->esz * (size_t)e->n_local, e->x, e->esz * (size_t)e->n_local,
-				                       hipMemcpyDeviceToHost, e->stream));
+				st = vec_to_host(e, (char*)ritz_vectors + (size_t)k * e->esz * (size_t)e->n_local, e->x);
+				if (st != LPP_OK) return st;
 				HIP_TRY(hipStreamSynchronize(e->stream));
 			}
 		} else {
@@ -559,9 +564,11 @@ lpp_status lpp_engine_lanczos(lpp_engine* e, const void* init, int32_t nstates, 
 			keep.spmv_ms_total += e->stats.spmv_ms_total;
 			keep.spmv_launches += e->stats.spmv_launches;
 			e->stats = keep;
-			for (int k = 0; k < nstates; k++)
-				HIP_TRY(hipMemcpy((char*)ritz_vectors + (size_t)k * e->esz * (size_t)e->n_local, e->zwork + (int64_t)k * e->nd_pad,
-				                  e->esz * (size_t)e->n_local, hipMemcpyDeviceToHost));
+			for (int k = 0; k < nstates; k++) {
+				st = vec_to_host(e, (char*)ritz_vectors + (size_t)k * e->esz * (size_t)e->n_local, e->zwork + (int64_t)k * e->nd_pad);
+				if (st != LPP_OK) return st;
+			}
+			HIP_TRY(hipStreamSynchronize(e->stream));
 			(void)hipFree(e->zwork);
 			e->zwork = nullptr;
 		}

@@ -642,3 +642,76 @@ def test_basis_block_is_detected_without_a_hint():
         assert e.layout()["rows_per_block"] != 924 and e.layout()["block_template"] == 0
         x0, y = oracle.fill_random(H.nrows, 3), oracle.fill_random(H.nrows, 4)
         assert rel(e.matrixVectorProduct(x0.copy(), y), oracle.spmv_acc(H, x0.copy(), y)) < SPMV_TOL
+
+
+PB_CASES = {
+    # name: (L, nup, ndown, hop, U, V)   -- N_up >= 512 so that device assembly takes the product-basis layout
+    "chain_L12": lambda: (12, 6, 5, chain(12, -1.0, True), np.where(np.arange(12) % 3 == 0, 2.0, 4.0), np.tile([0.25, -0.5, 0.0], 8)),
+    "ladder_2x6": lambda: (12, 6, 6, square(2, 6, -1.0, True), np.full(12, 4.0), np.zeros(24)),
+    "two_hoppings": lambda: (12, 5, 7, chain(12, -1.0, False) + 0.5 * (np.diag(np.ones(10), 2) + np.diag(np.ones(10), -2)), np.full(12, 3.0), np.zeros(24)),
+}
+
+
+@pytest.mark.parametrize("case", sorted(PB_CASES))
+def test_product_basis_layout(case, monkeypatch):
+    """Device assembly of Hubbard straight into the product-basis layout (T, C, diagonal codes; lpp_pb_kernels.h): the CSR it
+    stands for is the oracle's bit for bit, x += H y (two kernels, pitched vectors) matches the oracle, and every solver entry
+    point works on the pitched vectors; the general layout (LPP_PRODUCT_LAYOUT=0) gives the same numbers."""
+    L, nup, ndown, hop, U, V = PB_CASES[case]()
+    A = oracle.hubbard_csr(L, nup, ndown, hop, U, V)
+    x0, y = oracle.fill_random(A.nrows, 7), oracle.fill_random(A.nrows, 8)
+    xo = oracle.spmv_acc(A, x0.copy(), y)
+    init = oracle.fill_random(A.nrows, 4321)
+    eo, zo, so = oracle.lanczos_solve(A, oracle.fill_random(A.nrows, 1234), nstates=1)
+    steps_o, ao, bo, _, _ = oracle.lanczos_decomposition(A, init)
+    with LanczosEngine() as e:
+        e.assemble_hubbard(L, nup, ndown, hop, U, V)
+        lay = e.layout()
+        assert lay["kernel"] == 4 and lay["nnz"] == A.nnz and lay["resident_bytes"] < 0.05 * 12 * A.nnz
+        st = e.stats()
+        assert (st["nrows"], st["nnz"]) == (A.nrows, A.nnz)
+        rp, ci, va = e.get_csr()
+        assert np.array_equal(rp, A.rowptr) and np.array_equal(ci, A.colind) and np.array_equal(_bits(va), _bits(A.values))
+        xg = e.matrixVectorProduct(x0.copy(), y)
+        assert rel(xg, xo) < SPMV_TOL
+        assert rel(e.matrixVectorProduct(xg.copy(), y) - xg, xo - x0) < 1e-12  # accumulate semantics
+        eg, zg, st = e.lanczos(1, want_vectors=True)  # built-in start vector, pitched; two-pass or saved Ritz vector
+        assert abs(eg[0] - eo[0]) <= E_TOL * abs(eo[0]) and st["steps"] == so
+        r = oracle.spmv_acc(A, np.zeros_like(zg[0]), zg[0]) - eg[0] * zg[0]
+        assert np.linalg.norm(r) < 1e-5 and abs(np.linalg.norm(zg[0]) - 1) < 1e-8
+        ag, bg, _ = e.decomposition(init)  # host start vector into the pitched layout
+        assert len(ag) == steps_o and rel(ag, ao) < 1e-8 and rel(bg, bo) < 1e-8
+        ms = e.bench_spmv(1, 2)
+        assert ms > 0
+    with LanczosEngine(save_vectors=0) as e:  # scale-free recurrence + two-pass Ritz vector
+        e.assemble_hubbard(L, nup, ndown, hop, U, V)
+        eg2, zg2, st2 = e.lanczos(1, want_vectors=True)
+        assert st2["vectors_saved"] == 0 and abs(eg2[0] - eo[0]) <= E_TOL * abs(eo[0])
+        r = oracle.spmv_acc(A, np.zeros_like(zg2[0]), zg2[0]) - eg2[0] * zg2[0]
+        assert np.linalg.norm(r) < 1e-5
+    e3o, _, s3o = oracle.lanczos_solve(A, oracle.fill_random(A.nrows, 1234), nstates=3, max_steps=150, eps=1e-11, reortho=True)
+    with LanczosEngine(reortho=True, max_steps=150, eps=1e-11) as e:  # blocked CGS2 on pitched Krylov columns
+        e.assemble_hubbard(L, nup, ndown, hop, U, V)
+        e3, z3, st3 = e.lanczos(3, want_vectors=True)
+        assert st3["steps"] == s3o and rel(e3, e3o) < 1e-8
+        assert np.abs(z3 @ z3.T - np.eye(3)).max() < 1e-8
+    monkeypatch.setenv("LPP_PRODUCT_LAYOUT", "0")
+    with LanczosEngine() as e:
+        e.assemble_hubbard(L, nup, ndown, hop, U, V)
+        assert e.layout()["kernel"] == 3
+        xw = e.matrixVectorProduct(x0.copy(), y)
+        assert rel(xw, xg) < SPMV_TOL
+
+
+def test_product_basis_layout_falls_back_when_it_does_not_apply():
+    """more than 256 distinct diagonal values, or more than 8 distinct in-block values: the general layout takes over, results unchanged"""
+    L, nup, ndown = 12, 6, 6
+    rng = np.random.default_rng(5)
+    for hop, U in ((chain(L, -1.0, True), rng.uniform(1, 5, L)),  # random U: 2^12 distinct diagonals
+                   (chain(L, -1.0, True) * np.triu(1 + 0.01 * np.arange(L * L).reshape(L, L), 1) + (chain(L, -1.0, True) * np.triu(1 + 0.01 * np.arange(L * L).reshape(L, L), 1)).T, np.full(L, 4.0))):
+        A = oracle.hubbard_csr(L, nup, ndown, hop, U)
+        with LanczosEngine() as e:
+            e.assemble_hubbard(L, nup, ndown, hop, U)
+            assert e.layout()["kernel"] != 4
+            y = oracle.fill_random(A.nrows, 8)
+            assert rel(e.matrixVectorProduct(np.zeros(A.nrows), y), oracle.spmv_acc(A, np.zeros(A.nrows), y)) < SPMV_TOL
