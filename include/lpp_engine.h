@@ -252,12 +252,13 @@ lpp_status lpp_split_csr(int32_t rank, int32_t nranks, const int64_t* shard_star
 lpp_status lpp_tridiag_lowest(int32_t n, const double* d, const double* e, int32_t k, double* w, double* z);
 
 /* Product-basis layout, host part (used by lpp_engine_assemble_hubbard; exposed for the CPU test-suite): packs the in-block
- * matrix `rows` x `rows` (CSR, diagonal entries skipped) into per-slice, per-value-group streams of 16-bit LDS window indices with
- * a bank-conflict-free slot assignment (two indices per 32-bit word, [pair][lane]).  pitch: multiple of 16, >= rows.  Two-call
- * protocol: off/len/words NULL returns sizes only (ngroups, slices, nwords).  group_values holds 8 doubles. */
+ * matrix `rows` x `rows` (CSR, diagonal entries skipped) into per-slice, per-value-group streams of 16-bit LDS window indices
+ * (chunks of 4 slots = two 32-bit words per lane) with a slot assignment in which no LDS bank is asked for more than
+ * `bank_ways` (1..4) different addresses per half-wave and slot.  pitch: multiple of 16, >= rows.  Two-call protocol:
+ * off/len/words NULL returns sizes only (ngroups, slices, nwords).  group_values holds 8 doubles; off/len count chunks. */
 lpp_status lpp_pb_pack_template(int64_t rows, int64_t pitch, const int64_t* rowptr, const int32_t* colind, const double* values,
                                 int32_t* ngroups, double* group_values, int32_t* slices, int64_t* nwords, int32_t* off, uint16_t* len,
-                                uint32_t* words, int64_t* entries, int64_t* slots);
+                                uint32_t* words, int64_t* entries, int64_t* slots, int32_t bank_ways);
 
 #ifdef __cplusplus
 }

@@ -98,7 +98,7 @@ SYMBOLS = {
                                   C.POINTER(C.c_int64), C.POINTER(C.c_int64), _P, _P, _P, _P, _P, _P]),
     "lpp_tridiag_lowest": (C.c_int32, [C.c_int32, _P, _P, C.c_int32, _P, _P]),
     "lpp_pb_pack_template": (C.c_int32, [C.c_int64, C.c_int64, _P, _P, _P, C.POINTER(C.c_int32), _P, C.POINTER(C.c_int32),
-                                         C.POINTER(C.c_int64), _P, _P, _P, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+                                         C.POINTER(C.c_int64), _P, _P, _P, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int32]),
 }
 
 _lib = None

@@ -39,7 +39,8 @@ __device__ __forceinline__ void send_store(double2* send, int64_t i, double2 v, 
 template <bool NRM>
 __global__ __launch_bounds__(kBlock) void k_axpy_nrm(double2* __restrict__ x, const double2* __restrict__ y,
                                                       const double* __restrict__ a_ptr, const double* __restrict__ b2_prev,
-                                                      double2* __restrict__ send, int64_t n2, double* __restrict__ partial, int stream = 0, int64_t nd = 0)
+                                                      double2* __restrict__ send, int64_t n2, double* __restrict__ partial, int stream = 0, int64_t nd = 0,
+                                                      const double2* __restrict__ zadd = nullptr)
 {
 	__shared__ double smem[kBlock / 64];
 	double a = *a_ptr;
@@ -58,6 +59,14 @@ __global__ __launch_bounds__(kBlock) void k_axpy_nrm(double2* __restrict__ x, co
 		for (int k = 0; k < 4; k++) xv[k] = stream ? nt_load2(&x[i + k * stride]) : x[i + k * stride];
 #pragma unroll
 		for (int k = 0; k < 4; k++) yv[k] = stream ? nt_load2(&y[i + k * stride]) : y[i + k * stride];
+		if (zadd) { // a part of the product that was formed in a buffer of its own (product-basis layout: the block couplings)
+#pragma unroll
+			for (int k = 0; k < 4; k++) {
+				const double2 zv = nt_load2(&zadd[i + k * stride]);
+				xv[k].x += zv.x;
+				xv[k].y += zv.y;
+			}
+		}
 #pragma unroll
 		for (int k = 0; k < 4; k++) {
 			xv[k].x -= a * yv[k].x;
@@ -73,6 +82,10 @@ __global__ __launch_bounds__(kBlock) void k_axpy_nrm(double2* __restrict__ x, co
 	for (; i < n2; i += stride) {
 		double2 xv = x[i];
 		const double2 yv = y[i];
+		if (zadd) {
+			xv.x += zadd[i].x;
+			xv.y += zadd[i].y;
+		}
 		xv.x -= a * yv.x;
 		xv.y -= a * yv.y;
 		x[i] = xv;

@@ -110,7 +110,14 @@ struct PbState {
 	uint8_t* c_code = nullptr;
 	int64_t c_nnz = 0;
 	int rowcap = 0, ids_per_wg = 0, down_grid = 0;
+	size_t down_lds = 0;
+	int32_t* order = nullptr; // blocks of every workgroup's range by decreasing list length
 	int* pace = nullptr;
+	double* z = nullptr; // alpha C y of the product in flight (n_blk * pitch doubles)
+	double* u = nullptr; // alpha (T y + D y) of the product in flight
+	hipStream_t stream2 = nullptr; // k_pb_down runs here, beside k_pb_up on the engine's stream
+	hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+	double* xy = nullptr; // device scalar: Re<x|y> left by the last combine pass = the next step's <y | x_old>
 	// diagonal
 	double* dict = nullptr; // 256 doubles
 	int ndict = 0;
@@ -209,7 +216,9 @@ void free_pb(lpp_engine* e);
 // value; the caller fills pb.dcode (n_blk*pitch codes) afterwards
 lpp_status pb_build(lpp_engine* e, int64_t n_up, int64_t n_blk, const int64_t* t_rp, const int32_t* t_ci, const double* t_va,
                     const int64_t* c_rp, const int32_t* c_ci, const double* c_va, const double* dict256, int ndict);
-int pb_launch(lpp_engine* e, const void* y, void* x, double* partial, const EpiScale& sc = EpiScale { nullptr, nullptr, 0 });
+int pb_launch(lpp_engine* e, const void* y, void* x, double* partial, const EpiScale& sc = EpiScale { nullptr, nullptr, 0 }, bool defer_combine = false);
+// the streaming pass of the scale-free Lanczos step on a product-basis matrix: x = beta x + u + z - (a/b2_prev) y, |x|^2 partials
+int pb_combine_axpy(lpp_engine* e, void* x, const void* y, const EpiScale& sc, const double* a_ptr, const double* b2_prev, double* partial);
 lpp_status pb_get_csr(lpp_engine* e, int64_t* rowptr, int32_t* colind, void* values);
 int64_t pb_pitch_for(int64_t n_up);
 // host <-> device vector copies that know the pitched layout

@@ -236,20 +236,21 @@ namespace lpp {
 
 namespace {
 
-// Proper edge colouring of a bipartite multigraph (left: up to 32 rows, right: 32 LDS banks) with D = max degree colours
-// (Koenig's theorem; alternating-path recolouring).  edges[k] = (row, bank); returns the colour of every edge.
-int edge_colour(const std::vector<std::pair<int, int>>& edges, std::vector<int>& colour)
+// Proper edge colouring of a bipartite multigraph (left: up to 32 rows, right: nright bank slots) with D = max degree colours
+// (Koenig's theorem; alternating-path recolouring).  edges[k] = (row, right vertex); returns the colour of every edge.
+int edge_colour(const std::vector<std::pair<int, int>>& edges, int nright, std::vector<int>& colour)
 {
-	int degL[32] = { 0 }, degR[32] = { 0 };
+	std::vector<int> degL(32, 0), degR((size_t)nright, 0);
 	for (const auto& e : edges) {
-		degL[e.first]++;
-		degR[e.second]++;
+		degL[(size_t)e.first]++;
+		degR[(size_t)e.second]++;
 	}
 	int D = 0;
-	for (int i = 0; i < 32; i++) D = std::max(D, std::max(degL[i], degR[i]));
+	for (int d : degL) D = std::max(D, d);
+	for (int d : degR) D = std::max(D, d);
 	colour.assign(edges.size(), -1);
 	if (D == 0) return 0;
-	std::vector<int> atL(32 * (size_t)D, -1), atR(32 * (size_t)D, -1); // edge holding colour c at a vertex
+	std::vector<int> atL(32 * (size_t)D, -1), atR((size_t)nright * (size_t)D, -1); // edge holding colour c at a vertex
 	for (size_t k = 0; k < edges.size(); k++) {
 		const int u = edges[k].first, v = edges[k].second;
 		int a = 0, b = 0;
@@ -289,9 +290,10 @@ int edge_colour(const std::vector<std::pair<int, int>>& edges, std::vector<int>&
 
 } // namespace
 
-lpp_status pb_pack_template(int64_t rows, int64_t pitch, const int64_t* rp, const int32_t* ci, const double* va, PbTemplate& out)
+lpp_status pb_pack_template(int64_t rows, int64_t pitch, const int64_t* rp, const int32_t* ci, const double* va, PbTemplate& out, int bank_ways)
 {
 	if (rows <= 0 || pitch < rows || (pitch & 15) != 0 || pitch + kPbZeroSlotsHost > 65536) return fail(LPP_ERR_INVALID, "pb_pack_template: bad shape");
+	if (bank_ways < 1 || bank_ways > 4) return fail(LPP_ERR_INVALID, "pb_pack_template: bank_ways must be 1..4");
 	out = PbTemplate();
 	// value groups (bit patterns, first-seen order then sorted for determinism)
 	std::vector<uint64_t> keys;
@@ -326,6 +328,7 @@ lpp_status pb_pack_template(int64_t rows, int64_t pitch, const int64_t* rp, cons
 			for (int h = 0; h < 2; h++) {
 				edges.clear();
 				ecol.clear();
+				int seen[32] = { 0 };
 				for (int l = 0; l < 32; l++) {
 					const int64_t r = (int64_t)j * 64 + h * 32 + l;
 					if (r >= rows) break;
@@ -334,47 +337,52 @@ lpp_status pb_pack_template(int64_t rows, int64_t pitch, const int64_t* rp, cons
 						uint64_t k;
 						std::memcpy(&k, &va[p], 8);
 						if (!keys.empty() && k != keys[(size_t)g]) continue;
-						edges.emplace_back(l, (int)(ci[p] & 31));
+						// a bank serves `bank_ways` different addresses per slot: its entries are dealt over that many right vertices
+						const int bank = (int)(ci[p] & 31);
+						edges.emplace_back(l, bank * bank_ways + (seen[bank]++ % bank_ways));
 						ecol.push_back((int)ci[p]);
 					}
 				}
-				const int D = edge_colour(edges, colour);
+				const int D = edge_colour(edges, 32 * bank_ways, colour);
 				nslots = std::max(nslots, D);
 				for (size_t k = 0; k < edges.size(); k++) ents.push_back(Ent { h * 32 + edges[k].first, ecol[k], colour[k] });
 				out.entries += (int64_t)edges.size();
 			}
-			const int npairs = (nslots + 1) / 2;
-			nslots = npairs * 2;
+			// whole chunks of 4 slots (one 16-byte load per lane); the filling reads zero slots
+			const int nchunks = (nslots + 3) / 4;
+			nslots = nchunks * 4;
 			slot_idx.assign((size_t)nslots * 64, -1);
 			for (const Ent& e : ents) slot_idx[(size_t)e.slot * 64 + e.lane] = e.col;
-			// padding: a zero slot in a bank no real entry of this slot and half-wave uses
+			// padding: a zero slot in the bank that the real entries of this slot and half-wave use least
 			for (int s = 0; s < nslots; s++)
 				for (int h = 0; h < 2; h++) {
-					bool used[32] = { false };
+					int used[32] = { 0 };
 					bool any_pad = false;
 					for (int l = 0; l < 32; l++) {
 						const int c = slot_idx[(size_t)s * 64 + h * 32 + l];
 						if (c >= 0)
-							used[c & 31] = true;
+							used[c & 31]++;
 						else
 							any_pad = true;
 					}
 					if (!any_pad) continue;
 					int z = 0;
-					while (z < 31 && used[(pitch + z) & 31]) z++;
+					for (int t = 1; t < 32; t++)
+						if (used[(pitch + t) & 31] < used[(pitch + z) & 31]) z = t;
 					for (int l = 0; l < 32; l++)
 						if (slot_idx[(size_t)s * 64 + h * 32 + l] < 0) slot_idx[(size_t)s * 64 + h * 32 + l] = (int)(pitch + z);
 				}
-			out.off[(size_t)j * G + g] = (int32_t)out.words.size();
-			out.len[(size_t)j * G + g] = (uint16_t)npairs;
-			for (int p = 0; p < npairs; p++)
+			out.off[(size_t)j * G + g] = (int32_t)(out.words.size() / 128); // in chunks of 64 lanes x 2 words
+			out.len[(size_t)j * G + g] = (uint16_t)nchunks;
+			for (int c = 0; c < nchunks; c++)
 				for (int l = 0; l < 64; l++)
-					out.words.push_back((uint32_t)slot_idx[(size_t)(2 * p) * 64 + l] | ((uint32_t)slot_idx[(size_t)(2 * p + 1) * 64 + l] << 16));
+					for (int k = 0; k < 4; k += 2) // two 16-bit window indices per word: slot 4c+k in the low half, 4c+k+1 in the high half
+						out.words.push_back((uint32_t)slot_idx[(size_t)(4 * c + k) * 64 + l] | ((uint32_t)slot_idx[(size_t)(4 * c + k + 1) * 64 + l] << 16));
 			out.slots += (int64_t)nslots * 64;
 			if (out.words.size() > ((size_t)1 << 30)) return fail(LPP_ERR_INVALID, "pb_pack_template: template too large");
 		}
 	}
-	out.words.resize(out.words.size() + 64 * 8, (uint32_t)pitch | ((uint32_t)pitch << 16)); // slack for the pipelined word loads
+	out.words.resize(out.words.size() + 128 * 8, (uint32_t)pitch | ((uint32_t)pitch << 16)); // slack for the look-ahead loads
 	return LPP_OK;
 }
 
@@ -382,11 +390,11 @@ lpp_status pb_pack_template(int64_t rows, int64_t pitch, const int64_t* rp, cons
 
 extern "C" lpp_status lpp_pb_pack_template(int64_t rows, int64_t pitch, const int64_t* rowptr, const int32_t* colind, const double* values,
                                            int32_t* ngroups, double* group_values, int32_t* slices, int64_t* nwords, int32_t* off, uint16_t* len,
-                                           uint32_t* words, int64_t* entries, int64_t* slots)
+                                           uint32_t* words, int64_t* entries, int64_t* slots, int32_t bank_ways)
 {
 	if (!rowptr || !ngroups || !nwords) return lpp::fail(LPP_ERR_INVALID, "lpp_pb_pack_template: null argument");
 	lpp::PbTemplate t;
-	lpp_status st = lpp::pb_pack_template(rows, pitch, rowptr, colind, values, t);
+	lpp_status st = lpp::pb_pack_template(rows, pitch, rowptr, colind, values, t, bank_ways);
 	if (st != LPP_OK) return st;
 	*ngroups = t.G;
 	*nwords = (int64_t)t.words.size();

@@ -27,9 +27,10 @@ bool tridiag_qr(int n, const double* d, const double* e, double* w, double* z);
 
 // ---------------------------------------------------------------------------------------------
 // Product-basis layout (lpp_pb_kernels.h), host part: the in-block matrix T as per-slice, per-value-group streams of
-// 16-bit LDS window indices.  Within a half-wave (32 lanes = 32 consecutive rows) the entries of a group are assigned to
-// slots by a bipartite edge colouring (rows x LDS banks), so the 32 lanes of a slot hit 32 different banks: a
-// ds_read_b64 gather then takes its conflict-free 2 cycles instead of ~3.7x that for the entries in column order.
+// LDS window addresses.  Within a half-wave (32 lanes = 32 consecutive rows) the entries of a group are assigned to
+// slots by a bipartite edge colouring (rows x LDS banks) so that no bank is asked for more than `bank_ways` different
+// addresses in a slot: bank_ways = 1 is conflict-free (a ds_read_b64 gather in its 2 cycles instead of ~3.7x that for
+// entries in column order) at the price of more slots (filled with reads of zero slots); 2 halves the worst bank's share.
 // ---------------------------------------------------------------------------------------------
 namespace lpp {
 
@@ -40,9 +41,9 @@ struct PbTemplate {
 	int G = 0; // value groups
 	double gval[kPbGroupsMax] = { 0 };
 	int spb = 0; // 64-row slices
-	std::vector<int32_t> off; // [spb*G] first word of (slice, group)
-	std::vector<uint16_t> len; // [spb*G] slot pairs
-	std::vector<uint32_t> words; // [pair][lane] per (slice, group): low half = slot 2p, high half = slot 2p+1
+	std::vector<int32_t> off; // [spb*G] first chunk of (slice, group)
+	std::vector<uint16_t> len; // [spb*G] chunks (a chunk = 4 slots)
+	std::vector<uint32_t> words; // chunk c, lane l at [(c*64 + l)*2 + {0,1}]: window indices of slots 4c, 4c+1 | 4c+2, 4c+3 (16 bits each, low half first)
 	int64_t entries = 0; // real entries
 	int64_t slots = 0; // lane-slots incl. padding
 };
@@ -50,6 +51,6 @@ struct PbTemplate {
 // rows x rows CSR (rp, ci, va); entries with ci == row (the diagonal) are skipped.  pitch: the zero slots start at window
 // index `pitch` (a multiple of 16, >= rows; pitch + 32 <= 65536).  Fails (LPP_ERR_INVALID) when the off-diagonal part has more
 // than kPbGroupsMax distinct values.
-lpp_status pb_pack_template(int64_t rows, int64_t pitch, const int64_t* rp, const int32_t* ci, const double* va, PbTemplate& out);
+lpp_status pb_pack_template(int64_t rows, int64_t pitch, const int64_t* rp, const int32_t* ci, const double* va, PbTemplate& out, int bank_ways = 2);
 
 } // namespace lpp

@@ -196,7 +196,7 @@ lpp_status one_step(lpp_engine* e, const double* ritz, int nst)
 		np = nbp;
 	} else if (e->pb.active) {
 		SpmvTimer t(e);
-		np = pb_launch(e, ycur, xcur, e->partial, sc);
+		np = pb_launch(e, ycur, xcur, e->partial, sc, e->scalefree); // scale-free: x is formed by pb_combine_axpy below
 		t.stop();
 	} else if (e->kron.active) {
 		// matrix-free product with the all-gather: the down part needs the whole vector, so the gather completes first
@@ -228,10 +228,17 @@ lpp_status one_step(lpp_engine* e, const double* ritz, int nst)
 		np = spmv_launch(e, e->A_loc, ycur, xcur, ycur, e->partial, sc);
 		t.stop();
 	}
-	k_reduce_final<<<1, kBlock, 0, st>>>(e->partial, np, 1, 1, a_ptr);
+	const bool pb_sf = e->pb.active && e->scalefree;
+	if (pb_sf) // the product kernels never read x: raw_j = Re<y | u + z> + beta Re<y | x_old>
+		k_pb_reduce_a<<<1, kBlock, 0, st>>>(e->partial, np, e->pb.xy, sc, a_ptr);
+	else
+		k_reduce_final<<<1, kBlock, 0, st>>>(e->partial, np, 1, 1, a_ptr);
 	lpp_status rc = comm_allreduce(e, e->ab_off + 2 * j, 1);
 	if (rc != LPP_OK) return rc;
-	if (e->scalefree) {
+	int nb_nrm = nb;
+	if (pb_sf) {
+		nb_nrm = pb_combine_axpy(e, xcur, ycur, sc, a_ptr, b2_prev, e->partial);
+	} else if (e->scalefree) {
 		// streamed accesses once the two vectors no longer fit the 256 MiB Infinity Cache (measured: +4 % there, -7 % below)
 		const int stream_axpy = (size_t)e->n2 * 32 > ((size_t)256 << 20) ? 1 : 0;
 		k_axpy_nrm<true><<<nb, kBlock, 0, st>>>((double2*)xcur, (const double2*)ycur, a_ptr, b2_prev,
@@ -244,7 +251,7 @@ lpp_status one_step(lpp_engine* e, const double* ritz, int nst)
 	} else {
 		k_axpy_nrm<true><<<nb, kBlock, 0, st>>>((double2*)xcur, (const double2*)ycur, a_ptr, nullptr, nullptr, e->n2, e->partial);
 	}
-	k_reduce_final<<<1, kBlock, 0, st>>>(e->partial, nb, 1, 1, b2_ptr);
+	k_reduce_final<<<1, kBlock, 0, st>>>(e->partial, nb_nrm, 1, 1, b2_ptr);
 	rc = comm_allreduce(e, e->ab_off + 2 * j + 1, 1);
 	if (rc != LPP_OK) return rc;
 	if (e->scalefree) {
@@ -346,6 +353,7 @@ lpp_status begin_run(lpp_engine* e, const void* init, bool want_save)
 	lpp_status rc = comm_allreduce(e, e->tmp_off, 1);
 	if (rc != LPP_OK) return rc;
 	HIP_TRY(hipMemcpyAsync(e->h_scal + 2 * e->M, e->tmp_dev, sizeof(double), hipMemcpyDeviceToHost, st)); // |init|^2 = b_{-1}^2
+	if (e->pb.active) HIP_TRY(hipMemsetAsync(e->pb.xy, 0, sizeof(double) * 2, st)); // <y | x_old> of step 0: x_old = 0
 	if (e->scalefree) {
 		// r_0 = init stays unnormalised in e->x; e->y is the (zero) buffer of r_{-1}
 		e->ycur = e->x;

@@ -18,8 +18,14 @@ void free_pb(lpp_engine* e)
 {
 	PbState& B = e->pb;
 	for (void* p : { (void*)B.tw, (void*)B.tw_off, (void*)B.tw_len, (void*)B.t_ptr, (void*)B.t_col, (void*)B.t_val, (void*)B.c_ptr, (void*)B.c_col,
-	                 (void*)B.c_code, (void*)B.pace, (void*)B.dict, (void*)B.dcode, (void*)B.blockbase })
+	                 (void*)B.c_code, (void*)B.order, (void*)B.pace, (void*)B.z, (void*)B.u, (void*)B.xy, (void*)B.dict, (void*)B.dcode, (void*)B.blockbase })
 		if (p) (void)hipFree(p);
+	if (B.stream2) {
+		(void)hipStreamSynchronize(B.stream2);
+		(void)hipStreamDestroy(B.stream2);
+	}
+	if (B.ev_fork) (void)hipEventDestroy(B.ev_fork);
+	if (B.ev_join) (void)hipEventDestroy(B.ev_join);
 	B = PbState();
 	e->pitch = e->pitch_rows = e->pitch_blocks = 0;
 }
@@ -61,7 +67,9 @@ lpp_status pb_build(lpp_engine* e, int64_t n_up, int64_t n_blk, const int64_t* t
 	if ((size_t)(pitch + kPbZeroSlots) * sizeof(double) > (size_t)156 * 1024) return fail(LPP_ERR_INVALID, "pb_build: the block does not fit the LDS window");
 	if ((size_t)n_blk * (size_t)pitch * sizeof(double) >= ((size_t)1 << 32)) return fail(LPP_ERR_INVALID, "pb_build: vector beyond 32-bit byte offsets");
 	PbTemplate T;
-	lpp_status rc = pb_pack_template(n_up, pitch, t_rp, t_ci, t_va, T);
+	int ways = 2;
+	if (const char* s = getenv("LPP_PB_BANK_WAYS")) ways = std::max(1, std::min(atoi(s), 4));
+	lpp_status rc = pb_pack_template(n_up, pitch, t_rp, t_ci, t_va, T, ways);
 	if (rc != LPP_OK) return rc;
 	B.n_up = n_up;
 	B.n_blk = n_blk;
@@ -104,6 +112,7 @@ lpp_status pb_build(lpp_engine* e, int64_t n_up, int64_t n_blk, const int64_t* t
 		longest = std::max(longest, cp[(size_t)b + 1] - cp[(size_t)b]);
 	}
 	B.c_nnz = (int64_t)cc.size();
+	const int64_t longest_list = longest;
 	if ((rc = to_device(&B.t_ptr, tp, st)) != LPP_OK) return rc;
 	if ((rc = to_device(&B.t_col, tc, st)) != LPP_OK) return rc;
 	if ((rc = to_device(&B.t_val, tv, st)) != LPP_OK) return rc;
@@ -123,14 +132,40 @@ lpp_status pb_build(lpp_engine* e, int64_t n_up, int64_t n_blk, const int64_t* t
 	int grid = e->num_cus & ~7;
 	if (grid < 8) grid = e->num_cus; // fewer than 8 CUs: one group
 	const int slots = grid >= 8 ? grid / 8 : grid;
-	B.rowcap = (int)((longest + 7) & ~(int64_t)7);
+	B.rowcap = (int)std::max<int64_t>(4, (longest_list + 3) & ~(int64_t)3);
 	B.ids_per_wg = (int)((n_blk + slots - 1) / slots);
 	B.down_grid = grid;
-	if ((size_t)B.ids_per_wg * (size_t)B.rowcap * 5 > (size_t)150 * 1024) return fail(LPP_ERR_INVALID, "pb_build: block couplings of a workgroup exceed LDS");
+	B.down_lds = (size_t)B.ids_per_wg * ((size_t)(B.rowcap + 1) * 3 + 8) + 16;
+	if (n_blk > 65535) return fail(LPP_ERR_INVALID, "pb_build: more than 65535 blocks");
+	if (B.down_lds > (size_t)150 * 1024) return fail(LPP_ERR_INVALID, "pb_build: block couplings of a workgroup exceed LDS");
+	if (pb_up_lds_bytes(pitch, T.spb, T.G) > (size_t)160 * 1024 - 64) return fail(LPP_ERR_INVALID, "pb_build: window + template metadata exceed LDS");
+	{
+		// every workgroup takes its blocks in the order of decreasing list length (tasks of 8 blocks with equal trip counts)
+		std::vector<int32_t> order((size_t)n_blk);
+		for (int64_t b = 0; b < n_blk; b++) order[(size_t)b] = (int32_t)b;
+		for (int sl = 0; sl < slots; sl++) {
+			const int64_t lo = std::min<int64_t>((int64_t)sl * B.ids_per_wg, n_blk), hi = std::min<int64_t>(lo + B.ids_per_wg, n_blk);
+			std::stable_sort(order.begin() + lo, order.begin() + hi, [&](int32_t x, int32_t y) { return cp[(size_t)x + 1] - cp[(size_t)x] > cp[(size_t)y + 1] - cp[(size_t)y]; });
+		}
+		if ((rc = to_device(&B.order, order, st)) != LPP_OK) return rc;
+	}
 	if (!(getenv("LPP_PB_PACE") && atoi(getenv("LPP_PB_PACE")) == 0)) HIP_TRY_MEM(hipMalloc(&B.pace, sizeof(int) * 8 * (size_t)(pitch / 16)));
+	// the two parts of a product (padding stays zero) and the carried scalar
+	HIP_TRY_MEM(hipMalloc(&B.z, sizeof(double) * (size_t)n_blk * (size_t)pitch));
+	HIP_TRY(hipMemsetAsync(B.z, 0, sizeof(double) * (size_t)n_blk * (size_t)pitch, st));
+	HIP_TRY_MEM(hipMalloc(&B.u, sizeof(double) * (size_t)n_blk * (size_t)pitch));
+	HIP_TRY(hipMemsetAsync(B.u, 0, sizeof(double) * (size_t)n_blk * (size_t)pitch, st));
+	HIP_TRY_MEM(hipMalloc(&B.xy, sizeof(double) * 2));
+	HIP_TRY(hipMemsetAsync(B.xy, 0, sizeof(double) * 2, st));
 	HIP_TRY_MEM(hipMalloc(&B.dcode, (size_t)n_blk * (size_t)pitch));
 	HIP_TRY(hipMemsetAsync(B.dcode, 0, (size_t)n_blk * (size_t)pitch, st));
 	HIP_TRY(hipStreamSynchronize(st));
+	// second stream for k_pb_down (see pb_launch); without it the two kernels simply run one after the other
+	if (hipStreamCreateWithFlags(&B.stream2, hipStreamNonBlocking) != hipSuccess) B.stream2 = nullptr;
+	if (B.stream2 && (hipEventCreateWithFlags(&B.ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&B.ev_join, hipEventDisableTiming) != hipSuccess)) {
+		(void)hipStreamDestroy(B.stream2);
+		B.stream2 = nullptr;
+	}
 	e->pitch = pitch;
 	e->pitch_rows = n_up;
 	e->pitch_blocks = n_blk;
@@ -138,13 +173,52 @@ lpp_status pb_build(lpp_engine* e, int64_t n_up, int64_t n_blk, const int64_t* t
 	return LPP_OK;
 }
 
-// x = beta x + alpha H y (EpiScale semantics of the other product kernels); returns the number of partials written
-int pb_launch(lpp_engine* e, const void* y, void* x, double* partial, const EpiScale& sc)
+// x = beta x + alpha H y (EpiScale semantics of the other product kernels) as two independent kernels that only read y,
+//   k_pb_down  z = alpha C y            (+ partials of Re<y|z>)
+//   k_pb_up    u = alpha (T y + D y)    (+ partials of Re<y|u>, stored in front of the first kernel's)
+// and a streaming pass x = beta x + u + z (k_pb_combine).  defer_combine: the caller runs that pass itself, folded into its own
+// pass over x (pb_combine_axpy of the scale-free recurrence).  Returns the number of partials written; their sum is
+// Re<y | u + z>, to which the caller adds beta Re<y | x_old> (pb.xy, left by the previous combine pass).
+template <bool DOT, bool LEAN> static void launch_up(const PbState& B, const PbUpArgs& u, int nb, size_t lds, hipStream_t st)
 {
-	const PbState& B = e->pb;
+	int gt = B.G <= 2 ? B.G : 0;
+	if (getenv("LPP_PB_UP_GENERIC")) gt = 0;
+#define LPP_PB_UP(GT_)                                                                                                \
+	do {                                                                                                              \
+		(void)hipFuncSetAttribute((const void*)k_pb_up<DOT, GT_, LEAN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+		k_pb_up<DOT, GT_, LEAN><<<nb, kPbUpThreads, lds, st>>>(u);                                                      \
+	} while (0)
+	if (gt == 1) LPP_PB_UP(1);
+	else if (gt == 2) LPP_PB_UP(2);
+	else LPP_PB_UP(0);
+#undef LPP_PB_UP
+}
+
+static int combine_blocks(int64_t n2) { return (int)std::max<int64_t>(1, std::min<int64_t>((n2 + kBlock - 1) / kBlock, 2048)); }
+
+int pb_launch(lpp_engine* e, const void* y, void* x, double* partial, const EpiScale& sc, bool defer_combine)
+{
+	PbState& B = e->pb;
 	hipStream_t st = e->stream;
-	// block couplings first (it applies beta), then the in-block part + diagonal, which also forms Re<y|x> of the finished x
-	if (B.c_nnz > 0) {
+	const int nb = (int)std::max<int64_t>(1, std::min<int64_t>(B.n_blk, (int64_t)e->num_cus));
+	double* const want_dot = partial;
+	if (!defer_combine) partial = nullptr; // the combine pass below forms Re<y|x> of the finished x itself
+	int np = partial ? nb : 0;
+	// The two kernels are independent (both only read y).  LPP_PB_CONCURRENT=1 runs them side by side on the same CUs
+	// (k_pb_down on a second stream, forked and joined with events; the lean variant of k_pb_up and the 512-thread variant of
+	// k_pb_down together fit a CU's registers, LDS and wave slots).  Measured on the 4x4 cluster: 4.95 ms instead of 2.69 ms one
+	// after the other -- the in-block kernel's traffic evicts the panel from L2 and the paced workgroups are no longer all
+	// resident -- so the default is one after the other.
+	const bool both = B.c_nnz > 0;
+	bool concurrent = both && B.stream2 != nullptr && getenv("LPP_PB_CONCURRENT") && atoi(getenv("LPP_PB_CONCURRENT")) != 0;
+	hipStream_t sd = st;
+	if (concurrent) {
+		if (hipEventRecord(B.ev_fork, st) == hipSuccess && hipStreamWaitEvent(B.stream2, B.ev_fork, 0) == hipSuccess)
+			sd = B.stream2;
+		else
+			concurrent = false;
+	}
+	if (both) {
 		PbDownArgs d;
 		d.pitch = B.pitch;
 		d.n_blk = B.n_blk;
@@ -156,15 +230,22 @@ int pb_launch(lpp_engine* e, const void* y, void* x, double* partial, const EpiS
 		d.c_code = B.c_code;
 		d.dict = B.dict;
 		d.y = (const double*)y;
-		d.x = (double*)x;
+		d.z = B.z;
+		d.partial = partial ? partial + nb : nullptr;
 		d.sc = sc;
 		d.pace = B.pace;
-		d.nwaves = kPbDownThreads / 64;
-		if (const char* s = getenv("LPP_PB_DOWN_WAVES")) d.nwaves = std::max(1, std::min(atoi(s), kPbDownThreads / 64));
-		if (d.pace) (void)hipMemsetAsync(d.pace, 0, sizeof(int) * 8 * (size_t)d.npanels, st);
-		const size_t lds = (size_t)B.ids_per_wg * (size_t)B.rowcap * 5 + 16;
-		(void)hipFuncSetAttribute((const void*)k_pb_down, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-		k_pb_down<<<B.down_grid, kPbDownThreads, lds, st>>>(d);
+		d.order = B.order;
+		if (d.pace) (void)hipMemsetAsync(d.pace, 0, sizeof(int) * 8 * (size_t)d.npanels, sd);
+		int threads = concurrent ? 512 : 1024;
+		if (const char* s = getenv("LPP_PB_DOWN_THREADS")) threads = atoi(s);
+		if (threads == 512) {
+			(void)hipFuncSetAttribute((const void*)k_pb_down<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B.down_lds);
+			k_pb_down<512><<<B.down_grid, 512, B.down_lds, sd>>>(d);
+		} else {
+			(void)hipFuncSetAttribute((const void*)k_pb_down<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B.down_lds);
+			k_pb_down<1024><<<B.down_grid, 1024, B.down_lds, sd>>>(d);
+		}
+		if (partial) np += B.down_grid;
 	}
 	PbUpArgs u;
 	u.tw = B.tw;
@@ -179,20 +260,60 @@ int pb_launch(lpp_engine* e, const void* y, void* x, double* partial, const EpiS
 	u.n_blk = B.n_blk;
 	u.spb = B.spb;
 	u.y = (const double*)y;
-	u.x = (double*)x;
+	u.u = B.u;
 	u.partial = partial;
 	u.sc = sc;
-	if (B.c_nnz > 0) u.sc.beta_one = 1; // beta was applied by the first kernel
-	const size_t lds = sizeof(double) * (size_t)(B.pitch + kPbZeroSlots);
-	int nb = (int)std::max<int64_t>(1, std::min<int64_t>(B.n_blk, (int64_t)e->num_cus));
+	const size_t lds = pb_up_lds_bytes(B.pitch, B.spb, B.G);
+	bool lean = concurrent;
+	if (const char* s = getenv("LPP_PB_UP_LEAN")) lean = atoi(s) != 0;
 	if (partial) {
-		(void)hipFuncSetAttribute((const void*)k_pb_up<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-		k_pb_up<true><<<nb, kPbUpThreads, lds, st>>>(u);
+		if (lean) launch_up<true, true>(B, u, nb, lds, st);
+		else launch_up<true, false>(B, u, nb, lds, st);
 	} else {
-		(void)hipFuncSetAttribute((const void*)k_pb_up<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-		k_pb_up<false><<<nb, kPbUpThreads, lds, st>>>(u);
+		if (lean) launch_up<false, true>(B, u, nb, lds, st);
+		else launch_up<false, false>(B, u, nb, lds, st);
 	}
-	return partial ? nb : 0;
+	if (concurrent) { // join: everything later on the engine's stream sees z
+		(void)hipEventRecord(B.ev_join, B.stream2);
+		(void)hipStreamWaitEvent(st, B.ev_join, 0);
+	}
+	if (!defer_combine) {
+		PbCombineArgs c;
+		c.n2 = (B.n_blk * B.pitch) >> 1;
+		c.x = (double2*)x;
+		c.y = (const double2*)y;
+		c.u = (const double2*)B.u;
+		c.z = (const double2*)B.z;
+		c.sc = sc;
+		c.a_ptr = nullptr;
+		c.b2_prev = nullptr;
+		const int nbc = combine_blocks(c.n2);
+		c.partial_nrm = want_dot ? want_dot + nbc : nullptr; // |x|^2 partials: not used by these callers
+		c.partial_xy = want_dot;
+		k_pb_combine<<<nbc, kBlock, 0, st>>>(c);
+		if (want_dot) np = nbc;
+	}
+	return np;
+}
+
+int pb_combine_axpy(lpp_engine* e, void* x, const void* y, const EpiScale& sc, const double* a_ptr, const double* b2_prev, double* partial)
+{
+	const PbState& B = e->pb;
+	PbCombineArgs c;
+	c.n2 = (B.n_blk * B.pitch) >> 1;
+	c.x = (double2*)x;
+	c.y = (const double2*)y;
+	c.u = (const double2*)B.u;
+	c.z = (const double2*)B.z;
+	c.sc = sc;
+	c.a_ptr = a_ptr;
+	c.b2_prev = b2_prev;
+	const int nb = combine_blocks(c.n2);
+	c.partial_nrm = partial;
+	c.partial_xy = partial + nb;
+	k_pb_combine<<<nb, kBlock, 0, e->stream>>>(c);
+	k_reduce_final<<<1, kBlock, 0, e->stream>>>(partial + nb, nb, 1, 1, B.xy); // next step's <y | x_old>
+	return nb;
 }
 
 lpp_status pb_get_csr(lpp_engine* e, int64_t* rowptr, int32_t* colind, void* values)

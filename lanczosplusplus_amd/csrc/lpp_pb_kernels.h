@@ -23,108 +23,228 @@ namespace lpp {
 constexpr int kPbMaxGroups = 8; // distinct off-diagonal values of the in-block matrix
 constexpr int kPbZeroSlots = 32; // zero-valued window elements behind the row (one per LDS bank) that padding entries read
 constexpr int kPbUpThreads = 1024;
-constexpr int kPbDownThreads = 512;
 
 // ---------------------------------------------------------------------------------------------
 // in-block part + diagonal:  x[b][i] = beta' x[b][i] + alpha ( sum_k T[i][c_k] y[b][c_k] + D[b][i] y[b][i] )   (+ Re<y|x> partial)
 // ---------------------------------------------------------------------------------------------
 struct PbUpArgs {
-	// template: for slice j and value group g, npairs = tw_len[j*G+g] slot pairs at tw + tw_off[j*G+g]; word (pair p, lane l) at
-	// [p*64 + l] holds two 16-bit LDS window indices (slots 2p and 2p+1); padding entries index a zero slot
+	// template: for slice j and value group g, tw_len[j*G+g] chunks starting at chunk tw_off[j*G+g]; a chunk is 64 lanes x 2
+	// words = 4 slots, each a 16-bit window index (low half first); filling entries index a zero slot
 	const uint32_t* tw;
 	const int32_t* tw_off;
 	const uint16_t* tw_len;
 	int G;
 	double gval[kPbMaxGroups];
 	const double* dict; // 256 doubles (diagonal codes)
-	const uint8_t* dcode; // one code per row, pitched like the vectors (null: no diagonal)
+	const uint8_t* dcode; // one code per row, pitched like the vectors
 	int64_t n_up, pitch, n_blk;
 	int spb; // slices per block
 	const double* y;
-	double* x;
-	double* partial;
-	EpiScale sc;
+	double* u; // out: alpha (T y + D y), pitched
+	double* partial; // per-workgroup Re<y|u> (null: not wanted)
+	EpiScale sc; // only alpha is used
 };
 
-template <bool DOT> __global__ __launch_bounds__(kPbUpThreads) void k_pb_up(PbUpArgs a)
+constexpr int kPbPre = 4; // chunks (of 4 slots) of every (slice, group) requested one slice ahead
+
+// A wave's vector-memory results return IN ORDER (s_waitcnt vmcnt): a wait for an L2 load is also a wait for every HBM load
+// issued before it, whatever the look-ahead (measured on a version that read-modify-wrote x here: 77 % of the wave cycles
+// spent waiting; 47 % with a four-slice look-ahead, which the in-order queue defeats).  So this kernel touches HBM only in
+// bulk: the block's row of y and its diagonal codes are staged in LDS in front of the barrier that waits for them anyway,
+// the result u is stored and never read here, and x is not touched at all (the streaming pass that follows a product forms
+// x = beta x + u + z).  Inside the slice loop only template words are loaded (L2 hits), one slice ahead, into two fixed
+// register sets (a copy would wait for the load).  An entry is a 16-bit window index: one SDWA shift (index * 8 = LDS byte
+// address, the window sits at LDS address 0), one ds_read_b64, one v_add_f64.  Both ends of that were measured: with a
+// plain and/shift/add unpacking the kernel was VALU-bound (10 vector instructions per pair of entries); with ready-made
+// 32-bit addresses the template words (19 GB per product through a ~57 GB/s-per-CU L2->L1 path) bound it instead.
+template <int GT> struct PbWords {
+	uint2 w[GT][kPbPre];
+	int nc[GT];
+};
+
+// index * 8 of the low / high 16 bits of w in ONE instruction (the compiler emits and + shift)
+__device__ __forceinline__ uint32_t pb_lo8(uint32_t w)
+{
+	uint32_t r;
+	asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(r) : "v"(3u), "v"(w));
+	return r;
+}
+__device__ __forceinline__ uint32_t pb_hi8(uint32_t w)
+{
+	uint32_t r;
+	asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(r) : "v"(3u), "v"(w));
+	return r;
+}
+// LDS read at an absolute byte address (k_pb_up owns the whole LDS allocation: its dynamic array starts at address 0)
+typedef __attribute__((address_space(3))) const double pb_lds_cdouble;
+__device__ __forceinline__ double pb_lds_abs(uint32_t byte_addr) { return *(pb_lds_cdouble*)(uintptr_t)byte_addr; }
+
+// LDS layout (all dynamic, so that the window starts at LDS address 0 and a template word IS the address):
+//   [0, (pitch+32)*8) window + zero slots | dcode_s[pitch] | off_s[spb*G] | len_s[spb*G] | dict_s[256] | smem[16] | (pad)
+__host__ __device__ inline size_t pb_up_meta_offset(int64_t pitch) { return sizeof(double) * (size_t)(pitch + kPbZeroSlots) + (size_t)pitch; }
+__host__ __device__ inline size_t pb_up_dict_offset(int64_t pitch, int spb, int G) { return (pb_up_meta_offset(pitch) + (size_t)spb * (size_t)G * 6 + 15) & ~(size_t)15; }
+__host__ __device__ inline size_t pb_up_lds_bytes(int64_t pitch, int spb, int G)
+{
+	return pb_up_dict_offset(pitch, spb, G) + 256 * sizeof(double) + (kPbUpThreads / 64) * sizeof(double) + 16;
+}
+
+// GT = number of value groups (1 or 2: unrolled, with look-ahead; 0: any G <= 8, plain loop).
+// LEAN: at most 64 registers per lane (8 waves per SIMD's worth), so that a workgroup of k_pb_down fits on the same CU and the
+// two kernels -- one bound by LDS / vector issue, the other by L2 gathers, both waiting most of the time -- fill each other's
+// stalls: no second register set for the next slice's words (the other kernel's waves cover that latency instead).
+template <bool DOT, int GT, bool LEAN> __global__ __launch_bounds__(kPbUpThreads, LEAN ? 8 : 4) void k_pb_up(PbUpArgs a)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-	double* win = (double*)lds_raw; // pitch + kPbZeroSlots elements
-	__shared__ double smem[kPbUpThreads / 64];
-	__shared__ double dict_s[256];
-	__shared__ int next_slice;
+	double* win = (double*)lds_raw; // pitch + kPbZeroSlots elements, at LDS address 0
+	uint8_t* dcode_s = (uint8_t*)(win + a.pitch + kPbZeroSlots); // [pitch]
+	int32_t* off_s = (int32_t*)(lds_raw + pb_up_meta_offset(a.pitch)); // [spb*G]
+	uint16_t* len_s = (uint16_t*)(off_s + a.spb * a.G); // [spb*G]
+	double* dict_s = (double*)(lds_raw + pb_up_dict_offset(a.pitch, a.spb, a.G));
+	double* smem = dict_s + 256;
 	for (int i = threadIdx.x; i < 256; i += kPbUpThreads) dict_s[i] = a.dict[i];
-	double alpha, beta;
-	epi_coeffs(a.sc, alpha, beta);
-	const int lane = threadIdx.x & 63;
-	const int64_t p2 = a.pitch >> 1; // pitch is a multiple of 16
+	for (int i = threadIdx.x; i < a.spb * a.G; i += kPbUpThreads) {
+		off_s[i] = a.tw_off[i];
+		len_s[i] = a.tw_len[i];
+	}
+	double alpha, beta_unused;
+	epi_coeffs(a.sc, alpha, beta_unused);
+	constexpr int NW = kPbUpThreads / 64;
+	constexpr int GG = GT > 0 ? GT : 1;
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const int p2 = (int)(a.pitch >> 1), p16 = (int)(a.pitch >> 4); // pitch is a multiple of 16
 	double dot = 0.0;
+	// plain locals for everything the stage functions touch: a reference to the kernel-argument struct inside a lambda made
+	// hipcc keep a private copy of it in scratch memory
+	const uint2* const tw2 = (const uint2*)a.tw;
+	double* const uout = a.u;
+	const int spb = a.spb, n_up = (int)a.n_up, G = a.G;
+	double gv[GG];
+#pragma unroll
+	for (int g = 0; g < GG; g++) gv[g] = a.gval[g];
+	auto gather4 = [=](const uint2& w, double& s0, double& s1) __attribute__((always_inline)) {
+		s0 += pb_lds_abs(pb_lo8(w.x));
+		s1 += pb_lds_abs(pb_hi8(w.x));
+		s0 += pb_lds_abs(pb_lo8(w.y));
+		s1 += pb_lds_abs(pb_hi8(w.y));
+	};
 	for (int64_t blk = blockIdx.x; blk < a.n_blk; blk += gridDim.x) {
 		const double2* yb = (const double2*)(a.y + blk * a.pitch);
-		__syncthreads(); // everyone is done with the previous window
-		if (threadIdx.x == 0) next_slice = 0;
-		for (int64_t i0 = threadIdx.x; i0 < p2; i0 += 8 * kPbUpThreads) {
-			double2 t[8];
+		const uint4* db = (const uint4*)(a.dcode + blk * a.pitch);
+		const int64_t rowbase = blk * a.pitch;
+		__syncthreads(); // everyone is done with the previous window (and the metadata is in place)
+		// stage the row of y (8 independent 16-byte loads per thread in flight, branch-free: indices beyond the row are clamped,
+		// those threads re-load and re-store the last element) and the block's diagonal codes
+		{
+			constexpr int NS = LEAN ? 4 : 8; // loads per thread and pass
+			for (int pass = 0; pass < 8 / NS; pass++) {
+				double2 t[NS];
+				int idx[NS];
 #pragma unroll
-			for (int q = 0; q < 8; q++) t[q] = yb[min(i0 + (int64_t)q * kPbUpThreads, p2 - 1)];
+				for (int q = 0; q < NS; q++) idx[q] = min((int)threadIdx.x + (pass * NS + q) * kPbUpThreads, p2 - 1);
 #pragma unroll
-			for (int q = 0; q < 8; q++)
-				if (i0 + (int64_t)q * kPbUpThreads < p2) ((double2*)win)[i0 + (int64_t)q * kPbUpThreads] = t[q];
+				for (int q = 0; q < NS; q++) t[q] = yb[idx[q]];
+#pragma unroll
+				for (int q = 0; q < NS; q++) ((double2*)win)[idx[q]] = t[q];
+			}
+			const int di = min((int)threadIdx.x, p16 - 1);
+			((uint4*)dcode_s)[di] = db[di];
+			for (int i0 = threadIdx.x + 8 * kPbUpThreads; i0 < p2; i0 += kPbUpThreads) ((double2*)win)[i0] = yb[i0]; // rows beyond 16384 elements
+			for (int i0 = threadIdx.x + kPbUpThreads; i0 < p16; i0 += kPbUpThreads) ((uint4*)dcode_s)[i0] = db[i0];
 		}
 		if (threadIdx.x < kPbZeroSlots) win[a.pitch + threadIdx.x] = 0.0;
 		__syncthreads();
-		const double* xb = a.x + blk * a.pitch;
-		for (int j = next_slice_claim(&next_slice); j < a.spb; j = next_slice_claim(&next_slice)) {
+		auto epilogue = [=, &dot](int j, double acc) __attribute__((always_inline)) {
 			const int iu_raw = j * 64 + lane;
-			const bool valid = iu_raw < a.n_up;
-			const int iu = valid ? iu_raw : (int)a.n_up - 1;
-			const double xold = xb[iu];
-			uint32_t dc = 0;
-			if (a.dcode) dc = a.dcode[blk * a.pitch + iu];
-			double acc = 0.0;
-			for (int g = 0; g < a.G; g++) { // wave-uniform trip counts
-				const int np = a.tw_len[j * a.G + g];
-				const uint32_t* wp = a.tw + a.tw_off[j * a.G + g] + lane;
-				double s0 = 0.0, s1 = 0.0;
-				uint32_t w0[4], w1[4];
-				const int np4 = np & ~3;
-				if (np4 > 0) {
-#pragma unroll
-					for (int q = 0; q < 4; q++) w0[q] = wp[q * 64];
-				}
-				for (int p = 0; p < np4; p += 4) { // word loads of the next four pairs are in flight behind these LDS gathers
-					if (p + 4 < np4) {
-#pragma unroll
-						for (int q = 0; q < 4; q++) w1[q] = wp[(p + 4 + q) * 64];
-					}
-#pragma unroll
-					for (int q = 0; q < 4; q++) {
-						s0 += win[w0[q] & 0xffffu];
-						s1 += win[w0[q] >> 16];
-					}
-#pragma unroll
-					for (int q = 0; q < 4; q++) w0[q] = w1[q];
-				}
-				if (np4 < np) { // up to three pairs left: loaded together (clamped), the unused ones are skipped
-					uint32_t wr[3];
-#pragma unroll
-					for (int q = 0; q < 3; q++) wr[q] = wp[min(np4 + q, np - 1) * 64];
-#pragma unroll
-					for (int q = 0; q < 3; q++) {
-						if (np4 + q < np) {
-							s0 += win[wr[q] & 0xffffu];
-							s1 += win[wr[q] >> 16];
-						}
-					}
-				}
-				acc = fma(a.gval[g], s0 + s1, acc);
-			}
+			const bool valid = iu_raw < n_up;
+			const int iu = valid ? iu_raw : n_up - 1;
 			const double yc = win[iu];
-			if (a.dcode) acc = fma(dict_s[dc], yc, acc);
+			acc = fma(dict_s[dcode_s[iu]], yc, acc);
 			if (valid) {
-				const double xv = epi_lin(beta, xold, alpha, acc);
-				a.x[blk * a.pitch + iu] = xv;
-				if (DOT) dot += yc * xv;
+				const double uv = alpha * acc;
+				__builtin_nontemporal_store(uv, &uout[rowbase + iu]);
+				if (DOT) dot += yc * uv;
+			}
+		};
+		if (GT > 0) {
+			auto load_words = [=](int j, PbWords<GG>& s) __attribute__((always_inline)) {
+				if (j >= spb) return; // wave-uniform
+#pragma unroll
+				for (int g = 0; g < GG; g++) {
+					s.nc[g] = len_s[j * GG + g];
+					const uint2* wp = tw2 + (size_t)off_s[j * GG + g] * 64 + lane;
+#pragma unroll
+					for (int c = 0; c < kPbPre; c++) s.w[g][c] = wp[c * 64]; // chunks beyond the list belong to the next list (or the slack): never used
+				}
+			};
+			// one value group of a slice: sum of the window elements its (look-ahead) chunks index, longer lists streamed
+			auto group_sum = [=](int j, int g, int nc, const uint2* w) __attribute__((always_inline)) {
+				double s0 = 0.0, s1 = 0.0;
+				if (nc >= 2) { // 8 LDS gathers in flight
+					gather4(w[0], s0, s1);
+					gather4(w[1], s0, s1);
+				} else if (nc == 1) {
+					gather4(w[0], s0, s1);
+				}
+				if (nc >= 4) {
+					gather4(w[2], s0, s1);
+					gather4(w[3], s0, s1);
+				} else if (nc == 3) {
+					gather4(w[2], s0, s1);
+				}
+				if (nc > kPbPre) {
+					const uint2* wp = tw2 + (size_t)off_s[j * GG + g] * 64 + lane;
+					for (int c = kPbPre; c < nc; c++) {
+						const uint2 wr = wp[c * 64];
+						gather4(wr, s0, s1);
+					}
+				}
+				return s0 + s1;
+			};
+			auto compute = [=](int j, const PbWords<GG>& s) __attribute__((always_inline)) {
+				if (j >= spb) return; // wave-uniform
+				double acc = 0.0;
+#pragma unroll
+				for (int g = 0; g < GG; g++) acc = fma(gv[g], group_sum(j, g, s.nc[g], s.w[g]), acc);
+				epilogue(j, acc);
+			};
+			if (LEAN) { // one group's words at a time: 8 registers instead of 2 x 8 x GG
+				for (int j = wave; j < spb; j += NW) {
+					double acc = 0.0;
+#pragma unroll
+					for (int g = 0; g < GG; g++) {
+						const int nc = len_s[j * GG + g];
+						const uint2* wp = tw2 + (size_t)off_s[j * GG + g] * 64 + lane;
+						uint2 w[kPbPre];
+#pragma unroll
+						for (int c = 0; c < kPbPre; c++) w[c] = wp[c * 64];
+						acc = fma(gv[g], group_sum(j, g, nc, w), acc);
+					}
+					epilogue(j, acc);
+				}
+			} else {
+				PbWords<GG> wa, wb;
+				load_words(wave, wa);
+				for (int j0 = wave; j0 < spb; j0 += 2 * NW) {
+					load_words(j0 + NW, wb);
+					compute(j0, wa);
+					load_words(j0 + 2 * NW, wa);
+					compute(j0 + NW, wb);
+				}
+			}
+		} else {
+			for (int j = wave; j < spb; j += NW) {
+				double acc = 0.0;
+				for (int g = 0; g < G; g++) { // wave-uniform trip counts
+					const int nc = len_s[j * G + g];
+					const uint2* wp = tw2 + (size_t)off_s[j * G + g] * 64 + lane;
+					double s0 = 0.0, s1 = 0.0;
+					for (int c = 0; c < nc; c++) {
+						const uint2 wr = wp[c * 64];
+						gather4(wr, s0, s1);
+					}
+					acc = fma(a.gval[g], s0 + s1, acc);
+				}
+				epilogue(j, acc);
 			}
 		}
 	}
@@ -135,38 +255,50 @@ template <bool DOT> __global__ __launch_bounds__(kPbUpThreads) void k_pb_up(PbUp
 }
 
 // ---------------------------------------------------------------------------------------------
-// block couplings:  x[b][i] = beta x[b][i] + alpha sum_k C[b][b'_k] y[b'_k][i]
+// block couplings:  z[b][i] = alpha sum_k C[b][b'_k] y[b'_k][i]   (+ Re<y|z> partial); the caller adds z to the x of k_pb_up
 // One persistent workgroup per CU.  Workgroup w belongs to group w mod 8 (one XCD under round-robin dispatch: speed only) and
 // owns a fixed range of blocks for ALL panels of its group; the couplings of its blocks sit in LDS (byte offsets of the source
-// blocks + value codes), so nothing but y and x moves through L2.  Group k walks panels k, k+8, ...; the workgroups of a group
+// blocks + value codes), so nothing but y and z moves through L2.  Group k walks panels k, k+8, ...; the workgroups of a group
 // stay within two panels of each other (bounded pacing: per-group, per-panel counters), which keeps the panel in that L2.
-// A wave covers 8 blocks x 16 positions with 16-byte lanes; x is streamed with non-temporal accesses.
+// A wave task covers 8 blocks x 16 positions with 16-byte lanes.  The blocks of a workgroup are taken in the order of
+// decreasing list length (`order`), so the 8 blocks of a task have lists of (nearly) the same length and the task's trip count
+// is its longest list rounded up to 4 -- padded places cost real L1 traffic.
+// The kernel only READS y (L2 hits after the first touch of a line) and WRITES z (non-temporal): no HBM load sits in the
+// in-order return queue in front of the gathers (an x read-modify-write here cost an HBM round trip per task).
 // ---------------------------------------------------------------------------------------------
 struct PbDownArgs {
 	int64_t pitch, n_blk;
 	int npanels; // pitch / 16
 	int ids_per_wg; // blocks owned by one workgroup
-	int rowcap; // LDS places per block (longest coupling list rounded up to a multiple of 8)
+	int rowcap; // longest coupling list rounded up to a multiple of 4
 	const int64_t* c_ptr; // couplings: CSR over blocks, off-diagonal, ascending
 	const int32_t* c_col;
 	const uint8_t* c_code; // dictionary code of each coupling
+	const int32_t* order; // [n_blk] blocks of every workgroup's range sorted by decreasing list length (global block numbers)
 	const double* dict;
 	const double* y; // addressed with 32-bit byte offsets (< 4 GiB)
-	double* x;
-	EpiScale sc;
+	double* z;
+	double* partial; // per-workgroup Re<y|z> (null: not wanted)
+	EpiScale sc; // only alpha is used: z = alpha * C y
 	int* pace; // [8][npanels] finished-workgroup counters (zeroed before the launch); null: free-running
-	int nwaves; // waves per workgroup actually working (<= kPbDownThreads/64)
 };
 
-static __global__ __launch_bounds__(kPbDownThreads) void k_pb_down(PbDownArgs a)
+template <int THREADS> __global__ __launch_bounds__(THREADS) void k_pb_down(PbDownArgs a)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
 	__shared__ double dict_s[256];
-	uint32_t* off_s = (uint32_t*)lds_raw; // [ids_per_wg][rowcap] byte offset of the source block
-	uint8_t* code_s = (uint8_t*)(off_s + (size_t)a.ids_per_wg * a.rowcap); // [ids_per_wg][rowcap]
-	for (int i = threadIdx.x; i < 256; i += kPbDownThreads) dict_s[i] = a.dict[i];
-	double alpha, beta;
-	epi_coeffs(a.sc, alpha, beta);
+	// LDS image of this workgroup's coupling lists in `order` (block numbers and value codes, 3 bytes per place: a workgroup of
+	// k_pb_up must fit next to this one)
+	const int stride = a.rowcap + 1;
+	uint32_t* row_s = (uint32_t*)lds_raw; // [ids_per_wg] byte offset of the block itself
+	int32_t* len_s = (int32_t*)(row_s + a.ids_per_wg); // [ids_per_wg] list length
+	uint16_t* idx_s = (uint16_t*)(len_s + a.ids_per_wg); // [ids_per_wg][stride] source block (n_blk < 65536: the lists must fit LDS anyway)
+	uint8_t* code_s = (uint8_t*)(idx_s + (size_t)a.ids_per_wg * stride); // [ids_per_wg][stride]
+	__shared__ double smem_d[THREADS / 64];
+	for (int i = threadIdx.x; i < 256; i += THREADS) dict_s[i] = a.dict[i];
+	double alpha, beta_unused;
+	epi_coeffs(a.sc, alpha, beta_unused);
+	double dot = 0.0;
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = lane >> 3, c = lane & 7;
 	const int nx = (gridDim.x & 7) == 0 ? 8 : 1; // groups the panels are dealt over
 	const int grp = nx == 8 ? (int)(blockIdx.x & 7) : 0;
@@ -175,18 +307,26 @@ static __global__ __launch_bounds__(kPbDownThreads) void k_pb_down(PbDownArgs a)
 	const int64_t b0 = (int64_t)slot * a.ids_per_wg;
 	const int nown = (int)max((int64_t)0, min((int64_t)a.ids_per_wg, a.n_blk - b0));
 	const uint32_t rowbytes = (uint32_t)(a.pitch * 8);
-	for (int i = threadIdx.x; i < nown * a.rowcap; i += kPbDownThreads) {
+	for (int il = threadIdx.x; il < nown; il += THREADS) {
+		const int64_t b = a.order[b0 + il];
+		row_s[il] = (uint32_t)b * rowbytes;
+		len_s[il] = (int32_t)(a.c_ptr[b + 1] - a.c_ptr[b]);
+	}
+	for (int i = threadIdx.x; i < nown * a.rowcap; i += THREADS) {
 		const int il = i / a.rowcap, k = i - il * a.rowcap;
-		const int64_t b = b0 + il;
+		const int64_t b = a.order[b0 + il];
 		const int64_t p0 = a.c_ptr[b];
 		const bool in = k < (int)(a.c_ptr[b + 1] - p0);
-		// places beyond the list: the block itself with code 0 (+0.0): fixed trip count, no per-lane conditions
-		off_s[i] = (uint32_t)(in ? a.c_col[p0 + k] : (int32_t)b) * rowbytes;
-		code_s[i] = in ? a.c_code[p0 + k] : (uint8_t)0;
+		// places beyond the list carry code 0 (+0.0) and the address the task's first block (the longest list) reads at this
+		// place, so the filling lanes of a gather ask for a line that is requested anyway; no per-lane conditions in the loop
+		const int64_t bl = a.order[b0 + (il & ~7)];
+		const int64_t pl = a.c_ptr[bl];
+		const int32_t fill = k < (int)(a.c_ptr[bl + 1] - pl) ? a.c_col[pl + k] : (int32_t)bl;
+		idx_s[il * stride + k] = (uint16_t)(in ? a.c_col[p0 + k] : fill);
+		code_s[il * stride + k] = in ? a.c_code[p0 + k] : (uint8_t)0;
 	}
 	__syncthreads();
 	const int ngroups = (nown + 7) >> 3;
-	const int nchunk = a.rowcap >> 3;
 	const char* ysrc = (const char*)a.y;
 	for (int p = grp; p < a.npanels; p += nx) {
 		if (a.pace && p >= grp + 2 * nx) {
@@ -199,39 +339,51 @@ static __global__ __launch_bounds__(kPbDownThreads) void k_pb_down(PbDownArgs a)
 			__syncthreads();
 		}
 		const uint32_t colb = (uint32_t)(p * 128 + c * 16); // byte offset of this lane's two positions inside a row
-		if (wave < a.nwaves) {
-			for (int g = wave; g < ngroups; g += a.nwaves) {
-				const int il_raw = g * 8 + sub;
-				const bool valid = il_raw < nown;
-				const int il = min(il_raw, nown - 1);
-				const size_t rowb = (size_t)(b0 + il) * rowbytes + colb;
-				double2* xp = (double2*)((char*)a.x + rowb);
-				const double2 xold = double2 { __builtin_nontemporal_load(&xp->x), __builtin_nontemporal_load(&xp->y) };
-				const uint32_t* orow = off_s + il * a.rowcap;
-				const uint8_t* crow = code_s + il * a.rowcap;
-				double2 acc = double2 { 0.0, 0.0 };
-				double2 g0[8], g1[8];
+		for (int g = wave; g < ngroups; g += THREADS / 64) {
+			const int il = min(g * 8 + sub, nown - 1);
+			const bool valid = g * 8 + sub < nown;
+			// trip count of the task: the longest list is the first one (decreasing order), in chunks of 4
+			const int n4 = (__builtin_amdgcn_readfirstlane(len_s[g * 8]) + 3) >> 2;
+			const uint16_t* orow = idx_s + il * stride;
+			const uint8_t* crow = code_s + il * stride;
+			double2 acc = double2 { 0.0, 0.0 };
+			// three chunks of 4 gathers in flight; the chunk loop is unrolled by three with one fixed buffer per stage (a buffer
+			// rotated by register copies would wait for the loads it holds)
+			double2 ga[4], gb[4], gc[4];
+			auto issue = [&](int ch, double2* gbuf) __attribute__((always_inline)) {
 #pragma unroll
-				for (int q = 0; q < 8; q++) g0[q] = *(const double2*)(ysrc + (size_t)(orow[q] + colb));
-				for (int ch = 0; ch < nchunk; ch++) {
-					if (ch + 1 < nchunk) {
+				for (int q = 0; q < 4; q++) gbuf[q] = *(const double2*)(ysrc + (size_t)((uint32_t)orow[ch * 4 + q] * rowbytes + colb));
+			};
+			auto consume = [&](int ch, const double2* gbuf) __attribute__((always_inline)) {
 #pragma unroll
-						for (int q = 0; q < 8; q++) g1[q] = *(const double2*)(ysrc + (size_t)(orow[(ch + 1) * 8 + q] + colb));
-					}
-#pragma unroll
-					for (int q = 0; q < 8; q++) {
-						const double v = dict_s[crow[ch * 8 + q]];
-						acc.x = fma(v, g0[q].x, acc.x);
-						acc.y = fma(v, g0[q].y, acc.y);
-					}
-#pragma unroll
-					for (int q = 0; q < 8; q++) g0[q] = g1[q];
+				for (int q = 0; q < 4; q++) {
+					const double v = dict_s[crow[ch * 4 + q]];
+					acc.x = fma(v, gbuf[q].x, acc.x);
+					acc.y = fma(v, gbuf[q].y, acc.y);
 				}
-				if (valid) {
-					const double2 xv = double2 { beta * xold.x + alpha * acc.x, beta * xold.y + alpha * acc.y };
-					__builtin_nontemporal_store(xv.x, &xp->x);
-					__builtin_nontemporal_store(xv.y, &xp->y);
+			};
+			if (n4 > 0) issue(0, ga);
+			if (n4 > 1) issue(1, gb);
+			for (int ch = 0; ch < n4; ch += 3) { // wave-uniform conditions
+				if (ch + 2 < n4) issue(ch + 2, gc);
+				consume(ch, ga);
+				if (ch + 1 < n4) {
+					if (ch + 3 < n4) issue(ch + 3, ga);
+					consume(ch + 1, gb);
 				}
+				if (ch + 2 < n4) {
+					if (ch + 4 < n4) issue(ch + 4, gb);
+					consume(ch + 2, gc);
+				}
+			}
+			const double2 yown = *(const double2*)(ysrc + (size_t)(row_s[il] + colb)); // the panel is in L2
+			if (valid) {
+				double2* zp = (double2*)((char*)a.z + (size_t)row_s[il] + colb);
+				acc.x *= alpha;
+				acc.y *= alpha;
+				__builtin_nontemporal_store(acc.x, &zp->x);
+				__builtin_nontemporal_store(acc.y, &zp->y);
+				dot += yown.x * acc.x + yown.y * acc.y;
 			}
 		}
 		if (a.pace) {
@@ -239,6 +391,93 @@ static __global__ __launch_bounds__(kPbDownThreads) void k_pb_down(PbDownArgs a)
 			if (threadIdx.x == 0) __hip_atomic_fetch_add(a.pace + (int64_t)grp * a.npanels + p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		}
 	}
+	if (a.partial) {
+		const double r = block_sum_n<THREADS / 64>(dot, smem_d);
+		if (threadIdx.x == 0) a.partial[blockIdx.x] = r;
+	}
+}
+
+// The streaming pass behind a product.  The two product kernels leave u = alpha (T y + D y) and z = alpha C y; the new x is
+//   x = beta x + u + z - g y        g = 0 (plain product: x = beta x + alpha H y), or the scale-free Lanczos coefficient
+//                                   a_j / b_{j-1}^2 read from device memory (then this is k_axpy_nrm folded into the same pass)
+// with partial sums of |x|^2 and of Re<x|y> (the latter is the next step's <y | beta x_old>, which the product kernels cannot
+// form because they never read x).
+struct PbCombineArgs {
+	double2* x;
+	const double2 *y, *u, *z;
+	int64_t n2;
+	EpiScale sc; // beta
+	const double* a_ptr; // null: g = 0
+	const double* b2_prev; // g = *a_ptr / *b2_prev (unless tiny), as in k_axpy_nrm
+	double* partial_nrm; // null: no reductions
+	double* partial_xy;
+};
+
+static __global__ __launch_bounds__(kBlock) void k_pb_combine(PbCombineArgs a)
+{
+	__shared__ double smem[kBlock / 64];
+	double alpha_unused, beta;
+	epi_coeffs(a.sc, alpha_unused, beta);
+	double g = 0.0;
+	if (a.a_ptr) {
+		g = *a.a_ptr;
+		if (a.b2_prev) {
+			const double b2 = *a.b2_prev;
+			if (sqrt(b2) >= 1e-10) g /= b2;
+		}
+	}
+	double s = 0.0, c = 0.0;
+	const int64_t stride = (int64_t)gridDim.x * kBlock;
+	int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+	for (; i + stride < a.n2; i += 2 * stride) { // two elements per lane and stream in flight: 8 x 16-byte loads
+		double2 xv[2], yv[2], uv[2], zv[2];
+#pragma unroll
+		for (int k = 0; k < 2; k++) xv[k] = nt_load2(&a.x[i + k * stride]);
+#pragma unroll
+		for (int k = 0; k < 2; k++) yv[k] = nt_load2(&a.y[i + k * stride]);
+#pragma unroll
+		for (int k = 0; k < 2; k++) uv[k] = nt_load2(&a.u[i + k * stride]);
+#pragma unroll
+		for (int k = 0; k < 2; k++) zv[k] = nt_load2(&a.z[i + k * stride]);
+#pragma unroll
+		for (int k = 0; k < 2; k++) {
+			double2 r;
+			r.x = beta * xv[k].x + uv[k].x + zv[k].x - g * yv[k].x;
+			r.y = beta * xv[k].y + uv[k].y + zv[k].y - g * yv[k].y;
+			nt_store2(r, &a.x[i + k * stride]);
+			s += r.x * r.x + r.y * r.y;
+			c += r.x * yv[k].x + r.y * yv[k].y;
+		}
+	}
+	for (; i < a.n2; i += stride) {
+		const double2 xv = a.x[i], yv = a.y[i], uv = a.u[i], zv = a.z[i];
+		double2 r;
+		r.x = beta * xv.x + uv.x + zv.x - g * yv.x;
+		r.y = beta * xv.y + uv.y + zv.y - g * yv.y;
+		a.x[i] = r;
+		s += r.x * r.x + r.y * r.y;
+		c += r.x * yv.x + r.y * yv.y;
+	}
+	if (a.partial_nrm) {
+		const double rs = block_sum(s, smem);
+		if (threadIdx.x == 0) a.partial_nrm[blockIdx.x] = rs;
+		const double rc = block_sum(c, smem);
+		if (threadIdx.x == 0) a.partial_xy[blockIdx.x] = rc;
+	}
+}
+
+// a_j of the scale-free recurrence from the two product kernels' partials and the carried <y | x_old>:
+//   out = sum_p partial[p] + beta * (*xy)        (single block, fixed summation order)
+static __global__ __launch_bounds__(kBlock) void k_pb_reduce_a(const double* __restrict__ partial, int np, const double* __restrict__ xy, EpiScale sc,
+                                                               double* __restrict__ out)
+{
+	__shared__ double smem[kBlock / 64];
+	double alpha_unused, beta;
+	epi_coeffs(sc, alpha_unused, beta);
+	double s = 0.0;
+	for (int p = threadIdx.x; p < np; p += kBlock) s += partial[p];
+	const double r = block_sum(s, smem);
+	if (threadIdx.x == 0) out[0] = r + beta * xy[0];
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -301,6 +301,7 @@ typedef struct {
 
 static void hub_basis_init(hub_basis* B, int L, int nup, int ndown)
 {
+	do_combinatorial(); /* before any threaded region reads the table (it is filled lazily) */
 	B->L = L;
 	B->nup = nup;
 	B->ndown = ndown;
@@ -699,6 +700,7 @@ lppo_csr* lppo_heis_setup(int L, int twiceS, int szPlusConst, const double* jpm,
                           const double* magneticField, int nField, const double* anisotropy, int nAniso,
                           int literal_index)
 {
+	do_combinatorial();
 	int bits = lppo_heis_bits(twiceS);
 	word_t mask = heis_mask(bits);
 	int64_t hilbert = lppo_heis_basis(L, twiceS, szPlusConst, NULL);
@@ -865,6 +867,7 @@ lppo_csr* lppo_tj_setup(int L, int nup, int ndown, const double* hop_re, const d
                         const double* jzz, const double* w, const double* potentialV, int nPotentialV, int is_complex,
                         int literal_index)
 {
+	do_combinatorial();
 	int64_t hilbert = lppo_tj_basis(L, nup, ndown, NULL);
 	word_t* data = (word_t*)malloc(sizeof(word_t) * (size_t)(hilbert > 0 ? hilbert : 1));
 	lppo_tj_basis(L, nup, ndown, data);

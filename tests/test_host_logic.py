@@ -137,11 +137,12 @@ def test_input0_parsing_and_geometry():
 
 
 def test_product_template_is_bank_conflict_free_and_lossless():
-    """lpp_pb_pack_template (host part of the product-basis layout): the per-slice, per-value streams of 16-bit LDS indices
-    reproduce the in-block matrix entry for entry, padding only reads zero slots, and within every slot the 32 lanes of a
-    half-wave address 32 different LDS banks (bank = index mod 32 for ds_read_b64)."""
+    """lpp_pb_pack_template (host part of the product-basis layout): the per-slice, per-value streams of 16-bit window indices
+    reproduce the in-block matrix entry for entry, the filling only reads zero slots, and within every slot the 32 lanes of a
+    half-wave ask no LDS bank (bank = element index mod 32 for ds_read_b64) for more than `bank_ways` different addresses."""
     import ctypes as C
     import oracle
+    import scipy.sparse as sp
     from helpers import chain, square
     from lanczosplusplus_amd import _capi
     L = _capi.lib()
@@ -149,50 +150,58 @@ def test_product_template_is_bank_conflict_free_and_lossless():
     def vp(a):
         return a.ctypes.data_as(C.c_void_p)
 
+    def pack(A, pitch, ways):
+        n = A.nrows
+        ng, sl, nw, ent, slots = C.c_int32(), C.c_int32(), C.c_int64(), C.c_int64(), C.c_int64()
+        gv = np.zeros(8)
+        args = (n, pitch, vp(A.rowptr), vp(A.colind), vp(A.values), C.byref(ng), vp(gv), C.byref(sl), C.byref(nw))
+        rc = L.lpp_pb_pack_template(*args, None, None, None, C.byref(ent), C.byref(slots), ways)
+        if rc != 0:
+            return rc, None
+        G, spb = ng.value, sl.value
+        off, ln, words = np.zeros(spb * G, np.int32), np.zeros(spb * G, np.uint16), np.zeros(nw.value, np.uint32)
+        _capi.check(L.lpp_pb_pack_template(*args, vp(off), vp(ln), vp(words), C.byref(ent), C.byref(slots), ways))
+        return 0, (G, gv, spb, off, ln, words, ent.value, slots.value)
+
     cases = [(12, 6, chain(12, -1.0, True)), (10, 5, square(2, 5, -0.7)), (9, 3, chain(9, 1.3, True) + np.diag([0.5] * 8, 1) + np.diag([0.5] * 8, -1))]
     for (nsites, nup, hop) in cases:
         A = oracle.hubbard_csr(nsites, nup, 0, hop, np.zeros(nsites), np.linspace(-1, 1, nsites))  # one species: T plus a diagonal to be skipped
         n = A.nrows
         pitch = (n + 15) // 16 * 16
-        ng, sl, nw, ent, slots = C.c_int32(), C.c_int32(), C.c_int64(), C.c_int64(), C.c_int64()
-        gv = np.zeros(8)
-        _capi.check(L.lpp_pb_pack_template(n, pitch, vp(A.rowptr), vp(A.colind), vp(A.values), C.byref(ng), vp(gv), C.byref(sl), C.byref(nw),
-                                           None, None, None, C.byref(ent), C.byref(slots)))
-        G, spb = ng.value, sl.value
-        off, ln, words = np.zeros(spb * G, np.int32), np.zeros(spb * G, np.uint16), np.zeros(nw.value, np.uint32)
-        _capi.check(L.lpp_pb_pack_template(n, pitch, vp(A.rowptr), vp(A.colind), vp(A.values), C.byref(ng), vp(gv), C.byref(sl), C.byref(nw),
-                                           vp(off), vp(ln), vp(words), C.byref(ent), C.byref(slots)))
-        assert spb == (n + 63) // 64 and G == len(np.unique(A.values[A.colind != np.repeat(np.arange(n), np.diff(A.rowptr))]))
-        rows, cols, vals = [], [], []
-        for j in range(spb):
-            for g in range(G):
-                w = words[off[j * G + g]:off[j * G + g] + int(ln[j * G + g]) * 64].reshape(-1, 64)
-                for idx in (w & 0xffff, w >> 16):
-                    for slot in idx:
-                        for h in (0, 1):
-                            half = slot[h * 32:(h + 1) * 32]
-                            # distinct addresses of a half-wave never share a bank
-                            addr = np.unique(half)
-                            assert len(np.unique(addr & 31)) == len(addr)
-                        real = slot < n
-                        assert np.all((slot[~real] >= pitch) & (slot[~real] < pitch + 32))
-                        lanes = np.nonzero(real)[0]
-                        assert np.all(j * 64 + lanes < n)
-                        rows += list(j * 64 + lanes)
-                        cols += list(slot[real])
-                        vals += [gv[g]] * len(lanes)
-        import scipy.sparse as sp
-        M = sp.csr_matrix((vals, (rows, cols)), shape=(n, n))
         R = A.to_scipy().tolil()
         R.setdiag(0)
         R = R.tocsr()
         R.eliminate_zeros()
-        assert len(vals) == ent.value == R.nnz and abs(M - R).max() == 0
+        nslots = {}
+        for ways in (1, 2):
+            rc, (G, gv, spb, off, ln, words, ent, slots) = pack(A, pitch, ways)
+            assert rc == 0 and spb == (n + 63) // 64 and G == len(np.unique(R.data))
+            nslots[ways] = slots
+            rows, cols, vals = [], [], []
+            for j in range(spb):
+                for g in range(G):
+                    w = words[off[j * G + g] * 128:(off[j * G + g] + int(ln[j * G + g])) * 128].reshape(-1, 64, 2)  # [chunk][lane][word]
+                    idx = np.stack([w[:, :, 0] & 0xffff, w[:, :, 0] >> 16, w[:, :, 1] & 0xffff, w[:, :, 1] >> 16], axis=2)  # [chunk][lane][k]
+                    for chunk in idx:
+                        for k in range(4):
+                            slot = chunk[:, k]
+                            for h in (0, 1):
+                                addr = np.unique(slot[h * 32:(h + 1) * 32])
+                                assert np.bincount(addr & 31, minlength=32).max() <= ways
+                            real = slot < n
+                            assert np.all((slot[~real] >= pitch) & (slot[~real] < pitch + 32))
+                            lanes = np.nonzero(real)[0]
+                            assert np.all(j * 64 + lanes < n)
+                            rows += list(j * 64 + lanes)
+                            cols += list(slot[real])
+                            vals += [gv[g]] * len(lanes)
+            M = sp.csr_matrix((vals, (rows, cols)), shape=(n, n))
+            assert len(vals) == ent == R.nnz and abs(M - R).max() == 0
+        assert nslots[2] <= nslots[1]
     # more than 8 distinct in-block values: refused (the engine then keeps the general layout)
     rng = np.random.default_rng(0)
     hop = chain(10, -1.0) * (1 + 0.1 * rng.standard_normal((10, 10)))
     hop = (hop + hop.T) / 2
     A = oracle.hubbard_csr(10, 5, 0, hop, np.zeros(10))
-    rc = L.lpp_pb_pack_template(A.nrows, 256, vp(A.rowptr), vp(A.colind), vp(A.values), C.byref(ng), vp(gv), C.byref(sl), C.byref(nw),
-                                None, None, None, C.byref(ent), C.byref(slots))
+    rc, _ = pack(A, 256, 2)
     assert rc == _capi.LPP_ERR_INVALID
