@@ -178,6 +178,13 @@ lpp_status lpp_engine_assemble_hubbard(lpp_engine* e, const lpp_comm* comm, int3
                                        int32_t ndown, const double* hop_re, const double* hop_im, const double* U,
                                        const double* V);
 
+/* The same with the Coulomb term of Model=HubbardOneBandExtended (ModelSelector.h:76-80): the diagonal gains
+ * 0.5 * sum_{i,j} ninj[i*L+j] (n_i,up + n_i,down)(n_j,up + n_j,down), ninj = the second geometry term (HubbardHelper.h:167-177,362-366).
+ * ninj == NULL is lpp_engine_assemble_hubbard. */
+lpp_status lpp_engine_assemble_hubbard_ext(lpp_engine* e, const lpp_comm* comm, int32_t nsites, int32_t nup, int32_t ndown,
+                                           const double* hop_re, const double* hop_im, const double* U, const double* V,
+                                           const double* ninj);
+
 /* Matrix-free Hubbard product (the GPU counterpart of SolverOptions=InternalProductOnTheFly:
  * InternalProductOnTheFly.h:120-123 -> HubbardHelper::matrixVectorProduct, HubbardHelper.h:105-134).
  * No CSR is stored: H = H_up (x) 1 + 1 (x) H_down + diag(U n_up n_down) in the BasisHubbardLanczos ordering;
@@ -186,6 +193,10 @@ lpp_status lpp_engine_assemble_hubbard(lpp_engine* e, const lpp_comm* comm, int3
 lpp_status lpp_engine_setup_hubbard_onthefly(lpp_engine* e, const lpp_comm* comm, int32_t nsites, int32_t nup,
                                              int32_t ndown, const double* hop_re, const double* hop_im, const double* U,
                                              const double* V);
+
+lpp_status lpp_engine_setup_hubbard_onthefly_ext(lpp_engine* e, const lpp_comm* comm, int32_t nsites, int32_t nup, int32_t ndown,
+                                                 const double* hop_re, const double* hop_im, const double* U, const double* V,
+                                                 const double* ninj);
 
 /* On-device assembly of the S=1/2 Heisenberg Hamiltonian (Heisenberg.h:80-114,242-307) in the
  * BasisHeisenberg ordering (ascending words of fixed popcount, BasisHeisenberg.h:38-46). */

@@ -166,12 +166,15 @@ void hubbard_terms(int L, const double* hop_re, const double* hop_im, std::vecto
 	}
 }
 
-lpp_status common_setup(lpp_engine* e, int64_t nrows, int is_complex_input)
+// columns_are_local: every stored column index is rank-local (transposition exchange: own slice + transposed slice), so only
+// the per-rank sizes -- checked by the caller -- have to fit 32 bits, not the global dimension
+lpp_status common_setup(lpp_engine* e, int64_t nrows, int is_complex_input, bool columns_are_local = false)
 {
 	if (!e) return fail(LPP_ERR_INVALID, "assemble: null engine");
 	if (is_complex_input && !e->is_complex) return fail(LPP_ERR_INVALID, "assemble: complex couplings need a c128 engine");
 	if (nrows <= 0) return fail(LPP_ERR_INVALID, "assemble: empty Hilbert space");
-	if (nrows > (int64_t)INT32_MAX) return fail(LPP_ERR_INVALID, "assemble: Hilbert space exceeds the 32-bit column range of the stored CSR");
+	if (nrows > (int64_t)INT32_MAX && !columns_are_local)
+		return fail(LPP_ERR_INVALID, "assemble: Hilbert space exceeds the 32-bit column range of the stored CSR (partition it with the transposition exchange, or use the matrix-free engine)");
 	HIP_TRY(hipSetDevice(e->cfg.device));
 	return LPP_OK;
 }
@@ -223,6 +226,7 @@ lpp_status assemble_hubbard_pb(lpp_engine* e, AsmParams P, int nup, int ndown, i
 	} guard { Tm, Cm };
 	AsmParams P1 = P;
 	P1.d0 = zeroU_dev;
+	P1.d2 = nullptr;
 	P1.ndown = 0;
 	P1.part = 0;
 	P1.row0 = 0;
@@ -297,6 +301,13 @@ extern "C" {
 lpp_status lpp_engine_assemble_hubbard(lpp_engine* e, const lpp_comm* comm, int32_t L, int32_t nup, int32_t ndown,
                                        const double* hop_re, const double* hop_im, const double* U, const double* V)
 {
+	return lpp_engine_assemble_hubbard_ext(e, comm, L, nup, ndown, hop_re, hop_im, U, V, nullptr);
+}
+
+lpp_status lpp_engine_assemble_hubbard_ext(lpp_engine* e, const lpp_comm* comm, int32_t L, int32_t nup, int32_t ndown,
+                                           const double* hop_re, const double* hop_im, const double* U, const double* V,
+                                           const double* ninj)
+{
 	if (!e || !hop_re || !U || !V || L < 1 || L > 31 || nup < 0 || ndown < 0 || nup > L || ndown > L)
 		return fail(LPP_ERR_INVALID, "lpp_engine_assemble_hubbard: bad argument (1 <= L <= 31)");
 	const std::vector<uint64_t> comb = comb_table();
@@ -305,7 +316,9 @@ lpp_status lpp_engine_assemble_hubbard(lpp_engine* e, const lpp_comm* comm, int3
 	bool cplx_in = false;
 	if (hop_im)
 		for (int k = 0; k < L * L; k++) cplx_in |= (hop_im[k] != 0);
-	lpp_status st = common_setup(e, nrows, cplx_in);
+	// with the transposition exchange a rank stores columns of its own slice and of its transposed slice only
+	const bool local_columns = comm && comm->nranks > 1 && comm->exchange_begin && comm->exchange_end && comm->xchg_chunk > 0;
+	lpp_status st = common_setup(e, nrows, cplx_in, local_columns);
 	if (st != LPP_OK) return st;
 
 	std::vector<HostProc> hp;
@@ -322,6 +335,8 @@ lpp_status lpp_engine_assemble_hubbard(lpp_engine* e, const lpp_comm* comm, int3
 	if ((st = upload(e->stream, d_U, U, sizeof(double) * L)) != LPP_OK) return st;
 	if ((st = upload(e->stream, d_V, V, sizeof(double) * L)) != LPP_OK) return st;
 	if ((st = upload(e->stream, d_U0, zeroU.data(), sizeof(double) * L)) != LPP_OK) return st;
+	DevBuf d_ninj;
+	if (ninj && (st = upload(e->stream, d_ninj, ninj, sizeof(double) * L * L)) != LPP_OK) return st;
 
 	AsmParams P {};
 	P.model = ASM_HUBBARD;
@@ -336,6 +351,7 @@ lpp_status lpp_engine_assemble_hubbard(lpp_engine* e, const lpp_comm* comm, int3
 	P.comb = (const uint64_t*)d_comb.p;
 	P.d0 = (const double*)d_U.p;
 	P.d1 = (const double*)d_V.p;
+	P.d2 = ninj ? (const double*)d_ninj.p : nullptr; // Coulomb coupling of HubbardOneBandExtended
 
 	const bool multi = comm && comm->nranks > 1;
 	if (!multi) {
@@ -367,12 +383,16 @@ lpp_status lpp_engine_assemble_hubbard(lpp_engine* e, const lpp_comm* comm, int3
 		if (st != LPP_OK) return st;
 		const int64_t per = (n_dn + comm->nranks - 1) / comm->nranks;
 		if (comm->shard_stride != per * n_up) return fail(LPP_ERR_INVALID, "assemble_hubbard: comm.shard_stride must be ceil(N_down/nranks)*N_up");
-		if ((int64_t)comm->nranks * comm->shard_stride > (int64_t)INT32_MAX) return fail(LPP_ERR_INVALID, "assemble_hubbard: gathered vector exceeds 32-bit column range");
+		const bool transpose = comm->exchange_begin && comm->exchange_end && comm->xchg_chunk > 0;
+		// all-gather: remote columns index the gathered vector; transposition: columns index the rank's own slice (and its
+		// transposed slice, checked below), so the GLOBAL dimension may exceed 2^31 (e.g. the 3.0e9-state (7,6) sector of the 4x5 lattice)
+		if (!transpose && (int64_t)comm->nranks * comm->shard_stride > (int64_t)INT32_MAX)
+			return fail(LPP_ERR_INVALID, "assemble_hubbard: gathered vector exceeds 32-bit column range (use the transposition exchange)");
+		if (comm->shard_stride > (int64_t)INT32_MAX) return fail(LPP_ERR_INVALID, "assemble_hubbard: a rank's slice exceeds 32-bit column range");
 		P.row0 = starts[comm->rank];
 		P.nloc = starts[comm->rank + 1] - starts[comm->rank];
 		P.col_lo = starts[comm->rank];
 		P.col_hi = starts[comm->rank + 1];
-		const bool transpose = comm->exchange_begin && comm->exchange_end && comm->xchg_chunk > 0;
 		drop_product(e);
 		if (!transpose) {
 			e->tx = false;
@@ -693,6 +713,13 @@ extern "C" {
 lpp_status lpp_engine_setup_hubbard_onthefly(lpp_engine* e, const lpp_comm* comm, int32_t L, int32_t nup, int32_t ndown,
                                              const double* hop_re, const double* hop_im, const double* U, const double* V)
 {
+	return lpp_engine_setup_hubbard_onthefly_ext(e, comm, L, nup, ndown, hop_re, hop_im, U, V, nullptr);
+}
+
+lpp_status lpp_engine_setup_hubbard_onthefly_ext(lpp_engine* e, const lpp_comm* comm, int32_t L, int32_t nup, int32_t ndown,
+                                                 const double* hop_re, const double* hop_im, const double* U, const double* V,
+                                                 const double* ninj)
+{
 	if (!e || !hop_re || !U || !V || L < 1 || L > 31 || nup < 0 || ndown < 0 || nup > L || ndown > L)
 		return fail(LPP_ERR_INVALID, "lpp_engine_setup_hubbard_onthefly: bad argument (1 <= L <= 31)");
 	const std::vector<uint64_t> comb = comb_table();
@@ -773,6 +800,38 @@ lpp_status lpp_engine_setup_hubbard_onthefly(lpp_engine* e, const lpp_comm* comm
 	k_basis_words<<<(int)((n_dn + 255) / 256), 256, 0, e->stream>>>((const uint64_t*)d_comb.p, kCombDim, n_dn, ndown, L, K.dn_words);
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipStreamSynchronize(e->stream));
+	if (ninj) {
+		// Coulomb term of HubbardOneBandExtended, 0.5 sum_ij V_ij (n_i,up + n_i,dn)(n_j,up + n_j,dn) (HubbardHelper.h:167-177), split by
+		// species: a table per up word, a table per down word and the cross term sum_{i in up} (V n_dn)_i (V taken as given: i,j over all pairs)
+		std::vector<uint32_t> uw((size_t)n_up), dw((size_t)n_dn);
+		HIP_TRY(hipMemcpy(uw.data(), K.up_words, sizeof(uint32_t) * (size_t)n_up, hipMemcpyDeviceToHost));
+		HIP_TRY(hipMemcpy(dw.data(), K.dn_words, sizeof(uint32_t) * (size_t)n_dn, hipMemcpyDeviceToHost));
+		auto same_species = [&](uint32_t w) {
+			double s2 = 0.0;
+			for (int i = 0; i < L; i++)
+				if ((w >> i) & 1)
+					for (int j = 0; j < L; j++)
+						if ((w >> j) & 1) s2 += 0.5 * ninj[i * L + j];
+			return s2;
+		};
+		std::vector<double> cu((size_t)n_up), cd((size_t)n_dn), cx((size_t)n_dn * 32, 0.0);
+		for (int64_t i = 0; i < n_up; i++) cu[(size_t)i] = same_species(uw[(size_t)i]);
+		for (int64_t d = 0; d < n_dn; d++) {
+			cd[(size_t)d] = same_species(dw[(size_t)d]);
+			for (int i = 0; i < L; i++) {
+				double t = 0.0;
+				for (int j = 0; j < L; j++)
+					if ((dw[(size_t)d] >> j) & 1) t += 0.5 * (ninj[i * L + j] + ninj[j * L + i]);
+				cx[(size_t)d * 32 + i] = t;
+			}
+		}
+		HIP_TRY_MEM(hipMalloc(&K.cdiag_up, sizeof(double) * cu.size()));
+		HIP_TRY_MEM(hipMalloc(&K.cdiag_dn, sizeof(double) * cd.size()));
+		HIP_TRY_MEM(hipMalloc(&K.cross, sizeof(double) * cx.size()));
+		HIP_TRY(hipMemcpy(K.cdiag_up, cu.data(), sizeof(double) * cu.size(), hipMemcpyHostToDevice));
+		HIP_TRY(hipMemcpy(K.cdiag_dn, cd.data(), sizeof(double) * cd.size(), hipMemcpyHostToDevice));
+		HIP_TRY(hipMemcpy(K.cross, cx.data(), sizeof(double) * cx.size(), hipMemcpyHostToDevice));
+	}
 
 	K.L = L;
 	K.n_up = n_up;
@@ -826,6 +885,8 @@ void free_kron(lpp_engine* e)
 	if (K.pk_off) (void)hipFree(K.pk_off);
 	if (K.pk_len) (void)hipFree(K.pk_len);
 	if (K.pk_dict) (void)hipFree(K.pk_dict);
+	for (double* q : { K.cdiag_up, K.cdiag_dn, K.cross })
+		if (q) (void)hipFree(q);
 	K = KronState();
 }
 
@@ -850,6 +911,9 @@ template <typename T> static int kron_launch_t(lpp_engine* e, const void* ywin, 
 		pa.up_words = K.up_words;
 		pa.dn_words = K.dn_words;
 		pa.U = K.U;
+		pa.cdiag_up = K.cdiag_up;
+		pa.cdiag_dn = K.cdiag_dn;
+		pa.cross = K.cross;
 		pa.L = K.L;
 		pa.ywin = (const T*)ywin;
 		pa.ydown = (const T*)ydown;
@@ -932,6 +996,9 @@ template <typename T> static int kron_launch_t(lpp_engine* e, const void* ywin, 
 	a.up_words = K.up_words;
 	a.dn_words = K.dn_words;
 	a.U = K.U;
+	a.cdiag_up = K.cdiag_up;
+	a.cdiag_dn = K.cdiag_dn;
+	a.cross = K.cross;
 	a.L = K.L;
 	a.ywin = (const T*)ywin;
 	a.ydown = (const T*)ydown;

@@ -45,7 +45,7 @@ struct AsmParams {
 	const uint64_t* comb; // kCombDim x kCombDim binomials
 	const double* d0; // Hubbard U[L] | Heisenberg field[L] (nd0 valid) | t-J potentialV[2L]
 	const double* d1; // Hubbard V[L] | Heisenberg anisotropy[L] (nd1 valid) | t-J jzz[L*L]
-	const double* d2; // Heisenberg jzz[L*L] | t-J w[L*L]
+	const double* d2; // Hubbard Coulomb coupling[L*L] or null | Heisenberg jzz[L*L] | t-J w[L*L]
 	int nd0, nd1;
 	// Hubbard, transposed row layout (multi-GPU transposition scheme): row = id*peru + (iu - iu0) for the rank's
 	// UP-index range [iu0, iu0+nu) and ALL down indices id < n_dn; rows with iu_l >= nu or id >= n_dn are padding
@@ -153,12 +153,20 @@ template <int MODEL> __device__ double diag_of(const AsmParams& P, uint64_t w)
 {
 	const int L = P.L;
 	double s = 0.0;
-	if (MODEL == ASM_HUBBARD) { // HubbardHelper.h:147-187 (U and potentialV terms)
+	if (MODEL == ASM_HUBBARD) { // HubbardHelper.h:147-187 (U, Coulomb and potentialV terms, in that order per site)
 		const uint64_t up = w & ((1ull << L) - 1), down = w >> L;
 		for (int i = 0; i < L; i++) {
 			const int nu = (int)((up >> i) & 1), nd = (int)((down >> i) & 1);
 			s += P.d0[i] * nu * nd;
 			const double ne = nu + nd;
+			if (P.d2) { // HubbardOneBandExtended: 0.5 * coulombCoupling(i,j) n_i n_j over ALL j (HubbardHelper.h:167-177)
+				for (int j = 0; j < L; j++) {
+					const double value = 0.5 * P.d2[i * L + j];
+					if (value == 0) continue;
+					const double tmp2 = (double)(int)(((up >> j) & 1) + ((down >> j) & 1));
+					s += value * ne * tmp2;
+				}
+			}
 			const double tmp = P.d1[i];
 			if (tmp != 0) s += tmp * ne;
 		}

@@ -74,6 +74,7 @@ struct KronState {
 	DevCsr dn; // plain H_down
 	uint32_t *up_words = nullptr, *dn_words = nullptr;
 	double* U = nullptr;
+	double *cdiag_up = nullptr, *cdiag_dn = nullptr, *cross = nullptr; // Coulomb term of HubbardOneBandExtended (null: none)
 	int L = 0;
 	int64_t n_up = 0, n_dn = 0, id0 = 0, nid = 0;
 	bool window = false;

@@ -33,6 +33,10 @@ template <typename T> struct KronArgs {
 	const uint32_t* up_words; // basis words (L <= 31)
 	const uint32_t* dn_words;
 	const double* U;
+	// Coulomb term of HubbardOneBandExtended (null: none): 0.5 sum_ij V_ij n_i n_j = cdiag_up[iu] + cdiag_dn[id] + sum_{i in up} cross[id][i]
+	const double* cdiag_up;
+	const double* cdiag_dn;
+	const double* cross; // [N_down][32]: (V n_down)_i
 	int L;
 	const T* ywin; // local slice of y: (id-id0)*N_up + iu
 	const T* ydown; // y indexed globally (jd*N_up + iu): the gathered vector on several GPUs, == ywin on one
@@ -50,6 +54,7 @@ __global__ __launch_bounds__(kWinThreads) void k_spmv_kron(KronArgs<T> a)
 	__shared__ double smem[kWinThreads / 64];
 	__shared__ double dict_s[CODED ? 256 : 1];
 	__shared__ double U_s[32];
+	__shared__ double X_s[32];
 	__shared__ int32_t dcol_s[kKronDownCap];
 	__shared__ T dval_s[kKronDownCap];
 	load_dict<CODED>(dict_s, a.up.dict);
@@ -78,7 +83,9 @@ __global__ __launch_bounds__(kWinThreads) void k_spmv_kron(KronArgs<T> a)
 		const int64_t p0 = a.dn_rowptr[gid];
 		const int ndn = (int)(a.dn_rowptr[gid + 1] - p0);
 		const uint32_t dnw = a.dn_words[gid];
+		const double cdn = a.cross ? a.cdiag_dn[gid] : 0.0;
 		__syncthreads(); // previous block fully consumed (window, H_down row)
+		if (a.cross && threadIdx.x < 32) X_s[threadIdx.x] = a.cross[gid * 32 + threadIdx.x];
 		if (WINDOW) {
 			for (int64_t i0 = threadIdx.x; i0 < a.n_up; i0 += 8 * kWinThreads) {
 				T t[8];
@@ -137,6 +144,10 @@ __global__ __launch_bounds__(kWinThreads) void k_spmv_kron(KronArgs<T> a)
 				const T yc = WINDOW ? lds[iu] : yblk[iu];
 				double ud = 0.0;
 				for (uint32_t m = upw & dnw; m; m &= m - 1) ud += U_s[__ffs((int)m) - 1];
+				if (a.cross) {
+					ud += a.cdiag_up[iu] + cdn;
+					for (uint32_t m = upw; m; m &= m - 1) ud += X_s[__ffs((int)m) - 1];
+				}
 				T t = VT<T>::zero();
 				if (sizeof(T) == 16) {
 					cplx* tc = (cplx*)&t;
@@ -189,6 +200,7 @@ template <typename T> struct KronPackedArgs {
 	const uint32_t* up_words;
 	const uint32_t* dn_words;
 	const double* U;
+	const double *cdiag_up, *cdiag_dn, *cross; // Coulomb term (see KronArgs), null: none
 	int L;
 	const T* ywin;
 	const T* ydown;
@@ -218,6 +230,7 @@ __global__ __launch_bounds__(kWinThreads) void k_spmv_kron_packed(KronPackedArgs
 	__shared__ double smem[kWinThreads / 64];
 	__shared__ double dict_s[256];
 	__shared__ double U_s[32];
+	__shared__ double X_s[32];
 	__shared__ long long doff_s[kKronDownCap]; // jd * N_up
 	__shared__ T dval_s[kKronDownCap];
 	__shared__ int next_slice;
@@ -247,8 +260,11 @@ __global__ __launch_bounds__(kWinThreads) void k_spmv_kron_packed(KronPackedArgs
 		const int64_t p0 = a.dn_rowptr[gid];
 		const int ndn = (int)(a.dn_rowptr[gid + 1] - p0);
 		const uint32_t dnw = a.dn_words[gid];
+		const bool coul = a.cross != nullptr && a.part != 2;
+		const double cdn = coul ? a.cdiag_dn[gid] : 0.0;
 		__syncthreads(); // previous block fully consumed (window, H_down row)
 		if (threadIdx.x == 0) next_slice = 0;
+		if (coul && threadIdx.x < 32) X_s[threadIdx.x] = a.cross[gid * 32 + threadIdx.x];
 		if (WINDOW && a.part != 2) {
 			for (int64_t i0 = threadIdx.x; i0 < a.n_up; i0 += 8 * kWinThreads) {
 				T t[8];
@@ -319,6 +335,10 @@ __global__ __launch_bounds__(kWinThreads) void k_spmv_kron_packed(KronPackedArgs
 			const T yc = (a.part == 2) ? VT<T>::zero() : (WINDOW ? lds[iu] : yblk[iu]);
 			double ud = 0.0;
 			for (uint32_t m = upw & dnw; m; m &= m - 1) ud += U_s[__ffs((int)m) - 1];
+			if (coul) {
+				ud += a.cdiag_up[iu] + cdn;
+				for (uint32_t m = upw; m; m &= m - 1) ud += X_s[__ffs((int)m) - 1];
+			}
 			T t = VT<T>::zero();
 			if (sizeof(T) == 16) {
 				cplx* tc = (cplx*)&t;
@@ -365,6 +385,7 @@ __global__ __launch_bounds__(kWinThreads) void k_spmv_kron_chunked(KronChunkArgs
 	__shared__ double smem[kWinThreads / 64];
 	__shared__ double dict_s[256];
 	__shared__ double U_s[32];
+	__shared__ double X_s[32];
 	__shared__ long long doff_s[kKronDownCap];
 	__shared__ T dval_s[kKronDownCap];
 	__shared__ int next_slice;
@@ -393,6 +414,7 @@ __global__ __launch_bounds__(kWinThreads) void k_spmv_kron_chunked(KronChunkArgs
 				for (int q = 0; q < 8; q++)
 					if (i0 + (int64_t)q * kWinThreads < c1) lds[i0 - c0 + (int64_t)q * kWinThreads] = t[q];
 			}
+			if (c == 0 && a.cross && threadIdx.x < 32) X_s[threadIdx.x] = a.cross[gid * 32 + threadIdx.x];
 			if (c == 0 && (int)threadIdx.x < kKronDownCap) {
 				const bool in = (int)threadIdx.x < ndn;
 				doff_s[threadIdx.x] = (long long)(in ? a.dn_col[p0 + threadIdx.x] : (int32_t)gid) * a.n_up;
@@ -439,7 +461,12 @@ __global__ __launch_bounds__(kWinThreads) void k_spmv_kron_chunked(KronChunkArgs
 						for (int p = kKronDownCap; p < ndn; p++) VT<T>::mac(acc, a.dn_val[p0 + p], yd[(int64_t)a.dn_col[p0 + p] * a.n_up]);
 					// Hubbard U on the doubly occupied sites
 					double ud = 0.0;
-					for (uint32_t m = a.up_words[iu] & dnw; m; m &= m - 1) ud += U_s[__ffs((int)m) - 1];
+					const uint32_t upw = a.up_words[iu];
+					for (uint32_t m = upw & dnw; m; m &= m - 1) ud += U_s[__ffs((int)m) - 1];
+					if (a.cross) { // Coulomb term of HubbardOneBandExtended
+						ud += a.cdiag_up[iu] + a.cdiag_dn[gid];
+						for (uint32_t m = upw; m; m &= m - 1) ud += X_s[__ffs((int)m) - 1];
+					}
 					T t = yc;
 					double* td = (double*)&t;
 					td[0] *= ud;

@@ -429,18 +429,19 @@ static __global__ __launch_bounds__(kBlock) void k_pb_combine(PbCombineArgs a)
 	double s = 0.0, c = 0.0;
 	const int64_t stride = (int64_t)gridDim.x * kBlock;
 	int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-	for (; i + stride < a.n2; i += 2 * stride) { // two elements per lane and stream in flight: 8 x 16-byte loads
-		double2 xv[2], yv[2], uv[2], zv[2];
+	constexpr int U = 4; // elements per lane and stream in flight (16 x 16-byte loads); measured with scripts/experiments/calib_combine.hip
+	for (; i + (U - 1) * stride < a.n2; i += U * stride) {
+		double2 xv[U], yv[U], uv[U], zv[U];
 #pragma unroll
-		for (int k = 0; k < 2; k++) xv[k] = nt_load2(&a.x[i + k * stride]);
+		for (int k = 0; k < U; k++) xv[k] = nt_load2(&a.x[i + k * stride]);
 #pragma unroll
-		for (int k = 0; k < 2; k++) yv[k] = nt_load2(&a.y[i + k * stride]);
+		for (int k = 0; k < U; k++) yv[k] = nt_load2(&a.y[i + k * stride]);
 #pragma unroll
-		for (int k = 0; k < 2; k++) uv[k] = nt_load2(&a.u[i + k * stride]);
+		for (int k = 0; k < U; k++) uv[k] = nt_load2(&a.u[i + k * stride]);
 #pragma unroll
-		for (int k = 0; k < 2; k++) zv[k] = nt_load2(&a.z[i + k * stride]);
+		for (int k = 0; k < U; k++) zv[k] = nt_load2(&a.z[i + k * stride]);
 #pragma unroll
-		for (int k = 0; k < 2; k++) {
+		for (int k = 0; k < U; k++) {
 			double2 r;
 			r.x = beta * xv[k].x + uv[k].x + zv[k].x - g * yv[k].x;
 			r.y = beta * xv[k].y + uv[k].y + zv[k].y - g * yv[k].y;

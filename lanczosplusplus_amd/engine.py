@@ -101,26 +101,29 @@ class LanczosEngine:
         check(self._lib.lpp_engine_set_csr_partition(self._h, C.byref(comm.struct), global_rows, _vp(shard_starts),
                                                      _vp(rowptr), _vp(colind), _vp(values)))
 
-    def assemble_hubbard(self, L, nup, ndown, hop, U, V=None, comm=None):
+    def assemble_hubbard(self, L, nup, ndown, hop, U, V=None, comm=None, ninj=None):
+        """ninj: L x L Coulomb coupling of Model=HubbardOneBandExtended (the reference's second geometry term), or None."""
         hop = np.asarray(hop).reshape(L, L)
         hr = _mat(hop.real, L)
         hi = _mat(hop.imag, L) if np.iscomplexobj(hop) else None
         U = np.ascontiguousarray(U, np.float64)
         V = np.zeros(L) if V is None else np.ascontiguousarray(np.asarray(V, np.float64)[:L])
+        nj = None if ninj is None else _mat(ninj, L)
         self._comm_keepalive = comm
         cs = C.byref(comm.struct) if comm is not None else None
-        check(self._lib.lpp_engine_assemble_hubbard(self._h, cs, L, nup, ndown, _vp(hr), _vp(hi), _vp(U), _vp(V)))
+        check(self._lib.lpp_engine_assemble_hubbard_ext(self._h, cs, L, nup, ndown, _vp(hr), _vp(hi), _vp(U), _vp(V), _vp(nj)))
 
-    def setup_hubbard_onthefly(self, L, nup, ndown, hop, U, V=None, comm=None):
+    def setup_hubbard_onthefly(self, L, nup, ndown, hop, U, V=None, comm=None, ninj=None):
         """Matrix-free Hubbard product (InternalProductOnTheFly semantics): nothing but H_up and H_down is stored."""
         hop = np.asarray(hop).reshape(L, L)
         hr = _mat(hop.real, L)
         hi = _mat(hop.imag, L) if np.iscomplexobj(hop) else None
         U = np.ascontiguousarray(U, np.float64)
         V = np.zeros(L) if V is None else np.ascontiguousarray(np.asarray(V, np.float64)[:L])
+        nj = None if ninj is None else _mat(ninj, L)
         self._comm_keepalive = comm
         cs = C.byref(comm.struct) if comm is not None else None
-        check(self._lib.lpp_engine_setup_hubbard_onthefly(self._h, cs, L, nup, ndown, _vp(hr), _vp(hi), _vp(U), _vp(V)))
+        check(self._lib.lpp_engine_setup_hubbard_onthefly_ext(self._h, cs, L, nup, ndown, _vp(hr), _vp(hi), _vp(U), _vp(V), _vp(nj)))
 
     def assemble_heisenberg(self, L, szPlusConst, jpm, jzz, field=None):
         f = None if field is None else np.ascontiguousarray(field, np.float64)

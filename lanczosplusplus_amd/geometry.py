@@ -100,7 +100,8 @@ def terms_from_input(inp):
             mats.append(chain(L, conns[c][0], px))
             c += 1
         elif kinds[t] == "ladder":
-            leg = int(inp.get("LadderLeg", 2))
+            legs = inp.get("LadderLeg", 2)  # repeated labels (one per term) are consumed in order
+            leg = int(legs[min(t, len(legs) - 1)] if isinstance(legs, list) else legs)
             mats.append(ladder(L, leg, conns[c][0], conns[c + 1][0], px, py))
             c += 2
         else:

@@ -204,7 +204,7 @@ public:
 	InternalProductOnTheFly(const ModelType& model, SpecialSymmetryType& rs, const lpp_config& cfg) : rs_(rs), engine_(cfg), rows_(model.size())
 	{
 		const HubbardOneOrbital<ComplexOrRealType>* hub = dynamic_cast<const HubbardOneOrbital<ComplexOrRealType>*>(&model);
-		if (!hub) throw std::runtime_error("InternalProductOnTheFly: only Model=HubbardOneBand has an on-the-fly product\n");
+		if (!hub) throw std::runtime_error("InternalProductOnTheFly: only Model=HubbardOneBand / HubbardOneBandExtended have an on-the-fly product\n");
 		const SizeType n = model.geometry().numberOfSites();
 		std::vector<double> hr(n * n), hi(n * n);
 		for (SizeType k = 0; k < n * n; k++) {
@@ -212,8 +212,9 @@ public:
 			hi[k] = LppHost::imag(hub->hoppings()[k]);
 		}
 		const typename BasisType::PairIntType parts = model.basis().parts();
-		lppCheck(lpp_engine_setup_hubbard_onthefly(engine_.get(), nullptr, (int32_t)n, parts.first, parts.second, hr.data(),
-		                                           sizeof(ComplexOrRealType) == 16 ? hi.data() : nullptr, hub->hubbardU.data(), hub->potentialV.data()));
+		lppCheck(lpp_engine_setup_hubbard_onthefly_ext(engine_.get(), nullptr, (int32_t)n, parts.first, parts.second, hr.data(),
+		                                               sizeof(ComplexOrRealType) == 16 ? hi.data() : nullptr, hub->hubbardU.data(), hub->potentialV.data(),
+		                                               hub->coulombCoupling()));
 	}
 	SizeType rows() const { return rows_; }
 	void matrixVectorProduct(VectorType& x, const VectorType& y) const

@@ -376,3 +376,55 @@ def test_four_ranks_config5_lattice_transposition_exchange():
             assert rel(a[:40], ao[:40]) < 1e-8 and rel(b[:40], bo[:40]) < 1e-8
             assert np.array_equal(a, res[0]["a_" + tag])  # every rank takes bitwise-identical decisions
         assert abs(o["e_ff"] - exact) <= 1e-10 * abs(exact)
+
+
+def test_c_level_rccl_communicator_at_world_size_one():
+    """include/lpp_comm_rccl.h: the lpp_comm a non-Python host uses (ncclAllGather / ncclAllReduce / grouped send-recv on HIP
+    streams).  One rank only here (a one-GPU box cannot host two RCCL ranks): every callback runs once through
+    lpp_rccl_comm_selftest for the all-gather and the transposition layout, f64 and complex, and an engine created on the
+    communicator's stream with that lpp_comm solves a problem."""
+    import ctypes as C
+    import oracle
+    from helpers import chain
+    from lanczosplusplus_amd import LanczosEngine, _capi
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = C.CDLL(os.path.join(root, "lanczosplusplus_amd", "csrc", "liblpp_comm_rccl.so"))
+    lib.lpp_rccl_last_error.restype = C.c_char_p
+    lib.lpp_rccl_comm_get.restype = C.POINTER(_capi.Comm)
+    lib.lpp_rccl_comm_get.argtypes = [C.c_void_p]
+    lib.lpp_rccl_comm_create.argtypes = [C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_int32,
+                                         C.c_int32, C.c_int64]
+    lib.lpp_rccl_comm_destroy.argtypes = [C.c_void_p]
+    lib.lpp_rccl_comm_selftest.argtypes = [C.c_void_p]
+
+    def ok(rc):
+        assert rc == 0, lib.lpp_rccl_last_error().decode()
+
+    import torch
+    stream = torch.cuda.Stream(device=0)
+    L, nup, ndown = 8, 4, 3
+    n_up, n_dn = 70, 56
+    for is_complex in (0, 1):
+        for chunk in (0, n_dn * n_up):
+            ident = C.create_string_buffer(128)
+            ok(lib.lpp_rccl_unique_id(ident))
+            h = C.c_void_p()
+            ok(lib.lpp_rccl_comm_create(C.byref(h), 0, 1, ident, 0, C.c_void_p(stream.cuda_stream), n_dn * n_up, 200, is_complex, chunk))
+            ok(lib.lpp_rccl_comm_selftest(h))
+            cs = lib.lpp_rccl_comm_get(h)
+            assert cs.contents.nranks == 1 and cs.contents.shard_stride == n_dn * n_up and cs.contents.red_len >= 6 * 202 + 8
+            assert cs.contents.send_buf % 16 == 0 and cs.contents.gath_buf % 16 == 0
+            if not is_complex:
+                hop, U = chain(L, -1.0, True), np.full(L, 4.0)
+                A = oracle.hubbard_csr(L, nup, ndown, hop, U)
+                eo, _, so = oracle.lanczos_solve(A, oracle.fill_random(A.nrows, 1234), want_vectors=False)
+                with torch.cuda.stream(stream):
+                    e = LanczosEngine(max_steps=200, stream=C.c_void_p(stream.cuda_stream))
+
+                    class Holder:  # what engine.py expects of a communicator object
+                        struct = cs.contents
+                    e.assemble_hubbard(L, nup, ndown, hop, U, comm=Holder())
+                    eg, _, st = e.lanczos(1, want_vectors=False)
+                    e.close()
+                assert abs(eg[0] - eo[0]) <= 1e-10 * abs(eo[0]) and st["steps"] == so
+            ok(lib.lpp_rccl_comm_destroy(h))

@@ -715,3 +715,36 @@ def test_product_basis_layout_falls_back_when_it_does_not_apply():
             assert e.layout()["kernel"] != 4
             y = oracle.fill_random(A.nrows, 8)
             assert rel(e.matrixVectorProduct(np.zeros(A.nrows), y), oracle.spmv_acc(A, np.zeros(A.nrows), y)) < SPMV_TOL
+
+
+@pytest.mark.parametrize("case", ["small_general", "product_layout"])
+def test_hubbard_extended_coulomb_term(case):
+    """Model=HubbardOneBandExtended (ModelSelector.h:76-80): the Coulomb term 0.5 sum_ij V_ij n_i n_j of HubbardHelper.h:167-177 on
+    the device assembler (general layout and product-basis layout), bit-exact against the oracle's ninj path, and in the
+    matrix-free engine (the term split by species)."""
+    if case == "small_general":
+        L, nup, ndown = 8, 4, 3
+        hop, ninj = square(2, 4, -1.0, False), square(2, 4, 0.75, False) + 0.25 * chain(8, 1.0, True)
+        U, V = np.linspace(1.0, 4.5, L), np.linspace(-0.5, 0.5, 2 * L)
+    else:
+        L, nup, ndown = 12, 6, 5
+        hop, ninj = chain(L, -1.0, True), chain(L, 0.5, True)
+        U, V = np.full(L, 4.0), np.zeros(2 * L)
+    A = oracle.hubbard_csr(L, nup, ndown, hop, U, V, ninj=ninj)
+    A0 = oracle.hubbard_csr(L, nup, ndown, hop, U, V)
+    assert not np.array_equal(A.values, A0.values)
+    x0, y = oracle.fill_random(A.nrows, 7), oracle.fill_random(A.nrows, 8)
+    xo = oracle.spmv_acc(A, x0.copy(), y)
+    eo, _, so = oracle.lanczos_solve(A, oracle.fill_random(A.nrows, 1234), want_vectors=False)
+    with LanczosEngine() as e:
+        e.assemble_hubbard(L, nup, ndown, hop, U, V, ninj=ninj)
+        assert e.layout()["kernel"] == (4 if case == "product_layout" else e.layout()["kernel"])
+        rp, ci, va = e.get_csr()
+        assert np.array_equal(rp, A.rowptr) and np.array_equal(ci, A.colind) and np.array_equal(_bits(va), _bits(A.values))
+        assert rel(e.matrixVectorProduct(x0.copy(), y), xo) < SPMV_TOL
+        eg, _, st = e.lanczos(1, want_vectors=False)
+        assert abs(eg[0] - eo[0]) <= E_TOL * abs(eo[0]) and st["steps"] == so
+        e.setup_hubbard_onthefly(L, nup, ndown, hop, U, V, ninj=ninj)
+        assert rel(e.matrixVectorProduct(x0.copy(), y), xo) < SPMV_TOL
+        eg, _, st = e.lanczos(1, want_vectors=False)
+        assert abs(eg[0] - eo[0]) <= E_TOL * abs(eo[0]) and st["steps"] == so

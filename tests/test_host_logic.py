@@ -205,3 +205,18 @@ def test_product_template_is_bank_conflict_free_and_lossless():
     A = oracle.hubbard_csr(10, 5, 0, hop, np.zeros(10))
     rc, _ = pack(A, 256, 2)
     assert rc == _capi.LPP_ERR_INVALID
+
+
+def test_rccl_communicator_library_exports_its_symbols():
+    """liblpp_comm_rccl.so (include/lpp_comm_rccl.h): loads next to librccl and exports every declared entry point (no GPU call)."""
+    import ctypes as C
+    import re
+    path = os.path.join(ROOT, "lanczosplusplus_amd", "csrc", "liblpp_comm_rccl.so")
+    assert os.path.exists(path), "run __graft_entry__.build()"
+    lib = C.CDLL(path)
+    hdr = open(os.path.join(ROOT, "include", "lpp_comm_rccl.h")).read()
+    names = set(re.findall(r"\b(lpp_rccl_\w+)\s*\(", hdr))
+    assert {"lpp_rccl_unique_id", "lpp_rccl_comm_create", "lpp_rccl_comm_get", "lpp_rccl_comm_destroy", "lpp_rccl_comm_selftest",
+            "lpp_rccl_last_error"} <= names
+    for n in names:
+        assert hasattr(lib, n), n
