@@ -136,6 +136,9 @@ void lpp_config_default(lpp_config* cfg);
 
 lpp_status lpp_engine_create(lpp_engine** out, const lpp_config* cfg);
 lpp_status lpp_engine_destroy(lpp_engine* e);
+/* the hipStream_t the engine enqueues on (lpp_config.stream, or the engine-owned one): what a communicator
+ * (include/lpp_comm_rccl.h) has to order its collectives against */
+void* lpp_engine_stream(lpp_engine* e);
 
 /* Solver parameters after creation: the reference builds its LanczosSolver(hamiltonian, params) AFTER the InternalProduct that
  * owns the matrix (Engine.h:608-610), so the shim's LanczosSolver pushes ParametersForSolver (LanczosSteps=, LanczosMinSteps=,

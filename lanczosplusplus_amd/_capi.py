@@ -73,6 +73,7 @@ SYMBOLS = {
     "lpp_config_default": (None, [C.POINTER(Config)]),
     "lpp_engine_create": (C.c_int32, [C.POINTER(_P), C.POINTER(Config)]),
     "lpp_engine_destroy": (C.c_int32, [_P]),
+    "lpp_engine_stream": (C.c_void_p, [_P]),
     "lpp_engine_set_solver": (C.c_int32, [_P, C.c_int32, C.c_int32, C.c_double, C.c_int32, C.c_int32]),
     "lpp_engine_set_row_block": (C.c_int32, [_P, C.c_int64]),
     "lpp_engine_set_csr": (C.c_int32, [_P, C.c_int64, _P, _P, _P]),

@@ -816,6 +816,8 @@ lpp_status lpp_engine_create(lpp_engine** out, const lpp_config* cfg)
 	return LPP_OK;
 }
 
+void* lpp_engine_stream(lpp_engine* e) { return e ? (void*)e->stream : nullptr; }
+
 lpp_status lpp_engine_destroy(lpp_engine* e)
 {
 	if (!e) return LPP_OK;

@@ -5,10 +5,14 @@
 // SolverOptions=useComplex selects complex<double> (lanczos.cpp:194-226).  Observables (-g, -c, -m, ...)
 // are out of scope.
 #include <getopt.h>
+#include <unistd.h>
 
+#include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <iostream>
 
+#include "../../include/lpp_comm_rccl.h"
 #include "EngineGpu.h"
 
 using namespace LanczosPlusPlus;
@@ -39,20 +43,121 @@ template <typename ComplexOrRealType> int mainLoop0(LppHost::InputReadable& io, 
 	return mainLoop3<ModelType, SymmetryType, InternalProductStored>(model, io, device, precision);
 }
 
+static int envInt(const char* name, int dflt)
+{
+	const char* s = getenv(name);
+	return s ? atoi(s) : dflt;
+}
+
+static void rcclCheck(lpp_status st)
+{
+	if (st != LPP_OK) throw std::runtime_error(std::string("lpp_comm_rccl: ") + lpp_rccl_last_error() + "\n");
+}
+
+// rank 0 creates the id and publishes it atomically (write + rename); the others poll for the file
+static void shareUniqueId(char* id, int rank, int world)
+{
+	const char* path = getenv("LPP_RCCL_ID_FILE");
+	if (world > 1 && !path) throw std::runtime_error("lanczos -P: set LPP_RCCL_ID_FILE to a path every rank can read\n");
+	if (rank == 0) {
+		rcclCheck(lpp_rccl_unique_id(id));
+		if (world == 1) return;
+		const std::string tmp = std::string(path) + ".tmp";
+		FILE* f = fopen(tmp.c_str(), "wb");
+		if (!f || fwrite(id, 1, LPP_RCCL_ID_BYTES, f) != LPP_RCCL_ID_BYTES) throw std::runtime_error("lanczos -P: cannot write the RCCL id file\n");
+		fclose(f);
+		if (rename(tmp.c_str(), path) != 0) throw std::runtime_error("lanczos -P: cannot publish the RCCL id file\n");
+		return;
+	}
+	for (int tries = 0; tries < 6000; tries++) { // up to 10 minutes
+		FILE* f = fopen(path, "rb");
+		if (f) {
+			const size_t n = fread(id, 1, LPP_RCCL_ID_BYTES, f);
+			fclose(f);
+			if (n == LPP_RCCL_ID_BYTES) return;
+		}
+		usleep(100000);
+	}
+	throw std::runtime_error("lanczos -P: timed out waiting for the RCCL id file\n");
+}
+
+static long binomial(long n, long k)
+{
+	if (k < 0 || k > n) return 0;
+	long r = 1;
+	for (long i = 1; i <= k; i++) r = r * (n - k + i) / i;
+	return r;
+}
+
+// one process per GPU: this rank's rows are assembled on its GPU, the Lanczos loop runs on all ranks in lock step
+// (every rank takes bitwise-identical decisions), rank 0 prints the reference's "Energy=" line
+static int mainPartitioned(LppHost::InputReadable& io, int precision, bool onthefly)
+{
+	typedef LppHost::Geometry<double> GeometryType;
+	const int rank = envInt("RANK", 0), world = envInt("WORLD_SIZE", 1), local = envInt("LOCAL_RANK", rank);
+	GeometryType geometry(io);
+	ModelSelector<double> modelSelector(io, geometry);
+	const ModelBase<double>& model = modelSelector();
+	const HubbardOneOrbital<double>* hub = dynamic_cast<const HubbardOneOrbital<double>*>(&model);
+	if (!hub) throw std::runtime_error("lanczos -P: the partitioned path is built for Model=HubbardOneBand / HubbardOneBandExtended\n");
+	const int n = (int)geometry.numberOfSites();
+	const ModelBase<double>::BasisBaseType::PairIntType parts = model.basis().parts();
+	const long n_up = binomial(n, parts.first), n_dn = binomial(n, parts.second);
+	const long per = (n_dn + world - 1) / world, peru = (n_up + world - 1) / world;
+	std::string exchange = world >= 4 ? "transpose" : "allgather";
+	if (const char* s = getenv("LPP_EXCHANGE")) exchange = s;
+	const long chunk = exchange == "transpose" ? per * peru : 0;
+	ParametersForSolver<double> params(io, "Lanczos");
+	char id[LPP_RCCL_ID_BYTES];
+	shareUniqueId(id, rank, world);
+	lpp_config cfg;
+	lpp_config_default(&cfg);
+	cfg.device = local;
+	cfg.max_steps = (int32_t)params.steps;
+	cfg.min_steps = (int32_t)params.minSteps;
+	cfg.eps = params.tolerance;
+	cfg.reortho = params.options.find("reortho") != LppHost::String::npos;
+	cfg.save_vectors = 0; // energies only: no vector of the full length is ever gathered
+	EngineHandle engine(cfg); // engine-owned stream; the communicator is told which one below
+	lpp_rccl_comm* comm = nullptr;
+	rcclCheck(lpp_rccl_comm_create(&comm, rank, world, id, local, lpp_engine_stream(engine.get()), per * n_up, (int32_t)params.steps, 0, chunk));
+	std::vector<double> hr((size_t)n * n);
+	for (int k = 0; k < n * n; k++) hr[(size_t)k] = hub->hoppings()[(size_t)k];
+	if (onthefly)
+		lppCheck(lpp_engine_setup_hubbard_onthefly_ext(engine.get(), lpp_rccl_comm_get(comm), n, parts.first, parts.second, hr.data(), nullptr,
+		                                               hub->hubbardU.data(), hub->potentialV.data(), hub->coulombCoupling()));
+	else
+		lppCheck(lpp_engine_assemble_hubbard_ext(engine.get(), lpp_rccl_comm_get(comm), n, parts.first, parts.second, hr.data(), nullptr,
+		                                         hub->hubbardU.data(), hub->potentialV.data(), hub->coulombCoupling()));
+	double e0 = 0;
+	lpp_stats st;
+	lppCheck(lpp_engine_lanczos(engine.get(), nullptr, 1, &e0, nullptr, &st));
+	if (rank == 0) {
+		std::cout.precision(precision);
+		model.print(std::cout);
+		std::cout << "Energy=" << e0 << "\n";
+		std::cerr << "#LanczosSteps=" << st.steps << " rows=" << model.size() << " ranks=" << world << " exchange=" << (world > 1 ? exchange : "none") << "\n";
+	}
+	rcclCheck(lpp_rccl_comm_destroy(comm));
+	return 0;
+}
+
 int main(int argc, char** argv)
 {
 	LppHost::String file;
 	int device = 0, precision = 8, opt = 0;
-	while ((opt = getopt(argc, argv, "f:p:d:")) != -1) {
+	bool partitioned = false;
+	while ((opt = getopt(argc, argv, "f:p:d:P")) != -1) {
 		switch (opt) {
 		case 'f': file = optarg; break;
 		case 'p': precision = atoi(optarg); break;
 		case 'd': device = atoi(optarg); break;
-		default: std::cerr << "USAGE: " << argv[0] << " -f filename [-p precision] [-d device]\n"; return 1;
+		case 'P': partitioned = true; break;
+		default: std::cerr << "USAGE: " << argv[0] << " -f filename [-p precision] [-d device] [-P]\n"; return 1;
 		}
 	}
 	if (file.empty()) {
-		std::cerr << "USAGE: " << argv[0] << " -f filename [-p precision] [-d device]\n";
+		std::cerr << "USAGE: " << argv[0] << " -f filename [-p precision] [-d device] [-P]\n";
 		return 1;
 	}
 	try {
@@ -61,6 +166,10 @@ int main(int argc, char** argv)
 		if (io.has("SolverOptions=")) io.readline(options, "SolverOptions=");
 		const bool onthefly = options.find("InternalProductOnTheFly") != LppHost::String::npos;
 		const bool isComplex = options.find("useComplex") != LppHost::String::npos;
+		if (partitioned) {
+			if (isComplex) throw std::runtime_error("lanczos -P: real Hamiltonians only\n");
+			return mainPartitioned(io, precision, onthefly);
+		}
 		return isComplex ? mainLoop0<std::complex<double>>(io, device, precision, onthefly) : mainLoop0<double>(io, device, precision, onthefly);
 	} catch (std::exception& e) {
 		std::cerr << "lanczos: " << e.what();

@@ -150,3 +150,19 @@ def test_reference_constructors_honour_the_solver_parameters(tmp_path):
         so, ao, bo, _, _ = oracle.lanczos_decomposition(A, init, max_steps=steps, eps=eps)
         assert n == so == len(ab) and (n == 20 if eps == 0.0 else n < 200)
         assert np.abs(ab[:, 0] - ao).max() < 1e-8 and np.abs(ab[:, 1] - bo).max() < 1e-8
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["hubbard_ladder_2x4.inp", "hubbard_extended_2x4_onthefly.inp"])
+def test_partitioned_driver_over_rccl_at_world_size_one(name):
+    """lanczos -P: one process per GPU through liblpp_comm_rccl.so (no Python in the loop).  A one-GPU box hosts one rank: the
+    communicator is created (ncclCommInitRank), the rank's rows are assembled on the device, the energy line is the oracle's."""
+    exe = os.path.join(HOST, "lanczos")
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    res = subprocess.run([exe, "-f", os.path.join(GOLD, name), "-p", "12", "-P"], capture_output=True, text=True, timeout=300, env=env)
+    assert res.returncode == 0, res.stderr
+    e = float(re.search(r"^Energy=(\S+)$", res.stdout, re.M).group(1))
+    A = _oracle_csr(os.path.join(GOLD, name))
+    e0 = np.linalg.eigvalsh(A.to_scipy().toarray())[0]
+    assert abs(e - e0) <= 1e-10 * abs(e0)
+    assert "ranks=1" in res.stderr
