@@ -890,10 +890,13 @@ void free_kron(lpp_engine* e)
 	K = KronState();
 }
 
-template <typename T> static int kron_launch_t(lpp_engine* e, const void* ywin, const void* ydown, void* x, double* partial, const EpiScale& sc, int part)
+template <typename T> static int kron_launch_t(lpp_engine* e, const void* ywin, const void* ydown, void* x, double* partial, const EpiScale& sc, int part, int64_t b0, int64_t cnt)
 {
 	KronState& K = e->kron;
 	if (K.nid == 0 && part != 2) return 0;
+	if (cnt < 0) cnt = K.nid - b0; // default: every block of the slice
+	if (part != 2 && (b0 < 0 || b0 + cnt > K.nid)) return -1;
+	if (cnt == 0 && part != 2) return 0;
 	if (part != 0 && !K.packed) return -1;
 	if (K.packed) {
 		KronPackedArgs<T> pa;
@@ -903,8 +906,8 @@ template <typename T> static int kron_launch_t(lpp_engine* e, const void* ywin, 
 		pa.dict = K.pk_dict;
 		pa.spb = K.pk_spb;
 		pa.n_up = K.n_up;
-		pa.id0 = K.id0;
-		pa.nid = K.nid;
+		pa.id0 = K.id0 + b0; // a sub-range of blocks: the slice pointers move with it
+		pa.nid = cnt;
 		pa.dn_rowptr = K.dn.rowptr;
 		pa.dn_col = K.dn.col;
 		pa.dn_val = (const T*)K.dn.val;
@@ -915,9 +918,9 @@ template <typename T> static int kron_launch_t(lpp_engine* e, const void* ywin, 
 		pa.cdiag_dn = K.cdiag_dn;
 		pa.cross = K.cross;
 		pa.L = K.L;
-		pa.ywin = (const T*)ywin;
+		pa.ywin = ywin ? (const T*)ywin + b0 * K.n_up : nullptr;
 		pa.ydown = (const T*)ydown;
-		pa.x = (T*)x;
+		pa.x = (T*)x + (part == 2 ? 0 : b0 * K.n_up);
 		pa.partial = partial;
 		pa.xcd_map = (e->k2_variant >> 1) & 1;
 		pa.sc = sc;
@@ -988,8 +991,8 @@ template <typename T> static int kron_launch_t(lpp_engine* e, const void* ywin, 
 	a.up.tw_off = nullptr;
 	a.up.tw_len = nullptr;
 	a.n_up = K.n_up;
-	a.id0 = K.id0;
-	a.nid = K.nid;
+	a.id0 = K.id0 + b0;
+	a.nid = cnt;
 	a.dn_rowptr = K.dn.rowptr;
 	a.dn_col = K.dn.col;
 	a.dn_val = (const T*)K.dn.val;
@@ -1000,15 +1003,15 @@ template <typename T> static int kron_launch_t(lpp_engine* e, const void* ywin, 
 	a.cdiag_dn = K.cdiag_dn;
 	a.cross = K.cross;
 	a.L = K.L;
-	a.ywin = (const T*)ywin;
+	a.ywin = (const T*)ywin + b0 * K.n_up;
 	a.ydown = (const T*)ydown;
-	a.x = (T*)x;
+	a.x = (T*)x + b0 * K.n_up;
 	a.partial = partial;
 	a.xcd_map = (e->k2_variant >> 1) & 1;
 	a.sc = sc;
 	const size_t lds_bytes = K.window ? sizeof(T) * (size_t)std::max<int64_t>(K.n_up, 64) : 64;
 	const int per_cu = std::max(1, std::min(2, (int)((160 * 1024 - 8192) / (lds_bytes + 1))));
-	int nb = (int)std::max<int64_t>(1, std::min<int64_t>(K.nid, (int64_t)e->num_cus * per_cu));
+	int nb = (int)std::max<int64_t>(1, std::min<int64_t>(cnt, (int64_t)e->num_cus * per_cu));
 	if (nb >= 8) nb &= ~7;
 	const bool dot = partial != nullptr;
 	const int sel = (dot ? 4 : 0) | (K.window ? 2 : 0) | (K.up.coded ? 1 : 0);
@@ -1032,9 +1035,9 @@ template <typename T> static int kron_launch_t(lpp_engine* e, const void* ywin, 
 	return dot ? nb : 0;
 }
 
-int kron_launch(lpp_engine* e, const void* ywin, const void* ydown, void* x, double* partial, const EpiScale& sc, int part)
+int kron_launch(lpp_engine* e, const void* ywin, const void* ydown, void* x, double* partial, const EpiScale& sc, int part, int64_t b0, int64_t cnt)
 {
-	return e->is_complex ? kron_launch_t<cplx>(e, ywin, ydown, x, partial, sc, part) : kron_launch_t<double>(e, ywin, ydown, x, partial, sc, part);
+	return e->is_complex ? kron_launch_t<cplx>(e, ywin, ydown, x, partial, sc, part, b0, cnt) : kron_launch_t<double>(e, ywin, ydown, x, partial, sc, part, b0, cnt);
 }
 
 } // namespace lpp

@@ -190,17 +190,36 @@ __global__ __launch_bounds__(kBlock) void k_unpack_add_dot(T* __restrict__ x, co
 {
 	__shared__ double smem[kBlock / 64];
 	const int64_t n = nid * n_up;
-	double dot = 0.0;
+	double dot = 0.0, nrm = 0.0;
 	for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
 		const int64_t idl = i / n_up, iu = i - idl * n_up;
 		const int64_t p = iu / peru, iul = iu - p * peru;
 		const T xv = VT<T>::add(x[i], recv[p * chunk + idl * peru + iul]);
 		x[i] = xv;
-		if (DOT) dot += VT<T>::dot_re(y[i], xv);
+		if (DOT) {
+			dot += VT<T>::dot_re(y[i], xv);
+			nrm += VT<T>::dot_re(xv, xv);
+		}
 	}
-	if (DOT) {
+	if (DOT) { // partial[2b] = Re<y|x>, partial[2b+1] = |x|^2: both travel in ONE all-reduce (see k_b2_from_w)
 		const double r = block_sum(dot, smem);
-		if (threadIdx.x == 0) partial[blockIdx.x] = r;
+		if (threadIdx.x == 0) partial[2 * blockIdx.x] = r;
+		const double q = block_sum(nrm, smem);
+		if (threadIdx.x == 0) partial[2 * blockIdx.x + 1] = q;
+	}
+}
+
+// One all-reduce per Lanczos step.  In the scale-free recurrence r_{j+1} = w - (raw/b_{j-1}^2) r_j with
+// raw = Re<r_j|w> and |r_j|^2 = b_{j-1}^2, so   b_j^2 = |r_{j+1}|^2 = |w|^2 - raw^2 / b_{j-1}^2 :
+// the product's last kernel sums Re<r_j|w> and |w|^2 together, both are reduced over the ranks in one call, and this kernel
+// turns ab[1] from |w|^2 into b_j^2 -- the axpy pass then needs no reduction of its own.
+static __global__ void k_b2_from_w(double* __restrict__ ab, const double* __restrict__ b2_prev)
+{
+	if (threadIdx.x == 0 && blockIdx.x == 0) {
+		const double raw = ab[0], w2 = ab[1], bp = *b2_prev;
+		double b2 = w2;
+		if (sqrt(bp) >= 1e-10) b2 = w2 - raw * raw / bp;
+		ab[1] = b2 > 0.0 ? b2 : 0.0;
 	}
 }
 

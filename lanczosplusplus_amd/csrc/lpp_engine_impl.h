@@ -207,7 +207,8 @@ void free_csr(DevCsr& A);
 lpp_status finalize_csr(lpp_engine* e, DevCsr& A, bool allow_drop_plain, int force_mode = 0, int64_t force_block = 0);
 void free_kron(lpp_engine* e);
 void drop_product(lpp_engine* e); // matrix-free state, split flags: called by every matrix setup
-int kron_launch(lpp_engine* e, const void* ywin, const void* ydown, void* x, double* partial, const EpiScale& sc = EpiScale { nullptr, nullptr, 0 }, int part = 0);
+int kron_launch(lpp_engine* e, const void* ywin, const void* ydown, void* x, double* partial, const EpiScale& sc = EpiScale { nullptr, nullptr, 0 }, int part = 0,
+                int64_t b0 = 0, int64_t cnt = -1); // blocks [b0, b0+cnt) of the slice (parts 0 and 1)
 void set_spmv_bytes(lpp_engine* e);
 lpp_status alloc_work(lpp_engine* e);
 int spmv_launch(lpp_engine* e, const DevCsr& A, const void* src, void* x, const void* ydot, double* partial, const EpiScale& sc = EpiScale { nullptr, nullptr, 0 });

@@ -142,6 +142,7 @@ lpp_status one_step(lpp_engine* e, const double* ritz, int nst)
 	double* ycur = e->ycur;
 	double* xcur = e->xcur;
 	int np = 0;
+	bool tx_pair = false;
 	if (ritz) {
 		for (int k = 0; k < nst; k++)
 			k_axpy_const<<<nb, kBlock, 0, st>>>((double2*)(e->zwork + (int64_t)k * e->nd_pad), (const double2*)ycur, ritz[k], e->n2);
@@ -167,10 +168,14 @@ lpp_status one_step(lpp_engine* e, const double* ritz, int nst)
 		else
 			k_pack_transpose<double><<<nbp, kBlock, 0, st>>>((const double*)ycur, (double*)e->comm.send_buf, nid, n_up, e->tx_peru, chunk);
 		if (e->comm.exchange_begin(e->comm.ctx, 0) != 0) return fail(LPP_ERR_COMM, "exchange_begin(0) callback failed");
+		// The local part (diagonal / U + up-hops on the own slice) needs no exchange.  The matrix-free engine runs the first
+		// half of its blocks beside all-to-all #1 and the second half beside all-to-all #2, so both transfers have a kernel to
+		// hide behind; the stored local matrix is one launch, beside #1.
+		const int64_t half = e->kron.active ? (nid + 1) / 2 : nid;
 		{
 			SpmvTimer t(e); // overlaps all-to-all #1
 			if (e->kron.active)
-				kron_launch(e, ycur, ycur, xcur, nullptr, sc, 1);
+				kron_launch(e, ycur, ycur, xcur, nullptr, sc, 1, 0, half);
 			else
 				spmv_launch(e, e->A_loc, ycur, xcur, nullptr, nullptr, sc);
 			t.stop();
@@ -188,12 +193,18 @@ lpp_status one_step(lpp_engine* e, const double* ritz, int nst)
 			t.stop();
 		}
 		if (e->comm.exchange_begin(e->comm.ctx, 1) != 0) return fail(LPP_ERR_COMM, "exchange_begin(1) callback failed");
+		if (half < nid) {
+			SpmvTimer t(e); // overlaps all-to-all #2
+			kron_launch(e, ycur, ycur, xcur, nullptr, sc, 1, half, nid - half);
+			t.stop();
+		}
 		if (e->comm.exchange_end(e->comm.ctx, 1) != 0) return fail(LPP_ERR_COMM, "exchange_end(1) callback failed");
 		if (e->is_complex)
 			k_unpack_add_dot<cplx, true><<<nbp, kBlock, 0, st>>>((cplx*)xcur, (const cplx*)e->comm.recv2_buf, (const cplx*)ycur, nid, n_up, e->tx_peru, chunk, e->partial);
 		else
 			k_unpack_add_dot<double, true><<<nbp, kBlock, 0, st>>>((double*)xcur, (const double*)e->comm.recv2_buf, (const double*)ycur, nid, n_up, e->tx_peru, chunk, e->partial);
 		np = nbp;
+		tx_pair = true; // the partials come in (Re<y|x>, |x|^2) pairs
 	} else if (e->pb.active) {
 		SpmvTimer t(e);
 		np = pb_launch(e, ycur, xcur, e->partial, sc, e->scalefree); // scale-free: x is formed by pb_combine_axpy below
@@ -229,14 +240,22 @@ lpp_status one_step(lpp_engine* e, const double* ritz, int nst)
 		t.stop();
 	}
 	const bool pb_sf = e->pb.active && e->scalefree;
+	// transposition exchange + scale-free recurrence: a_j and b_j^2 share ONE all-reduce (k_b2_from_w)
+	const bool fused_ab = tx_pair && e->scalefree && !(getenv("LPP_FUSED_ALLREDUCE") && atoi(getenv("LPP_FUSED_ALLREDUCE")) == 0);
+	lpp_status rc = LPP_OK;
 	if (pb_sf) // the product kernels never read x: raw_j = Re<y | u + z> + beta Re<y | x_old>
 		k_pb_reduce_a<<<1, kBlock, 0, st>>>(e->partial, np, e->pb.xy, sc, a_ptr);
+	else if (tx_pair)
+		k_reduce_final<<<1, kBlock, 0, st>>>(e->partial, np, 2, fused_ab ? 2 : 1, a_ptr); // a_ptr[0] = a_j (raw), a_ptr[1] = |w|^2
 	else
 		k_reduce_final<<<1, kBlock, 0, st>>>(e->partial, np, 1, 1, a_ptr);
-	lpp_status rc = comm_allreduce(e, e->ab_off + 2 * j, 1);
+	rc = comm_allreduce(e, e->ab_off + 2 * j, fused_ab ? 2 : 1);
 	if (rc != LPP_OK) return rc;
 	int nb_nrm = nb;
-	if (pb_sf) {
+	if (fused_ab) {
+		k_b2_from_w<<<1, 64, 0, st>>>(a_ptr, b2_prev);
+		k_axpy_nrm<false><<<nb, kBlock, 0, st>>>((double2*)xcur, (const double2*)ycur, a_ptr, b2_prev, nullptr, e->n2, nullptr, 0, e->nd);
+	} else if (pb_sf) {
 		nb_nrm = pb_combine_axpy(e, xcur, ycur, sc, a_ptr, b2_prev, e->partial);
 	} else if (e->scalefree) {
 		// streamed accesses once the two vectors no longer fit the 256 MiB Infinity Cache (measured: +4 % there, -7 % below)
@@ -251,9 +270,11 @@ lpp_status one_step(lpp_engine* e, const double* ritz, int nst)
 	} else {
 		k_axpy_nrm<true><<<nb, kBlock, 0, st>>>((double2*)xcur, (const double2*)ycur, a_ptr, nullptr, nullptr, e->n2, e->partial);
 	}
-	k_reduce_final<<<1, kBlock, 0, st>>>(e->partial, nb_nrm, 1, 1, b2_ptr);
-	rc = comm_allreduce(e, e->ab_off + 2 * j + 1, 1);
-	if (rc != LPP_OK) return rc;
+	if (!fused_ab) {
+		k_reduce_final<<<1, kBlock, 0, st>>>(e->partial, nb_nrm, 1, 1, b2_ptr);
+		rc = comm_allreduce(e, e->ab_off + 2 * j + 1, 1);
+		if (rc != LPP_OK) return rc;
+	}
 	if (e->scalefree) {
 		// roles swap: the buffer that held r_{j-1} now holds r_{j+1}
 		e->ycur = xcur;

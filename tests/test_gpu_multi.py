@@ -180,8 +180,10 @@ def _worker_uneven(rank, world, port, q):
         with comm_t.stream_context():
             e = lp.LanczosEngine(max_steps=200, stream=comm_t.stream_handle)
             e.assemble_hubbard(L, nup, ndown, hop, U, comm=comm_t)
+            ar0 = comm_t.calls["allreduce"]
             eg, _, st = e.lanczos(1, want_vectors=False)  # scale-free recurrence
             out["e_tx"], out["steps_tx"] = float(eg[0]), st["steps"]
+            out["ar_tx"] = comm_t.calls["allreduce"] - ar0
             eg, zg, st = e.lanczos(1, want_vectors=True)  # normalised recurrence, Krylov basis kept
             out["e_tx2"] = float(eg[0])
             zs = [None] * world
@@ -237,6 +239,9 @@ def test_four_ranks_uneven_shards():
         assert abs(o["e_tx"] - o["e_oracle"]) <= 1e-10 * abs(o["e_oracle"]) and o["steps_tx"] == o["steps_oracle"]
         assert abs(o["e_tx2"] - o["e_oracle"]) <= 1e-10 * abs(o["e_oracle"])
         assert o["xchg_calls"] > 0
+        # a_j and b_j^2 travel in ONE all-reduce per step; the few extra calls are the start vector's norm
+        # and the steps already in flight when the lagged convergence check fires -- two per step would be >= 148 here
+        assert o["steps_tx"] <= o["ar_tx"] <= o["steps_tx"] + 8, (o["ar_tx"], o["steps_tx"])
         assert abs(o["e_kron_tx"] - o["e_oracle"]) <= 1e-10 * abs(o["e_oracle"]) and o["steps_kron_tx"] == o["steps_oracle"]
         assert abs(o["e_tx_c"] - o["e_oracle_c"]) <= 1e-10 * abs(o["e_oracle_c"]) and o["steps_tx_c"] == o["steps_oracle_c"]
         assert abs(o["e_kron_tx_c"] - o["e_oracle_c"]) <= 1e-10 * abs(o["e_oracle_c"])
