@@ -186,10 +186,12 @@ __global__ __launch_bounds__(kBlock) void k_pack_transpose(const T* __restrict__
 template <typename T, bool DOT>
 __global__ __launch_bounds__(kBlock) void k_unpack_add_dot(T* __restrict__ x, const T* __restrict__ recv,
                                                             const T* __restrict__ y, int64_t nid, int64_t n_up,
-                                                            int64_t peru, int64_t chunk, double* __restrict__ partial)
+                                                            int64_t peru, int64_t chunk, double* __restrict__ partial,
+                                                            const double* __restrict__ shift = nullptr)
 {
 	__shared__ double smem[kBlock / 64];
 	const int64_t n = nid * n_up;
+	const double sh = shift ? *shift : 0.0;
 	double dot = 0.0, nrm = 0.0;
 	for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
 		const int64_t idl = i / n_up, iu = i - idl * n_up;
@@ -197,11 +199,13 @@ __global__ __launch_bounds__(kBlock) void k_unpack_add_dot(T* __restrict__ x, co
 		const T xv = VT<T>::add(x[i], recv[p * chunk + idl * peru + iul]);
 		x[i] = xv;
 		if (DOT) {
-			dot += VT<T>::dot_re(y[i], xv);
-			nrm += VT<T>::dot_re(xv, xv);
+			const T yv = y[i];
+			const T d = VT<T>::sub_scaled(xv, sh, yv);
+			dot += VT<T>::dot_re(yv, xv);
+			nrm += VT<T>::dot_re(d, d);
 		}
 	}
-	if (DOT) { // partial[2b] = Re<y|x>, partial[2b+1] = |x|^2: both travel in ONE all-reduce (see k_b2_from_w)
+	if (DOT) { // partial[2b] = Re<y|x>, partial[2b+1] = |x - s y|^2: both travel in ONE all-reduce (see k_b2_from_w)
 		const double r = block_sum(dot, smem);
 		if (threadIdx.x == 0) partial[2 * blockIdx.x] = r;
 		const double q = block_sum(nrm, smem);
@@ -209,17 +213,28 @@ __global__ __launch_bounds__(kBlock) void k_unpack_add_dot(T* __restrict__ x, co
 	}
 }
 
-// One all-reduce per Lanczos step.  In the scale-free recurrence r_{j+1} = w - (raw/b_{j-1}^2) r_j with
-// raw = Re<r_j|w> and |r_j|^2 = b_{j-1}^2, so   b_j^2 = |r_{j+1}|^2 = |w|^2 - raw^2 / b_{j-1}^2 :
-// the product's last kernel sums Re<r_j|w> and |w|^2 together, both are reduced over the ranks in one call, and this kernel
-// turns ab[1] from |w|^2 into b_j^2 -- the axpy pass then needs no reduction of its own.
-static __global__ void k_b2_from_w(double* __restrict__ ab, const double* __restrict__ b2_prev)
+// One reduction per Lanczos step: b_j^2 without a pass (and an all-reduce) of its own.
+// In the scale-free recurrence r_{j+1} = w - (raw/b_{j-1}^2) r_j with raw = Re<r_j|w> and |r_j|^2 = b_{j-1}^2, and for ANY real s
+//     b_j^2 = |r_{j+1}|^2 = |w - s r_j|^2 - (raw - s b_{j-1}^2)^2 / b_{j-1}^2
+// (r_{j+1} does not depend on a shift of H).  With s = 0 this is |w|^2 - a_j^2: it cancels, and worse, the error of the previous
+// norm enters multiplied by a_j^2 / b_j^2 -- measured on the 12-site Hubbard chain (a = 12, b = 9): the coefficients drift apart
+// by a factor 1.7 per step and the run stops 16 steps early, 1.4e-7 off.  With s = a_{j-1} / b_{j-1} (last step's diagonal
+// coefficient as the shift) the subtracted term is (a_j - a_{j-1})^2, far below b_j^2, and the recursion contracts.
+// The product's last kernel therefore sums Re<r_j|w> and |w - s r_j|^2 ELEMENTWISE (s from *shift); both are reduced (over the
+// ranks: in one all-reduce) and this kernel turns ab[1] into b_j^2 and leaves the next step's s in *shift.
+static __global__ void k_b2_from_w(double* __restrict__ ab, const double* __restrict__ b2_prev, double* __restrict__ shift)
 {
 	if (threadIdx.x == 0 && blockIdx.x == 0) {
-		const double raw = ab[0], w2 = ab[1], bp = *b2_prev;
-		double b2 = w2;
-		if (sqrt(bp) >= 1e-10) b2 = w2 - raw * raw / bp;
-		ab[1] = b2 > 0.0 ? b2 : 0.0;
+		const double raw = ab[0], ws = ab[1], bp = *b2_prev, s = *shift;
+		double b2 = ws;
+		const bool ok = sqrt(bp) >= 1e-10;
+		if (ok) {
+			const double rs = raw - s * bp;
+			b2 = ws - rs * rs / bp;
+		}
+		b2 = b2 > 0.0 ? b2 : 0.0;
+		ab[1] = b2;
+		*shift = (ok && sqrt(b2) >= 1e-10) ? raw / (sqrt(bp) * sqrt(b2)) : 0.0;
 	}
 }
 

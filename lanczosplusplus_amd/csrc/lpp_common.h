@@ -49,6 +49,7 @@ template <> struct VT<double> {
 	static __device__ __forceinline__ void mac(double& acc, double v, double y) { acc += v * y; }
 	static __device__ __forceinline__ double add(double a, double b) { return a + b; }
 	static __device__ __forceinline__ double dot_re(double y, double x) { return y * x; } // Re(y conj x)
+	static __device__ __forceinline__ double sub_scaled(double x, double s, double y) { return x - s * y; }
 	static __device__ __forceinline__ double shfl_down(double v, int off, int w) { return __shfl_down(v, off, w); }
 };
 template <> struct VT<cplx> {
@@ -60,6 +61,7 @@ template <> struct VT<cplx> {
 	}
 	static __device__ __forceinline__ cplx add(cplx a, cplx b) { return cplx { a.re + b.re, a.im + b.im }; }
 	static __device__ __forceinline__ double dot_re(cplx y, cplx x) { return y.re * x.re + y.im * x.im; }
+	static __device__ __forceinline__ cplx sub_scaled(cplx x, double s, cplx y) { return cplx { x.re - s * y.re, x.im - s * y.im }; }
 	static __device__ __forceinline__ cplx shfl_down(cplx v, int off, int w)
 	{
 		return cplx { __shfl_down(v.re, off, w), __shfl_down(v.im, off, w) };

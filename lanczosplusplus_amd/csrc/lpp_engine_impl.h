@@ -119,6 +119,11 @@ struct PbState {
 	hipStream_t stream2 = nullptr; // k_pb_down runs here, beside k_pb_up on the engine's stream
 	hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 	double* xy = nullptr; // device scalar: Re<x|y> left by the last combine pass = the next step's <y | x_old>
+	// chained scale-free steps (pb_launch_chain): the pass r_{j+1} = w_j - g r_j of the last step has not been run yet;
+	// ycur holds w_j, xcur holds r_j, g = *pend_a / *pend_b2
+	bool pending = false;
+	const double* pend_a = nullptr;
+	const double* pend_b2 = nullptr;
 	// diagonal
 	double* dict = nullptr; // 256 doubles
 	int ndict = 0;
@@ -220,6 +225,9 @@ lpp_status pb_build(lpp_engine* e, int64_t n_up, int64_t n_blk, const int64_t* t
                     const int64_t* c_rp, const int32_t* c_ci, const double* c_va, const double* dict256, int ndict);
 int pb_launch(lpp_engine* e, const void* y, void* x, double* partial, const EpiScale& sc = EpiScale { nullptr, nullptr, 0 }, bool defer_combine = false);
 // the streaming pass of the scale-free Lanczos step on a product-basis matrix: x = beta x + u + z - (a/b2_prev) y, |x|^2 partials
+bool pb_chain_ok(const lpp_engine* e);
+int pb_launch_chain(lpp_engine* e, void* w, void* y, double* partial, const EpiScale& sc, const double* g_a, const double* g_b2, const double* shift);
+void pb_materialise(lpp_engine* e, void* y, const void* x, const double* g_a, const double* g_b2, double* partial);
 int pb_combine_axpy(lpp_engine* e, void* x, const void* y, const EpiScale& sc, const double* a_ptr, const double* b2_prev, double* partial);
 lpp_status pb_get_csr(lpp_engine* e, int64_t* rowptr, int32_t* colind, void* values);
 int64_t pb_pitch_for(int64_t n_up);

@@ -143,6 +143,13 @@ lpp_status one_step(lpp_engine* e, const double* ritz, int nst)
 	double* xcur = e->xcur;
 	int np = 0;
 	bool tx_pair = false;
+	// product-basis layout, no vectors kept: two launches per step, the axpy of step j rides in the product of step j+1
+	const bool pb_chain = e->pb.active && e->scalefree && !ritz && pb_chain_ok(e);
+	if (e->pb.pending && !pb_chain) { // someone needs r_j itself: run the pass the chain left out
+		pb_materialise(e, ycur, xcur, e->pb.pend_a, e->pb.pend_b2, e->partial);
+		e->pb.pending = false;
+	HIP_TRY(hipMemsetAsync(e->tmp_dev + 1, 0, sizeof(double), st)); // shift of the derived norm (k_b2_from_w): none at step 0
+	}
 	if (ritz) {
 		for (int k = 0; k < nst; k++)
 			k_axpy_const<<<nb, kBlock, 0, st>>>((double2*)(e->zwork + (int64_t)k * e->nd_pad), (const double2*)ycur, ritz[k], e->n2);
@@ -200,11 +207,16 @@ lpp_status one_step(lpp_engine* e, const double* ritz, int nst)
 		}
 		if (e->comm.exchange_end(e->comm.ctx, 1) != 0) return fail(LPP_ERR_COMM, "exchange_end(1) callback failed");
 		if (e->is_complex)
-			k_unpack_add_dot<cplx, true><<<nbp, kBlock, 0, st>>>((cplx*)xcur, (const cplx*)e->comm.recv2_buf, (const cplx*)ycur, nid, n_up, e->tx_peru, chunk, e->partial);
+			k_unpack_add_dot<cplx, true><<<nbp, kBlock, 0, st>>>((cplx*)xcur, (const cplx*)e->comm.recv2_buf, (const cplx*)ycur, nid, n_up, e->tx_peru, chunk, e->partial, e->scalefree ? e->tmp_dev + 1 : nullptr);
 		else
-			k_unpack_add_dot<double, true><<<nbp, kBlock, 0, st>>>((double*)xcur, (const double*)e->comm.recv2_buf, (const double*)ycur, nid, n_up, e->tx_peru, chunk, e->partial);
+			k_unpack_add_dot<double, true><<<nbp, kBlock, 0, st>>>((double*)xcur, (const double*)e->comm.recv2_buf, (const double*)ycur, nid, n_up, e->tx_peru, chunk, e->partial, e->scalefree ? e->tmp_dev + 1 : nullptr);
 		np = nbp;
 		tx_pair = true; // the partials come in (Re<y|x>, |x|^2) pairs
+	} else if (pb_chain) {
+		SpmvTimer t(e);
+		np = pb_launch_chain(e, ycur, xcur, e->partial, sc, e->pb.pending ? e->pb.pend_a : nullptr, e->pb.pend_b2, e->tmp_dev + 1);
+		t.stop();
+		tx_pair = true; // pairs (Re<r_j|w_j>, |w_j|^2)
 	} else if (e->pb.active) {
 		SpmvTimer t(e);
 		np = pb_launch(e, ycur, xcur, e->partial, sc, e->scalefree); // scale-free: x is formed by pb_combine_axpy below
@@ -239,9 +251,9 @@ lpp_status one_step(lpp_engine* e, const double* ritz, int nst)
 		np = spmv_launch(e, e->A_loc, ycur, xcur, ycur, e->partial, sc);
 		t.stop();
 	}
-	const bool pb_sf = e->pb.active && e->scalefree;
+	const bool pb_sf = e->pb.active && e->scalefree && !pb_chain;
 	// transposition exchange + scale-free recurrence: a_j and b_j^2 share ONE all-reduce (k_b2_from_w)
-	const bool fused_ab = tx_pair && e->scalefree && !(getenv("LPP_FUSED_ALLREDUCE") && atoi(getenv("LPP_FUSED_ALLREDUCE")) == 0);
+	const bool fused_ab = pb_chain || (tx_pair && e->scalefree && !(getenv("LPP_FUSED_ALLREDUCE") && atoi(getenv("LPP_FUSED_ALLREDUCE")) == 0));
 	lpp_status rc = LPP_OK;
 	if (pb_sf) // the product kernels never read x: raw_j = Re<y | u + z> + beta Re<y | x_old>
 		k_pb_reduce_a<<<1, kBlock, 0, st>>>(e->partial, np, e->pb.xy, sc, a_ptr);
@@ -252,8 +264,13 @@ lpp_status one_step(lpp_engine* e, const double* ritz, int nst)
 	rc = comm_allreduce(e, e->ab_off + 2 * j, fused_ab ? 2 : 1);
 	if (rc != LPP_OK) return rc;
 	int nb_nrm = nb;
-	if (fused_ab) {
-		k_b2_from_w<<<1, 64, 0, st>>>(a_ptr, b2_prev);
+	if (pb_chain) {
+		k_b2_from_w<<<1, 64, 0, st>>>(a_ptr, b2_prev, e->tmp_dev + 1);
+		e->pb.pending = true; // r_{j+1} = w_j - (raw_j / b_{j-1}^2) r_j is formed by the next step's k_pb_up
+		e->pb.pend_a = a_ptr;
+		e->pb.pend_b2 = b2_prev;
+	} else if (fused_ab) {
+		k_b2_from_w<<<1, 64, 0, st>>>(a_ptr, b2_prev, e->tmp_dev + 1);
 		k_axpy_nrm<false><<<nb, kBlock, 0, st>>>((double2*)xcur, (const double2*)ycur, a_ptr, b2_prev, nullptr, e->n2, nullptr, 0, e->nd);
 	} else if (pb_sf) {
 		nb_nrm = pb_combine_axpy(e, xcur, ycur, sc, a_ptr, b2_prev, e->partial);
@@ -375,6 +392,7 @@ lpp_status begin_run(lpp_engine* e, const void* init, bool want_save)
 	if (rc != LPP_OK) return rc;
 	HIP_TRY(hipMemcpyAsync(e->h_scal + 2 * e->M, e->tmp_dev, sizeof(double), hipMemcpyDeviceToHost, st)); // |init|^2 = b_{-1}^2
 	if (e->pb.active) HIP_TRY(hipMemsetAsync(e->pb.xy, 0, sizeof(double) * 2, st)); // <y | x_old> of step 0: x_old = 0
+	e->pb.pending = false;
 	if (e->scalefree) {
 		// r_0 = init stays unnormalised in e->x; e->y is the (zero) buffer of r_{-1}
 		e->ycur = e->x;

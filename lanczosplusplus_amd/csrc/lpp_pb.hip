@@ -232,6 +232,8 @@ int pb_launch(lpp_engine* e, const void* y, void* x, double* partial, const EpiS
 		d.dict = B.dict;
 		d.y = (const double*)y;
 		d.z = B.z;
+		d.u_in = nullptr;
+		d.shift = nullptr;
 		d.partial = partial ? partial + nb : nullptr;
 		d.sc = sc;
 		d.pace = B.pace;
@@ -264,6 +266,8 @@ int pb_launch(lpp_engine* e, const void* y, void* x, double* partial, const EpiS
 	u.u = B.u;
 	u.partial = partial;
 	u.sc = sc;
+	u.wbuf = u.ybuf = nullptr;
+	u.g_a = u.g_b2 = nullptr;
 	const size_t lds = pb_up_lds_bytes(B.pitch, B.spb, B.G);
 	bool lean = concurrent;
 	if (const char* s = getenv("LPP_PB_UP_LEAN")) lean = atoi(s) != 0;
@@ -295,6 +299,84 @@ int pb_launch(lpp_engine* e, const void* y, void* x, double* partial, const EpiS
 		if (want_dot) np = nbc;
 	}
 	return np;
+}
+
+// ---- the chained scale-free step (k_pb_up<KC>, k_pb_down<RMW>) -------------------------------------------------
+bool pb_chain_ok(const lpp_engine* e)
+{
+	const PbState& B = e->pb;
+	if (getenv("LPP_PB_CHAIN") && atoi(getenv("LPP_PB_CHAIN")) == 0) return false;
+	return B.active && B.c_nnz > 0 && (B.G == 1 || B.G == 2);
+}
+
+template <int GT> static void launch_up_chain(const PbUpArgs& u, int nb, size_t lds, hipStream_t st)
+{
+	(void)hipFuncSetAttribute((const void*)k_pb_up<false, GT, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+	k_pb_up<false, GT, false, true><<<nb, kPbUpThreads, lds, st>>>(u);
+}
+
+// One scale-free Lanczos step in two launches.  In: w (= w_{j-1}, or r_j itself when g_a is null) and y (= r_{j-1}).
+// Out: w holds r_j, y holds w_j = alpha H r_j + beta r_{j-1} (the in-block part passes through pb.u); partial holds pairs (Re<r_j|w_j>, |w_j|^2), their number is returned.
+int pb_launch_chain(lpp_engine* e, void* w, void* y, double* partial, const EpiScale& sc, const double* g_a, const double* g_b2, const double* shift)
+{
+	PbState& B = e->pb;
+	hipStream_t st = e->stream;
+	const int nb = (int)std::max<int64_t>(1, std::min<int64_t>(B.n_blk, (int64_t)e->num_cus));
+	PbUpArgs u;
+	u.tw = B.tw;
+	u.tw_off = B.tw_off;
+	u.tw_len = B.tw_len;
+	u.G = B.G;
+	for (int g = 0; g < kPbMaxGroups; g++) u.gval[g] = B.gval[g];
+	u.dict = B.dict;
+	u.dcode = B.dcode;
+	u.n_up = B.n_up;
+	u.pitch = B.pitch;
+	u.n_blk = B.n_blk;
+	u.spb = B.spb;
+	u.y = nullptr;
+	u.u = B.u;
+	u.partial = nullptr;
+	u.sc = sc;
+	u.wbuf = (double*)w;
+	u.ybuf = (double*)y;
+	u.g_a = g_a;
+	u.g_b2 = g_b2;
+	const size_t lds = pb_up_lds_bytes(B.pitch, B.spb, B.G);
+	if (B.G == 1) launch_up_chain<1>(u, nb, lds, st);
+	else launch_up_chain<2>(u, nb, lds, st);
+	PbDownArgs d;
+	d.pitch = B.pitch;
+	d.n_blk = B.n_blk;
+	d.npanels = (int)(B.pitch / 16);
+	d.ids_per_wg = B.ids_per_wg;
+	d.rowcap = B.rowcap;
+	d.c_ptr = B.c_ptr;
+	d.c_col = B.c_col;
+	d.c_code = B.c_code;
+	d.dict = B.dict;
+	d.y = (const double*)w;
+	d.z = (double*)y;
+	d.u_in = B.u;
+	d.shift = shift;
+	d.partial = partial;
+	d.sc = sc;
+	d.pace = B.pace;
+	d.order = B.order;
+	if (d.pace) (void)hipMemsetAsync(d.pace, 0, sizeof(int) * 8 * (size_t)d.npanels, st);
+	(void)hipFuncSetAttribute((const void*)k_pb_down<1024, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B.down_lds);
+	k_pb_down<1024, true><<<B.down_grid, 1024, B.down_lds, st>>>(d);
+	return B.down_grid;
+}
+
+// leave the chained form: run the pending pass y = y - g x and restore the carried <y | x_old>
+void pb_materialise(lpp_engine* e, void* y, const void* x, const double* g_a, const double* g_b2, double* partial)
+{
+	const PbState& B = e->pb;
+	const int64_t n2 = (B.n_blk * B.pitch) >> 1;
+	const int nb = combine_blocks(n2);
+	k_pb_materialise<<<nb, kBlock, 0, e->stream>>>((double2*)y, (const double2*)x, g_a, g_b2, n2, partial);
+	k_reduce_final<<<1, kBlock, 0, e->stream>>>(partial, nb, 1, 1, B.xy);
 }
 
 int pb_combine_axpy(lpp_engine* e, void* x, const void* y, const EpiScale& sc, const double* a_ptr, const double* b2_prev, double* partial)

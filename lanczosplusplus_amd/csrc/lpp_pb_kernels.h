@@ -42,7 +42,12 @@ struct PbUpArgs {
 	const double* y;
 	double* u; // out: alpha (T y + D y), pitched
 	double* partial; // per-workgroup Re<y|u> (null: not wanted)
-	EpiScale sc; // only alpha is used
+	EpiScale sc; // only alpha is used (chained form: alpha and beta)
+	// chained form (KC > 0), see k_pb_up: wbuf holds w_{j-1} and receives r_j, ybuf holds r_{j-1} and receives the in-block part of w_j
+	double* wbuf;
+	double* ybuf;
+	const double* g_a; // raw_{j-1} (null: the vector in wbuf is r_j already, nothing to subtract)
+	const double* g_b2; // b_{j-2}^2
 };
 
 constexpr int kPbPre = 4; // chunks (of 4 slots) of every (slice, group) requested one slice ahead
@@ -92,7 +97,16 @@ __host__ __device__ inline size_t pb_up_lds_bytes(int64_t pitch, int spb, int G)
 // LEAN: at most 64 registers per lane (8 waves per SIMD's worth), so that a workgroup of k_pb_down fits on the same CU and the
 // two kernels -- one bound by LDS / vector issue, the other by L2 gathers, both waiting most of the time -- fill each other's
 // stalls: no second register set for the next slice's words (the other kernel's waves cover that latency instead).
-template <bool DOT, int GT, bool LEAN> __global__ __launch_bounds__(kPbUpThreads, LEAN ? 8 : 4) void k_pb_up(PbUpArgs a)
+//
+// CHAIN: the chained form of the scale-free Lanczos step (pb_launch_chain).  The previous step left w = H r/b - (b/b') r' complete
+// in wbuf and its own vector r in ybuf, but did NOT run the pass  r_next = w - g r  (g = raw / b^2): this kernel does it while it
+// stages the row -- it reads both rows, keeps r_next in the LDS window and writes it back over w (k_pb_down gathers from there).
+// Its result u = alpha (T r_next + D r_next) goes to the buffer u as always; k_pb_down<RMW> then forms the new
+//   w = u + beta r + alpha C r_next   over r in ybuf.
+// A step is 8 passes over the vector (here: 2 reads, 2 writes; there: the gathers, 2 reads, 1 write) in two launches, instead of
+// 9 in three with the separate combine pass (2 + 2 + 5).  (Keeping the old row in registers for the beta term here would save
+// one more pass, but 2 x 13 registers on top of the look-ahead words spill: 476 bytes of scratch per lane at KC = 14.)
+template <bool DOT, int GT, bool LEAN, bool CHAIN = false> __global__ __launch_bounds__(kPbUpThreads, LEAN ? 8 : 4) void k_pb_up(PbUpArgs a)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
 	double* win = (double*)lds_raw; // pitch + kPbZeroSlots elements, at LDS address 0
@@ -108,6 +122,12 @@ template <bool DOT, int GT, bool LEAN> __global__ __launch_bounds__(kPbUpThreads
 	}
 	double alpha, beta_unused;
 	epi_coeffs(a.sc, alpha, beta_unused);
+	double gco = 0.0; // chained form: r_next = w - gco r
+	if (CHAIN && a.g_a) {
+		gco = *a.g_a;
+		const double b2 = *a.g_b2;
+		if (sqrt(b2) >= 1e-10) gco /= b2;
+	}
 	constexpr int NW = kPbUpThreads / 64;
 	constexpr int GG = GT > 0 ? GT : 1;
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -134,7 +154,35 @@ template <bool DOT, int GT, bool LEAN> __global__ __launch_bounds__(kPbUpThreads
 		__syncthreads(); // everyone is done with the previous window (and the metadata is in place)
 		// stage the row of y (8 independent 16-byte loads per thread in flight, branch-free: indices beyond the row are clamped,
 		// those threads re-load and re-store the last element) and the block's diagonal codes
-		{
+		if (CHAIN) {
+			double2* const wb = (double2*)(a.wbuf + rowbase);
+			const double2* const yo = (const double2*)(a.ybuf + rowbase);
+			constexpr int NS = 4;
+			for (int i0 = threadIdx.x; i0 < p2; i0 += NS * kPbUpThreads) {
+				// loads unconditional and clamped (all of them in flight together); stores only from the lane that owns the pair -- a
+				// clamped lane would subtract g r a second time from a pair its owner has already updated in place
+				double2 wv[NS], yv[NS];
+				int idx[NS];
+#pragma unroll
+				for (int q = 0; q < NS; q++) idx[q] = min(i0 + q * kPbUpThreads, p2 - 1);
+#pragma unroll
+				for (int q = 0; q < NS; q++) wv[q] = wb[idx[q]];
+				if (gco != 0.0) {
+#pragma unroll
+					for (int q = 0; q < NS; q++) yv[q] = yo[idx[q]];
+#pragma unroll
+					for (int q = 0; q < NS; q++) {
+						wv[q].x -= gco * yv[q].x; // padding: 0 - g 0
+						wv[q].y -= gco * yv[q].y;
+						if (i0 + q * kPbUpThreads < p2) wb[idx[q]] = wv[q];
+					}
+				}
+#pragma unroll
+				for (int q = 0; q < NS; q++)
+					if (i0 + q * kPbUpThreads < p2) ((double2*)win)[idx[q]] = wv[q];
+			}
+			for (int i0 = threadIdx.x; i0 < p16; i0 += kPbUpThreads) ((uint4*)dcode_s)[i0] = db[i0];
+		} else {
 			constexpr int NS = LEAN ? 4 : 8; // loads per thread and pass
 			for (int pass = 0; pass < 8 / NS; pass++) {
 				double2 t[NS];
@@ -278,12 +326,18 @@ struct PbDownArgs {
 	const double* dict;
 	const double* y; // addressed with 32-bit byte offsets (< 4 GiB)
 	double* z;
-	double* partial; // per-workgroup Re<y|z> (null: not wanted)
+	const double* u_in; // RMW: the in-block part of the product (k_pb_up's u)
+	const double* shift; // RMW: s of the second partial |w - s y|^2 (k_b2_from_w)
+	double* partial; // per-workgroup Re<y|z> (null: not wanted); RMW: pairs (Re<y|z>, |z|^2) of the finished z
 	EpiScale sc; // only alpha is used: z = alpha * C y
 	int* pace; // [8][npanels] finished-workgroup counters (zeroed before the launch); null: free-running
 };
 
-template <int THREADS> __global__ __launch_bounds__(THREADS) void k_pb_down(PbDownArgs a)
+// RMW (chained Lanczos step, see k_pb_up): z holds the previous Lanczos vector r' and receives the finished
+//   w = u_in + beta r' + alpha C y;   the partials are Re<y|w> and |w - s y|^2 (k_b2_from_w).
+// The two HBM loads per task this needs are issued BEHIND the task's first two chunks of gathers: those are consumed without
+// waiting for them (in-order return), and by the third chunk they have had two consume phases.
+template <int THREADS, bool RMW = false> __global__ __launch_bounds__(THREADS) void k_pb_down(PbDownArgs a)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
 	__shared__ double dict_s[256];
@@ -296,9 +350,10 @@ template <int THREADS> __global__ __launch_bounds__(THREADS) void k_pb_down(PbDo
 	uint8_t* code_s = (uint8_t*)(idx_s + (size_t)a.ids_per_wg * stride); // [ids_per_wg][stride]
 	__shared__ double smem_d[THREADS / 64];
 	for (int i = threadIdx.x; i < 256; i += THREADS) dict_s[i] = a.dict[i];
-	double alpha, beta_unused;
-	epi_coeffs(a.sc, alpha, beta_unused);
-	double dot = 0.0;
+	double alpha, beta;
+	epi_coeffs(a.sc, alpha, beta);
+	double dot = 0.0, nrm = 0.0;
+	const double sh = RMW ? *a.shift : 0.0;
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = lane >> 3, c = lane & 7;
 	const int nx = (gridDim.x & 7) == 0 ? 8 : 1; // groups the panels are dealt over
 	const int grp = nx == 8 ? (int)(blockIdx.x & 7) : 0;
@@ -364,6 +419,14 @@ template <int THREADS> __global__ __launch_bounds__(THREADS) void k_pb_down(PbDo
 			};
 			if (n4 > 0) issue(0, ga);
 			if (n4 > 1) issue(1, gb);
+			double2* const zp = (double2*)((char*)a.z + (size_t)row_s[il] + colb);
+			double2 told = double2 { 0.0, 0.0 };
+			if (RMW) {
+				const double2 uo = nt_load2((const double2*)((const char*)a.u_in + (size_t)row_s[il] + colb));
+				const double2 xo = nt_load2(zp);
+				told.x = fma(beta, xo.x, uo.x);
+				told.y = fma(beta, xo.y, uo.y);
+			}
 			for (int ch = 0; ch < n4; ch += 3) { // wave-uniform conditions
 				if (ch + 2 < n4) issue(ch + 2, gc);
 				consume(ch, ga);
@@ -378,12 +441,15 @@ template <int THREADS> __global__ __launch_bounds__(THREADS) void k_pb_down(PbDo
 			}
 			const double2 yown = *(const double2*)(ysrc + (size_t)(row_s[il] + colb)); // the panel is in L2
 			if (valid) {
-				double2* zp = (double2*)((char*)a.z + (size_t)row_s[il] + colb);
-				acc.x *= alpha;
-				acc.y *= alpha;
+				acc.x = fma(alpha, acc.x, told.x);
+				acc.y = fma(alpha, acc.y, told.y);
 				__builtin_nontemporal_store(acc.x, &zp->x);
 				__builtin_nontemporal_store(acc.y, &zp->y);
 				dot += yown.x * acc.x + yown.y * acc.y;
+				if (RMW) {
+					const double dx = acc.x - sh * yown.x, dy = acc.y - sh * yown.y;
+					nrm += dx * dx + dy * dy;
+				}
 			}
 		}
 		if (a.pace) {
@@ -393,8 +459,34 @@ template <int THREADS> __global__ __launch_bounds__(THREADS) void k_pb_down(PbDo
 	}
 	if (a.partial) {
 		const double r = block_sum_n<THREADS / 64>(dot, smem_d);
-		if (threadIdx.x == 0) a.partial[blockIdx.x] = r;
+		if (threadIdx.x == 0) a.partial[RMW ? 2 * blockIdx.x : blockIdx.x] = r;
+		if (RMW) {
+			const double q = block_sum_n<THREADS / 64>(nrm, smem_d);
+			if (threadIdx.x == 0) a.partial[2 * blockIdx.x + 1] = q;
+		}
 	}
+}
+
+// leaving the chained form: the pending pass  y = y - g x  (g = *g_a / *g_b2), with the partials of Re<y_new|x> that the
+// three-kernel form carries as <y | x_old>
+static __global__ __launch_bounds__(kBlock) void k_pb_materialise(double2* __restrict__ y, const double2* __restrict__ x, const double* __restrict__ g_a,
+                                                                  const double* __restrict__ g_b2, int64_t n2, double* __restrict__ partial)
+{
+	__shared__ double smem[kBlock / 64];
+	double g = *g_a;
+	const double b2 = *g_b2;
+	if (sqrt(b2) >= 1e-10) g /= b2;
+	double c = 0.0;
+	for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n2; i += (int64_t)gridDim.x * kBlock) {
+		const double2 xv = x[i];
+		double2 yv = y[i];
+		yv.x -= g * xv.x;
+		yv.y -= g * xv.y;
+		y[i] = yv;
+		c += yv.x * xv.x + yv.y * xv.y;
+	}
+	const double r = block_sum(c, smem);
+	if (threadIdx.x == 0) partial[blockIdx.x] = r;
 }
 
 // The streaming pass behind a product.  The two product kernels leave u = alpha (T y + D y) and z = alpha C y; the new x is
