@@ -26,7 +26,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured float4 copy is ~6290 GB/s
 METRIC = "Lanczos iterations/sec + SpMV achieved HBM GB/s vs roofline, 1/2/4/8 GPU"
 # environment switches that change the kernel or the layout: a committed PMC traffic figure only applies without them
-LAYOUT_ENV = ("LPP_COMPRESS_VALUES", "LPP_SHARED_OFFSETS", "LPP_LOCAL16", "LPP_DIAG_CODES", "LPP_BLOCK_TEMPLATE", "LPP_SPMV_KERNEL",
+LAYOUT_ENV = ("LPP_PB_CHAIN", "LPP_COMPRESS_VALUES", "LPP_SHARED_OFFSETS", "LPP_LOCAL16", "LPP_DIAG_CODES", "LPP_BLOCK_TEMPLATE", "LPP_SPMV_KERNEL",
               "LPP_WINDOW_ROWS", "LPP_K2_VARIANT", "LPP_KRON_NO_WINDOW", "LPP_KRON_NO_PACK", "LPP_TEMPLATE_PACK", "LPP_PRODUCT_LAYOUT")
 
 
@@ -209,7 +209,14 @@ def kernel_name(engine, layout):
     return {"window": "k_spmv_window (stored matrix, LDS source window; x += H y, fused a_j partial)",
             "sliced": "k_spmv_sliced (stored matrix, wave-interleaved slices; x += H y, fused a_j partial)",
             "rowgroup": "k_spmv_rowgroup (plain CSR; x += H y, fused a_j partial)",
-            "product": "k_pb_up + k_pb_down (stored product-basis matrix: in-block part from the LDS window, block couplings panel-wise from L2)"}.get(k, str(k))
+            "product": ("k_pb_up<CHAIN> + k_pb_down<RMW> (stored product-basis matrix: in-block part from the LDS window, block couplings "
+                        "panel-wise from L2; the two launches are the WHOLE scale-free Lanczos step -- the previous step's axpy rides in k_pb_up)"
+                        if pb_chained() else
+                        "k_pb_up + k_pb_down (stored product-basis matrix: in-block part from the LDS window, block couplings panel-wise from L2)")}.get(k, str(k))
+
+
+def pb_chained():
+    return os.environ.get("LPP_PB_CHAIN", "1") != "0"
 
 
 def per_rank_bytes(eng, comm, st, esz, engine):
@@ -217,7 +224,10 @@ def per_rank_bytes(eng, comm, st, esz, engine):
     n = st["nrows"]
     b = 2.0 * n * esz
     if engine == "stored":
-        b += eng.layout(0)["resident_bytes"]
+        lay = eng.layout(0)
+        b += lay["resident_bytes"]
+        if lay["kernel"] == 4:  # product-basis layout: the two parts of a product have buffers of their own (pb.u, pb.z)
+            b += 2.0 * n * esz
         if comm is not None:
             b += eng.layout(1)["resident_bytes"]
     if comm is not None:
@@ -398,6 +408,10 @@ def main():
                       "local16_columns": bool(lay["local16"]), "block_template": lay["block_template"], "diagonal_codes": bool(lay["diagonal_codes"]), "per_row_entries": lay["per_row_entries"],
                       "shared_offset_entries": lay["shared_entries"], "resident_GB": round(lay["resident_bytes"] / 1e9, 2)}
             min_bytes = float(lay["stream_bytes"]) + 3.0 * st0["nrows"] * esz
+            if lay["kernel"] == 4 and pb_chained():
+                # the timed launches are product AND recurrence update: a two-phase step (the reduction a_j sits between the
+                # phases) cannot move less than  w = beta x + alpha H y (y, x in; w out)  +  x = w - g y (w, y in; x out)
+                min_bytes = float(lay["stream_bytes"]) + 6.0 * st0["nrows"] * esz
             if world > 1:
                 lay1 = eng.layout(1)
                 min_bytes += float(lay1["stream_bytes"])
@@ -412,6 +426,7 @@ def main():
                     "traffic": traffic, "achieved_basis": "pmc_traffic" if traffic else "min_bytes", "traffic_note": traffic_note,
                     "min_bytes": min_bytes, "wasted": (traffic / min_bytes) if traffic else None,
                     "kernel": kernel_name(args.engine, layout), "spmv_ms": spmv_ms_per_step, "launches_timed": launches,
+                    "covers": ("product + recurrence update (whole step)" if (layout or {}).get("kernel") == "product" and pb_chained() else "product x += H y"),
                     # the plain-CSR figure of SURVEY 8(d) (12 B per entry for f64): what a kernel streaming the reference's
                     # CrsMatrix would have to sustain for this time -- a compression ratio times a bandwidth, NOT a roofline number
                     "csr_equivalent_bytes": csr_bytes, "csr_equivalent_GBps": (csr_bytes / 1e9) / spmv_s if spmv_s > 0 else 0.0}

@@ -206,6 +206,15 @@ lpp_status lpp_engine_setup_hubbard_onthefly_ext(lpp_engine* e, const lpp_comm* 
 lpp_status lpp_engine_assemble_heisenberg(lpp_engine* e, int32_t nsites, int32_t szPlusConst, const double* jpm,
                                           const double* jzz, const double* field, int32_t nfield);
 
+/* The same for any spin the reference's digit width holds (BasisHeisenberg.h:28-46: a state is L digits m_i + S of
+ * bits = 1 + floor(log2(twiceS+1)) bits, one bit less for odd twiceS; ascending words of digit sum szPlusConst), with
+ * the S+S- amplitudes of Heisenberg.h:278-307 and the single-ion anisotropy of Heisenberg.h:259.  Odd twiceS whose
+ * digits the reference cannot hold (twiceS + 1 not a power of two) -> LPP_ERR_INVALID.  twiceS == 1 gives the matrix
+ * of lpp_engine_assemble_heisenberg. */
+lpp_status lpp_engine_assemble_heisenberg_spin(lpp_engine* e, int32_t nsites, int32_t twiceS, int32_t szPlusConst,
+                                               const double* jpm, const double* jzz, const double* field, int32_t nfield,
+                                               const double* anisotropy, int32_t naniso);
+
 /* On-device assembly of the one-orbital t-J Hamiltonian (TjMultiOrb.h:100-131,586-783) in the
  * BasisTjMultiOrbLanczos ordering (sorted (down<<L)|up words without double occupancy). */
 lpp_status lpp_engine_assemble_tj(lpp_engine* e, int32_t nsites, int32_t nup, int32_t ndown, const double* hop_re,

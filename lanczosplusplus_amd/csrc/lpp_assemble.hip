@@ -517,6 +517,116 @@ lpp_status lpp_engine_assemble_heisenberg(lpp_engine* e, int32_t L, int32_t szPl
 	return alloc_work(e);
 }
 
+// Heisenberg with any spin the reference's digit width can hold (BasisHeisenberg.h:28-46: bits = 1 + floor(log2(twiceS + 1)), one
+// less for odd twiceS -- so odd spins fit only when twiceS + 1 is a power of two), with the anisotropy term (Heisenberg.h:259).
+// twiceS == 1 gives the matrix of lpp_engine_assemble_heisenberg through the digit basis (one-bit digits).
+// The S+S- value follows the reference to the letter: both square roots are taken of the LOWERED site's m (Heisenberg.h:296-303),
+// which is a constant for S <= 1 and makes the matrix non-symmetric from S = 3/2 on -- reproduced, not repaired.
+lpp_status lpp_engine_assemble_heisenberg_spin(lpp_engine* e, int32_t L, int32_t twiceS, int32_t szPlusConst, const double* jpm, const double* jzz,
+                                               const double* field, int32_t nfield, const double* anisotropy, int32_t naniso)
+{
+	if (!e || !jpm || !jzz || L < 1 || twiceS < 1 || szPlusConst < 0) return fail(LPP_ERR_INVALID, "lpp_engine_assemble_heisenberg_spin: bad argument");
+	nfield = std::max(nfield, 0);
+	naniso = std::max(naniso, 0);
+	if ((nfield > 0 && !field) || (naniso > 0 && !anisotropy)) return fail(LPP_ERR_INVALID, "lpp_engine_assemble_heisenberg_spin: null field / anisotropy");
+	int bits = 1;
+	while ((2 << (bits - 1)) <= twiceS + 1) bits++; // 1 + floor(log2(twiceS + 1))
+	if (twiceS & 1) bits--;
+	const int dmax = (twiceS & 1) ? (1 << bits) - 1 : twiceS; // even spins: digits above twiceS are filtered out (mOf, :204-227)
+	if (dmax < twiceS) return fail(LPP_ERR_INVALID, "lpp_engine_assemble_heisenberg_spin: the reference's digit width cannot hold this spin (odd twiceS with twiceS + 1 not a power of two)");
+	if ((int64_t)bits * L > 62) return fail(LPP_ERR_INVALID, "lpp_engine_assemble_heisenberg_spin: bits * L > 62");
+	if (szPlusConst > dmax * L) return fail(LPP_ERR_INVALID, "lpp_engine_assemble_heisenberg_spin: empty Hilbert space");
+	// digits[l][s]: l-digit strings with digit sum s
+	const int sdim = dmax * L + 1;
+	std::vector<uint64_t> dig((size_t)(L + 1) * sdim, 0);
+	dig[0] = 1;
+	for (int l = 1; l <= L; l++)
+		for (int sum = 0; sum < sdim; sum++) {
+			uint64_t c = 0;
+			for (int d = 0; d <= dmax && d <= sum; d++) c += dig[(size_t)(l - 1) * sdim + (sum - d)];
+			dig[(size_t)l * sdim + sum] = c;
+		}
+	const int64_t nrows = (int64_t)dig[(size_t)L * sdim + szPlusConst];
+	lpp_status st = common_setup(e, nrows, 0);
+	if (st != LPP_OK) return st;
+	// terms: raise digit i, lower digit j for every ordered pair with jpm_(i,j) != 0 (Heisenberg.h:101-106, 290-306); the sites ride in
+	// smask_ket / smask_bra until the list is sorted (they are not used as masks by this model)
+	std::vector<HostProc> hp;
+	for (int i = 0; i < L; i++)
+		for (int j = 0; j < L; j++) {
+			if (i == j || jpm[i * L + j] == 0) continue;
+			HostProc h {};
+			h.p.need_set = (uint64_t)(i * bits);
+			h.p.need_clear = (uint64_t)(j * bits);
+			h.p.smask_ket = (uint64_t)i;
+			h.p.smask_bra = (uint64_t)j;
+			h.p.real_only = 1;
+			h.delta = (int64_t)(1ull << (i * bits)) - (int64_t)(1ull << (j * bits));
+			hp.push_back(h);
+		}
+	std::vector<Proc> procs;
+	int nneg = 0;
+	st = finish_procs(hp, procs, &nneg);
+	if (st != LPP_OK) return st;
+	// value of term (i, j) on a ket whose digit j is v: the reference's expression, operation by operation (Heisenberg.h:296-304)
+	const double spin = twiceS * 0.5;
+	std::vector<double> amp(std::max<size_t>(procs.size() * (size_t)(twiceS + 1), 1), 0.0);
+	for (size_t p = 0; p < procs.size(); p++) {
+		const int i = (int)procs[p].smask_ket, j = (int)procs[p].smask_bra;
+		for (int v = 1; v <= twiceS; v++) {
+			int val2 = v;
+			const double m2 = val2 - spin;
+			val2--;
+			const double m1 = val2 - spin;
+			double tmp = std::sqrt(spin * (spin + 1.0) - m1 * (m1 + 1.0));
+			tmp *= std::sqrt(spin * (spin + 1.0) - m2 * (m2 - 1.0));
+			amp[p * (size_t)(twiceS + 1) + v] = 0.5 * tmp * jpm[i * L + j];
+		}
+		procs[p].smask_ket = procs[p].smask_bra = 0;
+	}
+	DevBuf d_procs, d_dig, d_f, d_a, d_z, d_amp;
+	if ((st = upload(e->stream, d_procs, procs.data(), sizeof(Proc) * procs.size())) != LPP_OK) return st;
+	if ((st = upload(e->stream, d_dig, dig.data(), sizeof(uint64_t) * dig.size())) != LPP_OK) return st;
+	if ((st = upload(e->stream, d_f, field, sizeof(double) * (size_t)nfield)) != LPP_OK) return st;
+	if ((st = upload(e->stream, d_a, anisotropy, sizeof(double) * (size_t)naniso)) != LPP_OK) return st;
+	if ((st = upload(e->stream, d_z, jzz, sizeof(double) * L * L)) != LPP_OK) return st;
+	if ((st = upload(e->stream, d_amp, amp.data(), sizeof(double) * amp.size())) != LPP_OK) return st;
+	AsmParams P {};
+	P.model = ASM_HEISENBERG_S;
+	P.L = L;
+	P.nproc = (int)procs.size();
+	P.nneg = nneg;
+	P.n_up = nrows;
+	P.nrows_global = nrows;
+	P.procs = (const Proc*)d_procs.p;
+	P.d0 = (const double*)d_f.p;
+	P.nd0 = std::min<int>(nfield, L);
+	P.d1 = (const double*)d_a.p;
+	P.nd1 = std::min<int>(naniso, L);
+	P.d2 = (const double*)d_z.p;
+	P.twiceS = twiceS;
+	P.bits = bits;
+	P.dmax = dmax;
+	P.msum = szPlusConst;
+	P.sdim = sdim;
+	P.digits = (const uint64_t*)d_dig.p;
+	P.amp = (const double*)d_amp.p;
+	P.row0 = 0;
+	P.nloc = nrows;
+	P.part = 0;
+	e->has_comm = false;
+	e->bind_scalars(e->scal_own);
+	free_csr(e->A_rem);
+	drop_product(e);
+	st = dispatch<ASM_HEISENBERG_S>(e, P, e->A_loc);
+	if (st != LPP_OK) return st;
+	e->n_local = e->n_global = nrows;
+	e->row_start = 0;
+	e->active = false;
+	set_spmv_bytes(e);
+	return alloc_work(e);
+}
+
 lpp_status lpp_engine_assemble_tj(lpp_engine* e, int32_t L, int32_t nup, int32_t ndown, const double* hop_re, const double* hop_im,
                                   const double* jpm, const double* jzz, const double* w, const double* potentialV, int32_t npot)
 {

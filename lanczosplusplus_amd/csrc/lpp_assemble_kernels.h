@@ -18,7 +18,7 @@
 
 namespace lpp {
 
-enum { ASM_HUBBARD = 0, ASM_HEISENBERG = 1, ASM_TJ = 2 };
+enum { ASM_HUBBARD = 0, ASM_HEISENBERG = 1, ASM_TJ = 2, ASM_HEISENBERG_S = 3 };
 
 struct Proc {
 	uint64_t need_set, need_clear, xmask;
@@ -52,6 +52,13 @@ struct AsmParams {
 	int tr;
 	int64_t iu0, nu, peru, n_dn;
 	int no_diag; // 1: do not emit the diagonal (the down-hop part of a split matrix)
+	// Heisenberg with spin S > 1/2 (ASM_HEISENBERG_S): a state is L digits of `bits` bits, digit = m + S in [0, dmax], digit sum = msum
+	// (BasisHeisenberg.h:28-46).  A term (i, j) raises digit i and lowers digit j: Proc.need_set = bit offset of i, Proc.need_clear =
+	// bit offset of j; its value depends on digit j only: amp[term * (twiceS + 1) + digit_j] (Heisenberg.h:278-307, formed on the host).
+	int twiceS, bits, dmax, msum;
+	int sdim; // row length of `digits`
+	const uint64_t* digits; // digits[l * sdim + s] = number of l-digit strings with digit sum s
+	const double* amp;
 };
 
 __device__ __forceinline__ uint64_t comb_at(const uint64_t* comb, int n, int m) { return comb[n * kCombDim + m]; }
@@ -108,9 +115,61 @@ __device__ __forceinline__ uint64_t pdep_sw(uint64_t v, uint64_t mask)
 	return out;
 }
 
+// Position of a digit string in the ascending list of all strings with the same digit sum (digits in [0, dmax]); ascending as
+// integers = lexicographic from the most significant digit.  BasisHeisenberg::perfectIndex (BasisHeisenberg.h:73-80) finds the
+// same position by scanning the stored list.
+__device__ __forceinline__ int64_t rank_digits(const AsmParams& P, uint64_t w)
+{
+	const uint64_t dm = (1ull << P.bits) - 1;
+	int srem = P.msum;
+	int64_t r = 0;
+	for (int p = P.L - 1; p >= 0; p--) {
+		const int d = (int)((w >> (p * P.bits)) & dm);
+		for (int k = 0; k < d; k++)
+			if (srem - k >= 0) r += (int64_t)P.digits[p * P.sdim + (srem - k)];
+		srem -= d;
+	}
+	return r;
+}
+__device__ __forceinline__ uint64_t unrank_digits(const AsmParams& P, int64_t r)
+{
+	uint64_t w = 0;
+	int srem = P.msum;
+	for (int p = P.L - 1; p >= 0; p--) {
+		int d = 0;
+		for (; d < P.dmax; d++) {
+			const int64_t c = (srem - d >= 0) ? (int64_t)P.digits[p * P.sdim + (srem - d)] : 0;
+			if (r < c) break;
+			r -= c;
+		}
+		w |= (uint64_t)d << (p * P.bits);
+		srem -= d;
+	}
+	return w;
+}
+
+// ket -> bra of one off-diagonal term; false when the term does not apply to this ket
+template <int MODEL> __device__ __forceinline__ bool proc_bra(const AsmParams& P, const Proc& pr, uint64_t ket, uint64_t& bra, int& dj)
+{
+	if (MODEL == ASM_HEISENBERG_S) {
+		const uint64_t dm = (1ull << P.bits) - 1;
+		const int si = (int)pr.need_set, sj = (int)pr.need_clear;
+		const int v1 = (int)((ket >> si) & dm);
+		dj = (int)((ket >> sj) & dm);
+		if (v1 == P.twiceS || dj == 0) return false; // Heisenberg.h:103 and :294
+		bra = ket + (1ull << si) - (1ull << sj);
+		return true;
+	}
+	dj = 0;
+	if ((ket & pr.need_set) != pr.need_set || (ket & pr.need_clear) != 0) return false;
+	bra = ket ^ pr.xmask;
+	return true;
+}
+
 template <int MODEL> __device__ __forceinline__ uint64_t state_of(const AsmParams& P, int64_t idx)
 {
 	const uint64_t lowmask = (P.L >= 64) ? ~0ull : ((1ull << P.L) - 1);
+	if (MODEL == ASM_HEISENBERG_S) return unrank_digits(P, idx);
 	if (MODEL == ASM_HEISENBERG) return unrank_comb(P.comb, idx, P.nup, P.L);
 	const int64_t iu = idx % P.n_up, id = idx / P.n_up;
 	const uint64_t down = unrank_comb(P.comb, id, P.ndown, P.L);
@@ -124,6 +183,7 @@ template <int MODEL> __device__ __forceinline__ uint64_t state_of(const AsmParam
 
 template <int MODEL> __device__ __forceinline__ int64_t index_of(const AsmParams& P, uint64_t w)
 {
+	if (MODEL == ASM_HEISENBERG_S) return rank_digits(P, w);
 	if (MODEL == ASM_HEISENBERG) return rank_comb(P.comb, w);
 	const uint64_t lowmask = (1ull << P.L) - 1;
 	const uint64_t up = w & lowmask, down = w >> P.L;
@@ -181,6 +241,31 @@ template <int MODEL> __device__ double diag_of(const AsmParams& P, uint64_t w)
 				s += tmp1 * tmp2 * P.d2[i * L + j];
 			}
 		}
+	} else if (MODEL == ASM_HEISENBERG_S) {
+		// Heisenberg.h:251-275 for any spin.  m_i = digit - S is a multiple of 1/2, so m_i m_j is exact, but its product with a
+		// coupling is not: every multiplication and addition must be rounded on its own, as the host compiler does it, for the
+		// sum to be the reference's double bit for bit -- so no contraction into fused multiply-adds in this block (measured:
+		// with it, 107 of 580 diagonal elements of an S = 3/2 chain are one unit in the last place off).
+#pragma clang fp contract(off)
+		const uint64_t dm = (1ull << P.bits) - 1;
+		const double half = P.twiceS * 0.5;
+		for (int i = 0; i < L; i++) {
+			const double tmp1 = (double)(int)((w >> (i * P.bits)) & dm) - half;
+			const double tmp1d = tmp1 * tmp1;
+			if (i < P.nd0) {
+				const double t = P.d0[i] * tmp1;
+				s = s + t;
+			}
+			if (i < P.nd1) {
+				const double t = P.d1[i] * tmp1d;
+				s = s + t;
+			}
+			for (int j = i + 1; j < L; j++) {
+				const double tmp2 = (double)(int)((w >> (j * P.bits)) & dm) - half;
+				const double t = tmp1 * tmp2 * P.d2[i * L + j];
+				s = s + t;
+			}
+		}
 	} else { // TjMultiOrb.h:597-645, orbitals == 1
 		const uint64_t up = w & ((1ull << L) - 1), down = w >> L;
 		for (int i = 0; i < L; i++) {
@@ -220,11 +305,13 @@ __global__ __launch_bounds__(kBlock) void k_asm_count(AsmParams P, int64_t* __re
 		int n = 0;
 		for (int p = 0; p < P.nproc; p++) {
 			const Proc& pr = P.procs[p];
-			if ((ket & pr.need_set) != pr.need_set || (ket & pr.need_clear) != 0) continue;
+			uint64_t bra;
+			int dj;
+			if (!proc_bra<MODEL>(P, pr, ket, bra, dj)) continue;
 			if (P.part == 0) {
 				n++;
 			} else {
-				const int64_t c = index_of<MODEL>(P, ket ^ pr.xmask);
+				const int64_t c = index_of<MODEL>(P, bra);
 				if (col_selected(P, c)) n++;
 			}
 		}
@@ -261,19 +348,30 @@ __global__ __launch_bounds__(kBlock) void k_asm_fill(AsmParams P, const int64_t*
 			}
 			if (p == P.nproc) break;
 			const Proc& pr = P.procs[p];
-			if ((ket & pr.need_set) != pr.need_set || (ket & pr.need_clear) != 0) continue;
-			const uint64_t bra = ket ^ pr.xmask;
+			uint64_t bra;
+			int dj;
+			if (!proc_bra<MODEL>(P, pr, ket, bra, dj)) continue;
 			const int64_t c = index_of<MODEL>(P, bra);
 			if (!col_selected(P, c)) continue;
-			const int par = (__popcll(ket & pr.smask_ket) + __popcll(bra & pr.smask_bra) + pr.sign_const) & 1;
-			const double sg = par ? -1.0 : 1.0;
 			col[q] = (int32_t)(c - shift);
 			T v;
-			if constexpr (sizeof(T) == 16) {
-				v.re = pr.amp_re * sg;
-				v.im = pr.real_only ? 0.0 : pr.amp_im * sg;
+			if (MODEL == ASM_HEISENBERG_S) { // no fermion sign; the value is tabulated per lowered digit
+				const double av = P.amp[p * (P.twiceS + 1) + dj];
+				if constexpr (sizeof(T) == 16) {
+					v.re = av;
+					v.im = 0.0;
+				} else {
+					v = av;
+				}
 			} else {
-				v = pr.amp_re * sg;
+				const int par = (__popcll(ket & pr.smask_ket) + __popcll(bra & pr.smask_bra) + pr.sign_const) & 1;
+				const double sg = par ? -1.0 : 1.0;
+				if constexpr (sizeof(T) == 16) {
+					v.re = pr.amp_re * sg;
+					v.im = pr.real_only ? 0.0 : pr.amp_im * sg;
+				} else {
+					v = pr.amp_re * sg;
+				}
 			}
 			val[q] = v;
 			q++;

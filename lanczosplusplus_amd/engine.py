@@ -125,10 +125,16 @@ class LanczosEngine:
         cs = C.byref(comm.struct) if comm is not None else None
         check(self._lib.lpp_engine_setup_hubbard_onthefly_ext(self._h, cs, L, nup, ndown, _vp(hr), _vp(hi), _vp(U), _vp(V), _vp(nj)))
 
-    def assemble_heisenberg(self, L, szPlusConst, jpm, jzz, field=None):
+    def assemble_heisenberg(self, L, szPlusConst, jpm, jzz, field=None, twiceS=1, anisotropy=None):
+        """Heisenberg.h:80-114 on the device; twiceS > 1 or an anisotropy take the any-spin assembler (digit basis)."""
         f = None if field is None else np.ascontiguousarray(field, np.float64)
-        check(self._lib.lpp_engine_assemble_heisenberg(self._h, L, szPlusConst, _vp(_mat(jpm, L)), _vp(_mat(jzz, L)),
-                                                       _vp(f), 0 if f is None else len(f)))
+        if twiceS == 1 and anisotropy is None:
+            check(self._lib.lpp_engine_assemble_heisenberg(self._h, L, szPlusConst, _vp(_mat(jpm, L)), _vp(_mat(jzz, L)),
+                                                           _vp(f), 0 if f is None else len(f)))
+            return
+        a = None if anisotropy is None else np.ascontiguousarray(anisotropy, np.float64)
+        check(self._lib.lpp_engine_assemble_heisenberg_spin(self._h, L, twiceS, szPlusConst, _vp(_mat(jpm, L)), _vp(_mat(jzz, L)),
+                                                            _vp(f), 0 if f is None else len(f), _vp(a), 0 if a is None else len(a)))
 
     def assemble_tj(self, L, nup, ndown, hop, jpm, jzz, w, potentialV=None):
         hop = np.asarray(hop).reshape(L, L)

@@ -140,28 +140,69 @@ private:
 	BasisOneSpin basis1_, basis2_;
 };
 
-// S = 1/2: all words with szPlusConst set bits, ascending (BasisHeisenberg.h:38-46 with bits_ == 1)
+// All words of nsite digits (bits_ bits each, digit = m + S) with digit sum szPlusConst, ascending (BasisHeisenberg.h:28-46).
+// The reference scans every word below 2^(bits*nsite) and keeps the matching ones, and finds a state's index by scanning the
+// list (:73-80); here the list is generated digit by digit in the same ascending order and searched by bisection -- same list,
+// same indices.  Even spins: digits above twiceS do not occur (mOf, :204-227); odd spins need twiceS + 1 to be a power of two
+// for the reference's digit width to hold them.
 class BasisHeisenberg : public BasisBase {
 public:
-	BasisHeisenberg(SizeType nsite, SizeType twiceS, SizeType szPlusConst) : twiceS_(twiceS), szPlusConst_(szPlusConst), basis_(nsite, szPlusConst)
+	BasisHeisenberg(SizeType nsite, SizeType twiceS, SizeType szPlusConst) : nsite_(nsite), twiceS_(twiceS), szPlusConst_(szPlusConst), bits_(0)
 	{
-		if (twiceS != 1) err("BasisHeisenberg (host shim): only HeisenbergTwiceS=1 is supported\n");
+		if (twiceS == 0) err("BasisHeisenberg: HeisenbergTwiceS must be positive\n");
+		SizeType lg = 0;
+		for (SizeType x = twiceS + 1; x >>= 1;) ++lg; // logBase2, :282-287
+		bits_ = 1 + lg;
+		if (twiceS & 1) bits_--;
+		mask_ = (WordType(1) << bits_) - 1;
+		dmax_ = (twiceS & 1) ? SizeType(mask_) : twiceS;
+		if (dmax_ < twiceS) err("BasisHeisenberg: the reference's digit width cannot hold this spin\n");
+		if (bits_ * nsite > 62) err("BasisHeisenberg: too many sites for a 64-bit word\n");
+		fill(0, nsite, szPlusConst);
 	}
 	PairIntType parts() const { return PairIntType(twiceS_, szPlusConst_); }
-	SizeType size() const { return basis_.size(); }
+	SizeType size() const { return data_.size(); }
 	SizeType dofs() const { return twiceS_ + 1; }
-	WordType operator()(SizeType i, SizeType) const { return basis_[i]; }
-	SizeType perfectIndex(WordType ket, WordType) const { return BasisOneSpin::perfectIndex(ket); }
+	WordType operator()(SizeType i, SizeType) const { return data_[i]; }
+	SizeType perfectIndex(WordType ket, WordType) const
+	{
+		const auto it = std::lower_bound(data_.begin(), data_.end(), ket);
+		if (it == data_.end() || *it != ket) throw LppHost::RuntimeError("BasisHeisenberg::perfectIndex: state not in the basis\n");
+		return SizeType(it - data_.begin());
+	}
 	SizeType isThereAnElectronAt(WordType, WordType, SizeType, SizeType, SizeType) const
 	{
 		throw LppHost::RuntimeError("BasisHeisenberg::isThereAnElectronAt\n");
 	}
-	SizeType getN(WordType ket1, WordType, SizeType site, SizeType, SizeType) const { return (ket1 >> site) & 1; }
+	SizeType getN(WordType ket1, WordType, SizeType site, SizeType, SizeType) const { return SizeType((ket1 >> (bits_ * site)) & mask_); } // :96-105
+	// getBra, :169-193: digit i becomes val1, digit j becomes val2
+	WordType getBra(WordType ket, SizeType i, SizeType val1, SizeType j, SizeType val2) const
+	{
+		WordType bra = ket;
+		bra &= ~(mask_ << (i * bits_));
+		bra &= ~(mask_ << (j * bits_));
+		bra |= WordType(val1) << (i * bits_);
+		bra |= WordType(val2) << (j * bits_);
+		return bra;
+	}
 	SizeType szPlusConst() const { return szPlusConst_; }
+	SizeType twiceS() const { return twiceS_; }
+	SizeType bits() const { return bits_; }
 
 private:
-	SizeType twiceS_, szPlusConst_;
-	BasisOneSpin basis_;
+	// most significant digit first, digits ascending: the words come out in ascending order
+	void fill(WordType prefix, SizeType left, SizeType sum)
+	{
+		if (left == 0) {
+			if (sum == 0) data_.push_back(prefix);
+			return;
+		}
+		if (sum > dmax_ * left) return;
+		for (SizeType d = 0; d <= dmax_ && d <= sum; d++) fill(prefix | (WordType(d) << (bits_ * (left - 1))), left - 1, sum - d);
+	}
+	SizeType nsite_, twiceS_, szPlusConst_, bits_, dmax_;
+	WordType mask_;
+	std::vector<WordType> data_;
 };
 
 // orbitals == 1: sorted words (down << n) | up with up & down == 0 (BasisTjMultiOrbLanczos.h:29-42,354-369).
