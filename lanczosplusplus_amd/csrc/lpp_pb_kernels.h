@@ -157,7 +157,10 @@ template <bool DOT, int GT, bool LEAN, bool CHAIN = false> __global__ __launch_b
 		if (CHAIN) {
 			double2* const wb = (double2*)(a.wbuf + rowbase);
 			const double2* const yo = (const double2*)(a.ybuf + rowbase);
-			constexpr int NS = 4;
+#ifndef LPP_PB_CHAIN_NS
+#define LPP_PB_CHAIN_NS 4 // pairs per thread and row in flight: 2 -> 1.58 ms, 4 -> 1.57 ms, 8 spills (3.5 ms)
+#endif
+			constexpr int NS = LPP_PB_CHAIN_NS;
 			for (int i0 = threadIdx.x; i0 < p2; i0 += NS * kPbUpThreads) {
 				// loads unconditional and clamped (all of them in flight together); stores only from the lane that owns the pair -- a
 				// clamped lane would subtract g r a second time from a pair its owner has already updated in place
@@ -335,8 +338,9 @@ struct PbDownArgs {
 
 // RMW (chained Lanczos step, see k_pb_up): z holds the previous Lanczos vector r' and receives the finished
 //   w = u_in + beta r' + alpha C y;   the partials are Re<y|w> and |w - s y|^2 (k_b2_from_w).
-// The two HBM loads per task this needs are issued BEHIND the task's first two chunks of gathers: those are consumed without
-// waiting for them (in-order return), and by the third chunk they have had two consume phases.
+// The two HBM loads per task this needs are only USED behind the gather loop.  Where they are issued (in front of the gathers,
+// behind the first or the second chunk: LPP_PB_RMW_POS) moved the kernel by less than 4 % (1.86 / 1.94 / 1.93 ms at BASELINE
+// config 2): it is bound by what goes through L1 -- 17 gathered lines + 3 streamed ones per line written -- not by the order.
 template <int THREADS, bool RMW = false> __global__ __launch_bounds__(THREADS) void k_pb_down(PbDownArgs a)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -417,16 +421,19 @@ template <int THREADS, bool RMW = false> __global__ __launch_bounds__(THREADS) v
 					acc.y = fma(v, gbuf[q].y, acc.y);
 				}
 			};
-			if (n4 > 0) issue(0, ga);
-			if (n4 > 1) issue(1, gb);
+#ifndef LPP_PB_RMW_POS
+#define LPP_PB_RMW_POS 0
+#endif
 			double2* const zp = (double2*)((char*)a.z + (size_t)row_s[il] + colb);
-			double2 told = double2 { 0.0, 0.0 };
-			if (RMW) {
-				const double2 uo = nt_load2((const double2*)((const char*)a.u_in + (size_t)row_s[il] + colb));
-				const double2 xo = nt_load2(zp);
-				told.x = fma(beta, xo.x, uo.x);
-				told.y = fma(beta, xo.y, uo.y);
+			double2 uo = double2 { 0.0, 0.0 }, xo = double2 { 0.0, 0.0 };
+			if (LPP_PB_RMW_POS >= 1 && n4 > 0) issue(0, ga);
+			if (LPP_PB_RMW_POS >= 2 && n4 > 1) issue(1, gb);
+			if (RMW) { // used only behind the gather loop: no wait here
+				uo = nt_load2((const double2*)((const char*)a.u_in + (size_t)row_s[il] + colb));
+				xo = nt_load2(zp);
 			}
+			if (LPP_PB_RMW_POS < 1 && n4 > 0) issue(0, ga);
+			if (LPP_PB_RMW_POS < 2 && n4 > 1) issue(1, gb);
 			for (int ch = 0; ch < n4; ch += 3) { // wave-uniform conditions
 				if (ch + 2 < n4) issue(ch + 2, gc);
 				consume(ch, ga);
@@ -441,8 +448,8 @@ template <int THREADS, bool RMW = false> __global__ __launch_bounds__(THREADS) v
 			}
 			const double2 yown = *(const double2*)(ysrc + (size_t)(row_s[il] + colb)); // the panel is in L2
 			if (valid) {
-				acc.x = fma(alpha, acc.x, told.x);
-				acc.y = fma(alpha, acc.y, told.y);
+				acc.x = fma(alpha, acc.x, fma(beta, xo.x, uo.x));
+				acc.y = fma(alpha, acc.y, fma(beta, xo.y, uo.y));
 				__builtin_nontemporal_store(acc.x, &zp->x);
 				__builtin_nontemporal_store(acc.y, &zp->y);
 				dot += yown.x * acc.x + yown.y * acc.y;
