@@ -201,9 +201,15 @@ lpp_status assemble_hubbard_pb(lpp_engine* e, AsmParams P, int nup, int ndown, i
 {
 	*done = false;
 	if (e->is_complex || n_up < 512) return LPP_OK;
+	// LPP_PRODUCT_LAYOUT = 0: never, 1: whenever it applies; unset: from 32 MB per vector on.  Below that everything sits in
+	// L2 / Infinity Cache anyway and the step is launch-bound: measured on Hubbard chains (scripts/experiments/pb_threshold.sh),
+	// 8.5e5 rows 17.2k (product) vs 18.8k (general) iterations/s, 1.2e7 rows 4164 vs 3833, 1.3e8 rows 385 vs 246
+	bool forced = false;
 	if (const char* s = getenv("LPP_PRODUCT_LAYOUT")) {
 		if (atoi(s) == 0) return LPP_OK;
+		forced = true;
 	}
+	if (!forced && (size_t)n_up * (size_t)n_dn * sizeof(double) < ((size_t)32 << 20)) return LPP_OK;
 	if (e->cfg.spmv_kernel != LPP_SPMV_AUTO || getenv("LPP_SPMV_KERNEL")) return LPP_OK;
 	int want = e->cfg.compress_values;
 	if (const char* s = getenv("LPP_COMPRESS_VALUES")) want = atoi(s);

@@ -26,6 +26,15 @@ static int blas_blocks(int64_t n2)
 	return (int)std::max<int64_t>(1, std::min<int64_t>(b, 2048));
 }
 
+// the 2-read 1-write pass of the scale-free recurrence: 4 pairs per lane in flight, up to 16384 blocks.  Measured with
+// scripts/experiments/calib_axpy.hip (non-temporal accesses): 2048 blocks 4.96 TB/s, 16384 blocks 5.52 TB/s on 1.33 GB vectors;
+// 5.18 -> 6.91 TB/s on the 0.32 GB vectors of the L = 28 Heisenberg chain
+static int axpy_blocks(int64_t n2)
+{
+	const int64_t b = (n2 + 4 * kBlock - 1) / (4 * kBlock);
+	return (int)std::max<int64_t>(1, std::min<int64_t>(b, 16384));
+}
+
 lpp_status lpp_engine::adopt_comm(const lpp_comm* c)
 {
 	if (c->nranks < 1 || c->rank < 0 || c->rank >= c->nranks) return fail(LPP_ERR_INVALID, "lpp_comm: bad rank/nranks");
@@ -277,7 +286,8 @@ lpp_status one_step(lpp_engine* e, const double* ritz, int nst)
 	} else if (e->scalefree) {
 		// streamed accesses once the two vectors no longer fit the 256 MiB Infinity Cache (measured: +4 % there, -7 % below)
 		const int stream_axpy = (size_t)e->n2 * 32 > ((size_t)256 << 20) ? 1 : 0;
-		k_axpy_nrm<true><<<nb, kBlock, 0, st>>>((double2*)xcur, (const double2*)ycur, a_ptr, b2_prev,
+		nb_nrm = stream_axpy ? axpy_blocks(e->n2) : nb;
+		k_axpy_nrm<true><<<nb_nrm, kBlock, 0, st>>>((double2*)xcur, (const double2*)ycur, a_ptr, b2_prev,
 		                                       (multi(e) && !e->tx) ? (double2*)e->comm.send_buf : nullptr, e->n2, e->partial, stream_axpy, e->nd);
 	} else if (e->cfg.reortho) {
 		k_axpy_nrm<false><<<nb, kBlock, 0, st>>>((double2*)xcur, (const double2*)ycur, a_ptr, nullptr, nullptr, e->n2, nullptr);

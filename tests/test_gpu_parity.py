@@ -648,6 +648,7 @@ PB_CASES = {
     # name: (L, nup, ndown, hop, U, V)   -- N_up >= 512 so that device assembly takes the product-basis layout
     "chain_L12": lambda: (12, 6, 5, chain(12, -1.0, True), np.where(np.arange(12) % 3 == 0, 2.0, 4.0), np.tile([0.25, -0.5, 0.0], 8)),
     "ladder_2x6": lambda: (12, 6, 6, square(2, 6, -1.0, True), np.full(12, 4.0), np.zeros(24)),
+    "open_chain_L12": lambda: (12, 6, 6, chain(12, -1.0, False), np.full(12, 4.0), np.zeros(24)),  # one value group (no sign changes); a_j > b_j
     "two_hoppings": lambda: (12, 5, 7, chain(12, -1.0, False) + 0.5 * (np.diag(np.ones(10), 2) + np.diag(np.ones(10), -2)), np.full(12, 3.0), np.zeros(24)),
 }
 
@@ -658,6 +659,7 @@ def test_product_basis_layout(case, monkeypatch):
     stands for is the oracle's bit for bit, x += H y (two kernels, pitched vectors) matches the oracle, and every solver entry
     point works on the pitched vectors; the general layout (LPP_PRODUCT_LAYOUT=0) gives the same numbers."""
     L, nup, ndown, hop, U, V = PB_CASES[case]()
+    monkeypatch.setenv("LPP_PRODUCT_LAYOUT", "1")  # these matrices are below the size from which the layout is chosen by itself
     A = oracle.hubbard_csr(L, nup, ndown, hop, U, V)
     x0, y = oracle.fill_random(A.nrows, 7), oracle.fill_random(A.nrows, 8)
     xo = oracle.spmv_acc(A, x0.copy(), y)
@@ -703,8 +705,9 @@ def test_product_basis_layout(case, monkeypatch):
         assert rel(xw, xg) < SPMV_TOL
 
 
-def test_product_basis_layout_falls_back_when_it_does_not_apply():
+def test_product_basis_layout_falls_back_when_it_does_not_apply(monkeypatch):
     """more than 256 distinct diagonal values, or more than 8 distinct in-block values: the general layout takes over, results unchanged"""
+    monkeypatch.setenv("LPP_PRODUCT_LAYOUT", "1")
     L, nup, ndown = 12, 6, 6
     rng = np.random.default_rng(5)
     for hop, U in ((chain(L, -1.0, True), rng.uniform(1, 5, L)),  # random U: 2^12 distinct diagonals
@@ -718,10 +721,11 @@ def test_product_basis_layout_falls_back_when_it_does_not_apply():
 
 
 @pytest.mark.parametrize("case", ["small_general", "product_layout"])
-def test_hubbard_extended_coulomb_term(case):
+def test_hubbard_extended_coulomb_term(case, monkeypatch):
     """Model=HubbardOneBandExtended (ModelSelector.h:76-80): the Coulomb term 0.5 sum_ij V_ij n_i n_j of HubbardHelper.h:167-177 on
     the device assembler (general layout and product-basis layout), bit-exact against the oracle's ninj path, and in the
     matrix-free engine (the term split by species)."""
+    monkeypatch.setenv("LPP_PRODUCT_LAYOUT", "1")  # where it applies (N_up >= 512): the second case
     if case == "small_general":
         L, nup, ndown = 8, 4, 3
         hop, ninj = square(2, 4, -1.0, False), square(2, 4, 0.75, False) + 0.25 * chain(8, 1.0, True)
