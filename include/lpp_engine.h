@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define LPP_ABI_VERSION 1
+#define LPP_ABI_VERSION 2 /* 2: lpp_layout.stream_bytes, lpp_pb_pack_template(bank_ways), set_solver / stream / _ext / _spin entry points */
 
 typedef int32_t lpp_status;
 enum {

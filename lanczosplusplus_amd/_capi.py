@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "liblpp_engine.so")
 
-LPP_ABI_VERSION = 1
+LPP_ABI_VERSION = 2
 LPP_OK, LPP_ERR_INVALID, LPP_ERR_HIP, LPP_ERR_NOMEM, LPP_ERR_NOCONV, LPP_ERR_STATE, LPP_ERR_COMM = range(7)
 LPP_F64, LPP_C128 = 0, 1
 LPP_SPMV_AUTO, LPP_SPMV_ROWGROUP, LPP_SPMV_SLICED, LPP_SPMV_WINDOW = 0, 1, 2, 3
