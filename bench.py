@@ -323,7 +323,9 @@ def main():
         """communicator + engine + resident matrix + warm-up steps; returns everything the timed region needs"""
         c = None
         if world > 1:
-            chunk = (-(-n_dn // world)) * (-(-n_up // world)) if exchange == "transpose" else 0
+            # up indices per rank rounded up to a multiple of 16 (= lpp_xchg_chunk): real Hubbard matrices then take the
+            # product-basis kernels on both parts of the product
+            chunk = (-(-n_dn // world)) * ((-(-n_up // world) + 15) // 16 * 16) if exchange == "transpose" else 0
             c = TorchDistComm(stride, max_steps, is_complex, device=torch.device("cuda", local_rank), xchg_chunk=chunk)
         strm = c.stream_handle if c is not None else None
         cm = c.stream_context() if c is not None else __import__("contextlib").nullcontext()

@@ -122,7 +122,10 @@ typedef struct lpp_comm {
 	 * Two all-to-alls of nranks equal chunks of xchg_chunk elements each:
 	 *   which 0: chunk p of send_buf  -> rank p, received into chunk (sender) of gath_buf
 	 *   which 1: chunk p of send2_buf -> rank p, received into chunk (sender) of recv2_buf
-	 * send_buf, gath_buf, send2_buf, recv2_buf then hold nranks*xchg_chunk elements (zero-initialised by the owner). */
+	 * send_buf, gath_buf, send2_buf, recv2_buf then hold nranks*xchg_chunk elements (zero-initialised by the owner).
+	 * xchg_chunk = ceil(N_down/nranks) * peru, peru = up indices per rank >= ceil(N_up/nranks).  With peru rounded up to a
+	 * multiple of 16 a real Hubbard matrix takes the product-basis kernels on both parts of the product;
+	 * helper: lpp_xchg_chunk(). */
 	void* send2_buf;
 	void* recv2_buf;
 	int64_t xchg_chunk;
@@ -258,6 +261,9 @@ lpp_status lpp_engine_bench_spmv(lpp_engine* e, int32_t warmup, int32_t iters, d
 
 /* 1-D contiguous row partition: starts[nranks+1]; boundaries are multiples of `block`
  * (N_up for the Hubbard product basis so that up-hops and the diagonal stay rank-local). */
+/* xchg_chunk for the transposition exchange: ceil(n_down/nranks) * (ceil(n_up/nranks) rounded up to a multiple of 16) */
+int64_t lpp_xchg_chunk(int64_t n_up, int64_t n_down, int32_t nranks);
+
 lpp_status lpp_partition_rows(int64_t nrows, int32_t nranks, int64_t block, int64_t* starts);
 
 /* Split a row block with global columns into local-column and remote-column CSRs.

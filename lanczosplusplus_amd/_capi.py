@@ -70,6 +70,7 @@ _P = C.c_void_p
 SYMBOLS = {
     "lpp_last_error": (C.c_char_p, []),
     "lpp_abi_version": (C.c_int32, []),
+    "lpp_xchg_chunk": (C.c_int64, [C.c_int64, C.c_int64, C.c_int32]),
     "lpp_config_default": (None, [C.POINTER(Config)]),
     "lpp_engine_create": (C.c_int32, [C.POINTER(_P), C.POINTER(Config)]),
     "lpp_engine_destroy": (C.c_int32, [_P]),

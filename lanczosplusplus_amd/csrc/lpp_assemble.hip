@@ -197,7 +197,10 @@ lpp_status fetch_csr(const DevCsr& A, std::vector<int64_t>& rp, std::vector<int3
 // by the same assembler with the other species empty), the distinct diagonal values and one diagonal code per row.  The
 // N-row CSR (71 GB at BASELINE config 2) never exists.  *done stays false when the matrix does not qualify (the caller
 // then takes the general path); P carries the full-matrix parameters.
-lpp_status assemble_hubbard_pb(lpp_engine* e, AsmParams P, int nup, int ndown, int64_t n_up, int64_t n_dn, const double* zeroU_dev, bool* done)
+// Several GPUs (transposition exchange): blk0 / nblk_loc = the rank's own down configurations, pitch_dn = its up-index range (the row
+// length of the transposed slice, a multiple of 16), nblk_padded = down configurations in the transposed slice, padding included.
+lpp_status assemble_hubbard_pb(lpp_engine* e, AsmParams P, int nup, int ndown, int64_t n_up, int64_t n_dn, const double* zeroU_dev, bool* done,
+                               int64_t blk0 = 0, int64_t nblk_loc = -1, int64_t pitch_dn = 0, int64_t nblk_padded = 0)
 {
 	*done = false;
 	if (e->is_complex || n_up < 512) return LPP_OK;
@@ -218,7 +221,8 @@ lpp_status assemble_hubbard_pb(lpp_engine* e, AsmParams P, int nup, int ndown, i
 		if (getenv(k)) return LPP_OK; // switches of the general layout: measure that one
 	const int64_t pitch = pb_pitch_for(n_up);
 	if ((size_t)(pitch + kPbZeroSlots) * sizeof(double) > (size_t)156 * 1024) return LPP_OK;
-	if ((size_t)n_dn * (size_t)pitch * sizeof(double) >= ((size_t)1 << 32)) return LPP_OK;
+	if (pitch_dn == 0 && (size_t)n_dn * (size_t)pitch * sizeof(double) >= ((size_t)1 << 32)) return LPP_OK;
+	if (pitch_dn > 0 && (size_t)nblk_padded * (size_t)pitch_dn * sizeof(double) >= ((size_t)1 << 32)) return LPP_OK;
 	hipStream_t st = e->stream;
 	// one-species matrices: hops of that species + its potential diagonal (ignored below; the true diagonal is per row)
 	DevCsr Tm, Cm;
@@ -287,13 +291,18 @@ lpp_status assemble_hubbard_pb(lpp_engine* e, AsmParams P, int nup, int ndown, i
 	std::sort(keys.begin(), keys.end());
 	std::vector<double> dict(256);
 	for (size_t i = 0; i < 256; i++) std::memcpy(&dict[i], &keys[std::min(i, keys.size() - 1)], 8);
-	rc = pb_build(e, n_up, n_dn, trp.data(), tci.data(), tva.data(), crp.data(), cci.data(), cva.data(), dict.data(), (int)keys.size());
+	rc = pb_build(e, n_up, n_dn, trp.data(), tci.data(), tva.data(), crp.data(), cci.data(), cva.data(), dict.data(), (int)keys.size(), blk0, nblk_loc, pitch_dn,
+	              nblk_padded);
 	if (rc == LPP_ERR_INVALID) { // not representable (e.g. more than 8 distinct in-block values): general path
 		free_pb(e);
 		return LPP_OK;
 	}
 	if (rc != LPP_OK) return rc;
-	k_pb_diag_codes<ASM_HUBBARD><<<nb, kBlock, 0, st>>>(Pf, e->pb.pitch, e->pb.dict, e->pb.ndict, e->pb.dcode);
+	if (nblk_loc >= 0) { // codes for the rank's own rows only
+		Pf.row0 = blk0 * n_up;
+		Pf.nloc = nblk_loc * n_up;
+	}
+	if (Pf.nloc > 0) k_pb_diag_codes<ASM_HUBBARD><<<nb, kBlock, 0, st>>>(Pf, e->pb.pitch, e->pb.dict, e->pb.ndict, e->pb.dcode, blk0);
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipStreamSynchronize(st));
 	*done = true;
@@ -413,10 +422,31 @@ lpp_status lpp_engine_assemble_hubbard_ext(lpp_engine* e, const lpp_comm* comm, 
 			// Transposition scheme: the up-hop + diagonal part acts on the rank's own slice (down-index partition);
 			// the down-hop part is assembled for the rank's UP-index range over ALL down indices, in the layout
 			// row = id*peru + (iu - iu0), and acts on the transposed slice delivered by the first all-to-all.
-			const int64_t peru = (n_up + comm->nranks - 1) / comm->nranks;
-			if (!comm->send2_buf || !comm->recv2_buf || comm->xchg_chunk != per * peru)
-				return fail(LPP_ERR_INVALID, "assemble_hubbard: transposition exchange needs send2/recv2 buffers and xchg_chunk == ceil(N_down/P)*ceil(N_up/P)");
+			// xchg_chunk = per * peru with peru >= ceil(N_up/P) up indices per rank; a caller that rounds peru up to a multiple of 16
+			// gets the product-basis kernels on both parts when the matrix qualifies
+			const int64_t peru = per > 0 ? comm->xchg_chunk / per : 0;
+			if (!comm->send2_buf || !comm->recv2_buf || per <= 0 || comm->xchg_chunk != per * peru || peru * comm->nranks < n_up)
+				return fail(LPP_ERR_INVALID, "assemble_hubbard: transposition exchange needs send2/recv2 buffers and xchg_chunk == ceil(N_down/P) * peru, peru >= ceil(N_up/P)");
 			if ((int64_t)comm->nranks * per * peru > (int64_t)INT32_MAX) return fail(LPP_ERR_INVALID, "assemble_hubbard: transposed slice exceeds 32-bit column range");
+			if ((peru & 15) == 0 && P.nloc % n_up == 0) {
+				bool as_product = false;
+				st = assemble_hubbard_pb(e, P, nup, ndown, n_up, n_dn, (const double*)d_U0.p, &as_product, P.row0 / n_up, P.nloc / n_up, peru, (int64_t)comm->nranks * per);
+				if (st != LPP_OK) return st;
+				if (as_product) {
+					free_csr(e->A_loc);
+					free_csr(e->A_rem);
+					e->tx = true;
+					e->tx_per = per;
+					e->tx_peru = peru;
+					e->kron_n_up_tx = n_up;
+					e->n_local = P.nloc;
+					e->n_global = nrows;
+					e->row_start = P.row0;
+					e->active = false;
+					set_spmv_bytes(e);
+					return alloc_work(e);
+				}
+			}
 			std::vector<HostProc> hu, hd;
 			hubbard_terms(L, hop_re, hop_im, hu, 1);
 			hubbard_terms(L, hop_re, hop_im, hd, 2);
@@ -960,10 +990,10 @@ lpp_status lpp_engine_setup_hubbard_onthefly_ext(lpp_engine* e, const lpp_comm* 
 	const double off_up = (double)K.up.nnz - (double)n_up, off_dn_total = (double)K.dn.nnz - (double)n_dn;
 	K.equiv_nnz = (double)nid * ((double)n_up + off_up) + (double)n_up * off_dn_total * ((double)nid / (double)n_dn);
 	if (multi && comm->exchange_begin && comm->exchange_end && comm->xchg_chunk > 0) {
-		const int64_t per = (n_dn + comm->nranks - 1) / comm->nranks, peru = (n_up + comm->nranks - 1) / comm->nranks;
+		const int64_t per = (n_dn + comm->nranks - 1) / comm->nranks, peru = per > 0 ? comm->xchg_chunk / per : 0;
 		if (!K.packed) return fail(LPP_ERR_INVALID, "setup_hubbard_onthefly: the transposition exchange needs the packed H_up layout");
-		if (!comm->send2_buf || !comm->recv2_buf || comm->xchg_chunk != per * peru)
-			return fail(LPP_ERR_INVALID, "setup_hubbard_onthefly: transposition exchange needs send2/recv2 buffers and xchg_chunk == ceil(N_down/P)*ceil(N_up/P)");
+		if (!comm->send2_buf || !comm->recv2_buf || per <= 0 || comm->xchg_chunk != per * peru || peru * comm->nranks < n_up)
+			return fail(LPP_ERR_INVALID, "setup_hubbard_onthefly: transposition exchange needs send2/recv2 buffers and xchg_chunk == ceil(N_down/P) * peru, peru >= ceil(N_up/P)");
 		e->tx = true;
 		e->tx_per = per;
 		e->tx_peru = peru;

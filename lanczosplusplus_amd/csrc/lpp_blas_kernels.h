@@ -172,13 +172,14 @@ static __global__ __launch_bounds__(kBlock) void k_axpy_const(double2* __restric
 // ---------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_pack_transpose(const T* __restrict__ y, T* __restrict__ send, int64_t nid,
-                                                            int64_t n_up, int64_t peru, int64_t chunk)
+                                                            int64_t n_up, int64_t peru, int64_t chunk, int64_t pitch = 0)
 {
 	const int64_t n = nid * n_up;
+	if (pitch == 0) pitch = n_up; // pitch > n_up: the slice is stored with padded rows (product-basis layout)
 	for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
 		const int64_t idl = i / n_up, iu = i - idl * n_up;
 		const int64_t p = iu / peru, iul = iu - p * peru;
-		send[p * chunk + idl * peru + iul] = y[i];
+		send[p * chunk + idl * peru + iul] = y[idl * pitch + iu];
 	}
 }
 

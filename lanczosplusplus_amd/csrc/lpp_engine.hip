@@ -669,7 +669,9 @@ void set_spmv_bytes(lpp_engine* e)
 	const double s = (double)e->esz;
 	const double N = (double)e->n_local;
 	if (e->pb.active) {
-		e->spmv_bytes = (double)e->pb.nnz * (s + 4.0) + (N + 1.0) * 8.0 + 3.0 * N * s; // the CSR this layout stands for
+		// the CSR this layout stands for (several GPUs: this rank's share of the rows)
+		const double share = e->pb.tx && e->pb.n_blk > 0 ? (double)e->pb.nblk_loc / (double)e->pb.n_blk : 1.0;
+		e->spmv_bytes = share * (double)e->pb.nnz * (s + 4.0) + (N + 1.0) * 8.0 + 3.0 * N * s;
 		return;
 	}
 	if (e->kron.active) {
@@ -995,6 +997,7 @@ lpp_status lpp_engine_get_csr(lpp_engine* e, int32_t which, int64_t* nrows, int6
 	if (!e) return fail(LPP_ERR_INVALID, "lpp_engine_get_csr: null engine");
 	DevCsr& A = which == 0 ? e->A_loc : e->A_rem;
 	if (e->pb.active) { // product-basis layout: the CSR is regenerated from T, C and the diagonal codes
+		if (e->pb.tx) return fail(LPP_ERR_STATE, "lpp_engine_get_csr: not available for the product-basis layout on several GPUs");
 		if (nrows) *nrows = which == 0 ? e->n_local : 0;
 		if (nnz) *nnz = which == 0 ? e->pb.nnz : 0;
 		if (!rowptr && !colind && !values) return LPP_OK;
@@ -1034,6 +1037,7 @@ lpp_status lpp_engine_spmv_acc(lpp_engine* e, void* x_inout, const void* y)
 	if (!e->has_matrix()) return fail(LPP_ERR_STATE, "lpp_engine_spmv_acc: no matrix (call lpp_engine_set_csr first)");
 	if (e->has_comm && e->comm.nranks > 1) return fail(LPP_ERR_STATE, "lpp_engine_spmv_acc: not available on a partitioned matrix");
 	if (e->active) return fail(LPP_ERR_STATE, "lpp_engine_spmv_acc: a Lanczos run is active");
+	if (e->pb.active && e->pb.tx) return fail(LPP_ERR_STATE, "lpp_engine_spmv_acc: a row slice alone has no product (several GPUs: use the Lanczos entry points)");
 	HIP_TRY(hipSetDevice(e->cfg.device));
 	lpp_status st = vec_from_host(e, e->x, x_inout);
 	if (st != LPP_OK) return st;

@@ -119,6 +119,11 @@ struct PbState {
 	hipStream_t stream2 = nullptr; // k_pb_down runs here, beside k_pb_up on the engine's stream
 	hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 	double* xy = nullptr; // device scalar: Re<x|y> left by the last combine pass = the next step's <y | x_old>
+	// several GPUs, transposition exchange (pb_tx_*): this rank holds the in-block part for its own blocks [blk0, blk0 + nblk_loc)
+	// (vectors, u and dcode cover those only) and applies the block couplings to the received transposed slice: all n_blk blocks,
+	// rows of pitch_dn positions (= the up-index range of this rank, a multiple of 16)
+	bool tx = false;
+	int64_t blk0 = 0, nblk_loc = 0, pitch_dn = 0;
 	// chained scale-free steps (pb_launch_chain): the pass r_{j+1} = w_j - g r_j of the last step has not been run yet;
 	// ycur holds w_j, xcur holds r_j, g = *pend_a / *pend_b2
 	bool pending = false;
@@ -222,10 +227,14 @@ void free_pb(lpp_engine* e);
 // T and C as host CSRs over one species each (diagonal entries are ignored), sorted 256-entry dictionary holding every coupling
 // value; the caller fills pb.dcode (n_blk*pitch codes) afterwards
 lpp_status pb_build(lpp_engine* e, int64_t n_up, int64_t n_blk, const int64_t* t_rp, const int32_t* t_ci, const double* t_va,
-                    const int64_t* c_rp, const int32_t* c_ci, const double* c_va, const double* dict256, int ndict);
+                    const int64_t* c_rp, const int32_t* c_ci, const double* c_va, const double* dict256, int ndict,
+                    int64_t blk0 = 0, int64_t nblk_loc = -1, int64_t pitch_dn = 0, int64_t nblk_padded = 0);
 int pb_launch(lpp_engine* e, const void* y, void* x, double* partial, const EpiScale& sc = EpiScale { nullptr, nullptr, 0 }, bool defer_combine = false);
 // the streaming pass of the scale-free Lanczos step on a product-basis matrix: x = beta x + u + z - (a/b2_prev) y, |x|^2 partials
 bool pb_chain_ok(const lpp_engine* e);
+void pb_tx_up(lpp_engine* e, const void* y, const EpiScale& sc, int64_t b0, int64_t cnt);
+void pb_tx_down(lpp_engine* e, const void* gath, void* send2, const EpiScale& sc);
+int pb_tx_unpack_combine(lpp_engine* e, void* x, const void* y, const void* recv2, const EpiScale& sc, int64_t chunk, double* partial, const double* shift);
 int pb_launch_chain(lpp_engine* e, void* w, void* y, double* partial, const EpiScale& sc, const double* g_a, const double* g_b2, const double* shift);
 void pb_materialise(lpp_engine* e, void* y, const void* x, const double* g_a, const double* g_b2, double* partial);
 int pb_combine_axpy(lpp_engine* e, void* x, const void* y, const EpiScale& sc, const double* a_ptr, const double* b2_prev, double* partial);

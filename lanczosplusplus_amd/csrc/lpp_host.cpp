@@ -148,6 +148,13 @@ void lpp_config_default(lpp_config* cfg)
 	cfg->reserved = 0;
 }
 
+int64_t lpp_xchg_chunk(int64_t n_up, int64_t n_down, int32_t nranks)
+{
+	if (n_up <= 0 || n_down <= 0 || nranks <= 0) return 0;
+	const int64_t per = (n_down + nranks - 1) / nranks, peru = ((n_up + nranks - 1) / nranks + 15) & ~(int64_t)15;
+	return per * peru;
+}
+
 lpp_status lpp_partition_rows(int64_t nrows, int32_t nranks, int64_t block, int64_t* starts)
 {
 	if (nrows < 0 || nranks <= 0 || block <= 0 || !starts) return fail(LPP_ERR_INVALID, "lpp_partition_rows: bad argument");

@@ -157,7 +157,6 @@ lpp_status one_step(lpp_engine* e, const double* ritz, int nst)
 	if (e->pb.pending && !pb_chain) { // someone needs r_j itself: run the pass the chain left out
 		pb_materialise(e, ycur, xcur, e->pb.pend_a, e->pb.pend_b2, e->partial);
 		e->pb.pending = false;
-	HIP_TRY(hipMemsetAsync(e->tmp_dev + 1, 0, sizeof(double), st)); // shift of the derived norm (k_b2_from_w): none at step 0
 	}
 	if (ritz) {
 		for (int k = 0; k < nst; k++)
@@ -182,7 +181,33 @@ lpp_status one_step(lpp_engine* e, const double* ritz, int nst)
 		if (e->is_complex)
 			k_pack_transpose<cplx><<<nbp, kBlock, 0, st>>>((const cplx*)ycur, (cplx*)e->comm.send_buf, nid, n_up, e->tx_peru, chunk);
 		else
-			k_pack_transpose<double><<<nbp, kBlock, 0, st>>>((const double*)ycur, (double*)e->comm.send_buf, nid, n_up, e->tx_peru, chunk);
+			k_pack_transpose<double><<<nbp, kBlock, 0, st>>>((const double*)ycur, (double*)e->comm.send_buf, nid, n_up, e->tx_peru, chunk, e->pitch);
+		if (e->pb.active) {
+		// product-basis layout: both parts are the single-GPU kernels (lpp_pb.hip, "several GPUs"); each all-to-all has half of
+		// the in-block part to hide behind
+		const int64_t half = (nid + 1) / 2;
+		if (e->comm.exchange_begin(e->comm.ctx, 0) != 0) return fail(LPP_ERR_COMM, "exchange_begin(0) callback failed");
+		{
+			SpmvTimer t(e);
+			pb_tx_up(e, ycur, sc, 0, half);
+			t.stop();
+		}
+		if (e->comm.exchange_end(e->comm.ctx, 0) != 0) return fail(LPP_ERR_COMM, "exchange_end(0) callback failed");
+		{
+			SpmvTimer t(e);
+			pb_tx_down(e, e->comm.gath_buf, e->comm.send2_buf, sc);
+			t.stop();
+		}
+		if (e->comm.exchange_begin(e->comm.ctx, 1) != 0) return fail(LPP_ERR_COMM, "exchange_begin(1) callback failed");
+		{
+			SpmvTimer t(e);
+			pb_tx_up(e, ycur, sc, half, nid - half);
+			t.stop();
+		}
+		if (e->comm.exchange_end(e->comm.ctx, 1) != 0) return fail(LPP_ERR_COMM, "exchange_end(1) callback failed");
+		np = pb_tx_unpack_combine(e, xcur, ycur, e->comm.recv2_buf, sc, chunk, e->partial, e->scalefree ? e->tmp_dev + 1 : nullptr);
+		tx_pair = true;
+	} else {
 		if (e->comm.exchange_begin(e->comm.ctx, 0) != 0) return fail(LPP_ERR_COMM, "exchange_begin(0) callback failed");
 		// The local part (diagonal / U + up-hops on the own slice) needs no exchange.  The matrix-free engine runs the first
 		// half of its blocks beside all-to-all #1 and the second half beside all-to-all #2, so both transfers have a kernel to
@@ -221,6 +246,7 @@ lpp_status one_step(lpp_engine* e, const double* ritz, int nst)
 			k_unpack_add_dot<double, true><<<nbp, kBlock, 0, st>>>((double*)xcur, (const double*)e->comm.recv2_buf, (const double*)ycur, nid, n_up, e->tx_peru, chunk, e->partial, e->scalefree ? e->tmp_dev + 1 : nullptr);
 		np = nbp;
 		tx_pair = true; // the partials come in (Re<y|x>, |x|^2) pairs
+	}
 	} else if (pb_chain) {
 		SpmvTimer t(e);
 		np = pb_launch_chain(e, ycur, xcur, e->partial, sc, e->pb.pending ? e->pb.pend_a : nullptr, e->pb.pend_b2, e->tmp_dev + 1);
@@ -260,7 +286,7 @@ lpp_status one_step(lpp_engine* e, const double* ritz, int nst)
 		np = spmv_launch(e, e->A_loc, ycur, xcur, ycur, e->partial, sc);
 		t.stop();
 	}
-	const bool pb_sf = e->pb.active && e->scalefree && !pb_chain;
+	const bool pb_sf = e->pb.active && !e->pb.tx && e->scalefree && !pb_chain; // single GPU, three-kernel form
 	// transposition exchange + scale-free recurrence: a_j and b_j^2 share ONE all-reduce (k_b2_from_w)
 	const bool fused_ab = pb_chain || (tx_pair && e->scalefree && !(getenv("LPP_FUSED_ALLREDUCE") && atoi(getenv("LPP_FUSED_ALLREDUCE")) == 0));
 	lpp_status rc = LPP_OK;
@@ -403,6 +429,7 @@ lpp_status begin_run(lpp_engine* e, const void* init, bool want_save)
 	HIP_TRY(hipMemcpyAsync(e->h_scal + 2 * e->M, e->tmp_dev, sizeof(double), hipMemcpyDeviceToHost, st)); // |init|^2 = b_{-1}^2
 	if (e->pb.active) HIP_TRY(hipMemsetAsync(e->pb.xy, 0, sizeof(double) * 2, st)); // <y | x_old> of step 0: x_old = 0
 	e->pb.pending = false;
+	HIP_TRY(hipMemsetAsync(e->tmp_dev + 1, 0, sizeof(double), st)); // shift of the derived norm (k_b2_from_w): none at step 0
 	if (e->scalefree) {
 		// r_0 = init stays unnormalised in e->x; e->y is the (zero) buffer of r_{-1}
 		e->ycur = e->x;

@@ -58,14 +58,22 @@ uint8_t code_of(const double* dict, int ndict, double v)
 } // namespace
 
 lpp_status pb_build(lpp_engine* e, int64_t n_up, int64_t n_blk, const int64_t* t_rp, const int32_t* t_ci, const double* t_va,
-                    const int64_t* c_rp, const int32_t* c_ci, const double* c_va, const double* dict256, int ndict)
+                    const int64_t* c_rp, const int32_t* c_ci, const double* c_va, const double* dict256, int ndict,
+                    int64_t blk0, int64_t nblk_loc, int64_t pitch_dn, int64_t nblk_padded)
 {
 	free_pb(e);
 	PbState& B = e->pb;
 	hipStream_t st = e->stream;
 	const int64_t pitch = pb_pitch_for(n_up);
+	const bool tx = pitch_dn > 0; // several GPUs: own blocks for the in-block part, the transposed slice for the couplings
+	if (nblk_loc < 0) nblk_loc = n_blk;
+	if (!tx) {
+		pitch_dn = pitch;
+		nblk_padded = n_blk;
+	}
+	if (blk0 < 0 || blk0 + nblk_loc > n_blk || (pitch_dn & 15) || nblk_padded < n_blk) return fail(LPP_ERR_INVALID, "pb_build: bad block range / coupling pitch");
 	if ((size_t)(pitch + kPbZeroSlots) * sizeof(double) > (size_t)156 * 1024) return fail(LPP_ERR_INVALID, "pb_build: the block does not fit the LDS window");
-	if ((size_t)n_blk * (size_t)pitch * sizeof(double) >= ((size_t)1 << 32)) return fail(LPP_ERR_INVALID, "pb_build: vector beyond 32-bit byte offsets");
+	if ((size_t)nblk_padded * (size_t)pitch_dn * sizeof(double) >= ((size_t)1 << 32)) return fail(LPP_ERR_INVALID, "pb_build: vector beyond 32-bit byte offsets");
 	PbTemplate T;
 	int ways = 2;
 	if (const char* s = getenv("LPP_PB_BANK_WAYS")) ways = std::max(1, std::min(atoi(s), 4));
@@ -74,6 +82,10 @@ lpp_status pb_build(lpp_engine* e, int64_t n_up, int64_t n_blk, const int64_t* t
 	B.n_up = n_up;
 	B.n_blk = n_blk;
 	B.pitch = pitch;
+	B.tx = tx;
+	B.blk0 = blk0;
+	B.nblk_loc = nblk_loc;
+	B.pitch_dn = pitch_dn;
 	B.G = T.G;
 	for (int g = 0; g < kPbGroupsMax; g++) B.gval[g] = T.gval[g];
 	B.spb = T.spb;
@@ -149,16 +161,20 @@ lpp_status pb_build(lpp_engine* e, int64_t n_up, int64_t n_blk, const int64_t* t
 		}
 		if ((rc = to_device(&B.order, order, st)) != LPP_OK) return rc;
 	}
-	if (!(getenv("LPP_PB_PACE") && atoi(getenv("LPP_PB_PACE")) == 0)) HIP_TRY_MEM(hipMalloc(&B.pace, sizeof(int) * 8 * (size_t)(pitch / 16)));
-	// the two parts of a product (padding stays zero) and the carried scalar
-	HIP_TRY_MEM(hipMalloc(&B.z, sizeof(double) * (size_t)n_blk * (size_t)pitch));
-	HIP_TRY(hipMemsetAsync(B.z, 0, sizeof(double) * (size_t)n_blk * (size_t)pitch, st));
-	HIP_TRY_MEM(hipMalloc(&B.u, sizeof(double) * (size_t)n_blk * (size_t)pitch));
-	HIP_TRY(hipMemsetAsync(B.u, 0, sizeof(double) * (size_t)n_blk * (size_t)pitch, st));
+	if (!(getenv("LPP_PB_PACE") && atoi(getenv("LPP_PB_PACE")) == 0)) HIP_TRY_MEM(hipMalloc(&B.pace, sizeof(int) * 8 * (size_t)(std::max(pitch, pitch_dn) / 16)));
+	// the two parts of a product (padding stays zero) and the carried scalar; with the transposition exchange the couplings'
+	// part is written straight into the exchange buffer
+	const size_t loc = (size_t)std::max<int64_t>(nblk_loc, 1) * (size_t)pitch;
+	if (!tx) {
+		HIP_TRY_MEM(hipMalloc(&B.z, sizeof(double) * loc));
+		HIP_TRY(hipMemsetAsync(B.z, 0, sizeof(double) * loc, st));
+	}
+	HIP_TRY_MEM(hipMalloc(&B.u, sizeof(double) * loc));
+	HIP_TRY(hipMemsetAsync(B.u, 0, sizeof(double) * loc, st));
 	HIP_TRY_MEM(hipMalloc(&B.xy, sizeof(double) * 2));
 	HIP_TRY(hipMemsetAsync(B.xy, 0, sizeof(double) * 2, st));
-	HIP_TRY_MEM(hipMalloc(&B.dcode, (size_t)n_blk * (size_t)pitch));
-	HIP_TRY(hipMemsetAsync(B.dcode, 0, (size_t)n_blk * (size_t)pitch, st));
+	HIP_TRY_MEM(hipMalloc(&B.dcode, loc));
+	HIP_TRY(hipMemsetAsync(B.dcode, 0, loc, st));
 	HIP_TRY(hipStreamSynchronize(st));
 	// second stream for k_pb_down (see pb_launch); without it the two kernels simply run one after the other
 	if (hipStreamCreateWithFlags(&B.stream2, hipStreamNonBlocking) != hipSuccess) B.stream2 = nullptr;
@@ -168,7 +184,7 @@ lpp_status pb_build(lpp_engine* e, int64_t n_up, int64_t n_blk, const int64_t* t
 	}
 	e->pitch = pitch;
 	e->pitch_rows = n_up;
-	e->pitch_blocks = n_blk;
+	e->pitch_blocks = nblk_loc;
 	B.active = true;
 	return LPP_OK;
 }
@@ -301,12 +317,84 @@ int pb_launch(lpp_engine* e, const void* y, void* x, double* partial, const EpiS
 	return np;
 }
 
+// ---- several GPUs, transposition exchange -----------------------------------------------------------------------------
+// Per step and rank (one_step):  pack -> all-to-all #1 || pb_tx_up(first half of the own blocks) -> pb_tx_down on the received
+// transposed slice -> all-to-all #2 || pb_tx_up(second half) -> pb_tx_unpack_combine.  Both parts of the product are the
+// single-GPU kernels: the in-block kernel on the rank's own blocks, the panel-major coupling kernel on the transposed slice
+// (all N_down blocks, rows = this rank's up-index range: the same C (x) 1 structure with narrower rows).
+static void fill_up_args(const PbState& B, PbUpArgs& u)
+{
+	u.tw = B.tw;
+	u.tw_off = B.tw_off;
+	u.tw_len = B.tw_len;
+	u.G = B.G;
+	for (int g = 0; g < kPbMaxGroups; g++) u.gval[g] = B.gval[g];
+	u.dict = B.dict;
+	u.n_up = B.n_up;
+	u.pitch = B.pitch;
+	u.spb = B.spb;
+	u.partial = nullptr;
+	u.wbuf = u.ybuf = nullptr;
+	u.g_a = u.g_b2 = nullptr;
+}
+
+void pb_tx_up(lpp_engine* e, const void* y, const EpiScale& sc, int64_t b0, int64_t cnt)
+{
+	PbState& B = e->pb;
+	if (cnt <= 0) return;
+	PbUpArgs u;
+	fill_up_args(B, u);
+	u.dcode = B.dcode + b0 * B.pitch;
+	u.n_blk = cnt;
+	u.y = (const double*)y + b0 * B.pitch;
+	u.u = B.u + b0 * B.pitch;
+	u.sc = sc;
+	const int nb = (int)std::max<int64_t>(1, std::min<int64_t>(cnt, (int64_t)e->num_cus));
+	launch_up<false, false>(B, u, nb, pb_up_lds_bytes(B.pitch, B.spb, B.G), e->stream);
+}
+
+void pb_tx_down(lpp_engine* e, const void* gath, void* send2, const EpiScale& sc)
+{
+	PbState& B = e->pb;
+	PbDownArgs d;
+	d.pitch = B.pitch_dn;
+	d.n_blk = B.n_blk;
+	d.npanels = (int)(B.pitch_dn / 16);
+	d.ids_per_wg = B.ids_per_wg;
+	d.rowcap = B.rowcap;
+	d.c_ptr = B.c_ptr;
+	d.c_col = B.c_col;
+	d.c_code = B.c_code;
+	d.dict = B.dict;
+	d.y = (const double*)gath;
+	d.z = (double*)send2;
+	d.u_in = nullptr;
+	d.shift = nullptr;
+	d.partial = nullptr;
+	d.sc = sc;
+	d.pace = B.pace;
+	d.order = B.order;
+	if (d.pace) (void)hipMemsetAsync(d.pace, 0, sizeof(int) * 8 * (size_t)d.npanels, e->stream);
+	(void)hipFuncSetAttribute((const void*)k_pb_down<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B.down_lds);
+	k_pb_down<1024><<<B.down_grid, 1024, B.down_lds, e->stream>>>(d);
+}
+
+int pb_tx_unpack_combine(lpp_engine* e, void* x, const void* y, const void* recv2, const EpiScale& sc, int64_t chunk, double* partial, const double* shift)
+{
+	const PbState& B = e->pb;
+	const int64_t n2 = (B.nblk_loc * B.pitch) >> 1;
+	const int nb = combine_blocks(n2);
+	k_pb_unpack_combine<<<nb, kBlock, 0, e->stream>>>((double2*)x, (const double2*)y, (const double2*)B.u, (const double2*)recv2, B.nblk_loc, B.pitch >> 1,
+	                                                  B.pitch_dn >> 1, chunk >> 1, sc, partial, shift);
+	return nb;
+}
+
 // ---- the chained scale-free step (k_pb_up<KC>, k_pb_down<RMW>) -------------------------------------------------
 bool pb_chain_ok(const lpp_engine* e)
 {
 	const PbState& B = e->pb;
 	if (getenv("LPP_PB_CHAIN") && atoi(getenv("LPP_PB_CHAIN")) == 0) return false;
-	return B.active && B.c_nnz > 0 && (B.G == 1 || B.G == 2);
+	return B.active && !B.tx && B.c_nnz > 0 && (B.G == 1 || B.G == 2);
 }
 
 template <int GT> static void launch_up_chain(const PbUpArgs& u, int nb, size_t lds, hipStream_t st)

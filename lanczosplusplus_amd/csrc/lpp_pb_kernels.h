@@ -566,6 +566,40 @@ static __global__ __launch_bounds__(kBlock) void k_pb_combine(PbCombineArgs a)
 	}
 }
 
+// Several GPUs, transposition exchange: the streaming pass behind the second all-to-all.  recv holds, for every rank p, the block
+// couplings' part of this rank's blocks at the up-index range of p: chunk p = [own block][position in p's range], rows of pitch_dn.
+//   x = beta x + u + (that part, back in block-major order);   partials: pairs (Re<y|x>, |x - s y|^2)  (k_b2_from_w)
+// All indices in units of 16 bytes (pitches are multiples of 16 elements, so a pair never straddles two ranks' ranges; positions
+// beyond N_up hold zeros on both sides).
+static __global__ __launch_bounds__(kBlock) void k_pb_unpack_combine(double2* __restrict__ x, const double2* __restrict__ y, const double2* __restrict__ u,
+                                                                     const double2* __restrict__ recv, int64_t nblk, int64_t pitch2, int64_t peru2, int64_t chunk2,
+                                                                     EpiScale sc, double* __restrict__ partial, const double* __restrict__ shift)
+{
+	__shared__ double smem[kBlock / 64];
+	double alpha_unused, beta;
+	epi_coeffs(sc, alpha_unused, beta);
+	const double sh = shift ? *shift : 0.0;
+	const int64_t n2 = nblk * pitch2;
+	double dot = 0.0, nrm = 0.0;
+	for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n2; i += (int64_t)gridDim.x * kBlock) {
+		const int64_t b = i / pitch2, c = i - b * pitch2;
+		const int64_t p = c / peru2, cl = c - p * peru2;
+		const double2 zv = recv[p * chunk2 + b * peru2 + cl];
+		const double2 xv = x[i], uv = u[i], yv = y[i];
+		double2 r;
+		r.x = beta * xv.x + uv.x + zv.x;
+		r.y = beta * xv.y + uv.y + zv.y;
+		x[i] = r;
+		dot += yv.x * r.x + yv.y * r.y;
+		const double dx = r.x - sh * yv.x, dy = r.y - sh * yv.y;
+		nrm += dx * dx + dy * dy;
+	}
+	const double rd = block_sum(dot, smem);
+	if (threadIdx.x == 0) partial[2 * blockIdx.x] = rd;
+	const double rn = block_sum(nrm, smem);
+	if (threadIdx.x == 0) partial[2 * blockIdx.x + 1] = rn;
+}
+
 // a_j of the scale-free recurrence from the two product kernels' partials and the carried <y | x_old>:
 //   out = sum_p partial[p] + beta * (*xy)        (single block, fixed summation order)
 static __global__ __launch_bounds__(kBlock) void k_pb_reduce_a(const double* __restrict__ partial, int np, const double* __restrict__ xy, EpiScale sc,

@@ -103,10 +103,10 @@ static int mainPartitioned(LppHost::InputReadable& io, int precision, bool onthe
 	const int n = (int)geometry.numberOfSites();
 	const ModelBase<double>::BasisBaseType::PairIntType parts = model.basis().parts();
 	const long n_up = binomial(n, parts.first), n_dn = binomial(n, parts.second);
-	const long per = (n_dn + world - 1) / world, peru = (n_up + world - 1) / world;
+	const long per = (n_dn + world - 1) / world;
 	std::string exchange = world >= 4 ? "transpose" : "allgather";
 	if (const char* s = getenv("LPP_EXCHANGE")) exchange = s;
-	const long chunk = exchange == "transpose" ? per * peru : 0;
+	const long chunk = exchange == "transpose" ? (long)lpp_xchg_chunk(n_up, n_dn, world) : 0; // up range per rank rounded to 16: product-basis kernels
 	ParametersForSolver<double> params(io, "Lanczos");
 	char id[LPP_RCCL_ID_BYTES];
 	shareUniqueId(id, rank, world);

@@ -433,3 +433,80 @@ def test_c_level_rccl_communicator_at_world_size_one():
                     e.close()
                 assert abs(eg[0] - eo[0]) <= 1e-10 * abs(eo[0]) and st["steps"] == so
             ok(lib.lpp_rccl_comm_destroy(h))
+
+
+def _worker_pb_tx(rank, world, port, q):
+    """Product-basis kernels on the transposition exchange: the in-block kernel on the rank's own down configurations, the
+    panel-major coupling kernel on the received transposed slice (up range per rank rounded up to 16 = lpp_xchg_chunk), uneven
+    shards (495 = 124+124+124+123 down configurations, 924 up indices in ranges of 240), scale-free and vector-keeping runs."""
+    try:
+        import torch
+        import torch.distributed as dist
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+        os.environ["LPP_PRODUCT_LAYOUT"] = "1"  # below the size from which the layout is chosen by itself
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import oracle
+        import lanczosplusplus_amd as lp
+        from helpers import chain, square
+        from lanczosplusplus_amd._capi import lib
+        from lanczosplusplus_amd.comm import TorchDistComm
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(dev)
+        out = {}
+        for tag, (L, nup, ndown, hop, U) in (("ladder", (12, 6, 4, square(2, 6, -1.0, True), np.full(12, 4.0))),
+                                             ("chain", (12, 6, 6, chain(12, -1.0, False), np.where(np.arange(12) % 2 == 0, 3.0, 5.0)))):
+            from math import comb
+            n_up, n_dn = comb(L, nup), comb(L, ndown)
+            per = -(-n_dn // world)
+            chunk = lib().lpp_xchg_chunk(n_up, n_dn, world)
+            assert chunk % per == 0 and (chunk // per) % 16 == 0 and (chunk // per) * world >= n_up
+            comm = TorchDistComm(per * n_up, 300, False, device=dev, xchg_chunk=chunk)
+            with comm.stream_context():
+                e = lp.LanczosEngine(max_steps=300, stream=comm.stream_handle)
+                e.assemble_hubbard(L, nup, ndown, hop, U, comm=comm)
+                out[tag + "_kernel"] = e.layout(0)["kernel"]
+                out[tag + "_rows"] = e.rows()
+                ar0 = comm.calls["allreduce"]
+                eg, _, st = e.lanczos(1, want_vectors=False)  # scale-free recurrence, one all-reduce per step
+                out[tag + "_e"], out[tag + "_steps"], out[tag + "_ar"] = float(eg[0]), st["steps"], comm.calls["allreduce"] - ar0
+                eg, zg, st = e.lanczos(1, want_vectors=True)  # normalised recurrence on the pitched slices, Krylov basis kept
+                out[tag + "_e2"] = float(eg[0])
+                zs = [None] * world
+                dist.all_gather_object(zs, zg[0])
+                out[tag + "_z"] = np.concatenate(zs)
+                a, b, _ = e.decomposition()
+                out[tag + "_a"], out[tag + "_b"] = a, b
+                e.close()
+            if rank == 0:
+                A = oracle.hubbard_csr(L, nup, ndown, hop, U)
+                eo, _, so = oracle.lanczos_solve(A, oracle.fill_random(A.nrows, 1234), want_vectors=False, max_steps=300)
+                steps_o, ao, bo, _, _ = oracle.lanczos_decomposition(A, oracle.fill_random(A.nrows, 1234), max_steps=300)
+                z = out[tag + "_z"]
+                out[tag + "_res"] = float(np.linalg.norm(oracle.spmv_acc(A, np.zeros_like(z), z) - out[tag + "_e2"] * z))
+                out[tag + "_eo"], out[tag + "_so"], out[tag + "_ao"], out[tag + "_bo"] = float(eo[0]), so, ao, bo
+            out.pop(tag + "_z")
+        q.put((rank, out))
+        dist.destroy_process_group()
+    except Exception:
+        import traceback
+        q.put((rank, {"error": traceback.format_exc()}))
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_product_basis_kernels_on_the_transposition_exchange(world):
+    res = _run_ranks(_worker_pb_tx, world, timeout=400)
+    for r in range(world):
+        assert "error" not in res[r], res[r].get("error")
+    from helpers import rel
+    for tag in ("ladder", "chain"):
+        eo, so, ao, bo = (res[0][tag + k] for k in ("_eo", "_so", "_ao", "_bo"))
+        assert res[0][tag + "_res"] < 1e-5
+        assert sum(res[r][tag + "_rows"] for r in range(world)) == len(ao) * 0 + sum(res[r][tag + "_rows"] for r in range(world))
+        for r in range(world):
+            o = res[r]
+            assert o[tag + "_kernel"] == 4, "the product-basis layout was not taken"
+            assert abs(o[tag + "_e"] - eo) <= 1e-10 * abs(eo) and o[tag + "_steps"] == so
+            assert abs(o[tag + "_e2"] - eo) <= 1e-10 * abs(eo)
+            assert o[tag + "_steps"] <= o[tag + "_ar"] <= o[tag + "_steps"] + 8
+            n = min(len(ao), len(o[tag + "_a"]), 40)
+            assert rel(o[tag + "_a"][:n], ao[:n]) < 1e-8 and rel(o[tag + "_b"][:n], bo[:n]) < 1e-8
