@@ -510,3 +510,63 @@ def test_product_basis_kernels_on_the_transposition_exchange(world):
             assert o[tag + "_steps"] <= o[tag + "_ar"] <= o[tag + "_steps"] + 8
             n = min(len(ao), len(o[tag + "_a"]), 40)
             assert rel(o[tag + "_a"][:n], ao[:n]) < 1e-8 and rel(o[tag + "_b"][:n], bo[:n]) < 1e-8
+
+
+def _worker_odd(rank, world, port, q):
+    """Odd slice lengths (f64): N_up = C(6,2) = 15 and 3 down configurations per rank = 45 doubles per slice.  The BLAS-1 kernels move
+    16-byte pairs; the copy for the next all-gather must stop at the 45th double of a send buffer that holds exactly 45."""
+    try:
+        import torch
+        import torch.distributed as dist
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import oracle
+        import lanczosplusplus_amd as lp
+        from helpers import chain
+        from lanczosplusplus_amd.comm import TorchDistComm
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(dev)
+        L, nup, ndown = 6, 2, 1
+        hop, U = chain(L, -1.0, True), np.linspace(2.0, 4.0, L)
+        n_up, n_dn = 15, 6
+        stride = (n_dn // world) * n_up
+        assert stride % 2 == 1
+        out = {}
+        for mode in ("stored", "onthefly"):
+            for keep in (0, 1):  # scale-free (k_axpy_nrm copies) / vectors kept (k_swap_scale, k_scale_copy copy)
+                comm = TorchDistComm(stride, 60, False, device=dev)
+                # the send buffer inside a guarded allocation: exactly `stride` doubles, sentinels on both sides
+                guard = torch.full((stride + 8,), 777.0, dtype=torch.float64, device=dev)
+                comm.send = guard[2:2 + stride]
+                comm.send.zero_()
+                comm.struct.send_buf = comm.send.data_ptr()
+                with comm.stream_context():
+                    e = lp.LanczosEngine(max_steps=60, save_vectors=keep, stream=comm.stream_handle)
+                    if mode == "stored":
+                        e.assemble_hubbard(L, nup, ndown, hop, U, comm=comm)
+                    else:
+                        e.setup_hubbard_onthefly(L, nup, ndown, hop, U, comm=comm)
+                    eg, _, st = e.lanczos(1, want_vectors=False)
+                    e.close()
+                torch.cuda.synchronize()
+                out["%s_%d" % (mode, keep)] = (float(eg[0]), st["steps"], bool((guard[:2] == 777.0).all() and (guard[2 + stride:] == 777.0).all()))
+        if rank == 0:
+            A = oracle.hubbard_csr(L, nup, ndown, hop, U)
+            out["e_dense"] = float(np.linalg.eigvalsh(A.to_scipy().toarray())[0])
+        q.put((rank, out))
+        dist.destroy_process_group()
+    except Exception:
+        import traceback
+        q.put((rank, {"error": traceback.format_exc()}))
+
+
+def test_two_ranks_odd_slice_lengths_stay_inside_the_send_buffer():
+    world = 2
+    res = _run_ranks(_worker_odd, world)
+    for r in range(world):
+        assert "error" not in res[r], res[r].get("error")
+    ed = res[0]["e_dense"]
+    for r in range(world):
+        for k, (e0, steps, intact) in [(k, v) for k, v in res[r].items() if k != "e_dense"]:
+            assert intact, (k, "wrote outside the send buffer")
+            assert abs(e0 - ed) <= 1e-10 * abs(ed), (k, e0, ed)
