@@ -319,6 +319,8 @@ def main():
             import torch.distributed as dist
             dist.barrier()
 
+    mem_used = [None]
+
     def setup(exchange):
         """communicator + engine + resident matrix + warm-up steps; returns everything the timed region needs"""
         c = None
@@ -332,10 +334,14 @@ def main():
         with cm:
             en = LanczosEngine(dtype="c128" if is_complex else "f64", device=local_rank, max_steps=max_steps, eps=0.0,
                                save_vectors=0, spmv_kernel=args.spmv_kernel, time_kernels=True, stream=strm)
+            free0 = torch.cuda.mem_get_info(local_rank)[0]
             t_a = time.time()
             assemble(en, name, c, onthefly=(args.engine == "onthefly"))
             en.sync()
             t_a = time.time() - t_a
+            # device memory the engine holds once the matrix is set (matrix + work vectors + product buffers), from the driver's
+            # own accounting; the product-basis assembler allocates nothing it frees again, so this is also its peak
+            mem_used[0] = (free0 - torch.cuda.mem_get_info(local_rank)[0]) / 1e9
             s0 = en.stats()
             en.begin(None)
             en.step(args.warmup)
@@ -449,6 +455,7 @@ def main():
                        "reortho": False, "assembly": "on-device", "assembly_s": round(t_asm, 3), "engine": args.engine,
                        "exchange": (("transpose" if comm.xchg_chunk > 0 else "allgather") if comm is not None else None),
                        "per_rank_memory_GB": round(per_rank_bytes(eng, comm, st0, esz, args.engine) / 1e9, 2),
+                       "device_memory_after_setup_GB": (round(mem_used[0], 2) if mem_used[0] is not None else None),
                        "layout": layout},
             "roofline": roofline,
             "e0_after_steps": e0,
