@@ -1,6 +1,6 @@
 import os, sys
 import numpy as np
-R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # repo root
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
 import oracle
 from helpers import chain

@@ -1,7 +1,7 @@
 """2 ranks sharing cuda:0 (gloo): product-basis kernels on the transposition exchange, first Lanczos coefficients vs the oracle"""
 import os, sys
 import numpy as np
-R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # repo root
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
 import torch.multiprocessing as mp
 

@@ -1,7 +1,7 @@
 """PCIe-inclusive cost of the host-CSR boundary: lpp_engine_set_csr of a host-assembled Hubbard chain L=14 (1.18e7 rows,
 1.77e8 non-zeros, 2.2 GB of CSR) -- upload + layout conversion -- then the solve."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import oracle
 from lanczosplusplus_amd import LanczosEngine
