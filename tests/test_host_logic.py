@@ -220,3 +220,18 @@ def test_rccl_communicator_library_exports_its_symbols():
             "lpp_rccl_last_error"} <= names
     for n in names:
         assert hasattr(lib, n), n
+
+
+def test_exchange_chunk_helper():
+    """lpp_xchg_chunk (include/lpp_engine.h): ceil(N_down/P) down configurations x (ceil(N_up/P) rounded up to 16) up indices"""
+    from lanczosplusplus_amd._capi import lib
+    L = lib()
+    assert L.lpp_xchg_chunk(12870, 12870, 8) == 1609 * 1616
+    assert L.lpp_xchg_chunk(924, 495, 4) == 124 * 240
+    assert L.lpp_xchg_chunk(252, 210, 4) == 53 * 64
+    assert L.lpp_xchg_chunk(16, 16, 1) == 16 * 16
+    assert L.lpp_xchg_chunk(0, 5, 2) == 0 and L.lpp_xchg_chunk(5, 5, 0) == 0
+    for n_up, n_dn, P in ((12870, 12870, 2), (77520, 38760, 8), (15, 6, 2)):
+        c = L.lpp_xchg_chunk(n_up, n_dn, P)
+        per = -(-n_dn // P)
+        assert c % per == 0 and (c // per) % 16 == 0 and (c // per) * P >= n_up and (c // per - 16) * P < n_up + 16 * P
