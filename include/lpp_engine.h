@@ -191,6 +191,14 @@ lpp_status lpp_engine_assemble_hubbard_ext(lpp_engine* e, const lpp_comm* comm, 
                                            const double* hop_re, const double* hop_im, const double* U, const double* V,
                                            const double* ninj);
 
+/* Model=SuperHubbardExtended (ModelSelector.h:76-80): Coulomb coupling ninj (geometry term 1) and spin coupling jcoup (term 2):
+ * sum_ij J_ij/2 Sz_i Sz_j on the diagonal (HubbardHelper.h:158-165) and the spin-flip terms of setJTermOffDiagonal (:282-330).
+ * Either may be NULL.  The spin-flip terms move both species, so the matrix takes the general layout and, on several GPUs, the
+ * all-gather exchange.  Model=KaneMeleHubbard needs no entry point of its own: its hoppings are term 0 + term 1 (:63-66). */
+lpp_status lpp_engine_assemble_hubbard_super(lpp_engine* e, const lpp_comm* comm, int32_t nsites, int32_t nup, int32_t ndown,
+                                             const double* hop_re, const double* hop_im, const double* U, const double* V,
+                                             const double* ninj, const double* jcoup);
+
 /* Matrix-free Hubbard product (the GPU counterpart of SolverOptions=InternalProductOnTheFly:
  * InternalProductOnTheFly.h:120-123 -> HubbardHelper::matrixVectorProduct, HubbardHelper.h:105-134).
  * No CSR is stored: H = H_up (x) 1 + 1 (x) H_down + diag(U n_up n_down) in the BasisHubbardLanczos ordering;

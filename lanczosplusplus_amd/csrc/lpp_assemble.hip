@@ -166,6 +166,32 @@ void hubbard_terms(int L, const double* hop_re, const double* hop_im, std::vecto
 	}
 }
 
+// Spin-flip terms of SuperHubbardExtended (HubbardHelper.h:282-330): S+_i S-_j moves an up electron j -> i and a down electron i -> j,
+// bra = (up ^ (bit i | bit j), down ^ (bit i | bit j)).  setJTermOffDiagonal adds it twice to a row -- from site i's loop with
+// J(i,j)/4 and from site j's loop with J(j,i)/4 -- and SparseRow::finalize sums the two; the sign (jTermSign, :332-343) is the
+// parity of the up AND the down electrons in [min, max) (BasisOneSpin::doSign, BasisOneSpin.h:100-119), evaluated on the ket.
+void super_terms(int L, const double* jcoup, std::vector<HostProc>& hp)
+{
+	for (int i = 0; i < L; i++)
+		for (int j = 0; j < L; j++) {
+			if (i == j) continue;
+			double a = 0.0, b = 0.0; // contribution of site i's loop (partner j) and of site j's loop (partner i)
+			if (jcoup[i * L + j] != 0) {
+				a = jcoup[i * L + j] * 0.5;
+				a *= 0.5;
+			}
+			if (jcoup[j * L + i] != 0) {
+				b = jcoup[j * L + i] * 0.5;
+				b *= 0.5;
+			}
+			if (jcoup[i * L + j] == 0 && jcoup[j * L + i] == 0) continue;
+			const int lo = std::min(i, j), hi = std::max(i, j);
+			const uint64_t both = bit(i) | bit(j), rng = range_mask(lo, hi);
+			const double amp = a + b; // one rounding at most, the same whichever of the two SparseRow::finalize meets first
+			push(hp, bit(j) | (bit(i) << L), bit(i) | (bit(j) << L), both | (both << L), rng | (rng << L), 0, 0, amp, 0.0, true);
+		}
+}
+
 // columns_are_local: every stored column index is rank-local (transposition exchange: own slice + transposed slice), so only
 // the per-rank sizes -- checked by the caller -- have to fit 32 bits, not the global dimension
 lpp_status common_setup(lpp_engine* e, int64_t nrows, int is_complex_input, bool columns_are_local = false)
@@ -204,6 +230,7 @@ lpp_status assemble_hubbard_pb(lpp_engine* e, AsmParams P, int nup, int ndown, i
 {
 	*done = false;
 	if (e->is_complex || n_up < 512) return LPP_OK;
+	if (P.d3) return LPP_OK; // spin-flip terms move both species: not of the form 1 (x) T + C (x) 1
 	// LPP_PRODUCT_LAYOUT = 0: never, 1: whenever it applies; unset: from 32 MB per vector on.  Below that everything sits in
 	// L2 / Infinity Cache anyway and the step is launch-bound: measured on Hubbard chains (scripts/experiments/pb_threshold.sh),
 	// 8.5e5 rows 17.2k (product) vs 18.8k (general) iterations/s, 1.2e7 rows 4164 vs 3833, 1.3e8 rows 385 vs 246
@@ -323,6 +350,13 @@ lpp_status lpp_engine_assemble_hubbard_ext(lpp_engine* e, const lpp_comm* comm, 
                                            const double* hop_re, const double* hop_im, const double* U, const double* V,
                                            const double* ninj)
 {
+	return lpp_engine_assemble_hubbard_super(e, comm, L, nup, ndown, hop_re, hop_im, U, V, ninj, nullptr);
+}
+
+lpp_status lpp_engine_assemble_hubbard_super(lpp_engine* e, const lpp_comm* comm, int32_t L, int32_t nup, int32_t ndown,
+                                             const double* hop_re, const double* hop_im, const double* U, const double* V,
+                                             const double* ninj, const double* jcoup)
+{
 	if (!e || !hop_re || !U || !V || L < 1 || L > 31 || nup < 0 || ndown < 0 || nup > L || ndown > L)
 		return fail(LPP_ERR_INVALID, "lpp_engine_assemble_hubbard: bad argument (1 <= L <= 31)");
 	const std::vector<uint64_t> comb = comb_table();
@@ -336,14 +370,20 @@ lpp_status lpp_engine_assemble_hubbard_ext(lpp_engine* e, const lpp_comm* comm, 
 	lpp_status st = common_setup(e, nrows, cplx_in, local_columns);
 	if (st != LPP_OK) return st;
 
+	bool has_j = false; // Model=SuperHubbardExtended: spin coupling (geometry term 2)
+	if (jcoup)
+		for (int k = 0; k < L * L; k++) has_j |= (jcoup[k] != 0);
+	if (!has_j) jcoup = nullptr;
 	std::vector<HostProc> hp;
 	hubbard_terms(L, hop_re, hop_im, hp);
+	if (jcoup) super_terms(L, jcoup, hp);
 	std::vector<Proc> procs;
 	int nneg = 0;
 	st = finish_procs(hp, procs, &nneg);
 	if (st != LPP_OK) return st;
 
-	DevBuf d_procs, d_comb, d_U, d_V, d_U0;
+	DevBuf d_procs, d_comb, d_U, d_V, d_U0, d_jc;
+	if (jcoup && (st = upload(e->stream, d_jc, jcoup, sizeof(double) * L * L)) != LPP_OK) return st;
 	const std::vector<double> zeroU((size_t)L, 0.0);
 	if ((st = upload(e->stream, d_procs, procs.data(), sizeof(Proc) * procs.size())) != LPP_OK) return st;
 	if ((st = upload(e->stream, d_comb, comb.data(), sizeof(uint64_t) * comb.size())) != LPP_OK) return st;
@@ -367,6 +407,7 @@ lpp_status lpp_engine_assemble_hubbard_ext(lpp_engine* e, const lpp_comm* comm, 
 	P.d0 = (const double*)d_U.p;
 	P.d1 = (const double*)d_V.p;
 	P.d2 = ninj ? (const double*)d_ninj.p : nullptr; // Coulomb coupling of HubbardOneBandExtended
+	P.d3 = jcoup ? (const double*)d_jc.p : nullptr; // spin coupling of SuperHubbardExtended
 
 	const bool multi = comm && comm->nranks > 1;
 	if (!multi) {
@@ -399,6 +440,7 @@ lpp_status lpp_engine_assemble_hubbard_ext(lpp_engine* e, const lpp_comm* comm, 
 		const int64_t per = (n_dn + comm->nranks - 1) / comm->nranks;
 		if (comm->shard_stride != per * n_up) return fail(LPP_ERR_INVALID, "assemble_hubbard: comm.shard_stride must be ceil(N_down/nranks)*N_up");
 		const bool transpose = comm->exchange_begin && comm->exchange_end && comm->xchg_chunk > 0;
+		if (transpose && jcoup) return fail(LPP_ERR_INVALID, "assemble_hubbard: spin-flip terms (SuperHubbardExtended) need the all-gather exchange");
 		// all-gather: remote columns index the gathered vector; transposition: columns index the rank's own slice (and its
 		// transposed slice, checked below), so the GLOBAL dimension may exceed 2^31 (e.g. the 3.0e9-state (7,6) sector of the 4x5 lattice)
 		if (!transpose && (int64_t)comm->nranks * comm->shard_stride > (int64_t)INT32_MAX)

@@ -46,6 +46,7 @@ struct AsmParams {
 	const double* d0; // Hubbard U[L] | Heisenberg field[L] (nd0 valid) | t-J potentialV[2L]
 	const double* d1; // Hubbard V[L] | Heisenberg anisotropy[L] (nd1 valid) | t-J jzz[L*L]
 	const double* d2; // Hubbard Coulomb coupling[L*L] or null | Heisenberg jzz[L*L] | t-J w[L*L]
+	const double* d3; // Hubbard spin coupling J[L*L] (SuperHubbardExtended) or null
 	int nd0, nd1;
 	// Hubbard, transposed row layout (multi-GPU transposition scheme): row = id*peru + (iu - iu0) for the rank's
 	// UP-index range [iu0, iu0+nu) and ALL down indices id < n_dn; rows with iu_l >= nu or id >= n_dn are padding
@@ -218,6 +219,15 @@ template <int MODEL> __device__ double diag_of(const AsmParams& P, uint64_t w)
 		for (int i = 0; i < L; i++) {
 			const int nu = (int)((up >> i) & 1), nd = (int)((down >> i) & 1);
 			s += P.d0[i] * nu * nd;
+			if (P.d3) { // SuperHubbardExtended: sum_j J(i,j) 0.5 Sz_i Sz_j (HubbardHelper.h:158-165); every product is exact
+				const double szi = 0.5 * (double)(nu - nd);
+				for (int j = 0; j < L; j++) {
+					const double value = P.d3[i * L + j];
+					if (value == 0) continue;
+					const double szj = 0.5 * (double)((int)((up >> j) & 1) - (int)((down >> j) & 1));
+					s += value * 0.5 * szi * szj;
+				}
+			}
 			const double ne = nu + nd;
 			if (P.d2) { // HubbardOneBandExtended: 0.5 * coulombCoupling(i,j) n_i n_j over ALL j (HubbardHelper.h:167-177)
 				for (int j = 0; j < L; j++) {

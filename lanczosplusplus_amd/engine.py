@@ -101,8 +101,9 @@ class LanczosEngine:
         check(self._lib.lpp_engine_set_csr_partition(self._h, C.byref(comm.struct), global_rows, _vp(shard_starts),
                                                      _vp(rowptr), _vp(colind), _vp(values)))
 
-    def assemble_hubbard(self, L, nup, ndown, hop, U, V=None, comm=None, ninj=None):
-        """ninj: L x L Coulomb coupling of Model=HubbardOneBandExtended (the reference's second geometry term), or None."""
+    def assemble_hubbard(self, L, nup, ndown, hop, U, V=None, comm=None, ninj=None, jcoup=None):
+        """ninj: L x L Coulomb coupling of Model=HubbardOneBandExtended (the reference's second geometry term), or None;
+        jcoup: L x L spin coupling (third term), with ninj Model=SuperHubbardExtended.  Model=KaneMeleHubbard: pass hop = term 0 + term 1."""
         hop = np.asarray(hop).reshape(L, L)
         hr = _mat(hop.real, L)
         hi = _mat(hop.imag, L) if np.iscomplexobj(hop) else None
@@ -111,7 +112,8 @@ class LanczosEngine:
         nj = None if ninj is None else _mat(ninj, L)
         self._comm_keepalive = comm
         cs = C.byref(comm.struct) if comm is not None else None
-        check(self._lib.lpp_engine_assemble_hubbard_ext(self._h, cs, L, nup, ndown, _vp(hr), _vp(hi), _vp(U), _vp(V), _vp(nj)))
+        jc = None if jcoup is None else _mat(jcoup, L)
+        check(self._lib.lpp_engine_assemble_hubbard_super(self._h, cs, L, nup, ndown, _vp(hr), _vp(hi), _vp(U), _vp(V), _vp(nj), _vp(jc)))
 
     def setup_hubbard_onthefly(self, L, nup, ndown, hop, U, V=None, comm=None, ninj=None):
         """Matrix-free Hubbard product (InternalProductOnTheFly semantics): nothing but H_up and H_down is stored."""

@@ -205,6 +205,7 @@ public:
 	{
 		const HubbardOneOrbital<ComplexOrRealType>* hub = dynamic_cast<const HubbardOneOrbital<ComplexOrRealType>*>(&model);
 		if (!hub) throw std::runtime_error("InternalProductOnTheFly: only Model=HubbardOneBand / HubbardOneBandExtended have an on-the-fly product\n");
+		if (hub->jCoupling()) throw std::runtime_error("InternalProductOnTheFly: the spin-flip terms of Model=SuperHubbardExtended are not in the matrix-free product\n");
 		const SizeType n = model.geometry().numberOfSites();
 		std::vector<double> hr(n * n), hi(n * n);
 		for (SizeType k = 0; k < n * n; k++) {

@@ -123,12 +123,13 @@ static int mainPartitioned(LppHost::InputReadable& io, int precision, bool onthe
 	rcclCheck(lpp_rccl_comm_create(&comm, rank, world, id, local, lpp_engine_stream(engine.get()), per * n_up, (int32_t)params.steps, 0, chunk));
 	std::vector<double> hr((size_t)n * n);
 	for (int k = 0; k < n * n; k++) hr[(size_t)k] = hub->hoppings()[(size_t)k];
+	if (onthefly && hub->jCoupling()) throw std::runtime_error("lanczos -P: the matrix-free product has no spin-flip terms (Model=SuperHubbardExtended): use the stored engine\n");
 	if (onthefly)
 		lppCheck(lpp_engine_setup_hubbard_onthefly_ext(engine.get(), lpp_rccl_comm_get(comm), n, parts.first, parts.second, hr.data(), nullptr,
 		                                               hub->hubbardU.data(), hub->potentialV.data(), hub->coulombCoupling()));
 	else
-		lppCheck(lpp_engine_assemble_hubbard_ext(engine.get(), lpp_rccl_comm_get(comm), n, parts.first, parts.second, hr.data(), nullptr,
-		                                         hub->hubbardU.data(), hub->potentialV.data(), hub->coulombCoupling()));
+		lppCheck(lpp_engine_assemble_hubbard_super(engine.get(), lpp_rccl_comm_get(comm), n, parts.first, parts.second, hr.data(), nullptr,
+		                                           hub->hubbardU.data(), hub->potentialV.data(), hub->coulombCoupling(), hub->jCoupling()));
 	double e0 = 0;
 	lpp_stats st;
 	lppCheck(lpp_engine_lanczos(engine.get(), nullptr, 1, &e0, nullptr, &st));

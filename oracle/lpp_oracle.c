@@ -356,11 +356,19 @@ typedef struct {
 	const double* hop_im; /* or NULL */
 	const double* U; /* L */
 	const double* V; /* L: potentialV[i], i<L, used for both spins (HubbardHelper.h:180-183) */
-	const double* ninj; /* L*L Coulomb coupling (HubbardOneBandExtended) or NULL */
+	const double* ninj; /* L*L Coulomb coupling (HubbardOneBandExtended, SuperHubbardExtended) or NULL */
+	const double* jcoup; /* L*L spin coupling J (SuperHubbardExtended, geometry term SUPER = 2, HubbardHelper.h:30,358-362) or NULL */
 } hub_params;
 
-/* calcDiagonalElements for one state, HubbardHelper.h:138-189
- * (jCoupling / potentialT branches are for SuperHubbardExtended / time-dependent runs: not restated) */
+/* szTerm, HubbardHelper.h:345-355 */
+static double hub_sz(word_t ket1, word_t ket2, int i)
+{
+	double sz = (ket1 & BIT(i)) ? 1 : 0;
+	sz -= (ket2 & BIT(i)) ? 1 : 0;
+	return 0.5 * sz;
+}
+
+/* calcDiagonalElements for one state, HubbardHelper.h:138-189 (the potentialT branch is for time-dependent runs: not restated) */
 static double hub_diag_one(const hub_params* P, word_t ket1, word_t ket2)
 {
 	int L = P->L;
@@ -369,6 +377,13 @@ static double hub_diag_one(const hub_params* P, word_t ket1, word_t ket2)
 		int nu = (ket1 & BIT(i)) ? 1 : 0;
 		int nd = (ket2 & BIT(i)) ? 1 : 0;
 		s += P->U[i] * nu * nd; /* :154-156 */
+		if (P->jcoup) {
+			for (int j = 0; j < L; j++) { /* SzSz :158-165 */
+				double value = P->jcoup[i * L + j];
+				if (value == 0) continue;
+				s += value * 0.5 * hub_sz(ket1, ket2, i) * hub_sz(ket1, ket2, j);
+			}
+		}
 		double ne = nu + nd; /* :168-169 */
 		if (P->ninj) {
 			for (int j = 0; j < L; j++) { /* :171-177 */
@@ -413,13 +428,58 @@ static void hub_set_hopping(const hub_params* P, const hub_basis* B, sparse_row*
 	}
 }
 
-/* HubbardHelper::setupHamiltonian, HubbardHelper.h:75-103 */
-lppo_csr* lppo_hubbard_setup(int L, int nup, int ndown, const double* hop_re, const double* hop_im,
-                             const double* U, const double* V, const double* ninj, int is_complex)
+/* BasisOneSpin::doSign(ket,i,j), BasisOneSpin.h:100-119: parity of the bits in [i, j) (the three getNbyKet ranges are
+ * [i+1,j), [i,i+1) and the empty [j,j)) */
+static int onespin_do_sign(word_t ket, int i, int j)
+{
+	int sum = 0;
+	for (int c = i + 1; c < j; c++)
+		if (ket & BIT(c)) sum++;
+	for (int c = i; c < i + 1; c++)
+		if (ket & BIT(c)) sum++;
+	return (sum & 1) ? -1 : 1;
+}
+
+/* jTermSign, HubbardHelper.h:332-343 */
+static int hub_jterm_sign(word_t ket1, word_t ket2, int i, int j)
+{
+	if (i > j) return hub_jterm_sign(ket1, ket2, j, i);
+	return onespin_do_sign(ket1, i, j) * onespin_do_sign(ket2, i, j); /* BasisHubbardLanczos::doSign :139-149 */
+}
+
+/* setSplusSminus, HubbardHelper.h:301-330: S+_i S-_j needs an up and no down at j, a down and no up at i */
+static void hub_splus_sminus(const hub_basis* B, sparse_row* row, word_t ket1, word_t ket2, int i, int j, double value)
+{
+	if (!(ket1 & BIT(j))) return;
+	if (ket1 & BIT(i)) return;
+	if (!(ket2 & BIT(i))) return;
+	if (ket2 & BIT(j)) return;
+	word_t bra1 = ket1 ^ (BIT(i) | BIT(j));
+	word_t bra2 = ket2 ^ (BIT(i) | BIT(j));
+	srow_add(row, hub_perfect_index(B, bra1, bra2), value, 0.0);
+}
+
+/* setJTermOffDiagonal for site i, HubbardHelper.h:282-299 */
+static void hub_set_jterm(const hub_params* P, const hub_basis* B, sparse_row* row, word_t ket1, word_t ket2, int i)
+{
+	if (!P->jcoup) return;
+	for (int j = 0; j < P->L; j++) {
+		double value = P->jcoup[i * P->L + j] * 0.5;
+		if (value == 0) continue;
+		value *= 0.5; /* double counting i,j */
+		double sign = hub_jterm_sign(ket1, ket2, i, j);
+		hub_splus_sminus(B, row, ket1, ket2, i, j, value * sign);
+		hub_splus_sminus(B, row, ket1, ket2, j, i, value * sign);
+	}
+}
+
+/* HubbardHelper::setupHamiltonian, HubbardHelper.h:75-103; jcoup != NULL: Model=SuperHubbardExtended */
+lppo_csr* lppo_hubbard_setup_super(int L, int nup, int ndown, const double* hop_re, const double* hop_im,
+                                   const double* U, const double* V, const double* ninj, const double* jcoup, int is_complex)
 {
 	hub_basis B;
 	hub_basis_init(&B, L, nup, ndown);
-	hub_params P = { L, is_complex, hop_re, hop_im, U, V, ninj };
+	hub_params P = { L, is_complex, hop_re, hop_im, U, V, ninj, jcoup };
 	int64_t hilbert = B.n1 * B.n2;
 	const int nchunks = asm_chunks(hilbert);
 	lppo_csr** parts = (lppo_csr**)calloc((size_t)nchunks, sizeof(lppo_csr*));
@@ -436,7 +496,10 @@ lppo_csr* lppo_hubbard_setup(int L, int nup, int ndown, const double* hop_re, co
 			word_t ket1 = B.b1[ispace % B.n1];
 			word_t ket2 = B.b2[ispace / B.n1];
 			srow_add(&row, ispace, hub_diag_one(&P, ket1, ket2), 0.0); /* :93 */
-			for (int i = 0; i < L; i++) hub_set_hopping(&P, &B, &row, ket1, ket2, i); /* :94-97 */
+			for (int i = 0; i < L; i++) { /* :94-97 */
+				hub_set_hopping(&P, &B, &row, ket1, ket2, i);
+				hub_set_jterm(&P, &B, &row, ket1, ket2, i);
+			}
 			srow_finalize(&row, m); /* :99 */
 		}
 		m->rowptr[c1 - c0] = m->nnz; /* :102 */
@@ -448,6 +511,12 @@ lppo_csr* lppo_hubbard_setup(int L, int nup, int ndown, const double* hop_re, co
 	return m;
 }
 
+lppo_csr* lppo_hubbard_setup(int L, int nup, int ndown, const double* hop_re, const double* hop_im,
+                             const double* U, const double* V, const double* ninj, int is_complex)
+{
+	return lppo_hubbard_setup_super(L, nup, ndown, hop_re, hop_im, U, V, ninj, NULL, is_complex);
+}
+
 /* HubbardHelper::matrixVectorProduct (on-the-fly, threaded over rows), HubbardHelper.h:105-134.
  * x += H y.  Rows [row0,row1) only (row1<=0 means all) so bench.py can time a bounded sample.
  * Real hoppings only (the reference's threaded CPU path; used as the CPU timing baseline). */
@@ -456,7 +525,7 @@ void lppo_hubbard_otf_mvp(int L, int nup, int ndown, const double* hop_re, const
 {
 	hub_basis B;
 	hub_basis_init(&B, L, nup, ndown);
-	hub_params P = { L, 0, hop_re, NULL, U, V, NULL };
+	hub_params P = { L, 0, hop_re, NULL, U, V, NULL, NULL };
 	int64_t hilbert = B.n1 * B.n2;
 	if (row1 <= 0 || row1 > hilbert) row1 = hilbert;
 	/* :110-114 serial diagonal pass */
@@ -567,7 +636,7 @@ lppo_hub_otf* lppo_hubbard_otf_new(int L, int nup, int ndown, const double* hop_
 	memcpy(H->hop_copy, hop_re, sizeof(double) * (size_t)L * L);
 	memcpy(H->U_copy, U, sizeof(double) * (size_t)L);
 	memcpy(H->V_copy, V, sizeof(double) * (size_t)L);
-	hub_params P = { L, 0, H->hop_copy, NULL, H->U_copy, H->V_copy, NULL };
+	hub_params P = { L, 0, H->hop_copy, NULL, H->U_copy, H->V_copy, NULL, NULL };
 	H->P = P;
 	hub_hops_build(&H->up, &H->P, &H->B, 0);
 	hub_hops_build(&H->dn, &H->P, &H->B, 1);

@@ -824,3 +824,42 @@ def test_heisenberg_spin_rejects_what_the_reference_basis_cannot_hold():
             e.assemble_heisenberg(L, 10, chain(L, 1.0), chain(L, 1.0), twiceS=5)  # 2 bits per site cannot hold m + S = 4, 5
         with pytest.raises(Exception):
             e.assemble_heisenberg(L, 99, chain(L, 1.0), chain(L, 1.0), twiceS=2)  # empty sector
+
+
+@pytest.mark.parametrize("case", ["ladder_real", "chain_long_range", "complex_hops"])
+def test_super_hubbard_extended_and_kane_mele(case):
+    """Model=SuperHubbardExtended (HubbardHelper.h:158-165 SzSz on the diagonal, :282-343 spin-flip terms with the sign of the
+    electrons in between) and Model=KaneMeleHubbard (hoppings = term 0 + term 1, :63-66) on the device assembler: bit-exact
+    against the oracle's restatement (itself checked against an independent Jordan-Wigner ED, tests/test_oracle_pins.py)."""
+    rng = np.random.default_rng(17)
+    if case == "ladder_real":
+        L, nup, ndown = 8, 4, 3
+        hop, nj, jc = square(2, 4, -1.0, False), square(2, 4, 0.6, False), square(2, 4, 0.8, False)
+        dt = "f64"
+    elif case == "chain_long_range":
+        L, nup, ndown = 10, 5, 5
+        hop, nj = chain(L, -1.0, True), chain(L, 0.5, True)
+        jc = chain(L, 0.7, True) + 0.35 * (np.diag(np.ones(L - 3), 3) + np.diag(np.ones(L - 3), -3))  # electrons in between
+        jc = jc * (1 + 0.1 * rng.random((L, L)))  # not symmetric: J(i,j) != J(j,i) are added separately
+        dt = "f64"
+    else:
+        L, nup, ndown = 8, 4, 4
+        t0 = chain(L, -1.0, True).astype(complex)
+        t1 = 0.25j * (np.diag(np.ones(L - 1), 1) - np.diag(np.ones(L - 1), -1))  # Kane-Mele-like second term
+        hop, nj, jc = t0 + t1, None, chain(L, 0.5, True)
+        dt = "c128"
+    U, V = np.linspace(3.0, 4.5, L), np.linspace(-0.2, 0.2, 2 * L)
+    A = oracle.hubbard_csr(L, nup, ndown, hop, U, V, ninj=nj, jcoup=jc)
+    A0 = oracle.hubbard_csr(L, nup, ndown, hop, U, V, ninj=nj)
+    assert A.nnz > A0.nnz  # the spin-flip entries are there
+    x0, y = oracle.fill_random(A.nrows, 7, A.is_complex), oracle.fill_random(A.nrows, 8, A.is_complex)
+    xo = oracle.spmv_acc(A, x0.copy(), y)
+    eo, _, so = oracle.lanczos_solve(A, oracle.fill_random(A.nrows, 1234, A.is_complex), want_vectors=False)
+    with LanczosEngine(dtype=dt) as e:
+        e.assemble_hubbard(L, nup, ndown, hop, U, V, ninj=nj, jcoup=jc)
+        rp, ci, va = e.get_csr()
+        assert np.array_equal(rp, A.rowptr) and np.array_equal(ci, A.colind)
+        assert np.array_equal(np.ascontiguousarray(va).view(np.uint64), np.ascontiguousarray(A.values).view(np.uint64))
+        assert rel(e.matrixVectorProduct(x0.copy(), y), xo) < SPMV_TOL
+        eg, _, st = e.lanczos(1, want_vectors=False)
+        assert abs(eg[0] - eo[0]) <= E_TOL * abs(eo[0]) and st["steps"] == so

@@ -20,9 +20,13 @@ def _oracle_csr(path):
     L = int(inp["TotalNumberOfSites"])
     terms = geometry.terms_from_input(inp)
     model = inp["Model"]
-    if model in ("HubbardOneBand", "HubbardOneBandExtended"):
-        return oracle.hubbard_csr(L, int(inp["TargetElectronsUp"]), int(inp["TargetElectronsDown"]), terms[0],
-                                  inp["hubbardU"], inp["potentialV"], ninj=(terms[1] if model == "HubbardOneBandExtended" else None))
+    if model in ("HubbardOneBand", "HubbardOneBandExtended", "SuperHubbardExtended", "KaneMeleHubbard"):
+        # ModelSelector.h:76-80; HubbardHelper.h:39-66: Coulomb coupling = term 1, spin coupling = term 2, Kane-Mele hoppings = term 0 + term 1
+        hop = terms[0] + terms[1] if model == "KaneMeleHubbard" else terms[0]
+        return oracle.hubbard_csr(L, int(inp["TargetElectronsUp"]), int(inp["TargetElectronsDown"]), hop,
+                                  inp["hubbardU"], inp["potentialV"],
+                                  ninj=(terms[1] if model in ("HubbardOneBandExtended", "SuperHubbardExtended") else None),
+                                  jcoup=(terms[2] if model == "SuperHubbardExtended" else None))
     if model == "Heisenberg":
         return oracle.heis_csr(L, int(inp["HeisenbergTwiceS"]), int(inp["TargetSzPlusConst"]), terms[0], terms[1],
                                field=inp.get("MagneticField"), aniso=inp.get("AnisotropyD"))
@@ -44,7 +48,8 @@ def _read_dump(path):
 
 @pytest.mark.parametrize("name", ["input0.inp", "hubbard_ladder_2x4.inp", "heisenberg_chain_L12.inp",
                                   "tj_chain_L8_complex.inp", "hubbard_chain_L12.inp", "hubbard_extended_2x4.inp",
-                                  "heisenberg_spin1_L8.inp", "heisenberg_spin32_L6.inp"])
+                                  "heisenberg_spin1_L8.inp", "heisenberg_spin32_L6.inp", "super_hubbard_2x4.inp",
+                                  "kane_mele_hubbard_chain_L8.inp"])
 def test_host_assembly_bit_exact(name, tmp_path):
     exe = os.path.join(HOST, "dump_csr")
     assert os.path.exists(exe), "run __graft_entry__.build()"
@@ -60,7 +65,8 @@ def test_host_assembly_bit_exact(name, tmp_path):
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", ["input0.inp", "hubbard_ladder_2x4.inp", "hubbard_ladder_2x4_onthefly.inp", "heisenberg_chain_L12.inp",
                                   "tj_chain_L8_complex.inp", "hubbard_chain_L12.inp", "hubbard_extended_2x4.inp",
-                                  "hubbard_extended_2x4_onthefly.inp", "heisenberg_spin1_L8.inp", "heisenberg_spin32_L6.inp"])
+                                  "hubbard_extended_2x4_onthefly.inp", "heisenberg_spin1_L8.inp", "heisenberg_spin32_L6.inp",
+                                  "super_hubbard_2x4.inp", "kane_mele_hubbard_chain_L8.inp"])
 def test_lanczos_driver_prints_reference_energy_line(name):
     # hubbard_chain_L12.inp is BASELINE config 1 (853,776 states): host assembly, upload with the N_up = 924 row-block
     # hint, i.e. the LDS-window kernel with the block template on an UPLOADED matrix

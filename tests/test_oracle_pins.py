@@ -180,6 +180,34 @@ def test_hubbard_spectrum_vs_jordan_wigner(L, nup, ndown):
     assert np.abs(e1 - e2).max() < 1e-10
 
 
+@pytest.mark.parametrize("L,nup,ndown", [(4, 2, 2), (4, 1, 2), (5, 2, 2), (5, 3, 2)])
+def test_super_hubbard_extended_spectrum_vs_jordan_wigner(L, nup, ndown):
+    """Model=SuperHubbardExtended (HubbardHelper.h:158-177 diagonal, :282-343 spin-flip terms): the oracle's restatement against
+    t + U + V + (1/2) sum V_ij n_i n_j + (1/2) sum_ij J_ij S_i . S_j built from Jordan-Wigner operators, S+_i = c+_{i up} c_{i down}."""
+    rng = np.random.default_rng(3 + L + nup)
+    hop = chain(L, -1.0, True) * (1 + 0.2 * rng.random((L, L)))
+    hop = (hop + hop.T) / 2
+    J = chain(L, 0.8, True) * (1 + 0.3 * rng.random((L, L)))
+    J = (J + J.T) / 2
+    if L == 5:
+        J[0, 2] = J[2, 0] = 0.45  # not nearest neighbours: the sign of the electrons in between matters
+    nj, U, V = chain(L, 0.5, True), rng.uniform(1, 5, L), rng.uniform(-1, 1, L)
+    A = oracle.hubbard_csr(L, nup, ndown, hop, U, np.concatenate([V, V]), ninj=nj, jcoup=J)
+    c = _jw_ops(2 * L)
+    H = _hubbard_dense(L, hop, U, V)
+    n = [x.conj().T @ x for x in c]
+    Sp = [c[i].conj().T @ c[i + L] for i in range(L)]
+    Sz = [0.5 * (n[i] - n[i + L]) for i in range(L)]
+    for i in range(L):
+        for j in range(L):
+            H = H + 0.5 * nj[i, j] * (n[i] + n[i + L]) @ (n[j] + n[j + L])
+            if i != j and J[i, j] != 0:
+                H = H + 0.5 * J[i, j] * (Sz[i] @ Sz[j] + 0.5 * (Sp[i] @ Sp[j].conj().T + Sp[j] @ Sp[i].conj().T))
+    m = (1 << L) - 1
+    Hs = _sector(H, 2 * L, lambda s: bin(s & m).count("1") == nup and bin(s >> L).count("1") == ndown)
+    assert np.abs(np.linalg.eigvalsh(A.to_scipy().toarray()) - np.linalg.eigvalsh(Hs)).max() < 1e-10
+
+
 def test_hubbard_complex_hopping_spectrum():
     L = 4
     hop = chain(L, -1.0, True).astype(complex)
