@@ -863,3 +863,25 @@ def test_super_hubbard_extended_and_kane_mele(case):
         assert rel(e.matrixVectorProduct(x0.copy(), y), xo) < SPMV_TOL
         eg, _, st = e.lanczos(1, want_vectors=False)
         assert abs(eg[0] - eo[0]) <= E_TOL * abs(eo[0]) and st["steps"] == so
+
+
+def test_recurrence_started_from_an_eigenvector(monkeypatch):
+    """Lucky breakdown: the start vector is a converged eigenvector, so a_0 = E0 and b_0 ~ 1e-7 * |a_0|.  The chained product-basis
+    step derives b_0^2 from |w|^2 (k_b2_from_w): it must stay finite, clip at zero, and stop where the general layout stops."""
+    L, nup, ndown = 12, 6, 5
+    hop, U = chain(L, -1.0, True), np.full(L, 4.0)
+    runs = {}
+    for layout in ("1", "0"):
+        monkeypatch.setenv("LPP_PRODUCT_LAYOUT", layout)
+        with LanczosEngine(max_steps=300, eps=1e-13) as e:
+            e.assemble_hubbard(L, nup, ndown, hop, U)
+            assert (e.layout()["kernel"] == 4) == (layout == "1")
+            eg, zg, _ = e.lanczos(1, want_vectors=True)
+        for sv in (0, 1):
+            with LanczosEngine(max_steps=50, save_vectors=sv) as e2:
+                e2.assemble_hubbard(L, nup, ndown, hop, U)
+                a, b, _ = e2.decomposition(zg[0])
+            assert np.all(np.isfinite(a)) and np.all(np.isfinite(b)) and np.all(b >= 0)
+            assert abs(a[0] - eg[0]) <= 1e-10 * abs(eg[0]) and b[0] < 1e-5
+            runs[(layout, sv)] = len(a)
+    assert len(set(runs.values())) == 1, runs
