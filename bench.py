@@ -231,9 +231,12 @@ def per_rank_bytes(eng, comm, st, esz, engine):
         if comm is not None:
             b += eng.layout(1)["resident_bytes"]
     if comm is not None:
-        for t in (comm.send, comm.gath, comm.send2, comm.recv2):
-            if t is not None:
-                b += t.numel() * 8
+        if hasattr(comm, "buffer_bytes"):  # the C-level communicator owns its buffers
+            b += comm.buffer_bytes
+        else:
+            for t in (comm.send, comm.gath, comm.send2, comm.recv2):
+                if t is not None:
+                    b += t.numel() * 8
     return b
 
 
@@ -275,6 +278,11 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     args = ap.parse_args()
 
+    # stdout carries ONE JSON line: everything libraries print there on their own (RCCL's version banner under the boxes'
+    # NCCL_DEBUG=VERSION is a plain printf) goes to stderr; the line itself is written to the saved descriptor at the end
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     import torch
     from lanczosplusplus_amd import LanczosEngine, tridiag_lowest
 
@@ -298,10 +306,10 @@ def main():
     max_steps = args.steps + args.warmup + 2
 
     comm = None
-    exchanges = [None]
+    attempts = [(None, None)]  # (exchange, communicator kind)
     if world > 1:
         import torch.distributed as dist
-        from lanczosplusplus_amd.comm import TorchDistComm
+        from lanczosplusplus_amd.comm import RcclComm, TorchDistComm
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:
@@ -313,27 +321,59 @@ def main():
         # all-to-alls of N/P each; 2/P of the volume, pays from 4 ranks on).  LPP_EXCHANGE overrides.
         first = os.environ.get("LPP_EXCHANGE", "transpose" if world >= 4 else "allgather")
         exchanges = [first] + (["allgather"] if first != "allgather" else [])
+        # communicator: the C-level one over librccl (include/lpp_comm_rccl.h; collectives issued from C, nothing of Python between
+        # the kernels of a step) when every rank has a GPU of its own, else / on any failure torch.distributed.  LPP_BENCH_COMM overrides.
+        kinds = ["rccl_c", "torch"] if backend == "nccl" else ["torch"]
+        if os.environ.get("LPP_BENCH_COMM"):
+            kinds = [os.environ["LPP_BENCH_COMM"]]
+        attempts = [(x, k) for k in kinds for x in exchanges]
+    elif os.environ.get("LPP_BENCH_COMM") == "rccl_c":
+        from lanczosplusplus_amd.comm import RcclComm
+        attempts = [("allgather", "rccl_c")]  # one rank, one-rank communicator: exercises the plumbing on a one-GPU box
 
     def barrier():
         if world > 1:
             import torch.distributed as dist
             dist.barrier()
 
+    def all_agree(ok):
+        """every rank takes the same branch: the minimum of the ranks' flags"""
+        if world > 1:
+            import torch.distributed as dist
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok = bool(int(flag.item()))
+        return ok
+
     mem_used = [None]
 
-    def setup(exchange):
+    def setup(exchange, kind):
         """communicator + engine + resident matrix + warm-up steps; returns everything the timed region needs"""
         c = None
-        if world > 1:
+        chunk = 0
+        if exchange is not None:
+            nd, nu, w = (n_dn, n_up, world) if world > 1 else (__import__("math").comb(p["L"], p["ndown"]), __import__("math").comb(p["L"], p["nup"]), 1)
             # up indices per rank rounded up to a multiple of 16 (= lpp_xchg_chunk): real Hubbard matrices then take the
             # product-basis kernels on both parts of the product
-            chunk = (-(-n_dn // world)) * ((-(-n_up // world) + 15) // 16 * 16) if exchange == "transpose" else 0
+            chunk = (-(-nd // w)) * ((-(-nu // w) + 15) // 16 * 16) if exchange == "transpose" else 0
+        if kind == "torch":
             c = TorchDistComm(stride, max_steps, is_complex, device=torch.device("cuda", local_rank), xchg_chunk=chunk)
         strm = c.stream_handle if c is not None else None
         cm = c.stream_context() if c is not None else __import__("contextlib").nullcontext()
         with cm:
             en = LanczosEngine(dtype="c128" if is_complex else "f64", device=local_rank, max_steps=max_steps, eps=0.0,
                                save_vectors=0, spmv_kernel=args.spmv_kernel, time_kernels=True, stream=strm)
+            if kind == "rccl_c":
+                # the 128-byte RCCL id travels by torch.distributed; the communicator runs on the engine's own stream
+                ident = torch.zeros(128, dtype=torch.uint8, device="cuda")
+                if rank == 0:
+                    ident.copy_(torch.frombuffer(bytearray(RcclComm.unique_id()), dtype=torch.uint8))
+                if world > 1:
+                    import torch.distributed as dist
+                    dist.broadcast(ident, 0)
+                st_ = stride if world > 1 else (-(-nd // w)) * nu
+                c = RcclComm(rank, world, bytes(ident.cpu().numpy().tobytes()), local_rank, en.stream_ptr(), st_, max_steps, is_complex, chunk)
+                c.selftest()  # every callback once, results checked on every rank
             free0 = torch.cuda.mem_get_info(local_rank)[0]
             t_a = time.time()
             assemble(en, name, c, onthefly=(args.engine == "onthefly"))
@@ -346,44 +386,66 @@ def main():
             en.begin(None)
             en.step(args.warmup)
             en.sync()
-        return c, cm, en, t_a, s0
+        return c, en, t_a, s0
+
+    def coefficients_match(a, b):
+        """the first Lanczos coefficients against the CPU-oracle fixture of the workload (same built-in start vector): a wrong
+        exchange shows up here at once.  None when the workload has no fixture."""
+        gold = os.path.join(ROOT, "tests", "golden", GOLDEN.get(name, ""))
+        if name not in GOLDEN or not os.path.exists(gold):
+            return None
+        g = json.load(open(gold))
+        n = min(len(a), len(g["a"]), 30)
+        if n == 0:
+            return None
+        da = max(abs(a[k] - g["a"][k]) / max(abs(g["a"][k]), 1e-300) for k in range(n))
+        db = max(abs(b[k] - g["b"][k]) / max(abs(g["b"][k]), 1e-300) for k in range(n))
+        return {"steps_compared": n, "max_rel_diff": max(da, db), "source": "tests/golden/" + GOLDEN[name]}
 
     comm = eng = None
-    for exchange in exchanges:
-        ok, err = 1, None
+    coeff_check = None
+    tried = []
+    for exchange, kind in attempts:
+        ok, err = True, None
         try:
-            comm, ctx, eng, t_asm, st0 = setup(exchange)
+            comm, eng, t_asm, st0 = setup(exchange, kind)
         except Exception as ex:  # e.g. a collective the backend lacks: every rank falls back together
-            ok, err = 0, ex
-        if world > 1:
-            import torch.distributed as dist
-            flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            ok = int(flag.item())
+            ok, err = False, ex
+        if ok:
+            try:
+                ctx = comm.stream_context() if comm is not None else __import__("contextlib").nullcontext()
+                with ctx:
+                    eng.stats()  # drains the warmup SpMV event timings
+                    w0 = eng.stats()
+                    torch.cuda.synchronize()
+                    barrier()
+                    t0 = time.perf_counter()
+                    eng.step(args.steps)
+                    eng.sync()
+                    torch.cuda.synchronize()
+                    barrier()
+                    t1 = time.perf_counter()
+                    w1 = eng.stats()
+                    a, b = eng.coeffs()
+                coeff_check = coefficients_match(a, b) if (rank == 0 and model == "hubbard") else None
+                if coeff_check is not None and not (coeff_check["max_rel_diff"] < 1e-6):
+                    ok, err = False, RuntimeError("Lanczos coefficients differ from the CPU-oracle fixture: %r" % coeff_check)
+            except Exception as ex:
+                ok, err = False, ex
+        ok = all_agree(ok)
+        tried.append({"exchange": exchange, "comm": kind, "ok": ok})
         if ok:
             break
         if rank == 0:
-            sys.stderr.write("bench: exchange %r failed (%r); falling back\n" % (exchange, err))
+            sys.stderr.write("bench: exchange %r over %r failed (%r); falling back\n" % (exchange, kind, err))
         if eng is not None:
             eng.close()
+        if comm is not None and hasattr(comm, "close"):
+            comm.close()
         comm = eng = None
     if eng is None:
         raise SystemExit("bench: could not set up the engine")
-
-    ctx = comm.stream_context() if comm is not None else __import__("contextlib").nullcontext()
-    with ctx:
-        eng.stats()  # drains the warmup SpMV event timings
-        w0 = eng.stats()
-        torch.cuda.synchronize()
-        barrier()
-        t0 = time.perf_counter()
-        eng.step(args.steps)
-        eng.sync()
-        torch.cuda.synchronize()
-        barrier()
-        t1 = time.perf_counter()
-        w1 = eng.stats()
-        a, b = eng.coeffs()
+    comm_kind = kind
 
     elapsed = t1 - t0
     if world > 1:
@@ -454,6 +516,8 @@ def main():
             "config": {"workload": name, "rows": nrows_g, "nnz": nnz_g, "parallelism": "1-D row partition x%d" % world,
                        "reortho": False, "assembly": "on-device", "assembly_s": round(t_asm, 3), "engine": args.engine,
                        "exchange": (("transpose" if comm.xchg_chunk > 0 else "allgather") if comm is not None else None),
+                       "communicator": ({"rccl_c": "liblpp_comm_rccl.so (collectives issued from C)", "torch": "torch.distributed (%s)" % backend}.get(comm_kind)),
+                       "attempts": tried, "coefficients_vs_cpu_oracle": coeff_check,
                        "per_rank_memory_GB": round(per_rank_bytes(eng, comm, st0, esz, args.engine) / 1e9, 2),
                        "device_memory_after_setup_GB": (round(mem_used[0], 2) if mem_used[0] is not None else None),
                        "layout": layout},
@@ -490,8 +554,10 @@ def main():
             except Exception as ex:  # the baseline must never take the bench line down
                 out["cpu_baseline"] = {"error": repr(ex)}
     if rank == 0:
-        print(json.dumps(out))
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     eng.close()
+    if comm is not None and hasattr(comm, "close"):
+        comm.close()
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()

@@ -149,3 +149,66 @@ class TorchDistComm:
         if self.stream is None:
             return contextlib.nullcontext()
         return torch.cuda.stream(self.stream)
+
+
+class RcclComm:
+    """The C-level communicator of include/lpp_comm_rccl.h (liblpp_comm_rccl.so) held from Python: the collectives of a Lanczos
+    step are issued from C on HIP streams -- no interpreter, no ctypes trampoline and no torch dispatch between the kernels of
+    a step (TorchDistComm pays those seven times per step).  The 128-byte RCCL id is carried to the other ranks by the caller
+    (bench.py broadcasts it with torch.distributed).  One GPU per rank (RCCL cannot put two ranks on one device)."""
+
+    _lib = None
+
+    @classmethod
+    def lib(cls):
+        if cls._lib is None:
+            import os
+            here = os.path.dirname(os.path.abspath(__file__))
+            L = C.CDLL(os.path.join(here, "csrc", "liblpp_comm_rccl.so"))
+            L.lpp_rccl_last_error.restype = C.c_char_p
+            L.lpp_rccl_unique_id.argtypes = [C.c_void_p]
+            L.lpp_rccl_comm_get.restype = C.POINTER(Comm)
+            L.lpp_rccl_comm_get.argtypes = [C.c_void_p]
+            L.lpp_rccl_comm_create.argtypes = [C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64,
+                                               C.c_int32, C.c_int32, C.c_int64]
+            L.lpp_rccl_comm_destroy.argtypes = [C.c_void_p]
+            L.lpp_rccl_comm_selftest.argtypes = [C.c_void_p]
+            cls._lib = L
+        return cls._lib
+
+    @classmethod
+    def unique_id(cls):
+        buf = C.create_string_buffer(128)
+        if cls.lib().lpp_rccl_unique_id(buf) != 0:
+            raise RuntimeError(cls.lib().lpp_rccl_last_error().decode())
+        return buf.raw
+
+    def __init__(self, rank, nranks, ident, device, stream_ptr, shard_stride, max_steps, is_complex=False, xchg_chunk=0):
+        L = self.lib()
+        self._h = C.c_void_p()
+        self.rank, self.nranks = int(rank), int(nranks)
+        self.shard_stride, self.xchg_chunk = int(shard_stride), int(xchg_chunk)
+        self._ident = C.create_string_buffer(bytes(ident), 128)
+        rc = L.lpp_rccl_comm_create(C.byref(self._h), self.rank, self.nranks, self._ident, int(device), stream_ptr, self.shard_stride,
+                                    int(max_steps), int(bool(is_complex)), self.xchg_chunk)
+        if rc != 0:
+            raise RuntimeError("lpp_rccl_comm_create: " + L.lpp_rccl_last_error().decode())
+        self.struct = L.lpp_rccl_comm_get(self._h).contents
+        ncomp = 2 if is_complex else 1
+        n = (self.nranks * self.xchg_chunk if self.xchg_chunk > 0 else self.shard_stride) * ncomp
+        g = (self.nranks * self.xchg_chunk if self.xchg_chunk > 0 else self.nranks * self.shard_stride) * ncomp
+        self.buffer_bytes = 8 * (n + g + (2 * n if self.xchg_chunk > 0 else 0))
+        self.calls = None  # issued from C: not counted
+
+    def selftest(self):
+        """every callback once on patterned buffers, results checked on every rank (collective: all ranks must call it)"""
+        if self.lib().lpp_rccl_comm_selftest(self._h) != 0:
+            raise RuntimeError("lpp_rccl_comm_selftest: " + self.lib().lpp_rccl_last_error().decode())
+
+    def stream_context(self):
+        return contextlib.nullcontext()
+
+    def close(self):
+        if self._h:
+            self.lib().lpp_rccl_comm_destroy(self._h)
+            self._h = C.c_void_p()

@@ -670,8 +670,7 @@ void set_spmv_bytes(lpp_engine* e)
 	const double N = (double)e->n_local;
 	if (e->pb.active) {
 		// the CSR this layout stands for (several GPUs: this rank's share of the rows)
-		const double share = e->pb.tx && e->pb.n_blk > 0 ? (double)e->pb.nblk_loc / (double)e->pb.n_blk : 1.0;
-		e->spmv_bytes = share * (double)e->pb.nnz * (s + 4.0) + (N + 1.0) * 8.0 + 3.0 * N * s;
+		e->spmv_bytes = (double)e->pb.nnz_loc * (s + 4.0) + (N + 1.0) * 8.0 + 3.0 * N * s;
 		return;
 	}
 	if (e->kron.active) {
@@ -1181,7 +1180,7 @@ lpp_status lpp_engine_get_stats(lpp_engine* e, lpp_stats* s)
 	e->collect_spmv_times();
 	*s = e->stats;
 	s->nrows = e->n_local;
-	s->nnz = e->pb.active ? e->pb.nnz : (e->kron.active ? (int64_t)e->kron.equiv_nnz : e->A_loc.nnz + e->A_rem.nnz);
+	s->nnz = e->pb.active ? e->pb.nnz_loc : (e->kron.active ? (int64_t)e->kron.equiv_nnz : e->A_loc.nnz + e->A_rem.nnz);
 	s->spmv_bytes = e->spmv_bytes;
 	return LPP_OK;
 }

@@ -124,6 +124,7 @@ struct PbState {
 	// rows of pitch_dn positions (= the up-index range of this rank, a multiple of 16)
 	bool tx = false;
 	int64_t blk0 = 0, nblk_loc = 0, pitch_dn = 0;
+	int64_t nnz_loc = 0; // entries of the CSR rows this rank holds (== nnz on one GPU)
 	// chained scale-free steps (pb_launch_chain): the pass r_{j+1} = w_j - g r_j of the last step has not been run yet;
 	// ycur holds w_j, xcur holds r_j, g = *pend_a / *pend_b2
 	bool pending = false;

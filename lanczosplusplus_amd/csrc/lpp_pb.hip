@@ -139,6 +139,7 @@ lpp_status pb_build(lpp_engine* e, int64_t n_up, int64_t n_blk, const int64_t* t
 	const int64_t zt = tp[(size_t)n_up];
 	for (int64_t b = 0; b < n_blk; b++) base[(size_t)b + 1] = base[(size_t)b] + zt + n_up * (1 + cp[(size_t)b + 1] - cp[(size_t)b]);
 	B.nnz = base[(size_t)n_blk];
+	B.nnz_loc = base[(size_t)(blk0 + nblk_loc)] - base[(size_t)blk0];
 	if ((rc = to_device(&B.blockbase, base, st)) != LPP_OK) return rc;
 	// k_pb_down geometry: one workgroup per CU, 8 groups; the couplings of a workgroup's blocks must fit LDS
 	int grid = e->num_cus & ~7;

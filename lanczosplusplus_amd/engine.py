@@ -51,6 +51,10 @@ class LanczosEngine:
         self._comm_keepalive = None
         check(self._lib.lpp_engine_create(C.byref(self._h), C.byref(cfg)))
 
+    def stream_ptr(self):
+        """the HIP stream the engine enqueues on (lpp_engine_stream), as a ctypes void pointer"""
+        return C.c_void_p(self._lib.lpp_engine_stream(self._h))
+
     # ---- lifetime -------------------------------------------------------------------------
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
