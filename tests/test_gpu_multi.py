@@ -570,3 +570,28 @@ def test_two_ranks_odd_slice_lengths_stay_inside_the_send_buffer():
         for k, (e0, steps, intact) in [(k, v) for k, v in res[r].items() if k != "e_dense"]:
             assert intact, (k, "wrote outside the send buffer")
             assert abs(e0 - ed) <= 1e-10 * abs(ed), (k, e0, ed)
+
+
+def test_python_held_c_level_communicator_at_world_size_one():
+    """lanczosplusplus_amd.comm.RcclComm (what bench.py --gpus N takes first over nccl): id, creation on the engine's own stream,
+    self-test, a solve with it, per-rank statistics."""
+    import oracle
+    from helpers import chain
+    from lanczosplusplus_amd import LanczosEngine
+    from lanczosplusplus_amd.comm import RcclComm
+    L, nup, ndown = 8, 4, 3
+    hop, U = chain(L, -1.0, True), np.full(L, 4.0)
+    A = oracle.hubbard_csr(L, nup, ndown, hop, U)
+    eo, _, so = oracle.lanczos_solve(A, oracle.fill_random(A.nrows, 1234), want_vectors=False)
+    for chunk in (0, 56 * 80):  # all-gather / transposition layout (70 up indices rounded up to 80)
+        ident = RcclComm.unique_id()  # one id per communicator
+        assert len(ident) == 128
+        with LanczosEngine(max_steps=200) as e:
+            c = RcclComm(0, 1, ident, 0, e.stream_ptr(), 56 * 70, 200, False, chunk)
+            c.selftest()
+            assert c.struct.nranks == 1 and c.struct.xchg_chunk == chunk and c.buffer_bytes > 0
+            e.assemble_hubbard(L, nup, ndown, hop, U, comm=c)
+            eg, _, st = e.lanczos(1, want_vectors=False)
+            assert abs(eg[0] - eo[0]) <= 1e-10 * abs(eo[0]) and st["steps"] == so
+            assert e.stats()["nnz"] == A.nnz
+        c.close()
