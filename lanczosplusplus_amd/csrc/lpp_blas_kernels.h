@@ -183,6 +183,27 @@ __global__ __launch_bounds__(kBlock) void k_pack_transpose(const T* __restrict__
 	}
 }
 
+// The same with the deferred recurrence update folded in (product-basis layout, scale-free recurrence): the slice still holds
+// w = H r/b - (b/b') r'; r_next = w - g r (g = *g_a / *g_b2, as k_axpy_nrm has it) is formed on the way, written back over w and
+// packed -- one pass and one launch less than k_axpy_nrm followed by k_pack_transpose.  Padding elements are not touched.
+static __global__ __launch_bounds__(kBlock) void k_pack_transpose_axpy(double* __restrict__ w, const double* __restrict__ r, const double* __restrict__ g_a,
+                                                                        const double* __restrict__ g_b2, double* __restrict__ send, int64_t nid, int64_t n_up,
+                                                                        int64_t peru, int64_t chunk, int64_t pitch)
+{
+	double g = *g_a;
+	const double b2 = *g_b2;
+	if (sqrt(b2) >= 1e-10) g /= b2;
+	const int64_t n = nid * n_up;
+	for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+		const int64_t idl = i / n_up, iu = i - idl * n_up;
+		const int64_t p = iu / peru, iul = iu - p * peru;
+		const int64_t k = idl * pitch + iu;
+		const double v = w[k] - g * r[k];
+		w[k] = v;
+		send[p * chunk + idl * peru + iul] = v;
+	}
+}
+
 // x[i] += recv[...] (the down-hop part computed on the UP-partitioned layout and sent back), fused Re<y|x> partial
 template <typename T, bool DOT>
 __global__ __launch_bounds__(kBlock) void k_unpack_add_dot(T* __restrict__ x, const T* __restrict__ recv,

@@ -1121,9 +1121,10 @@ lpp_status lpp_engine_get_layout(lpp_engine* e, int32_t which, lpp_layout* out)
 		L.rows_per_block = B.n_up;
 		const size_t small = sizeof(uint32_t) * (size_t)B.tw_words + (sizeof(int32_t) + sizeof(uint16_t)) * (size_t)B.spb * (size_t)B.G
 		    + (size_t)B.t_entries * 12 + sizeof(int64_t) * (size_t)(B.n_up + 1) + (size_t)B.c_nnz * 5 + sizeof(int64_t) * 2 * (size_t)(B.n_blk + 1) + 256 * sizeof(double);
-		L.resident_bytes = (int64_t)(small + (size_t)B.n_blk * (size_t)B.pitch);
+		const size_t codes = (size_t)(B.tx ? B.nblk_loc : B.n_blk) * (size_t)B.pitch; // one diagonal code per row this rank holds
+		L.resident_bytes = (int64_t)(small + codes);
 		// per product: one diagonal code per row; the template words and the couplings are re-read from L2 / LDS
-		L.stream_bytes = (int64_t)((size_t)B.n_blk * (size_t)B.pitch + sizeof(uint32_t) * (size_t)B.tw_words + (size_t)B.c_nnz * 5);
+		L.stream_bytes = (int64_t)(codes + sizeof(uint32_t) * (size_t)B.tw_words + (size_t)B.c_nnz * 5);
 		*out = L;
 		return LPP_OK;
 	}

@@ -29,6 +29,16 @@ static int blas_blocks(int64_t n2)
 // the 2-read 1-write pass of the scale-free recurrence: 4 pairs per lane in flight, up to 16384 blocks.  Measured with
 // scripts/experiments/calib_axpy.hip (non-temporal accesses): 2048 blocks 4.96 TB/s, 16384 blocks 5.52 TB/s on 1.33 GB vectors;
 // 5.18 -> 6.91 TB/s on the 0.32 GB vectors of the L = 28 Heisenberg chain
+// The local part of a product on the transposition exchange runs in two launches, one beside each all-to-all.  One workgroup per CU
+// walks the blocks in rounds of num_cus: cut at a whole number of rounds, or the two launches together take a round more than one
+// would (measured at 8 ranks of config 2, 1609 blocks: 2 x 805 = 4 + 4 rounds of 256 against 3 + 4 with the cut at 768).
+static int64_t split_blocks(int64_t nid, int num_cus)
+{
+	const int64_t half = (nid + 1) / 2;
+	if (num_cus <= 0 || half < num_cus) return half;
+	return half / num_cus * num_cus;
+}
+
 static int axpy_blocks(int64_t n2)
 {
 	const int64_t b = (n2 + 4 * kBlock - 1) / (4 * kBlock);
@@ -154,7 +164,10 @@ lpp_status one_step(lpp_engine* e, const double* ritz, int nst)
 	bool tx_pair = false;
 	// product-basis layout, no vectors kept: two launches per step, the axpy of step j rides in the product of step j+1
 	const bool pb_chain = e->pb.active && e->scalefree && !ritz && pb_chain_ok(e);
-	if (e->pb.pending && !pb_chain) { // someone needs r_j itself: run the pass the chain left out
+	// the same deferral on the transposition exchange: the update rides in the next step's pack kernel (k_pack_transpose_axpy)
+	const bool pb_lazy_tx = e->pb.active && e->pb.tx && multi(e) && e->tx && e->scalefree && !ritz &&
+	                        !(getenv("LPP_PB_LAZY_TX") && atoi(getenv("LPP_PB_LAZY_TX")) == 0);
+	if (e->pb.pending && !pb_chain && !pb_lazy_tx) { // someone needs r_j itself: run the pass the chain left out
 		pb_materialise(e, ycur, xcur, e->pb.pend_a, e->pb.pend_b2, e->partial);
 		e->pb.pending = false;
 	}
@@ -180,12 +193,14 @@ lpp_status one_step(lpp_engine* e, const double* ritz, int nst)
 		const int nbp = (int)std::max<int64_t>(1, std::min<int64_t>((e->n_local + kBlock - 1) / kBlock, 2048));
 		if (e->is_complex)
 			k_pack_transpose<cplx><<<nbp, kBlock, 0, st>>>((const cplx*)ycur, (cplx*)e->comm.send_buf, nid, n_up, e->tx_peru, chunk);
+		else if (pb_lazy_tx && e->pb.pending)
+			k_pack_transpose_axpy<<<nbp, kBlock, 0, st>>>(ycur, xcur, e->pb.pend_a, e->pb.pend_b2, (double*)e->comm.send_buf, nid, n_up, e->tx_peru, chunk, e->pitch);
 		else
 			k_pack_transpose<double><<<nbp, kBlock, 0, st>>>((const double*)ycur, (double*)e->comm.send_buf, nid, n_up, e->tx_peru, chunk, e->pitch);
 		if (e->pb.active) {
 		// product-basis layout: both parts are the single-GPU kernels (lpp_pb.hip, "several GPUs"); each all-to-all has half of
 		// the in-block part to hide behind
-		const int64_t half = (nid + 1) / 2;
+		const int64_t half = split_blocks(nid, e->num_cus);
 		if (e->comm.exchange_begin(e->comm.ctx, 0) != 0) return fail(LPP_ERR_COMM, "exchange_begin(0) callback failed");
 		{
 			SpmvTimer t(e);
@@ -212,7 +227,7 @@ lpp_status one_step(lpp_engine* e, const double* ritz, int nst)
 		// The local part (diagonal / U + up-hops on the own slice) needs no exchange.  The matrix-free engine runs the first
 		// half of its blocks beside all-to-all #1 and the second half beside all-to-all #2, so both transfers have a kernel to
 		// hide behind; the stored local matrix is one launch, beside #1.
-		const int64_t half = e->kron.active ? (nid + 1) / 2 : nid;
+		const int64_t half = e->kron.active ? split_blocks(nid, e->num_cus) : nid;
 		{
 			SpmvTimer t(e); // overlaps all-to-all #1
 			if (e->kron.active)
@@ -299,9 +314,9 @@ lpp_status one_step(lpp_engine* e, const double* ritz, int nst)
 	rc = comm_allreduce(e, e->ab_off + 2 * j, fused_ab ? 2 : 1);
 	if (rc != LPP_OK) return rc;
 	int nb_nrm = nb;
-	if (pb_chain) {
+	if (pb_chain || (pb_lazy_tx && fused_ab)) {
 		k_b2_from_w<<<1, 64, 0, st>>>(a_ptr, b2_prev, e->tmp_dev + 1);
-		e->pb.pending = true; // r_{j+1} = w_j - (raw_j / b_{j-1}^2) r_j is formed by the next step's k_pb_up
+		e->pb.pending = true; // r_{j+1} = w_j - (raw_j / b_{j-1}^2) r_j is formed by the next step's k_pb_up / pack kernel
 		e->pb.pend_a = a_ptr;
 		e->pb.pend_b2 = b2_prev;
 	} else if (fused_ab) {
