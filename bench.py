@@ -317,9 +317,11 @@ def main():
         from math import comb as binom
         n_up, n_dn = binom(p["L"], p["nup"]), binom(p["L"], p["ndown"])
         stride = -(-n_dn // world) * n_up
-        # exchange per step: all-gather of the vector (N/P per rank out, N in) or the transposition scheme (two
-        # all-to-alls of N/P each; 2/P of the volume, pays from 4 ranks on).  LPP_EXCHANGE overrides.
-        first = os.environ.get("LPP_EXCHANGE", "transpose" if world >= 4 else "allgather")
+        # exchange per step: all-gather of the vector (N/P per rank out, N in) or the transposition scheme (two all-to-alls of
+        # N/P each: 2/P of the volume).  At 2 ranks both move the same bytes over the pair's one link, but the transposition
+        # scheme runs the product-basis kernels (2.9 against 4.3 ms of compute per rank and step, tests/diagnostics/
+        # rank_share_timing.py) and sets up in 0.03 s instead of 0.3 s: it is the first choice throughout.  LPP_EXCHANGE overrides.
+        first = os.environ.get("LPP_EXCHANGE", "transpose")
         exchanges = [first] + (["allgather"] if first != "allgather" else [])
         # communicator: the C-level one over librccl (include/lpp_comm_rccl.h; collectives issued from C, nothing of Python between
         # the kernels of a step) when every rank has a GPU of its own, else / on any failure torch.distributed.  LPP_BENCH_COMM overrides.

@@ -104,7 +104,7 @@ static int mainPartitioned(LppHost::InputReadable& io, int precision, bool onthe
 	const ModelBase<double>::BasisBaseType::PairIntType parts = model.basis().parts();
 	const long n_up = binomial(n, parts.first), n_dn = binomial(n, parts.second);
 	const long per = (n_dn + world - 1) / world;
-	std::string exchange = world >= 4 ? "transpose" : "allgather";
+	std::string exchange = hub->jCoupling() ? "allgather" : "transpose"; // spin-flip terms (SuperHubbardExtended) need the gathered vector
 	if (const char* s = getenv("LPP_EXCHANGE")) exchange = s;
 	const long chunk = exchange == "transpose" ? (long)lpp_xchg_chunk(n_up, n_dn, world) : 0; // up range per rank rounded to 16: product-basis kernels
 	ParametersForSolver<double> params(io, "Lanczos");
