@@ -75,7 +75,16 @@ class TorchDistComm:
         def _reduce(_ctx, offset, count):
             try:
                 self.calls["allreduce"] += 1
-                dist.all_reduce(self.red[offset:offset + count], op=dist.ReduceOp.SUM, group=self.group)
+                view = self.red[offset:offset + count]
+                if view.is_cuda and dist.get_backend(self.group) != "nccl":
+                    # gloo (tests, rehearsals with ranks sharing one GPU): reduce a host copy, synchronously on both sides, so that
+                    # the kernels behind this call can never see the rank's own partial sum (gloo stages device tensors on
+                    # streams of its own -- the suspected cause of one wrong energy in about fourteen four-rank runs)
+                    host = view.cpu()  # waits for the current stream
+                    dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+                    view.copy_(host)
+                else:
+                    dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
                 return 0
             except Exception:
                 traceback.print_exc(file=sys.stderr)
