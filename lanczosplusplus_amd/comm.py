@@ -52,6 +52,13 @@ class TorchDistComm:
         def _begin(_ctx):
             try:
                 self.calls["allgather"] += 1
+                if self.send.is_cuda and dist.get_backend(self.group) != "nccl":
+                    # gloo with device buffers (tests: ranks sharing one GPU): gather host copies, see _reduce
+                    self._hsend = self.send.cpu()  # waits for the current stream
+                    self._hgath = [torch.empty_like(self._hsend) for _ in range(self.nranks)]
+                    self._work = dist.all_gather(self._hgath, self._hsend, group=self.group, async_op=True)
+                    return 0
+                self._hgath = None
                 try:
                     self._work = dist.all_gather_into_tensor(self.gath, self.send, group=self.group, async_op=True)
                 except (RuntimeError, NotImplementedError):
@@ -67,6 +74,10 @@ class TorchDistComm:
                 if self._work is not None:
                     self._work.wait()
                     self._work = None
+                if getattr(self, "_hgath", None) is not None:
+                    for q, t in enumerate(self.gath.chunk(self.nranks)):
+                        t.copy_(self._hgath[q])
+                    self._hgath = None
                 return 0
             except Exception:
                 traceback.print_exc(file=sys.stderr)
