@@ -26,7 +26,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured float4 copy is ~6290 GB/s
 METRIC = "Lanczos iterations/sec + SpMV achieved HBM GB/s vs roofline, 1/2/4/8 GPU"
 # environment switches that change the kernel or the layout: a committed PMC traffic figure only applies without them
-LAYOUT_ENV = ("LPP_PB_CHAIN", "LPP_COMPRESS_VALUES", "LPP_SHARED_OFFSETS", "LPP_LOCAL16", "LPP_DIAG_CODES", "LPP_BLOCK_TEMPLATE", "LPP_SPMV_KERNEL",
+LAYOUT_ENV = ("LPP_PB_CHAIN", "LPP_ONTHEFLY_KRON", "LPP_COMPRESS_VALUES", "LPP_SHARED_OFFSETS", "LPP_LOCAL16", "LPP_DIAG_CODES", "LPP_BLOCK_TEMPLATE", "LPP_SPMV_KERNEL",
               "LPP_WINDOW_ROWS", "LPP_K2_VARIANT", "LPP_KRON_NO_WINDOW", "LPP_KRON_NO_PACK", "LPP_TEMPLATE_PACK", "LPP_PRODUCT_LAYOUT")
 
 
@@ -203,16 +203,16 @@ GOLDEN = {"hubbard_4x4_half_filling_pbc_U4": "c2_hubbard4x4_U4.json"}
 
 
 def kernel_name(engine, layout):
-    if engine == "onthefly":
+    if engine == "onthefly" and (layout or {}).get("kernel") != "product":
         return "k_spmv_kron_packed / k_spmv_kron_chunked (matrix-free x += H y, fused a_j partial)"
     k = (layout or {}).get("kernel")
     return {"window": "k_spmv_window (stored matrix, LDS source window; x += H y, fused a_j partial)",
             "sliced": "k_spmv_sliced (stored matrix, wave-interleaved slices; x += H y, fused a_j partial)",
             "rowgroup": "k_spmv_rowgroup (plain CSR; x += H y, fused a_j partial)",
-            "product": ("k_pb_up<CHAIN> + k_pb_down<RMW> (stored product-basis matrix: in-block part from the LDS window, block couplings "
+            "product": ("k_pb_up<CHAIN> + k_pb_down<RMW> (product-basis form H = 1(x)T + C(x)1 + D: in-block part from the LDS window, block couplings "
                         "panel-wise from L2; the two launches are the WHOLE scale-free Lanczos step -- the previous step's axpy rides in k_pb_up)"
                         if pb_chained() else
-                        "k_pb_up + k_pb_down (stored product-basis matrix: in-block part from the LDS window, block couplings panel-wise from L2)")}.get(k, str(k))
+                        "k_pb_up + k_pb_down (product-basis form H = 1(x)T + C(x)1 + D: in-block part from the LDS window, block couplings panel-wise from L2)")}.get(k, str(k))
 
 
 def pb_chained():
@@ -228,6 +228,12 @@ def per_rank_bytes(eng, comm, st, esz, engine):
         b += lay["resident_bytes"]
         if lay["kernel"] == 4:  # product-basis layout: the two parts of a product have buffers of their own (pb.u, pb.z)
             b += 2.0 * n * esz
+    elif engine == "onthefly":
+        try:
+            lay = eng.layout(0)  # the product-basis form of the matrix-free engine
+            b += lay["resident_bytes"] + 2.0 * n * esz
+        except Exception:
+            pass
         if comm is not None:
             b += eng.layout(1)["resident_bytes"]
     if comm is not None:
@@ -474,8 +480,11 @@ def main():
     if rank == 0:
         e0 = float(tridiag_lowest(a, b[:-1] if len(b) > 1 else b, 1)[0]) if len(a) else float("nan")
         layout = None
-        if args.engine == "stored":
-            lay = eng.layout(0)
+        try:
+            lay = eng.layout(0)  # the matrix-free engine describes a layout only where it is the product-basis one
+        except Exception:
+            lay = None
+        if lay is not None and (args.engine == "stored" or lay["kernel"] == 4):
             layout = {"kernel": {1: "rowgroup", 2: "sliced", 3: "window", 4: "product"}.get(lay["kernel"]), "value_codes": bool(lay["coded"]),
                       "local16_columns": bool(lay["local16"]), "block_template": lay["block_template"], "diagonal_codes": bool(lay["diagonal_codes"]), "per_row_entries": lay["per_row_entries"],
                       "shared_offset_entries": lay["shared_entries"], "resident_GB": round(lay["resident_bytes"] / 1e9, 2)}
@@ -484,7 +493,7 @@ def main():
                 # the timed launches are product AND recurrence update: a two-phase step (the reduction a_j sits between the
                 # phases) cannot move less than  w = beta x + alpha H y (y, x in; w out)  +  x = w - g y (w, y in; x out)
                 min_bytes = float(lay["stream_bytes"]) + 6.0 * st0["nrows"] * esz
-            if world > 1:
+            if world > 1 and args.engine == "stored":
                 lay1 = eng.layout(1)
                 min_bytes += float(lay1["stream_bytes"])
         else:

@@ -203,7 +203,9 @@ lpp_status lpp_engine_assemble_hubbard_super(lpp_engine* e, const lpp_comm* comm
  * InternalProductOnTheFly.h:120-123 -> HubbardHelper::matrixVectorProduct, HubbardHelper.h:105-134).
  * No CSR is stored: H = H_up (x) 1 + 1 (x) H_down + diag(U n_up n_down) in the BasisHubbardLanczos ordering;
  * only the two one-species matrices live in HBM.  Same arguments as lpp_engine_assemble_hubbard; every
- * solver entry point works unchanged afterwards, lpp_engine_get_csr does not. */
+ * solver entry point works unchanged afterwards, lpp_engine_get_csr does not -- except where one species' row fits the LDS
+ * window (real hoppings, >= 32 MB per vector): there the matrix-free form is the product-basis layout (the two one-species
+ * matrices + one diagonal code per row), the engine lpp_engine_assemble_hubbard builds, and lpp_engine_get_csr / _get_layout work. */
 lpp_status lpp_engine_setup_hubbard_onthefly(lpp_engine* e, const lpp_comm* comm, int32_t nsites, int32_t nup,
                                              int32_t ndown, const double* hop_re, const double* hop_im, const double* U,
                                              const double* V);

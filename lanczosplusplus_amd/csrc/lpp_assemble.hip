@@ -950,6 +950,56 @@ lpp_status lpp_engine_setup_hubbard_onthefly_ext(lpp_engine* e, const lpp_comm* 
 	if ((st = upload(e->stream, d_comb, comb.data(), sizeof(uint64_t) * comb.size())) != LPP_OK) return st;
 	if ((st = upload(e->stream, d_U0, zeroU.data(), sizeof(double) * L)) != LPP_OK) return st;
 	if ((st = upload(e->stream, d_V, V, sizeof(double) * L)) != LPP_OK) return st;
+	// Where one species' row fits the LDS window the matrix-free product IS the product-basis one: H = 1 (x) T + C (x) 1 + D with T, C
+	// (a few hundred KB) and one diagonal code per row -- an eighth of a vector -- is everything it keeps, and its two kernels move a
+	// third of what the fused block-order kernel below moves (10.9 against 31.3 GB per step at BASELINE config 2).  The kernels
+	// below serve what does not qualify: rows beyond the window (config 5's sectors), complex hoppings, small problems.
+	// LPP_ONTHEFLY_KRON=1 keeps them for everything (tests cross-check the two).
+	if (!e->is_complex && !(getenv("LPP_ONTHEFLY_KRON") && atoi(getenv("LPP_ONTHEFLY_KRON")) != 0)) {
+		DevBuf d_U, d_nj;
+		if ((st = upload(e->stream, d_U, U, sizeof(double) * L)) != LPP_OK) return st;
+		if (ninj && (st = upload(e->stream, d_nj, ninj, sizeof(double) * L * L)) != LPP_OK) return st;
+		AsmParams Pf {};
+		Pf.model = ASM_HUBBARD;
+		Pf.L = L;
+		Pf.nup = nup;
+		Pf.ndown = ndown;
+		Pf.nproc = (int)procs.size();
+		Pf.nneg = nneg;
+		Pf.n_up = n_up;
+		Pf.nrows_global = n_up * n_dn;
+		Pf.procs = (const Proc*)d_procs.p;
+		Pf.comb = (const uint64_t*)d_comb.p;
+		Pf.d0 = (const double*)d_U.p;
+		Pf.d1 = (const double*)d_V.p;
+		Pf.d2 = ninj ? (const double*)d_nj.p : nullptr;
+		Pf.row0 = id0 * n_up;
+		Pf.nloc = nid * n_up;
+		bool as_product = false;
+		if (!multi) {
+			st = assemble_hubbard_pb(e, Pf, nup, ndown, n_up, n_dn, (const double*)d_U0.p, &as_product);
+		} else if (comm->exchange_begin && comm->exchange_end && comm->xchg_chunk > 0 && comm->send2_buf && comm->recv2_buf) {
+			const int64_t per = (n_dn + comm->nranks - 1) / comm->nranks, peru = per > 0 ? comm->xchg_chunk / per : 0;
+			if (per > 0 && comm->xchg_chunk == per * peru && peru * comm->nranks >= n_up && (peru & 15) == 0) {
+				st = assemble_hubbard_pb(e, Pf, nup, ndown, n_up, n_dn, (const double*)d_U0.p, &as_product, id0, nid, peru, (int64_t)comm->nranks * per);
+				if (st == LPP_OK && as_product) {
+					e->tx = true;
+					e->tx_per = per;
+					e->tx_peru = peru;
+					e->kron_n_up_tx = n_up;
+				}
+			}
+		}
+		if (st != LPP_OK) return st;
+		if (as_product) {
+			e->n_local = nid * n_up;
+			e->n_global = n_up * n_dn;
+			e->row_start = id0 * n_up;
+			e->active = false;
+			set_spmv_bytes(e);
+			return alloc_work(e);
+		}
+	}
 	// one-species matrices = the Hubbard assembler with the other species empty: hops of that species plus
 	// its potential diagonal sum_i V_i n_i (HubbardHelper.h:180-183); the U term is applied by the kernel
 	AsmParams P {};

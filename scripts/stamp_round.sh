@@ -2,12 +2,12 @@
 # copy the round's profile sets from gpurun_out/ into profiles/ and stamp profiles/traffic.json with the current source hash
 # usage: bash scripts/stamp_round.sh r02      (after scripts/profile_others.sh <tag> and scripts/profile_round.sh <tag>_c2_stored ...)
 T=${1:-r02}
-for t in c2_stored c2_stored_3k c3 c4 c2otf c1; do
+for t in c2_stored c2_stored_3k c3 c4 c2otf c2otf_kron c1; do
   [ -d gpurun_out/profile_${T}_$t ] || continue
   for f in bench.json kernel_stats.csv pmc_summary.csv; do cp gpurun_out/profile_${T}_$t/$f profiles/${T}_${t}_$f; done
 done
 python scripts/traffic_stamp.py stored hubbard_4x4_half_filling_pbc_U4 profiles/${T}_c2_stored_pmc_summary.csv "k_pb_up,k_pb_down" &&
-python scripts/traffic_stamp.py onthefly hubbard_4x4_half_filling_pbc_U4 profiles/${T}_c2otf_pmc_summary.csv k_spmv_kron_packed &&
+python scripts/traffic_stamp.py onthefly hubbard_4x4_half_filling_pbc_U4 profiles/${T}_c2otf_pmc_summary.csv "k_pb_up,k_pb_down" &&
 python scripts/traffic_stamp.py stored heisenberg_chain_L28_sz0_obc profiles/${T}_c3_pmc_summary.csv k_spmv_window &&
 python scripts/traffic_stamp.py stored tj_4x5_9up9down_complex profiles/${T}_c4_pmc_summary.csv k_spmv_sliced &&
 python scripts/traffic_stamp.py stored hubbard_chain_L12_half_filling_U4 profiles/${T}_c1_pmc_summary.csv k_spmv_window

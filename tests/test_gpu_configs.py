@@ -29,8 +29,12 @@ def _bits(a):
     return np.ascontiguousarray(a).view(np.uint64)
 
 
-@pytest.mark.parametrize("engine", ["stored", "onthefly"])
-def test_config2_hubbard4x4_U4_against_the_cpu_oracle(engine):
+@pytest.mark.parametrize("engine", ["stored", "onthefly", "onthefly_kron"])
+def test_config2_hubbard4x4_U4_against_the_cpu_oracle(engine, monkeypatch):
+    """onthefly: where a species' row fits the LDS window the matrix-free engine is the product-basis one (T, C, a code per row);
+    onthefly_kron: the fused block-order kernel that serves everything else (LPP_ONTHEFLY_KRON=1), kept under the same fixture."""
+    if engine == "onthefly_kron":
+        monkeypatch.setenv("LPP_ONTHEFLY_KRON", "1")
     g = json.load(open(os.path.join(GOLD, "c2_hubbard4x4_U4.json")))
     L = g["L"]
     hop, U = square(4, 4, -1.0, pbc=True), np.full(L, g["U"])
@@ -39,6 +43,11 @@ def test_config2_hubbard4x4_U4_against_the_cpu_oracle(engine):
             e.assemble_hubbard(L, g["nup"], g["ndown"], hop, U)
         else:
             e.setup_hubbard_onthefly(L, g["nup"], g["ndown"], hop, U)
+            if engine == "onthefly":
+                assert e.layout()["kernel"] == 4 and e.layout()["resident_bytes"] < 0.3e9
+            else:
+                with pytest.raises(Exception):
+                    e.layout()  # the block-order kernel stores no matrix to describe
         assert e.rows() == g["rows"]
         a, b, st = e.decomposition()  # built-in start vector == the oracle's splitmix64 stream (seed 1234)
     e0 = tridiag_lowest(a, b[:-1], 1)[0]

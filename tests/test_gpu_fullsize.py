@@ -42,8 +42,10 @@ def test_2e9_states_matrix_free_free_fermions():
     assert abs(eg[0] - exact) <= 1e-10 * abs(exact), (eg[0], exact, st["steps"])
 
 
-def test_config2_shape_matrix_free_equals_stored_energy_with_U():
-    """Same 4x4 matrix, U=4: the stored-CSR engine and the matrix-free engine agree to 1e-10."""
+def test_config2_shape_matrix_free_equals_stored_energy_with_U(monkeypatch):
+    """Same 4x4 matrix, U=4: the stored engine (product-basis kernels) and the matrix-free engine's fused block-order kernel
+    (LPP_ONTHEFLY_KRON=1: two independent implementations of the product) agree to 1e-10."""
+    monkeypatch.setenv("LPP_ONTHEFLY_KRON", "1")
     L = 16
     hop, U = square(4, 4, -1.0, pbc=True), np.full(L, 4.0)
     with LanczosEngine(max_steps=300, eps=1e-11, save_vectors=0) as e:
@@ -57,7 +59,7 @@ def test_config2_shape_matrix_free_equals_stored_energy_with_U():
     assert abs(e2[0] - (-13.62185)) < 2e-4
 
 
-def test_config2_shape_products_agree_and_are_hermitian():
+def test_config2_shape_products_agree_and_are_hermitian(monkeypatch):
     """x += H y at config 2's full size: the stored engine (compressed layout: shared offsets, block template, diagonal
     codes) and the matrix-free engine give the same vector, the product is linear, and <u|H v> = <H u|v>."""
     L = 16
@@ -78,6 +80,7 @@ def test_config2_shape_products_agree_and_are_hermitian():
     assert np.max(np.abs(acc - (u + hv))) <= 1e-12 * np.max(np.abs(hv))
     assert np.max(np.abs(lin - (2.0 * hu - 0.5 * hv))) <= 1e-12 * np.max(np.abs(hv))
     assert abs(np.dot(u, hv) - np.dot(hu, v)) <= 1e-11 * abs(np.dot(u, hv))
+    monkeypatch.setenv("LPP_ONTHEFLY_KRON", "1")  # the fused block-order kernel: an implementation of its own
     with LanczosEngine(save_vectors=0) as e:
         e.setup_hubbard_onthefly(L, 8, 8, hop, U)
         hv2 = e.matrixVectorProduct(np.zeros(n), v)
