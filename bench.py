@@ -228,14 +228,14 @@ def per_rank_bytes(eng, comm, st, esz, engine):
         b += lay["resident_bytes"]
         if lay["kernel"] == 4:  # product-basis layout: the two parts of a product have buffers of their own (pb.u, pb.z)
             b += 2.0 * n * esz
+        elif comm is not None:  # general layout on several ranks: the remote part is a matrix of its own
+            b += eng.layout(1)["resident_bytes"]
     elif engine == "onthefly":
         try:
             lay = eng.layout(0)  # the product-basis form of the matrix-free engine
             b += lay["resident_bytes"] + 2.0 * n * esz
         except Exception:
-            pass
-        if comm is not None:
-            b += eng.layout(1)["resident_bytes"]
+            pass  # the fused block-order kernels: two one-species matrices, negligible
     if comm is not None:
         if hasattr(comm, "buffer_bytes"):  # the C-level communicator owns its buffers
             b += comm.buffer_bytes
