@@ -453,8 +453,9 @@ def _worker_pb_tx(rank, world, port, q):
         dev = torch.device("cuda", 0)
         torch.cuda.set_device(dev)
         out = {}
-        for tag, (L, nup, ndown, hop, U) in (("ladder", (12, 6, 4, square(2, 6, -1.0, True), np.full(12, 4.0))),
-                                             ("chain", (12, 6, 6, chain(12, -1.0, False), np.where(np.arange(12) % 2 == 0, 3.0, 5.0)))):
+        for tag, (L, nup, ndown, hop, U, ninj) in (("ladder", (12, 6, 4, square(2, 6, -1.0, True), np.full(12, 4.0), None)),
+                                                   ("chain", (12, 6, 6, chain(12, -1.0, False), np.where(np.arange(12) % 2 == 0, 3.0, 5.0),
+                                                              chain(12, 0.5, False)))):  # HubbardOneBandExtended: Coulomb term in the diagonal codes
             from math import comb
             n_up, n_dn = comb(L, nup), comb(L, ndown)
             per = -(-n_dn // world)
@@ -463,7 +464,7 @@ def _worker_pb_tx(rank, world, port, q):
             comm = TorchDistComm(per * n_up, 300, False, device=dev, xchg_chunk=chunk)
             with comm.stream_context():
                 e = lp.LanczosEngine(max_steps=300, stream=comm.stream_handle)
-                e.assemble_hubbard(L, nup, ndown, hop, U, comm=comm)
+                e.assemble_hubbard(L, nup, ndown, hop, U, comm=comm, ninj=ninj)
                 out[tag + "_kernel"] = e.layout(0)["kernel"]
                 out[tag + "_rows"] = e.rows()
                 ar0 = comm.calls["allreduce"]
@@ -478,7 +479,7 @@ def _worker_pb_tx(rank, world, port, q):
                 out[tag + "_a"], out[tag + "_b"] = a, b
                 e.close()
             if rank == 0:
-                A = oracle.hubbard_csr(L, nup, ndown, hop, U)
+                A = oracle.hubbard_csr(L, nup, ndown, hop, U, ninj=ninj)
                 eo, _, so = oracle.lanczos_solve(A, oracle.fill_random(A.nrows, 1234), want_vectors=False, max_steps=300)
                 steps_o, ao, bo, _, _ = oracle.lanczos_decomposition(A, oracle.fill_random(A.nrows, 1234), max_steps=300)
                 z = out[tag + "_z"]
