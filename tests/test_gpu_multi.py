@@ -477,6 +477,11 @@ def _worker_pb_tx(rank, world, port, q):
                 out[tag + "_z"] = np.concatenate(zs)
                 a, b, _ = e.decomposition()
                 out[tag + "_a"], out[tag + "_b"] = a, b
+                # the matrix-free entry point takes the same kernels where a species' row fits the LDS window
+                e.setup_hubbard_onthefly(L, nup, ndown, hop, U, comm=comm, ninj=ninj)
+                out[tag + "_mf_kernel"] = e.layout(0)["kernel"]
+                eg, _, st = e.lanczos(1, want_vectors=False)
+                out[tag + "_mf_e"], out[tag + "_mf_steps"] = float(eg[0]), st["steps"]
                 e.close()
             if rank == 0:
                 A = oracle.hubbard_csr(L, nup, ndown, hop, U, ninj=ninj)
@@ -509,6 +514,7 @@ def test_product_basis_kernels_on_the_transposition_exchange(world):
             assert abs(o[tag + "_e"] - eo) <= 1e-10 * abs(eo) and o[tag + "_steps"] == so
             assert abs(o[tag + "_e2"] - eo) <= 1e-10 * abs(eo)
             assert o[tag + "_steps"] <= o[tag + "_ar"] <= o[tag + "_steps"] + 8
+            assert o[tag + "_mf_kernel"] == 4 and abs(o[tag + "_mf_e"] - eo) <= 1e-10 * abs(eo) and o[tag + "_mf_steps"] == so
             n = min(len(ao), len(o[tag + "_a"]), 40)
             assert rel(o[tag + "_a"][:n], ao[:n]) < 1e-8 and rel(o[tag + "_b"][:n], bo[:n]) < 1e-8
 
