@@ -685,6 +685,16 @@ def test_product_basis_layout(case, monkeypatch):
         assert len(ag) == steps_o and rel(ag, ao) < 1e-8 and rel(bg, bo) < 1e-8
         ms = e.bench_spmv(1, 2)
         assert ms > 0
+        # the matrix-free entry point builds the same thing where a species' row fits the LDS window ...
+        e.setup_hubbard_onthefly(L, nup, ndown, hop, U, V)
+        assert e.layout()["kernel"] == 4
+        assert rel(e.matrixVectorProduct(x0.copy(), y), xo) < SPMV_TOL
+        monkeypatch.setenv("LPP_ONTHEFLY_KRON", "1")  # ... and the fused block-order kernel otherwise: same product
+        e.setup_hubbard_onthefly(L, nup, ndown, hop, U, V)
+        with pytest.raises(LppError):
+            e.layout()
+        assert rel(e.matrixVectorProduct(x0.copy(), y), xo) < SPMV_TOL
+        monkeypatch.delenv("LPP_ONTHEFLY_KRON")
     with LanczosEngine(save_vectors=0) as e:  # scale-free recurrence + two-pass Ritz vector
         e.assemble_hubbard(L, nup, ndown, hop, U, V)
         eg2, zg2, st2 = e.lanczos(1, want_vectors=True)
