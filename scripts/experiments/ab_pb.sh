@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B of the product-basis kernels: kernel-trace averages of k_pb_up / k_pb_down / k_axpy_nrm for a list of environment variants.
-# usage: bash scripts/ab_pb.sh "VAR1=a VAR2=b" "VAR3=c" ...   (an empty string = defaults); output under gpurun_out/ab_pb/
+# usage: bash scripts/experiments/ab_pb.sh "VAR1=a VAR2=b" "VAR3=c" ...   (an empty string = defaults); output under gpurun_out/ab_pb/
 R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=$(pwd)
 export TMPDIR=/tmp
 O=$R/gpurun_out/ab_pb

@@ -1,6 +1,6 @@
 #!/bin/bash
 # kernel times (rocprofv3 --kernel-trace --stats) + L2-miss read requests (separate --pmc pass) of one bench configuration:
-#   BENCH_ARGS="--workload ... --engine ..." bash scripts/prof_traffic.sh <tag>
+#   BENCH_ARGS="--workload ... --engine ..." bash scripts/experiments/prof_traffic.sh <tag>
 R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=$(pwd)
 export TMPDIR=/tmp
 TAG=${1:-traffic}
