@@ -284,6 +284,25 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # Not under a launcher: start the N ranks ourselves, as children of a parent that never touches the GPU (no torch
+        # import, no HIP call before or after -- a process that has initialised the GPU must not exec, and this one does not
+        # need to), relay rank 0's one JSON line and leave with the children's status.
+        import socket
+        import subprocess
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        child = subprocess.run(cmd, stdout=subprocess.PIPE)
+        lines = [ln for ln in child.stdout.decode(errors="replace").splitlines() if ln.startswith("{")]
+        if lines:
+            sys.stdout.write(lines[-1] + "\n")
+            sys.stdout.flush()
+        raise SystemExit(child.returncode if child.returncode != 0 or lines else 1)
+
     # stdout carries ONE JSON line: everything libraries print there on their own (RCCL's version banner under the boxes'
     # NCCL_DEBUG=VERSION is a plain printf) goes to stderr; the line itself is written to the saved descriptor at the end
     sys.stdout.flush()
@@ -296,9 +315,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
-        args.gpus = world
+        args.gpus = world  # under a launcher the launcher decides
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
     # rehearsal on a one-GPU box: LPP_BENCH_BACKEND=gloo lets several ranks share cuda:0 (RCCL needs one GPU per rank)
@@ -355,46 +372,75 @@ def main():
 
     mem_used = [None]
 
-    def setup(exchange, kind):
-        """communicator + engine + resident matrix + warm-up steps; returns everything the timed region needs"""
-        c = None
-        chunk = 0
-        if exchange is not None:
-            nd, nu, w = (n_dn, n_up, world) if world > 1 else (__import__("math").comb(p["L"], p["ndown"]), __import__("math").comb(p["L"], p["nup"]), 1)
+    def close_all(st):
+        """release whatever an attempt created: communicator first (include/lpp_comm_rccl.h), then the engine"""
+        en, c = st.get("en"), st.get("c")
+        if en is not None:
+            try:
+                en.sync()
+            except Exception:
+                pass
+        if c is not None and hasattr(c, "close"):
+            c.close()
+        if en is not None:
+            en.close()
+        st.clear()
+
+    def stages(exchange, kind, st):
+        """An attempt in stages; the ranks compare notes (all_agree) after every stage, and only the stages marked COLLECTIVE
+        enqueue anything another rank waits for -- a rank that fails alone (an allocation, a missing library) is noticed by
+        all of them before anyone blocks inside a collective it will never join."""
+        nd, nu, w = (n_dn, n_up, world) if world > 1 else (__import__("math").comb(p["L"], p["ndown"]), __import__("math").comb(p["L"], p["nup"]), 1)
+
+        def create():  # local
             # up indices per rank rounded up to a multiple of 16 (= lpp_xchg_chunk): real Hubbard matrices then take the
             # product-basis kernels on both parts of the product
-            chunk = (-(-nd // w)) * ((-(-nu // w) + 15) // 16 * 16) if exchange == "transpose" else 0
-        if kind == "torch":
-            c = TorchDistComm(stride, max_steps, is_complex, device=torch.device("cuda", local_rank), xchg_chunk=chunk)
-        strm = c.stream_handle if c is not None else None
-        cm = c.stream_context() if c is not None else __import__("contextlib").nullcontext()
-        with cm:
-            en = LanczosEngine(dtype="c128" if is_complex else "f64", device=local_rank, max_steps=max_steps, eps=0.0,
-                               save_vectors=0, spmv_kernel=args.spmv_kernel, time_kernels=True, stream=strm)
+            st["chunk"] = ((-(-nd // w)) * ((-(-nu // w) + 15) // 16 * 16) if exchange == "transpose" else 0) if exchange is not None else 0
+            if kind == "torch":
+                st["c"] = TorchDistComm(stride, max_steps, is_complex, device=torch.device("cuda", local_rank), xchg_chunk=st["chunk"])
+            c = st.get("c")
+            strm = c.stream_handle if c is not None else None
+            with (c.stream_context() if c is not None else __import__("contextlib").nullcontext()):
+                st["en"] = LanczosEngine(dtype="c128" if is_complex else "f64", device=local_rank, max_steps=max_steps, eps=0.0,
+                                         save_vectors=0, spmv_kernel=args.spmv_kernel, time_kernels=True, stream=strm)
             if kind == "rccl_c":
-                # the 128-byte RCCL id travels by torch.distributed; the communicator runs on the engine's own stream
-                ident = torch.zeros(128, dtype=torch.uint8, device="cuda")
+                RcclComm.lib()  # a missing library fails here, on this rank alone, before anything collective
+                st["ident"] = torch.zeros(128, dtype=torch.uint8, device="cuda")
                 if rank == 0:
-                    ident.copy_(torch.frombuffer(bytearray(RcclComm.unique_id()), dtype=torch.uint8))
-                if world > 1:
-                    import torch.distributed as dist
-                    dist.broadcast(ident, 0)
-                st_ = stride if world > 1 else (-(-nd // w)) * nu
-                c = RcclComm(rank, world, bytes(ident.cpu().numpy().tobytes()), local_rank, en.stream_ptr(), st_, max_steps, is_complex, chunk)
-                c.selftest()  # every callback once, results checked on every rank
-            free0 = torch.cuda.mem_get_info(local_rank)[0]
-            t_a = time.time()
-            assemble(en, name, c, onthefly=(args.engine == "onthefly"))
-            en.sync()
-            t_a = time.time() - t_a
-            # device memory the engine holds once the matrix is set (matrix + work vectors + product buffers), from the driver's
-            # own accounting; the product-basis assembler allocates nothing it frees again, so this is also its peak
-            mem_used[0] = (free0 - torch.cuda.mem_get_info(local_rank)[0]) / 1e9
-            s0 = en.stats()
-            en.begin(None)
-            en.step(args.warmup)
-            en.sync()
-        return c, en, t_a, s0
+                    st["ident"].copy_(torch.frombuffer(bytearray(RcclComm.unique_id()), dtype=torch.uint8))
+
+        def join():  # COLLECTIVE (rccl_c only): the 128-byte RCCL id travels by torch.distributed, ncclCommInitRank joins the ranks
+            if kind != "rccl_c":
+                return
+            if world > 1:
+                import torch.distributed as dist
+                dist.broadcast(st["ident"], 0)
+            st_ = stride if world > 1 else (-(-nd // w)) * nu
+            st["c"] = RcclComm(rank, world, bytes(st["ident"].cpu().numpy().tobytes()), local_rank, st["en"].stream_ptr(), st_, max_steps, is_complex, st["chunk"])
+
+        def matrix():  # local: assembly issues no collective
+            c, en = st.get("c"), st["en"]
+            with (c.stream_context() if c is not None else __import__("contextlib").nullcontext()):
+                free0 = torch.cuda.mem_get_info(local_rank)[0]
+                t_a = time.time()
+                assemble(en, name, c, onthefly=(args.engine == "onthefly"))
+                en.sync()
+                st["t_asm"] = time.time() - t_a
+                # device memory the engine holds once the matrix is set (matrix + work vectors + product buffers), from the driver's
+                # own accounting; the product-basis assembler allocates nothing it frees again, so this is also its peak
+                mem_used[0] = (free0 - torch.cuda.mem_get_info(local_rank)[0]) / 1e9
+                st["s0"] = en.stats()
+
+        def warm():  # COLLECTIVE: self-test of every callback (checked on every rank), then the warm-up steps
+            c, en = st.get("c"), st["en"]
+            with (c.stream_context() if c is not None else __import__("contextlib").nullcontext()):
+                if kind == "rccl_c":
+                    c.selftest()
+                en.begin(None)
+                en.step(args.warmup)
+                en.sync()
+
+        return [create, join, matrix, warm]
 
     def coefficients_match(a, b):
         """the first Lanczos coefficients against the CPU-oracle fixture of the workload (same built-in start vector): a wrong
@@ -413,13 +459,19 @@ def main():
     comm = eng = None
     coeff_check = None
     tried = []
+    state = {}
     for exchange, kind in attempts:
         ok, err = True, None
-        try:
-            comm, eng, t_asm, st0 = setup(exchange, kind)
-        except Exception as ex:  # e.g. a collective the backend lacks: every rank falls back together
-            ok, err = False, ex
+        for stage in stages(exchange, kind, state):
+            try:
+                stage()
+            except Exception as ex:  # e.g. a collective the backend lacks, an allocation that fails on one rank
+                ok, err = False, ex
+            ok = all_agree(ok)
+            if not ok:
+                break
         if ok:
+            comm, eng, t_asm, st0 = state.get("c"), state["en"], state["t_asm"], state["s0"]
             try:
                 ctx = comm.stream_context() if comm is not None else __import__("contextlib").nullcontext()
                 with ctx:
@@ -435,21 +487,20 @@ def main():
                     t1 = time.perf_counter()
                     w1 = eng.stats()
                     a, b = eng.coeffs()
+                # several ranks: this gate is mandatory -- a wrong exchange or a mis-ordered collective shows up in the first
+                # coefficients at once, and the attempt is then abandoned on every rank
                 coeff_check = coefficients_match(a, b) if (rank == 0 and model == "hubbard") else None
                 if coeff_check is not None and not (coeff_check["max_rel_diff"] < 1e-6):
                     ok, err = False, RuntimeError("Lanczos coefficients differ from the CPU-oracle fixture: %r" % coeff_check)
             except Exception as ex:
                 ok, err = False, ex
-        ok = all_agree(ok)
+            ok = all_agree(ok)
         tried.append({"exchange": exchange, "comm": kind, "ok": ok})
         if ok:
             break
         if rank == 0:
             sys.stderr.write("bench: exchange %r over %r failed (%r); falling back\n" % (exchange, kind, err))
-        if eng is not None:
-            eng.close()
-        if comm is not None and hasattr(comm, "close"):
-            comm.close()
+        close_all(state)
         comm = eng = None
     if eng is None:
         raise SystemExit("bench: could not set up the engine")
@@ -526,6 +577,12 @@ def main():
             "data": "synthetic",
             "config": {"workload": name, "rows": nrows_g, "nnz": nnz_g, "parallelism": "1-D row partition x%d" % world,
                        "reortho": False, "assembly": "on-device", "assembly_s": round(t_asm, 3), "engine": args.engine,
+                       # what the engine actually keeps: the matrix-free entry point builds the product-basis layout (T, C and ONE
+                       # diagonal code per row: N bytes resident, counted in per_rank_memory_GB) wherever a species' row fits the LDS
+                       # window; only the fused block-order kernels (LPP_ONTHEFLY_KRON=1, rows beyond the window, complex hoppings)
+                       # keep nothing per row, as the reference's InternalProductOnTheFly does
+                       "engine_effective": ("product-basis layout: T, C, one diagonal code per row" if (layout or {}).get("kernel") == "product" else
+                                            ("matrix-free: two one-species matrices, nothing per row" if args.engine == "onthefly" else "stored CSR, " + str((layout or {}).get("kernel")) + " layout")),
                        "exchange": (("transpose" if comm.xchg_chunk > 0 else "allgather") if comm is not None else None),
                        "communicator": ({"rccl_c": "liblpp_comm_rccl.so (collectives issued from C)", "torch": "torch.distributed (%s)" % backend}.get(comm_kind)),
                        "attempts": tried, "coefficients_vs_cpu_oracle": coeff_check,
@@ -540,6 +597,10 @@ def main():
         gold = os.path.join(ROOT, "tests", "golden", GOLDEN.get(name, ""))
         if name in GOLDEN and os.path.exists(gold) and not args.no_e0_check:
             g = json.load(open(gold))
+            if comm is not None and hasattr(comm, "close"):
+                eng.sync()
+                comm.close()
+                comm = None
             eng.close()
             with LanczosEngine(dtype="f64", device=local_rank, max_steps=g["max_steps"], min_steps=g["min_steps"], eps=g["eps"],
                                save_vectors=0, seed=g["seed"], spmv_kernel=args.spmv_kernel) as e2:
@@ -554,6 +615,11 @@ def main():
         # the generic (uncompressed, 12 B per entry) CSR kernel on the same matrix: the north_star's ">= 60 % of the HBM
         # roofline on the CSR SpMV" is about THIS kernel; its algorithmic bytes are the SURVEY 8(d) figure
         if args.engine == "stored" and not args.no_generic_csr:
+            if comm is not None and hasattr(comm, "close"):
+                if not eng.closed:
+                    eng.sync()
+                comm.close()
+                comm = None
             eng.close()
             try:
                 out["generic_csr"] = generic_csr_leg(name, is_complex, local_rank)
@@ -566,9 +632,12 @@ def main():
                 out["cpu_baseline"] = {"error": repr(ex)}
     if rank == 0:
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
-    eng.close()
+    # the communicator goes before the engine whose stream it was ordered against (include/lpp_comm_rccl.h)
     if comm is not None and hasattr(comm, "close"):
+        if not eng.closed:
+            eng.sync()
         comm.close()
+    eng.close()
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()

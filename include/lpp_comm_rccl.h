@@ -12,6 +12,7 @@
  *       allgather_end    the compute stream waits for the gather's event
  *       allreduce_sum    ncclAllReduce (sum, in place) of red_buf[offset .. offset+count) on the compute stream
  *       exchange_*       the transposition exchange: grouped ncclSend / ncclRecv of nranks equal chunks (an all-to-all)
+ *   The all-gather, exchange 0 and exchange 1 each have their own (ready, done) event pair between the two streams.
  *   `stream` is the hipStream_t the engine runs on (pass the same pointer as lpp_config.stream).
  * All functions return an lpp_status; lpp_last_error() of liblpp_engine.so is NOT shared: use lpp_rccl_last_error().
  */
@@ -36,6 +37,9 @@ lpp_status lpp_rccl_comm_create(lpp_rccl_comm** out, int32_t rank, int32_t nrank
                                 int64_t shard_stride, int32_t max_steps, int32_t is_complex, int64_t xchg_chunk);
 /* the communicator in the form the engine takes (valid until lpp_rccl_comm_destroy) */
 const lpp_comm* lpp_rccl_comm_get(lpp_rccl_comm* c);
+/* Order of destruction: lpp_engine_sync (or lpp_engine_destroy) FIRST, then this.  The communicator never touches the engine's
+ * stream here (an engine that owns its stream destroys it): it drains its own side stream and events and frees its buffers, so
+ * nothing of the engine may still be queued against them. */
 lpp_status lpp_rccl_comm_destroy(lpp_rccl_comm* c);
 /* runs every callback once on patterned buffers and checks the results (at nranks == 1 the collectives are identities,
  * which still exercises stream ordering, buffer sizes and the group call): the unit test of the C-level communicator */

@@ -9,9 +9,23 @@ the process group); the engine gets raw pointers plus three callbacks:
 Backend "nccl" is RCCL over xGMI on MI355X; "gloo" (CPU or GPU tensors) is used by the tests.
 The engine must run on the torch stream that is current when the callbacks fire: create the
 engine with stream=comm.stream_handle and call it inside `with comm.stream_context():`.
+
+Stream order, per collective (DESIGN.md section 7 has the table for all three communicators): the input is produced on the
+engine's stream S; torch.distributed orders its own stream behind an event of the CURRENT stream (= S inside
+stream_context()) when the collective is issued and makes the current stream wait for the collective's end event in
+work.wait() (nccl: ProcessGroupNCCL's syncStream / WorkNCCL::synchronize; gloo with device tensors: initializeStreamsEvents /
+AsyncWork::synchronize), so the consumer kernels, enqueued on S behind the callback, see the result.
+
+LPP_COMM_RECORD=1 (the multi-rank tests set it) records every all-reduce WITHOUT disturbing that order: a copy of the slot on
+S in front of the collective (this rank's partial) and one behind it (exactly what the next kernel on S will read).
+verify_record() then checks on every rank that each recorded result is the sum of the ranks' partials and bitwise the same
+on all ranks -- a wrong energy on several ranks leaves a record of which call, which rank and what it saw.
+LPP_GLOO_STREAM_ORDERED=1 makes the gloo emulation hand device tensors to gloo (stream-ordered, like nccl) instead of
+reducing / gathering host copies synchronously.
 """
 import contextlib
 import ctypes as C
+import os
 import sys
 import traceback
 
@@ -48,11 +62,19 @@ class TorchDistComm:
         self.calls = {"allgather": 0, "allreduce": 0, "exchange": 0}
         self._xwork = None
         self._xstage = None
+        # gloo with device buffers (tests, rehearsals with ranks sharing one GPU): host-staged and synchronous by default
+        self._host_staged = self.device.type == "cuda" and dist.get_backend(self.group) != "nccl" and os.environ.get("LPP_GLOO_STREAM_ORDERED", "0") == "0"
+        # recorder (module docstring): kRecWidth leading doubles of every all-reduce, before and after, copied on the engine's stream
+        self._rec_cap = int(os.environ.get("LPP_COMM_RECORD_CALLS", "16384")) if os.environ.get("LPP_COMM_RECORD", "0") != "0" else 0
+        self._rec_meta = []
+        if self._rec_cap:
+            self._rec_in = torch.zeros((self._rec_cap, self.kRecWidth), dtype=torch.float64, device=self.device)
+            self._rec_out = torch.zeros((self._rec_cap, self.kRecWidth), dtype=torch.float64, device=self.device)
 
         def _begin(_ctx):
             try:
                 self.calls["allgather"] += 1
-                if self.send.is_cuda and dist.get_backend(self.group) != "nccl":
+                if self._host_staged:
                     # gloo with device buffers (tests: ranks sharing one GPU): gather host copies, see _reduce
                     self._hsend = self.send.cpu()  # waits for the current stream
                     self._hgath = [torch.empty_like(self._hsend) for _ in range(self.nranks)]
@@ -87,15 +109,21 @@ class TorchDistComm:
             try:
                 self.calls["allreduce"] += 1
                 view = self.red[offset:offset + count]
-                if view.is_cuda and dist.get_backend(self.group) != "nccl":
-                    # gloo (tests, rehearsals with ranks sharing one GPU): reduce a host copy, synchronously on both sides, so that
-                    # the kernels behind this call can never see the rank's own partial sum (gloo stages device tensors on
-                    # streams of its own -- the suspected cause of one wrong energy in about fourteen four-rank runs)
+                k = len(self._rec_meta)
+                rec = k < self._rec_cap
+                w = min(count, self.kRecWidth)
+                if rec:
+                    self._rec_in[k, :w].copy_(view[:w])  # on the engine's stream, no host synchronisation
+                if self._host_staged:
+                    # gloo (tests, rehearsals with ranks sharing one GPU): reduce a host copy, synchronously on both sides
                     host = view.cpu()  # waits for the current stream
                     dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
                     view.copy_(host)
                 else:
                     dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
+                if rec:
+                    self._rec_out[k, :w].copy_(view[:w])  # what the next kernel on this stream will read
+                    self._rec_meta.append((int(offset), int(count)))
                 return 0
             except Exception:
                 traceback.print_exc(file=sys.stderr)
@@ -160,6 +188,43 @@ class TorchDistComm:
             s.xchg_chunk = self.xchg_chunk
             s.exchange_begin, s.exchange_end = self._cb[3], self._cb[4]
         self.struct = s
+
+    kRecWidth = 4
+
+    def verify_record(self, rtol=1e-12):
+        """Collective (every rank calls it, outside a run): checks the recorded all-reduces.  Returns a list of findings, empty
+        when every recorded result is the sum of the ranks' partials (to rounding: the backend's summation order is its own)
+        and bitwise identical on all ranks.  A finding names the call, its slot in the scalar buffer, the rank that saw a wrong
+        value, that value, the expected sum and every rank's partial."""
+        if not self._rec_cap:
+            return []
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
+        n = len(self._rec_meta)
+        mine = {"meta": list(self._rec_meta), "in": self._rec_in[:n].cpu().numpy(), "out": self._rec_out[:n].cpu().numpy()}
+        everyone = [None] * self.nranks
+        dist.all_gather_object(everyone, mine, group=self.group)
+        findings = []
+        metas = [tuple(r["meta"]) for r in everyone]
+        if any(m != metas[0] for m in metas):
+            findings.append({"what": "the ranks issued different all-reduce sequences", "calls": [len(m) for m in metas]})
+            n = min(len(m) for m in metas)
+        import numpy as np
+        for k in range(n):
+            off, cnt = metas[0][k]
+            w = min(cnt, self.kRecWidth)
+            parts = np.stack([r["in"][k, :w] for r in everyone])
+            want = parts.sum(axis=0)
+            scale = np.abs(parts).sum(axis=0) + 1e-300
+            for q, r in enumerate(everyone):
+                got = r["out"][k, :w]
+                bad = ~(np.abs(got - want) <= rtol * scale)  # catches NaN too
+                differs = got.tobytes() != everyone[0]["out"][k, :w].tobytes()
+                if bad.any() or differs:
+                    findings.append({"what": "wrong sum" if bad.any() else "ranks disagree bitwise", "call": k, "offset": off, "count": cnt, "rank": q,
+                                     "saw": got.tolist(), "expected": want.tolist(), "partials": parts.tolist()})
+        self._rec_meta = []
+        return findings
 
     @property
     def stream_handle(self):

@@ -34,7 +34,10 @@ struct lpp_rccl_comm {
 	ncclComm_t nccl = nullptr;
 	hipStream_t compute = nullptr; // the engine's stream
 	hipStream_t side = nullptr; // all-gather / exchange run here so that the local product overlaps them
-	hipEvent_t ev_ready = nullptr, ev_done = nullptr;
+	// one (ready, done) event pair per collective that runs on the side stream: [0] all-gather, [1] exchange 0, [2] exchange 1.
+	// A shared pair is correct only while begin/end strictly alternate; with pairs of their own a begin of one collective can
+	// never re-record an event another collective's end has still to wait for.
+	hipEvent_t ev_ready[3] = { nullptr, nullptr, nullptr }, ev_done[3] = { nullptr, nullptr, nullptr };
 	int ncomp = 1;
 	size_t n_send = 0, n_gath = 0;
 };
@@ -44,15 +47,17 @@ namespace {
 int32_t cb_allgather_begin(void* ctx)
 {
 	lpp_rccl_comm* m = (lpp_rccl_comm*)ctx;
-	if (hipEventRecord(m->ev_ready, m->compute) != hipSuccess) return 1; // the slice was written on the compute stream
-	if (hipStreamWaitEvent(m->side, m->ev_ready, 0) != hipSuccess) return 1;
+	// the slice was written on the compute stream, and the last readers of gath_buf (the previous step's remote-column
+	// product) were enqueued there too: the side stream starts behind both
+	if (hipEventRecord(m->ev_ready[0], m->compute) != hipSuccess) return 1;
+	if (hipStreamWaitEvent(m->side, m->ev_ready[0], 0) != hipSuccess) return 1;
 	if (ncclAllGather(m->c.send_buf, m->c.gath_buf, (size_t)m->c.shard_stride * m->ncomp, ncclDouble, m->nccl, m->side) != ncclSuccess) return 1;
-	return hipEventRecord(m->ev_done, m->side) == hipSuccess ? 0 : 1;
+	return hipEventRecord(m->ev_done[0], m->side) == hipSuccess ? 0 : 1;
 }
 int32_t cb_allgather_end(void* ctx)
 {
 	lpp_rccl_comm* m = (lpp_rccl_comm*)ctx;
-	return hipStreamWaitEvent(m->compute, m->ev_done, 0) == hipSuccess ? 0 : 1;
+	return hipStreamWaitEvent(m->compute, m->ev_done[0], 0) == hipSuccess ? 0 : 1;
 }
 int32_t cb_allreduce(void* ctx, int32_t offset, int32_t count)
 {
@@ -66,8 +71,10 @@ int32_t cb_exchange_begin(void* ctx, int32_t which)
 	const double* src = (const double*)(which == 0 ? m->c.send_buf : m->c.send2_buf);
 	double* dst = (double*)(which == 0 ? m->c.gath_buf : m->c.recv2_buf);
 	const size_t n = (size_t)m->c.xchg_chunk * m->ncomp;
-	if (hipEventRecord(m->ev_ready, m->compute) != hipSuccess) return 1;
-	if (hipStreamWaitEvent(m->side, m->ev_ready, 0) != hipSuccess) return 1;
+	if (which != 0 && which != 1) return 1;
+	hipEvent_t ready = m->ev_ready[1 + which], done = m->ev_done[1 + which];
+	if (hipEventRecord(ready, m->compute) != hipSuccess) return 1;
+	if (hipStreamWaitEvent(m->side, ready, 0) != hipSuccess) return 1;
 	// all-to-all of nranks equal chunks: chunk p goes to rank p, chunk q comes from rank q (xGMI is point to point:
 	// every pair has its own link, a grouped send/recv uses them all at once)
 	if (ncclGroupStart() != ncclSuccess) return 1;
@@ -77,12 +84,13 @@ int32_t cb_exchange_begin(void* ctx, int32_t which)
 		ok = ok && ncclRecv(dst + (size_t)p * n, n, ncclDouble, p, m->nccl, m->side) == ncclSuccess;
 	}
 	if (ncclGroupEnd() != ncclSuccess || !ok) return 1;
-	return hipEventRecord(m->ev_done, m->side) == hipSuccess ? 0 : 1;
+	return hipEventRecord(done, m->side) == hipSuccess ? 0 : 1;
 }
-int32_t cb_exchange_end(void* ctx, int32_t)
+int32_t cb_exchange_end(void* ctx, int32_t which)
 {
 	lpp_rccl_comm* m = (lpp_rccl_comm*)ctx;
-	return hipStreamWaitEvent(m->compute, m->ev_done, 0) == hipSuccess ? 0 : 1;
+	if (which != 0 && which != 1) return 1;
+	return hipStreamWaitEvent(m->compute, m->ev_done[1 + which], 0) == hipSuccess ? 0 : 1;
 }
 } // namespace
 
@@ -117,8 +125,10 @@ lpp_status lpp_rccl_comm_create(lpp_rccl_comm** out, int32_t rank, int32_t nrank
 		return fail(LPP_ERR_COMM, std::string("ncclCommInitRank: ") + ncclGetErrorString(r));
 	}
 	hipError_t he = hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking);
-	if (he == hipSuccess) he = hipEventCreateWithFlags(&m->ev_ready, hipEventDisableTiming);
-	if (he == hipSuccess) he = hipEventCreateWithFlags(&m->ev_done, hipEventDisableTiming);
+	for (int k = 0; k < 3; k++) {
+		if (he == hipSuccess) he = hipEventCreateWithFlags(&m->ev_ready[k], hipEventDisableTiming);
+		if (he == hipSuccess) he = hipEventCreateWithFlags(&m->ev_done[k], hipEventDisableTiming);
+	}
 	lpp_comm& c = m->c;
 	c.rank = rank;
 	c.nranks = nranks;
@@ -159,12 +169,18 @@ const lpp_comm* lpp_rccl_comm_get(lpp_rccl_comm* c) { return c ? &c->c : nullptr
 lpp_status lpp_rccl_comm_destroy(lpp_rccl_comm* m)
 {
 	if (!m) return LPP_OK;
+	// Only what this object owns is touched: the engine's stream may already be gone (an engine that owns its stream destroys
+	// it in lpp_engine_destroy).  Everything the compute stream still has to do with these buffers sits in front of the last
+	// `done` event's wait, or was drained by lpp_engine_destroy / lpp_engine_sync -- close the communicator after one of them.
 	if (m->side) (void)hipStreamSynchronize(m->side);
-	if (m->compute) (void)hipStreamSynchronize(m->compute);
+	for (int k = 0; k < 3; k++)
+		if (m->ev_done[k]) (void)hipEventSynchronize(m->ev_done[k]);
 	for (void* p : { m->c.send_buf, m->c.gath_buf, (void*)m->c.red_buf, m->c.send2_buf, m->c.recv2_buf })
 		if (p) (void)hipFree(p);
-	if (m->ev_ready) (void)hipEventDestroy(m->ev_ready);
-	if (m->ev_done) (void)hipEventDestroy(m->ev_done);
+	for (int k = 0; k < 3; k++) {
+		if (m->ev_ready[k]) (void)hipEventDestroy(m->ev_ready[k]);
+		if (m->ev_done[k]) (void)hipEventDestroy(m->ev_done[k]);
+	}
 	if (m->side) (void)hipStreamDestroy(m->side);
 	if (m->nccl) (void)ncclCommDestroy(m->nccl);
 	delete m;

@@ -56,6 +56,10 @@ class LanczosEngine:
         return C.c_void_p(self._lib.lpp_engine_stream(self._h))
 
     # ---- lifetime -------------------------------------------------------------------------
+    @property
+    def closed(self):
+        return not (getattr(self, "_h", None) is not None and self._h)
+
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
             self._lib.lpp_engine_destroy(self._h)

@@ -5,11 +5,13 @@
 // SolverOptions=useComplex selects complex<double> (lanczos.cpp:194-226).  Observables (-g, -c, -m, ...)
 // are out of scope.
 #include <getopt.h>
+#include <sys/stat.h>
 #include <unistd.h>
 
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <iostream>
 
 #include "../../include/lpp_comm_rccl.h"
@@ -54,31 +56,60 @@ static void rcclCheck(lpp_status st)
 	if (st != LPP_OK) throw std::runtime_error(std::string("lpp_comm_rccl: ") + lpp_rccl_last_error() + "\n");
 }
 
-// rank 0 creates the id and publishes it atomically (write + rename); the others poll for the file
+// Rank 0 creates the id and publishes it atomically (write + rename); the others poll for the file.  The file is
+//   "LPPRCCL1" | 8-byte launch nonce | 128-byte id
+// and a reader accepts it only with ITS OWN launch nonce (a hash of LPP_RCCL_NONCE, else of the launcher's
+// TORCHELASTIC_RUN_ID / MASTER_ADDR:MASTER_PORT, which every rank of one launch shares) and only when it is not older than
+// the reader itself by more than five minutes: a file left behind by a crashed run is never joined.  Rank 0 unlinks any old
+// file before it writes and removes the new one once ncclCommInitRank has returned (a collective: every rank has read it).
+static const char kIdMagic[8] = { 'L', 'P', 'P', 'R', 'C', 'C', 'L', '1' };
+
+static uint64_t launchNonce()
+{
+	std::string key;
+	if (const char* s = getenv("LPP_RCCL_NONCE")) key = s;
+	else {
+		for (const char* name : { "TORCHELASTIC_RUN_ID", "MASTER_ADDR", "MASTER_PORT", "SLURM_JOB_ID", "SLURM_STEP_ID" })
+			if (const char* v = getenv(name)) key += std::string(name) + "=" + v + ";";
+	}
+	uint64_t h = 1469598103934665603ull; // FNV-1a
+	for (unsigned char c : key) h = (h ^ c) * 1099511628211ull;
+	return h;
+}
+
 static void shareUniqueId(char* id, int rank, int world)
 {
 	const char* path = getenv("LPP_RCCL_ID_FILE");
 	if (world > 1 && !path) throw std::runtime_error("lanczos -P: set LPP_RCCL_ID_FILE to a path every rank can read\n");
+	const uint64_t nonce = launchNonce();
 	if (rank == 0) {
 		rcclCheck(lpp_rccl_unique_id(id));
 		if (world == 1) return;
+		(void)unlink(path); // never leave a previous run's id where a reader could find it
 		const std::string tmp = std::string(path) + ".tmp";
 		FILE* f = fopen(tmp.c_str(), "wb");
-		if (!f || fwrite(id, 1, LPP_RCCL_ID_BYTES, f) != LPP_RCCL_ID_BYTES) throw std::runtime_error("lanczos -P: cannot write the RCCL id file\n");
-		fclose(f);
+		const bool ok = f && fwrite(kIdMagic, 1, 8, f) == 8 && fwrite(&nonce, 1, 8, f) == 8 && fwrite(id, 1, LPP_RCCL_ID_BYTES, f) == LPP_RCCL_ID_BYTES;
+		if (f) fclose(f);
+		if (!ok) throw std::runtime_error("lanczos -P: cannot write the RCCL id file\n");
 		if (rename(tmp.c_str(), path) != 0) throw std::runtime_error("lanczos -P: cannot publish the RCCL id file\n");
 		return;
 	}
+	const time_t started = time(nullptr);
 	for (int tries = 0; tries < 6000; tries++) { // up to 10 minutes
 		FILE* f = fopen(path, "rb");
 		if (f) {
-			const size_t n = fread(id, 1, LPP_RCCL_ID_BYTES, f);
+			char magic[8];
+			uint64_t got = 0;
+			struct stat sb;
+			const bool fresh = fstat(fileno(f), &sb) == 0 && sb.st_mtime + 300 >= started;
+			const bool ok = fread(magic, 1, 8, f) == 8 && std::memcmp(magic, kIdMagic, 8) == 0 && fread(&got, 1, 8, f) == 8 && got == nonce
+			    && fread(id, 1, LPP_RCCL_ID_BYTES, f) == LPP_RCCL_ID_BYTES;
 			fclose(f);
-			if (n == LPP_RCCL_ID_BYTES) return;
+			if (ok && fresh) return;
 		}
 		usleep(100000);
 	}
-	throw std::runtime_error("lanczos -P: timed out waiting for the RCCL id file\n");
+	throw std::runtime_error("lanczos -P: timed out waiting for this launch's RCCL id file (stale files are ignored)\n");
 }
 
 static long binomial(long n, long k)
@@ -109,6 +140,9 @@ static int mainPartitioned(LppHost::InputReadable& io, int precision, bool onthe
 	const long chunk = exchange == "transpose" ? (long)lpp_xchg_chunk(n_up, n_dn, world) : 0; // up range per rank rounded to 16: product-basis kernels
 	ParametersForSolver<double> params(io, "Lanczos");
 	char id[LPP_RCCL_ID_BYTES];
+	// everything that can throw on ONE rank comes before the communicator exists: afterwards a rank that leaves alone would
+	// strand its peers inside a collective
+	if (onthefly && hub->jCoupling()) throw std::runtime_error("lanczos -P: the matrix-free product has no spin-flip terms (Model=SuperHubbardExtended): use the stored engine\n");
 	shareUniqueId(id, rank, world);
 	lpp_config cfg;
 	lpp_config_default(&cfg);
@@ -121,9 +155,10 @@ static int mainPartitioned(LppHost::InputReadable& io, int precision, bool onthe
 	EngineHandle engine(cfg); // engine-owned stream; the communicator is told which one below
 	lpp_rccl_comm* comm = nullptr;
 	rcclCheck(lpp_rccl_comm_create(&comm, rank, world, id, local, lpp_engine_stream(engine.get()), per * n_up, (int32_t)params.steps, 0, chunk));
+	if (rank == 0 && world > 1) (void)unlink(getenv("LPP_RCCL_ID_FILE")); // ncclCommInitRank is a collective: every rank has read the id
+	rcclCheck(lpp_rccl_comm_selftest(comm)); // every callback once, checked on every rank, before any step depends on them
 	std::vector<double> hr((size_t)n * n);
 	for (int k = 0; k < n * n; k++) hr[(size_t)k] = hub->hoppings()[(size_t)k];
-	if (onthefly && hub->jCoupling()) throw std::runtime_error("lanczos -P: the matrix-free product has no spin-flip terms (Model=SuperHubbardExtended): use the stored engine\n");
 	if (onthefly)
 		lppCheck(lpp_engine_setup_hubbard_onthefly_ext(engine.get(), lpp_rccl_comm_get(comm), n, parts.first, parts.second, hr.data(), nullptr,
 		                                               hub->hubbardU.data(), hub->potentialV.data(), hub->coulombCoupling()));
@@ -139,6 +174,7 @@ static int mainPartitioned(LppHost::InputReadable& io, int precision, bool onthe
 		std::cout << "Energy=" << e0 << "\n";
 		std::cerr << "#LanczosSteps=" << st.steps << " rows=" << model.size() << " ranks=" << world << " exchange=" << (world > 1 ? exchange : "none") << "\n";
 	}
+	lppCheck(lpp_engine_sync(engine.get())); // the communicator's buffers are released next: nothing of the engine may be queued on them
 	rcclCheck(lpp_rccl_comm_destroy(comm));
 	return 0;
 }

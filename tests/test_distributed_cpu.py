@@ -31,7 +31,7 @@ def _np_view(t):
 
 def _worker(rank, world, port, q):
     try:
-        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LPP_COMM_RECORD="1")
         dist.init_process_group("gloo", rank=rank, world_size=world)
         import lanczosplusplus_amd as lp
         from lanczosplusplus_amd.comm import TorchDistComm
@@ -80,11 +80,20 @@ def _worker(rank, world, port, q):
             b.append(bj)
         e0 = oracle.tridiag_eig(np.array(a), np.array(b))[0]
         eo, _, _ = oracle.lanczos_solve(A, oracle.fill_random(A.nrows, 1234), max_steps=40, eps=0.0, want_vectors=False)
-        q.put((rank, float(e0), float(eo[0]), comm.calls["allgather"], comm.calls["allreduce"]))
+        # the recorder (lanczosplusplus_amd/comm.py): all 81 all-reduces on record, every result the sum of the two partials
+        # and bitwise the same on both ranks; then one more call whose result rank 1 overwrites with its own partial -- what a
+        # consumer kernel would see if it ran ahead of the collective -- which must come back as a finding naming call and rank
+        clean = comm.verify_record()
+        red[200] = 1.0 + rank
+        assert s.allreduce_sum(None, 200, 1) == 0
+        if rank == 1:
+            comm._rec_out[len(comm._rec_meta) - 1, 0] = 2.0
+        bad = comm.verify_record()
+        q.put((rank, float(e0), float(eo[0]), comm.calls["allgather"], comm.calls["allreduce"], clean, bad))
         dist.destroy_process_group()
     except Exception as ex:  # surface failures in the parent
         import traceback
-        q.put((rank, "error", traceback.format_exc(), 0, 0))
+        q.put((rank, "error", traceback.format_exc(), 0, 0, None, None))
 
 
 def test_two_rank_partitioned_lanczos_over_gloo():
@@ -104,7 +113,9 @@ def test_two_rank_partitioned_lanczos_over_gloo():
                 p.kill()
     for r in res:
         assert r[1] != "error", r[2]
-    for rank, e0, eo, ng, nr in res:
+    for rank, e0, eo, ng, nr, clean, bad in res:
         assert abs(e0 - eo) < 1e-10 * abs(eo)
-        assert ng == 40 and nr == 81
+        assert ng == 40 and nr == 82
+        assert clean == []
+        assert [(f["call"], f["offset"], f["rank"], f["saw"], f["expected"]) for f in bad] == [(0, 200, 1, [2.0], [3.0])], bad
     assert res[0][1] == res[1][1]  # both ranks hold bitwise identical coefficients -> identical decisions

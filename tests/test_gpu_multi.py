@@ -25,7 +25,11 @@ def _free_port():
 
 
 def _run_ranks(target, world, timeout=300):
-    """Spawn `world` ranks; never leave a hung child behind (a deadlocked collective must fail the test, not the run)."""
+    """Spawn `world` ranks; never leave a hung child behind (a deadlocked collective must fail the test, not the run).
+    Every all-reduce of every communicator is recorded on the engine's stream (LPP_COMM_RECORD, lanczosplusplus_amd/comm.py)
+    and checked on all ranks afterwards: a rank whose kernels saw anything but the sum of the partials fails the test with
+    the call, the rank and the values on record."""
+    os.environ["LPP_COMM_RECORD"] = "1"
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -43,7 +47,15 @@ def _run_ranks(target, world, timeout=300):
         for p in procs:
             if p.is_alive():
                 p.kill()
+    for r, o in sorted(res.items()):
+        assert not o.get("findings"), "rank %d: recorded all-reduces are wrong: %r" % (r, o["findings"][:4])
     return res
+
+
+def _audit(comm, out):
+    """collective: every rank checks the all-reduces this communicator recorded"""
+    out.setdefault("findings", []).extend(comm.verify_record())
+    out["recorded"] = out.get("recorded", 0) + comm.calls["allreduce"]
 
 
 def _worker(rank, world, port, q):
@@ -94,6 +106,7 @@ def _worker(rank, world, port, q):
             ek, _, stk = e.lanczos(1, want_vectors=False)
             out["e_kron"], out["steps_kron"] = float(ek[0]), stk["steps"]
             e.close()
+        _audit(comm, out)
         eo, _, so = oracle.lanczos_solve(A, oracle.fill_random(A.nrows, 1234), want_vectors=False)
         out["e_hub_oracle"], out["steps_oracle"] = float(eo[0]), so
 
@@ -112,6 +125,7 @@ def _worker(rank, world, port, q):
             eg, _, st = e.lanczos(2, init=init[lo:hi].copy(), want_vectors=False)
             out["e_tj"] = [float(v) for v in eg]
             e.close()
+        _audit(comm2, out)
         out["e_tj_dense"] = [float(v) for v in np.linalg.eigvalsh(T.to_scipy().toarray())[:2]]
         q.put((rank, out))
         dist.destroy_process_group()
@@ -174,6 +188,7 @@ def _worker_uneven(rank, world, port, q):
             eg, zg, st = e.lanczos(2, want_vectors=True)  # keeps vectors: normalised recurrence on the matrix-free product
             out["e_kron"], out["steps_kron"] = [float(v) for v in eg], st["steps"]
             e.close()
+        _audit(comm, out)
         # transposition exchange: same matrix, two all-to-alls per step instead of the all-gather
         per, peru = -(-210 // world), -(-n_up // world)
         comm_t = TorchDistComm(stride, 200, False, device=dev, xchg_chunk=per * peru)
@@ -195,6 +210,7 @@ def _worker_uneven(rank, world, port, q):
             eg, _, st = e.lanczos(1, want_vectors=False)
             out["e_kron_tx"], out["steps_kron_tx"] = float(eg[0]), st["steps"]
             e.close()
+        _audit(comm_t, out)
         A = oracle.hubbard_csr(L, nup, ndown, hop, U)
         eo, _, so = oracle.lanczos_solve(A, oracle.fill_random(A.nrows, 1234), want_vectors=False)
         out["e_oracle"], out["steps_oracle"] = float(eo[0]), so
@@ -216,6 +232,7 @@ def _worker_uneven(rank, world, port, q):
             eg, _, st = e.lanczos(1, want_vectors=False)
             out["e_kron_tx_c"] = float(eg[0])
             e.close()
+        _audit(comm_c, out)
         Ac = oracle.hubbard_csr(L2, 4, 4, hc, U2)
         ec, _, sc = oracle.lanczos_solve(Ac, oracle.fill_random(Ac.nrows, 1234, True), want_vectors=False)
         out["e_oracle_c"], out["steps_oracle_c"] = float(ec[0]), sc
@@ -283,6 +300,7 @@ def _worker_beyond_lds(rank, world, port, q):
                 eg, _, st = e.lanczos(1, want_vectors=False)
                 out["e_" + name], out["steps_" + name] = float(eg[0]), st["steps"]
                 e.close()
+            _audit(comm, out)
         if rank == 0:
             A = oracle.hubbard_csr(L, nup, ndown, hop, U)
             eo, _, so = oracle.lanczos_solve(A, oracle.fill_random(A.nrows, 1234), want_vectors=False, max_steps=300)
@@ -338,6 +356,7 @@ def _worker_4x5(rank, world, port, q):
             out["a_mf"], out["b_mf"] = a, b
             out["xchg_calls"] = comm.calls["exchange"]
             e.close()
+        _audit(comm, out)
         if rank == 0:
             A = oracle.hubbard_csr(L, 3, 3, hop, U)
             so, ao, bo, _, hist = oracle.lanczos_decomposition(A, oracle.fill_random(A.nrows, 1234), max_steps=300, nthreads=0)
@@ -352,6 +371,7 @@ def _worker_4x5(rank, world, port, q):
             eg, _, st = e.lanczos(1, want_vectors=False)
             out["e_ff"] = float(eg[0])
             e.close()
+        _audit(comm2, out)
         q.put((rank, out))
         dist.destroy_process_group()
     except Exception:
@@ -381,6 +401,33 @@ def test_four_ranks_config5_lattice_transposition_exchange():
             assert rel(a[:40], ao[:40]) < 1e-8 and rel(b[:40], bo[:40]) < 1e-8
             assert np.array_equal(a, res[0]["a_" + tag])  # every rank takes bitwise-identical decisions
         assert abs(o["e_ff"] - exact) <= 1e-10 * abs(exact)
+
+
+@pytest.mark.parametrize("worker", ["uneven", "pb_tx"])
+def test_four_ranks_stream_ordered_collectives_are_recorded_and_correct(worker, monkeypatch):
+    """The communicators a multi-GPU node runs (torch.distributed over nccl, liblpp_comm_rccl.so) are stream-ordered: nothing
+    waits on the host between a collective and the kernels that consume it.  A one-GPU box cannot run them with more than one
+    rank, so the gloo emulation is switched to its stream-ordered form here (device tensors handed to gloo, which forks and
+    joins the engine's stream with events exactly as ProcessGroupNCCL does) and every all-reduce is recorded on the engine's
+    stream: the partial that went in and the value the next kernel reads.  _run_ranks fails on any record that is not the
+    sum of the partials or differs between ranks; energies and coefficients are checked as in the host-staged runs."""
+    monkeypatch.setenv("LPP_GLOO_STREAM_ORDERED", "1")
+    world = 4
+    res = _run_ranks(_worker_uneven if worker == "uneven" else _worker_pb_tx, world, timeout=400)
+    for r in range(world):
+        assert "error" not in res[r], res[r].get("error")
+        assert res[r]["recorded"] > 100  # the record is not empty
+        o = res[r]
+        if worker == "uneven":
+            for key in ("e_stored", "e_tx", "e_tx2", "e_kron_tx"):
+                assert abs(o[key] - o["e_oracle"]) <= 1e-10 * abs(o["e_oracle"]), (key, o[key], o["e_oracle"])
+            assert abs(o["e_kron"][0] - o["e_oracle"]) <= 1e-10 * abs(o["e_oracle"])
+            assert abs(o["e_tx_c"] - o["e_oracle_c"]) <= 1e-10 * abs(o["e_oracle_c"])
+        else:
+            for tag in ("ladder", "chain"):
+                eo = res[0][tag + "_eo"]
+                assert abs(o[tag + "_e"] - eo) <= 1e-10 * abs(eo) and abs(o[tag + "_e2"] - eo) <= 1e-10 * abs(eo) and abs(o[tag + "_mf_e"] - eo) <= 1e-10 * abs(eo)
+                assert np.array_equal(o[tag + "_a"], res[0][tag + "_a"]) and np.array_equal(o[tag + "_b"], res[0][tag + "_b"])
 
 
 def test_c_level_rccl_communicator_at_world_size_one():
@@ -483,6 +530,7 @@ def _worker_pb_tx(rank, world, port, q):
                 eg, _, st = e.lanczos(1, want_vectors=False)
                 out[tag + "_mf_e"], out[tag + "_mf_steps"] = float(eg[0]), st["steps"]
                 e.close()
+            _audit(comm, out)
             if rank == 0:
                 A = oracle.hubbard_csr(L, nup, ndown, hop, U, ninj=ninj)
                 eo, _, so = oracle.lanczos_solve(A, oracle.fill_random(A.nrows, 1234), want_vectors=False, max_steps=300)
@@ -556,6 +604,7 @@ def _worker_odd(rank, world, port, q):
                     eg, _, st = e.lanczos(1, want_vectors=False)
                     e.close()
                 torch.cuda.synchronize()
+                _audit(comm, out)
                 out["%s_%d" % (mode, keep)] = (float(eg[0]), st["steps"], bool((guard[:2] == 777.0).all() and (guard[2 + stride:] == 777.0).all()))
         if rank == 0:
             A = oracle.hubbard_csr(L, nup, ndown, hop, U)
@@ -574,7 +623,7 @@ def test_two_ranks_odd_slice_lengths_stay_inside_the_send_buffer():
         assert "error" not in res[r], res[r].get("error")
     ed = res[0]["e_dense"]
     for r in range(world):
-        for k, (e0, steps, intact) in [(k, v) for k, v in res[r].items() if k != "e_dense"]:
+        for k, (e0, steps, intact) in [(k, v) for k, v in res[r].items() if k not in ("e_dense", "findings", "recorded")]:
             assert intact, (k, "wrote outside the send buffer")
             assert abs(e0 - ed) <= 1e-10 * abs(ed), (k, e0, ed)
 
@@ -601,4 +650,26 @@ def test_python_held_c_level_communicator_at_world_size_one():
             eg, _, st = e.lanczos(1, want_vectors=False)
             assert abs(eg[0] - eo[0]) <= 1e-10 * abs(eo[0]) and st["steps"] == so
             assert e.stats()["nnz"] == A.nnz
-        c.close()
+            e.sync()
+            c.close()  # the communicator goes first (include/lpp_comm_rccl.h): the engine's stream is still alive here
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` without a launcher: the parent (which never touches the GPU) starts the two ranks through
+    torch.distributed.run, relays rank 0's one JSON line and returns the children's status.  Two ranks share cuda:0 over gloo
+    here (LPP_BENCH_BACKEND=gloo); the line is the partitioned run's, with the transposition exchange."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, LPP_BENCH_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--workload",
+                          "hubbard_chain_L12_half_filling_U4", "--no-cpu-baseline"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    lines = out.stdout.decode().strip().splitlines()
+    assert len(lines) == 1, lines
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 4 and j["value"] > 0 and j["config"]["rows"] == 853776
+    assert j["config"]["exchange"] == "transpose" and j["config"]["attempts"][-1]["ok"]
