@@ -160,16 +160,28 @@ def cpu_baseline(name, nrows, budget_s=15.0):
         t0 = time.time()
         oracle.hubbard_otf_mvp(L, p["nup"], p["ndown"], hop, U, V, x, y, 0, m2, cores)
         dt = time.time() - t0
-        its = (m2 / dt) / nrows
+        # the three BLAS-1 passes of an iteration (dot; axpy + norm; swap/scale: SURVEY 8(d), 9 N s bytes) on the same m2 rows,
+        # numpy on one core as the reference's LanczosSolver runs them (PsimagLite vectors, no threading)
+        xs, ys = x[:m2], y[:m2].copy()
+        t0 = time.time()
+        a = float(ys @ xs)
+        xs -= a * ys
+        b = float(np.sqrt(xs @ xs)) or 1.0
+        ys, xs = xs / b, -b * ys
+        dt_blas = time.time() - t0
+        its_spmv = (m2 / dt) / nrows
+        its = (m2 / (dt + dt_blas)) / nrows
         # BASELINE.md section 3 single-thread leg (mirrors the reference's serial CrsMatrix loop), a tenth of the budget
         m1 = int(min(nrows, max(100_000, rate / max(cores, 1) * budget_s / 10)))
         t0 = time.time()
         oracle.hubbard_otf_mvp(L, p["nup"], p["ndown"], hop, U, V, x, y, 0, m1, 1)
         its1 = (m1 / max(time.time() - t0, 1e-9)) / nrows
-        sample = ("SpMV-only, extrapolated: on-the-fly x+=Hy (oracle port of HubbardHelper::matrixVectorProduct, HubbardHelper.h:105-134) "
-                  "timed over the first %d of %d rows (%.1f s) and scaled to all rows; the three BLAS-1 passes of an iteration are not included" % (m2, nrows, dt))
-        return {"value": its, "unit": "iterations/s", "cores": cores, "kind": "port", "sample": sample,
-                "what": "SpMV-only, extrapolated from a row sample", "single_thread_value": its1, "single_thread_rows": m1}
+        sample = ("whole iteration, extrapolated: on-the-fly x+=Hy (oracle port of HubbardHelper::matrixVectorProduct, HubbardHelper.h:105-134, %d threads) "
+                  "plus the three BLAS-1 passes of the recurrence (numpy, one thread) timed over the first %d of %d rows (%.1f s + %.2f s) and scaled to all rows"
+                  % (cores, m2, nrows, dt, dt_blas))
+        return {"value": its, "unit": "iterations/s", "cores": cores, "kind": "port", "sample": sample, "rows_timed": m2,
+                "what": "whole iteration (product + BLAS-1), extrapolated from a row sample", "spmv_only_value": its_spmv,
+                "single_thread_value": its1, "single_thread_rows": m1, "single_thread_what": "x+=Hy only, one thread"}
     # other models: the reference's stored path (serial CrsMatrix::matrixVectorProduct) restated with OpenMP rows on the
     # oracle's own assembly of the same Hamiltonian, plus the three BLAS-1 passes of an iteration
     L = p["L"]
@@ -199,19 +211,24 @@ def cpu_baseline(name, nrows, budget_s=15.0):
             "sample": "%d full Lanczos iterations (OpenMP stored-CSR x+=Hy from the oracle + numpy BLAS-1) on the same %d x %d matrix, %.1f s" % (reps, A.nrows, A.nrows, dt)}
 
 
-GOLDEN = {"hubbard_4x4_half_filling_pbc_U4": "c2_hubbard4x4_U4.json"}
+GOLDEN = {"hubbard_4x4_half_filling_pbc_U4": "c2_hubbard4x4_U4.json",  # CPU-oracle Lanczos runs at full size (tests/golden/make_*.py)
+          "heisenberg_chain_L28_sz0_obc": "c3_heisenberg_L28.json", "tj_4x5_9up9down_complex": "c4_tj_4x5_complex.json"}
 
 
 def kernel_name(engine, layout):
     if engine == "onthefly" and (layout or {}).get("kernel") != "product":
         return "k_spmv_kron_packed / k_spmv_kron_chunked (matrix-free x += H y, fused a_j partial)"
     k = (layout or {}).get("kernel")
+    if k == "product" and (layout.get("pieces", 1) > 1 or not layout.get("chained_step")):
+        return ("k_pb_down%s + k_pb_up%s + k_pb_combine (product-basis form H = 1(x)T + C(x)1 + D; rows of %d LDS-window pieces, entries that leave a piece read "
+                "from the row in L2; the streaming pass forms x and applies the recurrence update: the three launches are the WHOLE scale-free Lanczos step)"
+                % ("_parts" if layout.get("coupling_parts", 1) > 1 else "", "_big" if layout.get("pieces", 1) > 1 else "", layout.get("pieces", 1)))
     return {"window": "k_spmv_window (stored matrix, LDS source window; x += H y, fused a_j partial)",
             "sliced": "k_spmv_sliced (stored matrix, wave-interleaved slices; x += H y, fused a_j partial)",
             "rowgroup": "k_spmv_rowgroup (plain CSR; x += H y, fused a_j partial)",
             "product": ("k_pb_up<CHAIN> + k_pb_down<RMW> (product-basis form H = 1(x)T + C(x)1 + D: in-block part from the LDS window, block couplings "
                         "panel-wise from L2; the two launches are the WHOLE scale-free Lanczos step -- the previous step's axpy rides in k_pb_up)"
-                        if pb_chained() else
+                        if (layout or {}).get("chained_step") else
                         "k_pb_up + k_pb_down (product-basis form H = 1(x)T + C(x)1 + D: in-block part from the LDS window, block couplings panel-wise from L2)")}.get(k, str(k))
 
 
@@ -269,6 +286,39 @@ def generic_csr_leg(name, is_complex, device, iters=10):
             "frac": gbs / HBM_PEAK_GBS, "target_frac": 0.60, "resident_GB": round(lay["resident_bytes"] / 1e9, 2), "launches_timed": iters}
 
 
+def reortho_leg(name, is_complex, device, onthefly, nrows, steps=24):
+    """Blocked CGS2 against the on-device Krylov basis (north_star: "a blocked Gram-Schmidt"): `steps` Lanczos steps with
+    LanczosOptions=reortho, every k_multi_dot / k_multi_axpy sweep of a step bracketed by HIP events on the engine's stream
+    (lpp_stats.reortho_*).  Step j orthogonalises against j+1 columns, twice.  Bytes: the SURVEY 8(d) figure (per pass: the j+1
+    columns read for the dots and again for the update, x read and written once = (2(j+1) + 2) N s) and what the blocked kernels
+    move (panels of 8 columns: x is read once per panel by the dot sweep, read and written once per panel by the update)."""
+    from lanczosplusplus_amd import LanczosEngine
+    esz = 16 if is_complex else 8
+    with LanczosEngine(dtype="c128" if is_complex else "f64", device=device, max_steps=steps + 2, eps=0.0, reortho=True, time_kernels=True) as e:
+        assemble(e, name, None, onthefly=onthefly)
+        e.begin(None)
+        e.step(2)
+        e.sync()
+        s0 = e.stats()
+        t0 = time.perf_counter()
+        e.step(steps - 2)
+        e.sync()
+        dt = time.perf_counter() - t0
+        s1 = e.stats()
+        lay_rows = nrows
+    calls = s1["reortho_calls"] - s0["reortho_calls"]
+    ms = s1["reortho_ms_total"] - s0["reortho_ms_total"]
+    cols = s1["reortho_columns"] - s0["reortho_columns"]
+    panels = sum(-(-(j + 1) // 8) for j in range(2, steps))
+    alg = 2.0 * (2.0 * cols + 2.0 * calls) * lay_rows * esz
+    moved = 2.0 * (2.0 * cols + 3.0 * panels) * lay_rows * esz
+    return {"what": "blocked CGS2 (k_multi_dot + k_multi_axpy, panels of 8 Krylov columns, two passes) on the engine's work vectors", "steps_timed": calls,
+            "first_step": 2, "columns_total": cols, "ms_total": ms, "ms_per_step_avg": ms / max(calls, 1), "step_ms_with_reortho_avg": 1e3 * dt / max(steps - 2, 1),
+            "algorithmic_bytes": alg, "achieved": (alg / 1e9) / (ms / 1e3) if ms > 0 else 0.0, "kernel_model_bytes": moved,
+            "moved_GBps": (moved / 1e9) / (ms / 1e3) if ms > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": ((alg / 1e9) / (ms / 1e3) / HBM_PEAK_GBS) if ms > 0 else 0.0}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -281,6 +331,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-generic-csr", action="store_true", help="skip the plain-CSR kernel leg (second roofline object)")
     ap.add_argument("--no-e0-check", action="store_true", help="skip the converged solve against the CPU-oracle fixture")
+    ap.add_argument("--no-reortho-leg", action="store_true", help="skip the blocked Gram-Schmidt leg (24 steps with LanczosOptions=reortho)")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     args = ap.parse_args()
 
@@ -489,7 +540,7 @@ def main():
                     a, b = eng.coeffs()
                 # several ranks: this gate is mandatory -- a wrong exchange or a mis-ordered collective shows up in the first
                 # coefficients at once, and the attempt is then abandoned on every rank
-                coeff_check = coefficients_match(a, b) if (rank == 0 and model == "hubbard") else None
+                coeff_check = coefficients_match(a, b) if rank == 0 else None
                 if coeff_check is not None and not (coeff_check["max_rel_diff"] < 1e-6):
                     ok, err = False, RuntimeError("Lanczos coefficients differ from the CPU-oracle fixture: %r" % coeff_check)
             except Exception as ex:
@@ -537,10 +588,11 @@ def main():
             lay = None
         if lay is not None and (args.engine == "stored" or lay["kernel"] == 4):
             layout = {"kernel": {1: "rowgroup", 2: "sliced", 3: "window", 4: "product"}.get(lay["kernel"]), "value_codes": bool(lay["coded"]),
+                      "pieces": lay["pieces"], "coupling_parts": lay["coupling_parts"], "chained_step": bool(lay["chained_step"]),
                       "local16_columns": bool(lay["local16"]), "block_template": lay["block_template"], "diagonal_codes": bool(lay["diagonal_codes"]), "per_row_entries": lay["per_row_entries"],
                       "shared_offset_entries": lay["shared_entries"], "resident_GB": round(lay["resident_bytes"] / 1e9, 2)}
             min_bytes = float(lay["stream_bytes"]) + 3.0 * st0["nrows"] * esz
-            if lay["kernel"] == 4 and pb_chained():
+            if lay["kernel"] == 4 and world == 1:
                 # the timed launches are product AND recurrence update: a two-phase step (the reduction a_j sits between the
                 # phases) cannot move less than  w = beta x + alpha H y (y, x in; w out)  +  x = w - g y (w, y in; x out)
                 min_bytes = float(lay["stream_bytes"]) + 6.0 * st0["nrows"] * esz
@@ -558,7 +610,7 @@ def main():
                     "traffic": traffic, "achieved_basis": "pmc_traffic" if traffic else "min_bytes", "traffic_note": traffic_note,
                     "min_bytes": min_bytes, "wasted": (traffic / min_bytes) if traffic else None,
                     "kernel": kernel_name(args.engine, layout), "spmv_ms": spmv_ms_per_step, "launches_timed": launches,
-                    "covers": ("product + recurrence update (whole step)" if (layout or {}).get("kernel") == "product" and pb_chained() else "product x += H y"),
+                    "covers": ("product + recurrence update (whole step)" if (layout or {}).get("kernel") == "product" and world == 1 else "product x += H y"),
                     # the plain-CSR figure of SURVEY 8(d) (12 B per entry for f64): what a kernel streaming the reference's
                     # CrsMatrix would have to sustain for this time -- a compression ratio times a bandwidth, NOT a roofline number
                     "csr_equivalent_bytes": csr_bytes, "csr_equivalent_GBps": (csr_bytes / 1e9) / spmv_s if spmv_s > 0 else 0.0}
@@ -602,7 +654,7 @@ def main():
                 comm.close()
                 comm = None
             eng.close()
-            with LanczosEngine(dtype="f64", device=local_rank, max_steps=g["max_steps"], min_steps=g["min_steps"], eps=g["eps"],
+            with LanczosEngine(dtype="c128" if is_complex else "f64", device=local_rank, max_steps=g["max_steps"], min_steps=g["min_steps"], eps=g["eps"],
                                save_vectors=0, seed=g["seed"], spmv_kernel=args.spmv_kernel) as e2:
                 assemble(e2, name, None, onthefly=(args.engine == "onthefly"))
                 t_s = time.time()
@@ -611,7 +663,7 @@ def main():
             eg = float(tridiag_lowest(a2, b2[:-1], 1)[0])
             out["e0_check"] = {"e0_gpu": eg, "e0_cpu": g["e0"], "abs_diff": abs(eg - g["e0"]), "rel_diff": abs(eg - g["e0"]) / abs(g["e0"]),
                                "steps_gpu": len(a2), "steps_cpu": g["steps"], "solve_s": round(t_s, 3),
-                               "cpu_source": "tests/golden/" + GOLDEN[name] + " (oracle on-the-fly Lanczos, " + g["generator"] + ")"}
+                               "cpu_source": "tests/golden/" + GOLDEN[name] + " (" + g["what"] + ", " + g["generator"] + ")"}
         # the generic (uncompressed, 12 B per entry) CSR kernel on the same matrix: the north_star's ">= 60 % of the HBM
         # roofline on the CSR SpMV" is about THIS kernel; its algorithmic bytes are the SURVEY 8(d) figure
         if args.engine == "stored" and not args.no_generic_csr:
@@ -625,6 +677,17 @@ def main():
                 out["generic_csr"] = generic_csr_leg(name, is_complex, local_rank)
             except Exception as ex:
                 out["generic_csr"] = {"error": repr(ex)}
+        if not args.no_reortho_leg and nrows_g * esz * 28 < 200e9:  # 26 Krylov columns + work vectors must fit
+            if comm is not None and hasattr(comm, "close"):
+                if not eng.closed:
+                    eng.sync()
+                comm.close()
+                comm = None
+            eng.close()
+            try:
+                out["reortho"] = reortho_leg(name, is_complex, local_rank, args.engine == "onthefly", nrows_g)
+            except Exception as ex:
+                out["reortho"] = {"error": repr(ex)}
         if not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(name, nrows_g, args.cpu_budget)

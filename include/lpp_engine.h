@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define LPP_ABI_VERSION 2 /* 2: lpp_layout.stream_bytes, lpp_pb_pack_template(bank_ways), set_solver / stream / _ext / _spin entry points */
+#define LPP_ABI_VERSION 3 /* 2: lpp_layout.stream_bytes, lpp_pb_pack_template(bank_ways), set_solver / stream / _ext / _spin entry points; 3: lpp_layout.pieces / coupling_parts / diagonal_plain / chained_step, lpp_stats.reortho_* */
 
 typedef int32_t lpp_status;
 enum {
@@ -79,6 +79,9 @@ typedef struct lpp_stats {
 	double spmv_ms_total; /* sum of event-timed SpMV launches (time_kernels=1) */
 	int64_t spmv_launches;
 	double spmv_bytes; /* algorithmic bytes of one SpMV: Z(s+4) + (N+1)8 + 3Ns */
+	double reortho_ms_total; /* sum of event-timed blocked Gram-Schmidt calls (time_kernels=1, reortho=1): both CGS2 passes of a step */
+	int64_t reortho_calls;
+	double reortho_columns; /* Krylov columns orthogonalised against, summed over the timed calls */
 } lpp_stats;
 
 /* How a stored matrix is laid out in HBM (introspection for tests, bench.py and DESIGN.md; no effect on results). */
@@ -97,6 +100,11 @@ typedef struct lpp_layout {
 	int64_t stream_bytes; /* bytes of matrix data ONE product has to read at least once (arrays kept only for
 	                         lpp_engine_get_csr and block-0 templates that stay in L2 are not streamed);
 	                         stream_bytes + 3*rows*sizeof(value) is the least HBM traffic of x += H y in this layout */
+	int32_t pieces; /* product-basis layout: LDS-window pieces a block's row is cut into (1: the whole row fits one window) */
+	int32_t coupling_parts; /* product-basis layout: parts of the source-block range the coupling kernel walks per panel (1: whole panel) */
+	int32_t diagonal_plain; /* product-basis layout: 1 = the diagonal is a plain f64 stream (more than 256 distinct values), 0 = one code per row */
+	int32_t chained_step; /* product-basis layout: 1 = a scale-free Lanczos step is the chained pair of launches (k_pb_up<CHAIN> + k_pb_down<RMW>),
+	                         0 = product kernels + one streaming pass that also applies the recurrence update */
 } lpp_layout;
 
 /* Communicator for the 1-D row-partitioned multi-GPU path.  The engine never

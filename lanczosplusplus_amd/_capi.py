@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "liblpp_engine.so")
 
-LPP_ABI_VERSION = 2
+LPP_ABI_VERSION = 3
 LPP_OK, LPP_ERR_INVALID, LPP_ERR_HIP, LPP_ERR_NOMEM, LPP_ERR_NOCONV, LPP_ERR_STATE, LPP_ERR_COMM = range(7)
 LPP_F64, LPP_C128 = 0, 1
 LPP_SPMV_AUTO, LPP_SPMV_ROWGROUP, LPP_SPMV_SLICED, LPP_SPMV_WINDOW = 0, 1, 2, 3
@@ -36,7 +36,7 @@ class Stats(C.Structure):
     _fields_ = [("steps", C.c_int32), ("steps_enqueued", C.c_int32), ("converged", C.c_int32),
                 ("vectors_saved", C.c_int32), ("nrows", C.c_int64), ("nnz", C.c_int64),
                 ("seconds_total", C.c_double), ("spmv_ms_total", C.c_double), ("spmv_launches", C.c_int64),
-                ("spmv_bytes", C.c_double)]
+                ("spmv_bytes", C.c_double), ("reortho_ms_total", C.c_double), ("reortho_calls", C.c_int64), ("reortho_columns", C.c_double)]
 
     def as_dict(self):
         return {name: getattr(self, name) for name, _ in self._fields_}
@@ -46,7 +46,8 @@ class Layout(C.Structure):
     _fields_ = [("kernel", C.c_int32), ("coded", C.c_int32), ("local16", C.c_int32), ("shared_stride", C.c_int32),
                 ("block_template", C.c_int32), ("diagonal_codes", C.c_int32),
                 ("nnz", C.c_int64), ("per_row_entries", C.c_int64), ("shared_entries", C.c_int64),
-                ("rows_per_block", C.c_int64), ("resident_bytes", C.c_int64), ("stream_bytes", C.c_int64)]
+                ("rows_per_block", C.c_int64), ("resident_bytes", C.c_int64), ("stream_bytes", C.c_int64),
+                ("pieces", C.c_int32), ("coupling_parts", C.c_int32), ("diagonal_plain", C.c_int32), ("chained_step", C.c_int32)]
 
     def as_dict(self):
         return {name: getattr(self, name) for name, _ in self._fields_}

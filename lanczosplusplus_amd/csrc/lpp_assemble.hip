@@ -247,9 +247,15 @@ lpp_status assemble_hubbard_pb(lpp_engine* e, AsmParams P, int nup, int ndown, i
 	for (const char* k : { "LPP_SHARED_OFFSETS", "LPP_LOCAL16", "LPP_DIAG_CODES", "LPP_BLOCK_TEMPLATE", "LPP_WINDOW_ROWS" })
 		if (getenv(k)) return LPP_OK; // switches of the general layout: measure that one
 	const int64_t pitch = pb_pitch_for(n_up);
-	if ((size_t)(pitch + kPbZeroSlots) * sizeof(double) > (size_t)156 * 1024) return LPP_OK;
-	if (pitch_dn == 0 && (size_t)n_dn * (size_t)pitch * sizeof(double) >= ((size_t)1 << 32)) return LPP_OK;
-	if (pitch_dn > 0 && (size_t)nblk_padded * (size_t)pitch_dn * sizeof(double) >= ((size_t)1 << 32)) return LPP_OK;
+	// rows beyond one LDS window and vectors beyond 4 GiB take the pieces / parts kernels (lpp_pbig_kernels.h); what the layout
+	// cannot hold at all (more than 65535 blocks, coupling lists beyond LDS) comes back from pb_build as "does not apply"
+	if (n_dn > 65535 || n_up >= ((int64_t)1 << 24)) return LPP_OK;
+	{
+		// two work vectors + the two parts of a product + one code per row must fit beside everything else
+		const int64_t nloc = (nblk_loc >= 0 ? nblk_loc : n_dn) * pitch;
+		size_t free_b = 0, total_b = 0;
+		if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && (size_t)nloc * 33 + ((size_t)2 << 30) > free_b) return LPP_OK;
+	}
 	hipStream_t st = e->stream;
 	// one-species matrices: hops of that species + its potential diagonal (ignored below; the true diagonal is per row)
 	DevCsr Tm, Cm;
@@ -299,14 +305,22 @@ lpp_status assemble_hubbard_pb(lpp_engine* e, AsmParams P, int nup, int ndown, i
 	HIP_TRY(hipMemcpyAsync(host.data(), table.p, sizeof(unsigned long long) * kDictTable, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipMemcpyAsync(&ov, overflow.p, sizeof(int), hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipStreamSynchronize(st));
-	if (ov) return LPP_OK;
+	// More than 256 distinct diagonal values (site-dependent hubbardU / potentialV, HubbardHelper.h:138-189: disorder) do not
+	// end the layout: the diagonal then travels as ONE plain f64 stream (8 instead of 1 byte per row), added by the streaming
+	// pass behind the two product kernels (PbCombineArgs::d); T and C stay what they are.  LPP_PB_PLAIN_DIAG=1 forces it (tests).
 	std::vector<unsigned long long> keys;
 	keys.push_back(0ull); // code 0 = +0.0 (padding places of k_pb_down)
 	auto add_key = [&](unsigned long long k) {
 		if (std::find(keys.begin(), keys.end(), k) == keys.end()) keys.push_back(k);
 	};
+	size_t ndiag = 0;
 	for (unsigned long long k : host)
-		if (k != kDictEmpty) add_key(k);
+		if (k != kDictEmpty) ndiag++;
+	bool plain_diag = ov != 0 || ndiag > 250 || (getenv("LPP_PB_PLAIN_DIAG") && atoi(getenv("LPP_PB_PLAIN_DIAG")) != 0);
+	if (plain_diag && getenv("LPP_PB_PLAIN_DIAG") && atoi(getenv("LPP_PB_PLAIN_DIAG")) == 0) return LPP_OK; // switched off: general layout
+	if (!plain_diag)
+		for (unsigned long long k : host)
+			if (k != kDictEmpty) add_key(k);
 	for (int64_t b = 0; b < n_dn; b++)
 		for (int64_t p = crp[(size_t)b]; p < crp[(size_t)b + 1] && keys.size() <= 256; p++)
 			if (cci[(size_t)p] != b) {
@@ -321,6 +335,7 @@ lpp_status assemble_hubbard_pb(lpp_engine* e, AsmParams P, int nup, int ndown, i
 	rc = pb_build(e, n_up, n_dn, trp.data(), tci.data(), tva.data(), crp.data(), cci.data(), cva.data(), dict.data(), (int)keys.size(), blk0, nblk_loc, pitch_dn,
 	              nblk_padded);
 	if (rc == LPP_ERR_INVALID) { // not representable (e.g. more than 8 distinct in-block values): general path
+		if (getenv("LPP_VERBOSE")) fprintf(stderr, "lpp: the product-basis layout does not apply: %s\n", lpp_last_error());
 		free_pb(e);
 		return LPP_OK;
 	}
@@ -329,7 +344,13 @@ lpp_status assemble_hubbard_pb(lpp_engine* e, AsmParams P, int nup, int ndown, i
 		Pf.row0 = blk0 * n_up;
 		Pf.nloc = nblk_loc * n_up;
 	}
-	if (Pf.nloc > 0) k_pb_diag_codes<ASM_HUBBARD><<<nb, kBlock, 0, st>>>(Pf, e->pb.pitch, e->pb.dict, e->pb.ndict, e->pb.dcode, blk0);
+	if (plain_diag) {
+		const size_t loc = (size_t)std::max<int64_t>(e->pb.nblk_loc, 1) * (size_t)e->pb.pitch;
+		HIP_TRY_MEM(hipMalloc(&e->pb.dval, sizeof(double) * loc));
+		HIP_TRY(hipMemsetAsync(e->pb.dval, 0, sizeof(double) * loc, st));
+		if (Pf.nloc > 0) k_pb_diag_values<ASM_HUBBARD><<<nb, kBlock, 0, st>>>(Pf, e->pb.pitch, e->pb.dval, blk0); // the codes stay 0 (+0.0)
+	} else if (Pf.nloc > 0)
+		k_pb_diag_codes<ASM_HUBBARD><<<nb, kBlock, 0, st>>>(Pf, e->pb.pitch, e->pb.dict, e->pb.ndict, e->pb.dcode, blk0);
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipStreamSynchronize(st));
 	*done = true;

@@ -431,6 +431,18 @@ __global__ __launch_bounds__(kBlock) void k_pb_diag_codes(AsmParams P, int64_t p
 	}
 }
 
+// the diagonal as plain doubles (more than 256 distinct values), pitched like the vectors
+template <int MODEL>
+__global__ __launch_bounds__(kBlock) void k_pb_diag_values(AsmParams P, int64_t pitch, double* __restrict__ dval, int64_t blk0 = 0)
+{
+	for (int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x; r < P.nloc; r += (int64_t)gridDim.x * kBlock) {
+		const int64_t row = P.row0 + r;
+		const uint64_t ket = state_of<MODEL>(P, row);
+		const int64_t b = row / P.n_up, i = row - b * P.n_up;
+		dval[(b - blk0) * pitch + i] = diag_of<MODEL>(P, ket);
+	}
+}
+
 // ---------------------------------------------------------------------------------------------
 // exclusive scan of int64 (three phases, chunk = 2048 elements per block)
 // ---------------------------------------------------------------------------------------------

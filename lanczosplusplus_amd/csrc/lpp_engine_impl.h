@@ -9,6 +9,7 @@
 #include "lpp_host.h"
 #include "lpp_kernels.h"
 #include "lpp_pb_kernels.h"
+#include "lpp_pbig_kernels.h"
 
 #define HIP_TRY(expr)                                                                                                  \
 	do {                                                                                                               \
@@ -130,10 +131,23 @@ struct PbState {
 	bool pending = false;
 	const double* pend_a = nullptr;
 	const double* pend_b2 = nullptr;
+	// rows beyond one LDS window / vectors beyond 4 GiB (lpp_pbig_kernels.h)
+	bool big = false; // in-block part by pieces of W positions (k_pb_up_big)
+	int W = 0, npieces = 1;
+	uint32_t* fw = nullptr; // entries that leave their piece
+	int32_t* f_off = nullptr;
+	uint16_t* f_len = nullptr;
+	int64_t f_words = 0, f_entries = 0;
+	bool wide = false; // vector beyond 4 GiB: k_pb_down<WIDE> (64-bit addresses from line numbers)
+	bool parts = false; // couplings over parts of the source range (k_pb_down_parts; 64-bit addresses too)
+	int nparts = 1, ent_cap = 0, pace_stride = 0, maxr = 0;
+	int64_t part_blocks = 0;
+	int32_t* c_pstart = nullptr;
 	// diagonal
 	double* dict = nullptr; // 256 doubles
 	int ndict = 0;
 	uint8_t* dcode = nullptr; // n_blk * pitch codes
+	double* dval = nullptr; // the diagonal as a plain f64 stream (n_blk * pitch doubles) when it has more than 256 distinct values; the codes are then all 0
 	int64_t* blockbase = nullptr; // first CSR entry of every block (n_blk + 1), for get_csr
 };
 
@@ -194,6 +208,7 @@ struct lpp_engine {
 	bool scalefree = false; // unnormalised Lanczos vectors, scalings folded into the SpMV epilogue (no swap pass)
 	std::vector<hipEvent_t> step_events;
 	std::vector<std::pair<hipEvent_t, hipEvent_t>> spmv_events;
+	std::vector<int> spmv_event_cols; // per bracket: 0 = a product, > 0 = a blocked Gram-Schmidt call against that many columns
 	size_t spmv_events_used = 0;
 	hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;
 	lpp_stats stats {};

@@ -297,11 +297,16 @@ int edge_colour(const std::vector<std::pair<int, int>>& edges, int nright, std::
 
 } // namespace
 
-lpp_status pb_pack_template(int64_t rows, int64_t pitch, const int64_t* rp, const int32_t* ci, const double* va, PbTemplate& out, int bank_ways)
+lpp_status pb_pack_template(int64_t rows, int64_t pitch, const int64_t* rp, const int32_t* ci, const double* va, PbTemplate& out, int bank_ways, int64_t window)
 {
-	if (rows <= 0 || pitch < rows || (pitch & 15) != 0 || pitch + kPbZeroSlotsHost > 65536) return fail(LPP_ERR_INVALID, "pb_pack_template: bad shape");
+	if (rows <= 0 || pitch < rows || (pitch & 15) != 0) return fail(LPP_ERR_INVALID, "pb_pack_template: bad shape");
+	if (window == 0 && pitch + kPbZeroSlotsHost > 65536) return fail(LPP_ERR_INVALID, "pb_pack_template: bad shape");
+	if (window != 0 && (window < 64 || (window & 63) != 0 || window + kPbZeroSlotsHost > 65536 || rows >= ((int64_t)1 << 24)))
+		return fail(LPP_ERR_INVALID, "pb_pack_template: window must be a multiple of 64 below 65504, rows below 2^24");
 	if (bank_ways < 1 || bank_ways > 4) return fail(LPP_ERR_INVALID, "pb_pack_template: bank_ways must be 1..4");
 	out = PbTemplate();
+	out.W = window;
+	const int64_t zero_at = window ? window : pitch; // window index of the first zero slot
 	// value groups (bit patterns, first-seen order then sorted for determinism)
 	std::vector<uint64_t> keys;
 	for (int64_t r = 0; r < rows; r++)
@@ -322,10 +327,86 @@ lpp_status pb_pack_template(int64_t rows, int64_t pitch, const int64_t* rp, cons
 	out.spb = (int)((rows + 63) / 64);
 	out.off.assign((size_t)out.spb * G, 0);
 	out.len.assign((size_t)out.spb * G, 0);
+	if (window) {
+		out.foff.assign((size_t)out.spb, 0);
+		out.flen.assign((size_t)out.spb, 0);
+	}
 	std::vector<std::pair<int, int>> edges;
 	std::vector<int> ecol, colour;
 	std::vector<int> slot_idx; // [slot][lane] window index or -1
 	for (int j = 0; j < out.spb; j++) {
+		// the piece this slice belongs to: columns [c0, c1) are read from the LDS window, the others from memory
+		const int64_t c0 = window ? ((int64_t)j * 64 / window) * window : 0, c1 = window ? std::min<int64_t>(c0 + window, rows) : rows;
+		if (window) {
+			struct Far {
+				int lane, g;
+				int64_t col;
+			};
+			std::vector<Far> far;
+			for (int l = 0; l < 64; l++) {
+				const int64_t r = (int64_t)j * 64 + l;
+				if (r >= rows) break;
+				for (int64_t p = rp[r]; p < rp[r + 1]; p++) {
+					if (ci[p] == r || (ci[p] >= c0 && ci[p] < c1)) continue;
+					uint64_t k;
+					std::memcpy(&k, &va[p], 8);
+					const int g = (int)(std::find(keys.begin(), keys.end(), k) - keys.begin());
+					far.push_back(Far { l, g, (int64_t)ci[p] });
+				}
+			}
+			// groups of equal column offset, largest first; a group takes the first slot in which all its lanes are free
+			std::vector<size_t> order(far.size());
+			for (size_t k = 0; k < far.size(); k++) order[k] = k;
+			auto offs = [&](size_t k) { return far[k].col - ((int64_t)j * 64 + far[k].lane); };
+			std::sort(order.begin(), order.end(), [&](size_t x, size_t y) { return offs(x) != offs(y) ? offs(x) < offs(y) : far[x].lane < far[y].lane; });
+			struct Grp {
+				size_t first, count;
+			};
+			std::vector<Grp> groups;
+			for (size_t k = 0; k < order.size();) {
+				size_t k2 = k;
+				while (k2 < order.size() && offs(order[k2]) == offs(order[k])) k2++;
+				groups.push_back(Grp { k, k2 - k });
+				k = k2;
+			}
+			std::stable_sort(groups.begin(), groups.end(), [](const Grp& x, const Grp& y) { return x.count > y.count; });
+			std::vector<uint64_t> busy; // lanes taken, per slot
+			std::vector<uint32_t> fw; // [slot][lane]
+			for (const Grp& gr : groups) {
+				// a row may hold two entries of one offset only if it holds the same column twice: never in a CSR row, so a group has one entry per lane
+				uint64_t mask = 0;
+				for (size_t k = 0; k < gr.count; k++) mask |= 1ull << far[order[gr.first + k]].lane;
+				size_t s = 0;
+				while (s < busy.size() && (busy[s] & mask)) s++;
+				if (s == busy.size()) {
+					busy.push_back(0);
+					fw.resize(fw.size() + 64, 0u);
+				}
+				busy[s] |= mask;
+				for (size_t k = 0; k < gr.count; k++) {
+					const Far& f = far[order[gr.first + k]];
+					fw[s * 64 + (size_t)f.lane] = (uint32_t)f.col | ((uint32_t)f.g << 24) | 0x80000000u;
+				}
+			}
+			while (busy.size() & 3) { // whole groups of 4 slots (the kernel's unit), the rest is filling
+				busy.push_back(0);
+				fw.resize(fw.size() + 64, 0u);
+			}
+			if (busy.size() > 65535) return fail(LPP_ERR_INVALID, "pb_pack_template: too many entries leave the window");
+			for (size_t s = 0; s < busy.size(); s++)
+				for (int l = 0; l < 64; l++) {
+					uint32_t& w = fw[s * 64 + (size_t)l];
+					if (w & 0x80000000u)
+						w &= 0x7fffffffu;
+					else // filling: the row's own element (a valid address inside the vector) times 0.0
+						w = (uint32_t)std::min<int64_t>((int64_t)j * 64 + l, rows - 1) | ((uint32_t)G << 24);
+				}
+			out.foff[(size_t)j] = (int32_t)(out.fwords.size() / 64);
+			out.flen[(size_t)j] = (uint16_t)busy.size();
+			out.fwords.insert(out.fwords.end(), fw.begin(), fw.end());
+			out.far_entries += (int64_t)far.size();
+			if (out.fwords.size() > ((size_t)1 << 30)) return fail(LPP_ERR_INVALID, "pb_pack_template: template too large");
+		}
 		for (int g = 0; g < G; g++) {
 			int nslots = 0;
 			struct Ent {
@@ -341,13 +422,14 @@ lpp_status pb_pack_template(int64_t rows, int64_t pitch, const int64_t* rp, cons
 					if (r >= rows) break;
 					for (int64_t p = rp[r]; p < rp[r + 1]; p++) {
 						if (ci[p] == r) continue;
+						if (ci[p] < c0 || ci[p] >= c1) continue; // leaves the window: kept in the far list above
 						uint64_t k;
 						std::memcpy(&k, &va[p], 8);
 						if (!keys.empty() && k != keys[(size_t)g]) continue;
 						// a bank serves `bank_ways` different addresses per slot: its entries are dealt over that many right vertices
-						const int bank = (int)(ci[p] & 31);
+						const int bank = (int)(ci[p] & 31); // c0 is a multiple of 64: the bank of the window index
 						edges.emplace_back(l, bank * bank_ways + (seen[bank]++ % bank_ways));
-						ecol.push_back((int)ci[p]);
+						ecol.push_back((int)(ci[p] - c0));
 					}
 				}
 				const int D = edge_colour(edges, 32 * bank_ways, colour);
@@ -375,9 +457,9 @@ lpp_status pb_pack_template(int64_t rows, int64_t pitch, const int64_t* rp, cons
 					if (!any_pad) continue;
 					int z = 0;
 					for (int t = 1; t < 32; t++)
-						if (used[(pitch + t) & 31] < used[(pitch + z) & 31]) z = t;
+						if (used[(zero_at + t) & 31] < used[(zero_at + z) & 31]) z = t;
 					for (int l = 0; l < 32; l++)
-						if (slot_idx[(size_t)s * 64 + h * 32 + l] < 0) slot_idx[(size_t)s * 64 + h * 32 + l] = (int)(pitch + z);
+						if (slot_idx[(size_t)s * 64 + h * 32 + l] < 0) slot_idx[(size_t)s * 64 + h * 32 + l] = (int)(zero_at + z);
 				}
 			out.off[(size_t)j * G + g] = (int32_t)(out.words.size() / 128); // in chunks of 64 lanes x 2 words
 			out.len[(size_t)j * G + g] = (uint16_t)nchunks;
@@ -389,7 +471,8 @@ lpp_status pb_pack_template(int64_t rows, int64_t pitch, const int64_t* rp, cons
 			if (out.words.size() > ((size_t)1 << 30)) return fail(LPP_ERR_INVALID, "pb_pack_template: template too large");
 		}
 	}
-	out.words.resize(out.words.size() + 128 * 8, (uint32_t)pitch | ((uint32_t)pitch << 16)); // slack for the look-ahead loads
+	out.words.resize(out.words.size() + 128 * 8, (uint32_t)zero_at | ((uint32_t)zero_at << 16)); // slack for the look-ahead loads
+	if (window) out.fwords.resize(out.fwords.size() + 64 * 8, (uint32_t)G << 24); // the same for the far lists (row 0 times 0.0)
 	return LPP_OK;
 }
 

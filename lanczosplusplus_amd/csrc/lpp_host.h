@@ -46,11 +46,24 @@ struct PbTemplate {
 	std::vector<uint32_t> words; // chunk c, lane l at [(c*64 + l)*2 + {0,1}]: window indices of slots 4c, 4c+1 | 4c+2, 4c+3 (16 bits each, low half first)
 	int64_t entries = 0; // real entries
 	int64_t slots = 0; // lane-slots incl. padding
+	// rows beyond one LDS window (pb_pack_template with window W > 0): the row is cut into pieces of W consecutive positions
+	// (W a multiple of 64, so a slice never straddles two pieces); the streams above hold the entries whose column lies in the
+	// row's OWN piece, as indices relative to the piece (zero slots at index W), and the entries that leave the piece are kept
+	// per slice as 32-bit words  column (24 bits) | value group << 24  (group G = filling, multiplies by 0.0, column = the row
+	// itself), slot-major.  Entries with the same column offset share a slot wherever their lanes are free: basis words are
+	// ascending, so a hop among the high sites moves 64 consecutive rows by the same amount and the slot is ONE coalesced read.
+	int64_t W = 0;
+	std::vector<int32_t> foff; // [spb] first far slot of the slice (a slot = 64 words)
+	std::vector<uint16_t> flen; // [spb] far slots
+	std::vector<uint32_t> fwords;
+	int64_t far_entries = 0;
 };
 
 // rows x rows CSR (rp, ci, va); entries with ci == row (the diagonal) are skipped.  pitch: the zero slots start at window
 // index `pitch` (a multiple of 16, >= rows; pitch + 32 <= 65536).  Fails (LPP_ERR_INVALID) when the off-diagonal part has more
 // than kPbGroupsMax distinct values.
-lpp_status pb_pack_template(int64_t rows, int64_t pitch, const int64_t* rp, const int32_t* ci, const double* va, PbTemplate& out, int bank_ways = 2);
+// window > 0: pieces of `window` positions (see PbTemplate::W); the zero slots then sit at window index `window`.
+lpp_status pb_pack_template(int64_t rows, int64_t pitch, const int64_t* rp, const int32_t* ci, const double* va, PbTemplate& out, int bank_ways = 2,
+                            int64_t window = 0);
 
 } // namespace lpp

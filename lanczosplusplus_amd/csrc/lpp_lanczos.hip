@@ -74,8 +74,14 @@ void lpp_engine::collect_spmv_times()
 	for (size_t i = 0; i < spmv_events_used; i++) {
 		float ms = 0;
 		if (hipEventElapsedTime(&ms, spmv_events[i].first, spmv_events[i].second) == hipSuccess) {
-			stats.spmv_ms_total += ms;
-			stats.spmv_launches += 1;
+			if (spmv_event_cols.size() > i && spmv_event_cols[i] > 0) { // a blocked Gram-Schmidt bracket
+				stats.reortho_ms_total += ms;
+				stats.reortho_calls += 1;
+				stats.reortho_columns += spmv_event_cols[i];
+			} else {
+				stats.spmv_ms_total += ms;
+				stats.spmv_launches += 1;
+			}
 		}
 	}
 	spmv_events_used = 0;
@@ -96,7 +102,8 @@ struct SpmvTimer {
 	lpp_engine* e;
 	bool on;
 	size_t idx = 0;
-	explicit SpmvTimer(lpp_engine* e_) : e(e_), on(e_->cfg.time_kernels != 0)
+	// cols > 0: the bracket times a blocked Gram-Schmidt call against that many Krylov columns (lpp_stats.reortho_*)
+	explicit SpmvTimer(lpp_engine* e_, int cols = 0) : e(e_), on(e_->cfg.time_kernels != 0)
 	{
 		if (!on) return;
 		if (e->spmv_events_used == e->spmv_events.size()) {
@@ -108,6 +115,8 @@ struct SpmvTimer {
 			e->spmv_events.emplace_back(a, b);
 		}
 		idx = e->spmv_events_used++;
+		if (e->spmv_event_cols.size() <= idx) e->spmv_event_cols.resize(idx + 1, 0);
+		e->spmv_event_cols[idx] = cols;
 		(void)hipEventRecord(e->spmv_events[idx].first, e->stream);
 	}
 	void stop()
@@ -162,6 +171,7 @@ lpp_status one_step(lpp_engine* e, const double* ritz, int nst)
 	double* xcur = e->xcur;
 	int np = 0;
 	bool tx_pair = false;
+	SpmvTimer* pb_timer = nullptr;
 	// product-basis layout, no vectors kept: two launches per step, the axpy of step j rides in the product of step j+1
 	const bool pb_chain = e->pb.active && e->scalefree && !ritz && pb_chain_ok(e);
 	// the same deferral on the transposition exchange: the update rides in the next step's pack kernel (k_pack_transpose_axpy)
@@ -268,9 +278,15 @@ lpp_status one_step(lpp_engine* e, const double* ritz, int nst)
 		t.stop();
 		tx_pair = true; // pairs (Re<r_j|w_j>, |w_j|^2)
 	} else if (e->pb.active) {
-		SpmvTimer t(e);
-		np = pb_launch(e, ycur, xcur, e->partial, sc, e->scalefree); // scale-free: x is formed by pb_combine_axpy below
-		t.stop();
+		// scale-free: x is formed by pb_combine_axpy below, together with the recurrence update; the bracket then closes behind that
+		// pass (pb_timer), so that the timed launches are the WHOLE step as in the chained form
+		pb_timer = new SpmvTimer(e);
+		np = pb_launch(e, ycur, xcur, e->partial, sc, e->scalefree);
+		if (!e->scalefree || multi(e)) {
+			pb_timer->stop();
+			delete pb_timer;
+			pb_timer = nullptr;
+		}
 	} else if (e->kron.active) {
 		// matrix-free product with the all-gather: the down part needs the whole vector, so the gather completes first
 		if (multi(e)) {
@@ -324,6 +340,7 @@ lpp_status one_step(lpp_engine* e, const double* ritz, int nst)
 		k_axpy_nrm<false><<<nb, kBlock, 0, st>>>((double2*)xcur, (const double2*)ycur, a_ptr, b2_prev, nullptr, e->n2, nullptr, 0, e->nd);
 	} else if (pb_sf) {
 		nb_nrm = pb_combine_axpy(e, xcur, ycur, sc, a_ptr, b2_prev, e->partial);
+		if (pb_timer) pb_timer->stop();
 	} else if (e->scalefree) {
 		// streamed accesses once the two vectors no longer fit the 256 MiB Infinity Cache (measured: +4 % there, -7 % below)
 		const int stream_axpy = (size_t)e->n2 * 32 > ((size_t)256 << 20) ? 1 : 0;
@@ -332,11 +349,19 @@ lpp_status one_step(lpp_engine* e, const double* ritz, int nst)
 		                                       (multi(e) && !e->tx) ? (double2*)e->comm.send_buf : nullptr, e->n2, e->partial, stream_axpy, e->nd);
 	} else if (e->cfg.reortho) {
 		k_axpy_nrm<false><<<nb, kBlock, 0, st>>>((double2*)xcur, (const double2*)ycur, a_ptr, nullptr, nullptr, e->n2, nullptr);
-		rc = cgs2(e, j + 1);
+		{
+			SpmvTimer t(e, j + 1);
+			rc = cgs2(e, j + 1);
+			t.stop();
+		}
 		if (rc != LPP_OK) return rc;
 		k_dot<<<nb, kBlock, 0, st>>>((const double2*)xcur, (const double2*)xcur, e->n2, e->partial);
 	} else {
 		k_axpy_nrm<true><<<nb, kBlock, 0, st>>>((double2*)xcur, (const double2*)ycur, a_ptr, nullptr, nullptr, e->n2, e->partial);
+	}
+	if (pb_timer) {
+		delete pb_timer; // stopped above on every path that created it
+		pb_timer = nullptr;
 	}
 	if (!fused_ab) {
 		k_reduce_final<<<1, kBlock, 0, st>>>(e->partial, nb_nrm, 1, 1, b2_ptr);
@@ -450,6 +475,10 @@ lpp_status begin_run(lpp_engine* e, const void* init, bool want_save)
 		e->ycur = e->x;
 		e->xcur = e->y;
 		HIP_TRY(hipMemsetAsync(e->y, 0, sizeof(double) * (size_t)e->nd_pad, st));
+		if (e->pb.active && e->pb.dval && !e->pb.tx) { // plain-stream diagonal: <r_0 | D r_0> for step 0's a_j (the combine pass carries it from then on)
+			k_pb_dq<<<nb, kBlock, 0, st>>>((const double2*)e->x, (const double2*)e->pb.dval, e->n2, e->partial);
+			k_reduce_final<<<1, kBlock, 0, st>>>(e->partial, nb, 1, 1, e->pb.xy + 1);
+		}
 		if (multi(e) && !e->tx) HIP_TRY(hipMemcpyAsync(e->comm.send_buf, e->x, sizeof(double) * (size_t)e->nd, hipMemcpyDeviceToDevice, st));
 	} else {
 		e->ycur = e->saving ? e->V : e->y;

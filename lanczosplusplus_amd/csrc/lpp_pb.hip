@@ -18,7 +18,8 @@ void free_pb(lpp_engine* e)
 {
 	PbState& B = e->pb;
 	for (void* p : { (void*)B.tw, (void*)B.tw_off, (void*)B.tw_len, (void*)B.t_ptr, (void*)B.t_col, (void*)B.t_val, (void*)B.c_ptr, (void*)B.c_col,
-	                 (void*)B.c_code, (void*)B.order, (void*)B.pace, (void*)B.z, (void*)B.u, (void*)B.xy, (void*)B.dict, (void*)B.dcode, (void*)B.blockbase })
+	                 (void*)B.c_code, (void*)B.order, (void*)B.pace, (void*)B.z, (void*)B.u, (void*)B.xy, (void*)B.dict, (void*)B.dcode, (void*)B.blockbase,
+	                 (void*)B.fw, (void*)B.f_off, (void*)B.f_len, (void*)B.c_pstart, (void*)B.dval })
 		if (p) (void)hipFree(p);
 	if (B.stream2) {
 		(void)hipStreamSynchronize(B.stream2);
@@ -72,12 +73,33 @@ lpp_status pb_build(lpp_engine* e, int64_t n_up, int64_t n_blk, const int64_t* t
 		nblk_padded = n_blk;
 	}
 	if (blk0 < 0 || blk0 + nblk_loc > n_blk || (pitch_dn & 15) || nblk_padded < n_blk) return fail(LPP_ERR_INVALID, "pb_build: bad block range / coupling pitch");
-	if ((size_t)(pitch + kPbZeroSlots) * sizeof(double) > (size_t)156 * 1024) return fail(LPP_ERR_INVALID, "pb_build: the block does not fit the LDS window");
-	if ((size_t)nblk_padded * (size_t)pitch_dn * sizeof(double) >= ((size_t)1 << 32)) return fail(LPP_ERR_INVALID, "pb_build: vector beyond 32-bit byte offsets");
+	// Rows beyond one LDS window are cut into pieces (k_pb_up_big): two 512-thread workgroups of <= 80 KB per CU.  LPP_PB_PIECE_ROWS
+	// forces pieces of (at most) that many positions on any matrix (tests run the small cases of the suite through them).
+	int64_t wmax = 0;
+	if ((size_t)(pitch + kPbZeroSlots) * sizeof(double) > (size_t)156 * 1024) wmax = 8768;
+	if (const char* s = getenv("LPP_PB_PIECE_ROWS")) wmax = std::max<int64_t>(64, std::min<int64_t>(atoll(s), 16384)) & ~(int64_t)63;
+	int64_t W = 0;
+	if (wmax > 0) {
+		const int64_t np = (n_up + wmax - 1) / wmax;
+		W = (((n_up + np - 1) / np) + 63) & ~(int64_t)63;
+		if (n_up >= ((int64_t)1 << 24)) return fail(LPP_ERR_INVALID, "pb_build: more than 2^24 positions per block");
+	}
+	// Couplings: the panel of 16 positions of all blocks has to stay in one XCD's L2 (4 MiB) while it is gathered from.  Beyond
+	// ~1.6 MB the source blocks are walked in parts (k_pb_down_parts, which also forms 64-bit addresses: vectors beyond 4 GiB).
+	const size_t vec_bytes = (size_t)nblk_padded * (size_t)pitch_dn * sizeof(double);
+	// (the pacing of k_pb_down_parts keeps the workgroups of a group within two consecutive parts: two parts of <= 1.7 MB live)
+	// Measured at N_dn = 38760 (panel 4.96 MB, 3.0e9 states, scripts/experiments/r03_parts_ab.sh): whole panel 46.6 ms per product
+	// (the misses of an over-full L2 are Infinity-Cache hits), 2 parts 51.4, 3 parts 56.7, 4 parts 63.4, 6 parts 84.3 -- the part
+	// phases cost more (a wait per part, lists padded per part) than the L2 hits return.  So parts are kept for panels beyond
+	// 6 MB only; up to there the whole-panel kernel runs, with 64-bit addresses where the vector needs them (k_pb_down<WIDE>).
+	int nparts = (size_t)nblk_padded * 128 <= (size_t)6 << 20 ? 1 : 2;
+	if (const char* s = getenv("LPP_PB_PARTS")) nparts = std::max(1, std::min(atoi(s), kPbMaxParts));
+	const bool parts = nparts > 1 || getenv("LPP_PB_PARTS") != nullptr;
+	const bool wide = vec_bytes >= ((size_t)1 << 32) || getenv("LPP_PB_WIDE") != nullptr;
 	PbTemplate T;
 	int ways = 2;
 	if (const char* s = getenv("LPP_PB_BANK_WAYS")) ways = std::max(1, std::min(atoi(s), 4));
-	lpp_status rc = pb_pack_template(n_up, pitch, t_rp, t_ci, t_va, T, ways);
+	lpp_status rc = pb_pack_template(n_up, pitch, t_rp, t_ci, t_va, T, ways, W);
 	if (rc != LPP_OK) return rc;
 	B.n_up = n_up;
 	B.n_blk = n_blk;
@@ -95,6 +117,17 @@ lpp_status pb_build(lpp_engine* e, int64_t n_up, int64_t n_blk, const int64_t* t
 	if ((rc = to_device(&B.tw, T.words, st)) != LPP_OK) return rc;
 	if ((rc = to_device(&B.tw_off, T.off, st)) != LPP_OK) return rc;
 	if ((rc = to_device(&B.tw_len, T.len, st)) != LPP_OK) return rc;
+	B.big = W > 0;
+	B.W = (int)W;
+	B.npieces = W > 0 ? (int)((n_up + W - 1) / W) : 1;
+	if (B.big) {
+		B.f_words = (int64_t)T.fwords.size();
+		B.f_entries = T.far_entries;
+		if ((rc = to_device(&B.fw, T.fwords, st)) != LPP_OK) return rc;
+		if ((rc = to_device(&B.f_off, T.foff, st)) != LPP_OK) return rc;
+		if ((rc = to_device(&B.f_len, T.flen, st)) != LPP_OK) return rc;
+		if (pb_big_lds_bytes(B.W) > (size_t)160 * 1024 - 64) return fail(LPP_ERR_INVALID, "pb_build: piece exceeds LDS");
+	}
 	// plain off-diagonal copies of T and C (lpp_engine_get_csr walks them; k_pb_down stages C in LDS)
 	std::vector<int64_t> tp((size_t)n_up + 1, 0), cp((size_t)n_blk + 1, 0);
 	std::vector<int32_t> tc, cc;
@@ -150,19 +183,71 @@ lpp_status pb_build(lpp_engine* e, int64_t n_up, int64_t n_blk, const int64_t* t
 	B.down_grid = grid;
 	B.down_lds = (size_t)B.ids_per_wg * ((size_t)(B.rowcap + 1) * 3 + 8) + 16;
 	if (n_blk > 65535) return fail(LPP_ERR_INVALID, "pb_build: more than 65535 blocks");
+	B.parts = parts;
+	B.wide = wide;
+	if (parts) {
+		// per block and part: where the part's entries start in the (ascending) list; per part: the longest list, in whole chunks of 4
+		B.nparts = nparts;
+		B.part_blocks = (n_blk + nparts - 1) / nparts;
+		std::vector<int32_t> pstart((size_t)n_blk * (size_t)(nparts + 1), 0);
+		for (int64_t b = 0; b < n_blk; b++) {
+			int32_t* ps = pstart.data() + (size_t)b * (size_t)(nparts + 1);
+			const int64_t len = cp[(size_t)b + 1] - cp[(size_t)b];
+			if (len > 1020) return fail(LPP_ERR_INVALID, "pb_build: coupling list too long");
+			int h = 0;
+			for (int64_t k = 0; k < len; k++) {
+				const int hk = (int)std::min<int64_t>(cc[(size_t)(cp[(size_t)b] + k)] / B.part_blocks, nparts - 1);
+				while (h < hk) ps[++h] = (int32_t)k;
+			}
+			while (h < nparts) ps[++h] = (int32_t)len;
+		}
+		if ((rc = to_device(&B.c_pstart, pstart, st)) != LPP_OK) return rc;
+		// list entries per workgroup (contiguous ranges of ids_per_wg blocks): the largest sizes the LDS image
+		int64_t ent_cap = 0;
+		for (int64_t lo = 0; lo < n_blk; lo += B.ids_per_wg) ent_cap = std::max(ent_cap, cp[(size_t)std::min<int64_t>(lo + B.ids_per_wg, n_blk)] - cp[(size_t)lo]);
+		if (ent_cap > 65000) return fail(LPP_ERR_INVALID, "pb_build: block couplings of a workgroup exceed the 16-bit places of the LDS image");
+		B.ent_cap = (int)ent_cap;
+		B.down_lds = pb_parts_lds_bytes(B.ids_per_wg, B.ent_cap, nparts);
+		constexpr int nw = kPbPartsThreads / 64;
+		const int rounds = (((B.ids_per_wg + 7) / 8) + nw - 1) / nw; // tasks of 8 blocks over the waves of a workgroup
+		B.maxr = (rounds + 3) / 4 * 4;
+		if (rounds > 24) return fail(LPP_ERR_INVALID, "pb_build: too many blocks per workgroup for the register accumulators");
+		const int64_t npanels = std::max(pitch, pitch_dn) / 16;
+		B.pace_stride = (int)(((npanels + 7) / 8 + 1) * nparts);
+		if (grid < 8) B.pace_stride = (int)((npanels + 1) * nparts);
+	}
 	if (B.down_lds > (size_t)150 * 1024) return fail(LPP_ERR_INVALID, "pb_build: block couplings of a workgroup exceed LDS");
-	if (pb_up_lds_bytes(pitch, T.spb, T.G) > (size_t)160 * 1024 - 64) return fail(LPP_ERR_INVALID, "pb_build: window + template metadata exceed LDS");
+	if (!B.big && pb_up_lds_bytes(pitch, T.spb, T.G) > (size_t)160 * 1024 - 64) return fail(LPP_ERR_INVALID, "pb_build: window + template metadata exceed LDS");
+	if ((size_t)nblk_padded * (size_t)(pitch_dn >> 4) >= ((size_t)1 << 32)) return fail(LPP_ERR_INVALID, "pb_build: vector beyond 32-bit line numbers");
 	{
 		// every workgroup takes its blocks in the order of decreasing list length (tasks of 8 blocks with equal trip counts)
 		std::vector<int32_t> order((size_t)n_blk);
 		for (int64_t b = 0; b < n_blk; b++) order[(size_t)b] = (int32_t)b;
 		for (int sl = 0; sl < slots; sl++) {
 			const int64_t lo = std::min<int64_t>((int64_t)sl * B.ids_per_wg, n_blk), hi = std::min<int64_t>(lo + B.ids_per_wg, n_blk);
+			if (parts) {
+				// tasks of 8 consecutive blocks run as long as their longest list IN EVERY PART: blocks with the same profile of
+				// part lengths belong together (measured on N_dn = 38760 in 3 parts: 1.11 instead of 1.19 gathers issued per entry)
+				const int64_t pbk = (n_blk + nparts - 1) / nparts;
+				auto profile = [&](int32_t b, int* out) {
+					for (int q = 0; q < nparts; q++) out[q] = 0;
+					for (int64_t p = cp[(size_t)b]; p < cp[(size_t)b + 1]; p++) out[std::min<int64_t>(cc[(size_t)p] / pbk, nparts - 1)]++;
+				};
+				std::stable_sort(order.begin() + lo, order.begin() + hi, [&](int32_t x, int32_t y) {
+					int px[kPbMaxParts], py[kPbMaxParts];
+					profile(x, px);
+					profile(y, py);
+					for (int q = 0; q < nparts; q++)
+						if (px[q] != py[q]) return px[q] > py[q];
+					return false;
+				});
+			} else
 			std::stable_sort(order.begin() + lo, order.begin() + hi, [&](int32_t x, int32_t y) { return cp[(size_t)x + 1] - cp[(size_t)x] > cp[(size_t)y + 1] - cp[(size_t)y]; });
 		}
 		if ((rc = to_device(&B.order, order, st)) != LPP_OK) return rc;
 	}
-	if (!(getenv("LPP_PB_PACE") && atoi(getenv("LPP_PB_PACE")) == 0)) HIP_TRY_MEM(hipMalloc(&B.pace, sizeof(int) * 8 * (size_t)(std::max(pitch, pitch_dn) / 16)));
+	if (!(getenv("LPP_PB_PACE") && atoi(getenv("LPP_PB_PACE")) == 0))
+		HIP_TRY_MEM(hipMalloc(&B.pace, sizeof(int) * 8 * (parts ? (size_t)B.pace_stride : (size_t)(std::max(pitch, pitch_dn) / 16))));
 	// the two parts of a product (padding stays zero) and the carried scalar; with the transposition exchange the couplings'
 	// part is written straight into the exchange buffer
 	const size_t loc = (size_t)std::max<int64_t>(nblk_loc, 1) * (size_t)pitch;
@@ -211,6 +296,103 @@ template <bool DOT, bool LEAN> static void launch_up(const PbState& B, const PbU
 #undef LPP_PB_UP
 }
 
+
+// ---- rows beyond one LDS window / vectors beyond 4 GiB (lpp_pbig_kernels.h) -------------------------------------------
+static int big_grid(const lpp_engine* e, int64_t cnt)
+{
+	const PbState& B = e->pb;
+	const size_t lds = pb_big_lds_bytes(B.W);
+	const int per_cu = std::max(1, std::min(2, (int)(((size_t)160 * 1024) / (lds + 512))));
+	int nb = (int)std::max<int64_t>(1, std::min<int64_t>(cnt * B.npieces, (int64_t)e->num_cus * per_cu));
+	if (nb >= 8) nb &= ~7;
+	return nb;
+}
+
+// in-block part by pieces: `cnt` blocks from `y` (pitched), result to `u`; returns the number of partials written
+static int launch_up_big(lpp_engine* e, const double* y, double* u, const uint8_t* dcode, int64_t cnt, double* partial, const EpiScale& sc, hipStream_t st)
+{
+	const PbState& B = e->pb;
+	PbUpBigArgs a;
+	a.tw = B.tw;
+	a.tw_off = B.tw_off;
+	a.tw_len = B.tw_len;
+	a.fw = B.fw;
+	a.f_off = B.f_off;
+	a.f_len = B.f_len;
+	a.G = B.G;
+	for (int g = 0; g <= kPbMaxGroups; g++) a.gval[g] = g < B.G ? B.gval[g] : 0.0;
+	a.dict = B.dict;
+	a.dcode = dcode;
+	a.n_up = B.n_up;
+	a.pitch = B.pitch;
+	a.n_blk = cnt;
+	a.W = B.W;
+	a.npieces = B.npieces;
+	a.y = y;
+	a.u = u;
+	a.partial = partial;
+	a.sc = sc;
+	const size_t lds = pb_big_lds_bytes(B.W);
+	const int nb = big_grid(e, cnt);
+	int gt = B.G <= 2 ? B.G : 0;
+	if (getenv("LPP_PB_UP_GENERIC")) gt = 0;
+#define LPP_PB_BIG(DOT_, GT_)                                                                                          \
+	do {                                                                                                              \
+		(void)hipFuncSetAttribute((const void*)k_pb_up_big<DOT_, GT_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+		k_pb_up_big<DOT_, GT_><<<nb, kPbBigThreads, lds, st>>>(a);                                                      \
+	} while (0)
+	if (partial) {
+		if (gt == 1) LPP_PB_BIG(true, 1);
+		else if (gt == 2) LPP_PB_BIG(true, 2);
+		else LPP_PB_BIG(true, 0);
+	} else {
+		if (gt == 1) LPP_PB_BIG(false, 1);
+		else if (gt == 2) LPP_PB_BIG(false, 2);
+		else LPP_PB_BIG(false, 0);
+	}
+#undef LPP_PB_BIG
+	return partial ? nb : 0;
+}
+
+// block couplings over parts of the source range: z = alpha C y on rows of `pitch` positions; returns the number of partials written
+static int launch_down_parts(lpp_engine* e, const double* y, double* z, int64_t pitch, double* partial, const EpiScale& sc, hipStream_t st)
+{
+	const PbState& B = e->pb;
+	PbDownPartsArgs d;
+	d.pitch = pitch;
+	d.n_blk = B.n_blk;
+	d.npanels = (int)(pitch / 16);
+	d.ids_per_wg = B.ids_per_wg;
+	d.nparts = B.nparts;
+	d.ent_cap = B.ent_cap;
+	d.c_ptr = B.c_ptr;
+	d.c_col = B.c_col;
+	d.c_code = B.c_code;
+	d.c_pstart = B.c_pstart;
+	d.order = B.order;
+	d.dict = B.dict;
+	d.y = y;
+	d.z = z;
+	d.partial = partial;
+	d.sc = sc;
+	d.pace = B.pace;
+	d.pace_stride = B.pace_stride;
+	if (d.pace) (void)hipMemsetAsync(d.pace, 0, sizeof(int) * 8 * (size_t)B.pace_stride, st);
+#define LPP_PB_PARTS(R_)                                                                                               \
+	do {                                                                                                              \
+		(void)hipFuncSetAttribute((const void*)k_pb_down_parts<kPbPartsThreads, R_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B.down_lds); \
+		k_pb_down_parts<kPbPartsThreads, R_><<<B.down_grid, kPbPartsThreads, B.down_lds, st>>>(d);                      \
+	} while (0)
+	if (B.maxr <= 4) LPP_PB_PARTS(4);
+	else if (B.maxr <= 8) LPP_PB_PARTS(8);
+	else if (B.maxr <= 12) LPP_PB_PARTS(12);
+	else if (B.maxr <= 16) LPP_PB_PARTS(16);
+	else if (B.maxr <= 20) LPP_PB_PARTS(20);
+	else LPP_PB_PARTS(24);
+#undef LPP_PB_PARTS
+	return partial ? B.down_grid : 0;
+}
+
 // 8192 blocks x 4 elements in flight: 5.2 TB/s for the 4-read 1-write mix (4.7 with 2048 x 2), scripts/experiments/calib_combine.hip
 static int combine_blocks(int64_t n2) { return (int)std::max<int64_t>(1, std::min<int64_t>((n2 + 4 * kBlock - 1) / (4 * kBlock), 8192)); }
 
@@ -218,7 +400,7 @@ int pb_launch(lpp_engine* e, const void* y, void* x, double* partial, const EpiS
 {
 	PbState& B = e->pb;
 	hipStream_t st = e->stream;
-	const int nb = (int)std::max<int64_t>(1, std::min<int64_t>(B.n_blk, (int64_t)e->num_cus));
+	const int nb = B.big ? big_grid(e, B.n_blk) : (int)std::max<int64_t>(1, std::min<int64_t>(B.n_blk, (int64_t)e->num_cus));
 	double* const want_dot = partial;
 	if (!defer_combine) partial = nullptr; // the combine pass below forms Re<y|x> of the finished x itself
 	int np = partial ? nb : 0;
@@ -236,7 +418,10 @@ int pb_launch(lpp_engine* e, const void* y, void* x, double* partial, const EpiS
 		else
 			concurrent = false;
 	}
-	if (both) {
+	if (both && B.parts) {
+		const int n = launch_down_parts(e, (const double*)y, B.z, B.pitch, partial ? partial + nb : nullptr, sc, sd);
+		if (partial) np += n;
+	} else if (both) {
 		PbDownArgs d;
 		d.pitch = B.pitch;
 		d.n_blk = B.n_blk;
@@ -261,12 +446,18 @@ int pb_launch(lpp_engine* e, const void* y, void* x, double* partial, const EpiS
 		if (threads == 512) {
 			(void)hipFuncSetAttribute((const void*)k_pb_down<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B.down_lds);
 			k_pb_down<512><<<B.down_grid, 512, B.down_lds, sd>>>(d);
+		} else if (B.wide) {
+			(void)hipFuncSetAttribute((const void*)k_pb_down<1024, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B.down_lds);
+			k_pb_down<1024, false, true><<<B.down_grid, 1024, B.down_lds, sd>>>(d);
 		} else {
 			(void)hipFuncSetAttribute((const void*)k_pb_down<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B.down_lds);
 			k_pb_down<1024><<<B.down_grid, 1024, B.down_lds, sd>>>(d);
 		}
 		if (partial) np += B.down_grid;
 	}
+	if (B.big) {
+		launch_up_big(e, (const double*)y, B.u, B.dcode, B.n_blk, partial, sc, st); // nb partials, in front of the couplings'
+	} else {
 	PbUpArgs u;
 	u.tw = B.tw;
 	u.tw_off = B.tw_off;
@@ -295,6 +486,7 @@ int pb_launch(lpp_engine* e, const void* y, void* x, double* partial, const EpiS
 		if (lean) launch_up<false, true>(B, u, nb, lds, st);
 		else launch_up<false, false>(B, u, nb, lds, st);
 	}
+	}
 	if (concurrent) { // join: everything later on the engine's stream sees z
 		(void)hipEventRecord(B.ev_join, B.stream2);
 		(void)hipStreamWaitEvent(st, B.ev_join, 0);
@@ -309,6 +501,8 @@ int pb_launch(lpp_engine* e, const void* y, void* x, double* partial, const EpiS
 		c.sc = sc;
 		c.a_ptr = nullptr;
 		c.b2_prev = nullptr;
+		c.d = (const double2*)B.dval;
+		c.partial_dq = nullptr;
 		const int nbc = combine_blocks(c.n2);
 		c.partial_nrm = want_dot ? want_dot + nbc : nullptr; // |x|^2 partials: not used by these callers
 		c.partial_xy = want_dot;
@@ -343,6 +537,10 @@ void pb_tx_up(lpp_engine* e, const void* y, const EpiScale& sc, int64_t b0, int6
 {
 	PbState& B = e->pb;
 	if (cnt <= 0) return;
+	if (B.big) {
+		launch_up_big(e, (const double*)y + b0 * B.pitch, B.u + b0 * B.pitch, B.dcode + b0 * B.pitch, cnt, nullptr, sc, e->stream);
+		return;
+	}
 	PbUpArgs u;
 	fill_up_args(B, u);
 	u.dcode = B.dcode + b0 * B.pitch;
@@ -357,6 +555,10 @@ void pb_tx_up(lpp_engine* e, const void* y, const EpiScale& sc, int64_t b0, int6
 void pb_tx_down(lpp_engine* e, const void* gath, void* send2, const EpiScale& sc)
 {
 	PbState& B = e->pb;
+	if (B.parts) {
+		launch_down_parts(e, (const double*)gath, (double*)send2, B.pitch_dn, nullptr, sc, e->stream);
+		return;
+	}
 	PbDownArgs d;
 	d.pitch = B.pitch_dn;
 	d.n_blk = B.n_blk;
@@ -376,6 +578,11 @@ void pb_tx_down(lpp_engine* e, const void* gath, void* send2, const EpiScale& sc
 	d.pace = B.pace;
 	d.order = B.order;
 	if (d.pace) (void)hipMemsetAsync(d.pace, 0, sizeof(int) * 8 * (size_t)d.npanels, e->stream);
+	if (B.wide) {
+		(void)hipFuncSetAttribute((const void*)k_pb_down<1024, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B.down_lds);
+		k_pb_down<1024, false, true><<<B.down_grid, 1024, B.down_lds, e->stream>>>(d);
+		return;
+	}
 	(void)hipFuncSetAttribute((const void*)k_pb_down<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B.down_lds);
 	k_pb_down<1024><<<B.down_grid, 1024, B.down_lds, e->stream>>>(d);
 }
@@ -386,7 +593,7 @@ int pb_tx_unpack_combine(lpp_engine* e, void* x, const void* y, const void* recv
 	const int64_t n2 = (B.nblk_loc * B.pitch) >> 1;
 	const int nb = combine_blocks(n2);
 	k_pb_unpack_combine<<<nb, kBlock, 0, e->stream>>>((double2*)x, (const double2*)y, (const double2*)B.u, (const double2*)recv2, B.nblk_loc, B.pitch >> 1,
-	                                                  B.pitch_dn >> 1, chunk >> 1, sc, partial, shift);
+	                                                  B.pitch_dn >> 1, chunk >> 1, sc, partial, shift, (const double2*)B.dval);
 	return nb;
 }
 
@@ -395,7 +602,7 @@ bool pb_chain_ok(const lpp_engine* e)
 {
 	const PbState& B = e->pb;
 	if (getenv("LPP_PB_CHAIN") && atoi(getenv("LPP_PB_CHAIN")) == 0) return false;
-	return B.active && !B.tx && B.c_nnz > 0 && (B.G == 1 || B.G == 2);
+	return B.active && !B.tx && !B.big && !B.parts && !B.wide && !B.dval && B.c_nnz > 0 && (B.G == 1 || B.G == 2);
 }
 
 template <int GT> static void launch_up_chain(const PbUpArgs& u, int nb, size_t lds, hipStream_t st)
@@ -483,8 +690,11 @@ int pb_combine_axpy(lpp_engine* e, void* x, const void* y, const EpiScale& sc, c
 	const int nb = combine_blocks(c.n2);
 	c.partial_nrm = partial;
 	c.partial_xy = partial + nb;
+	c.d = (const double2*)B.dval;
+	c.partial_dq = B.dval ? partial + 2 * nb : nullptr;
 	k_pb_combine<<<nb, kBlock, 0, e->stream>>>(c);
 	k_reduce_final<<<1, kBlock, 0, e->stream>>>(partial + nb, nb, 1, 1, B.xy); // next step's <y | x_old>
+	if (B.dval) k_reduce_final<<<1, kBlock, 0, e->stream>>>(partial + 2 * nb, nb, 1, 1, B.xy + 1); // and its <y | D y>
 	return nb;
 }
 
@@ -505,7 +715,7 @@ lpp_status pb_get_csr(lpp_engine* e, int64_t* rowptr, int32_t* colind, void* val
 		HIP_TRY_MEM(hipMalloc(&dva.p, sizeof(double) * (size_t)std::max<int64_t>(B.nnz, 1)));
 	}
 	k_pb_rebuild<<<(int)((n + 255) / 256), 256, 0, e->stream>>>(B.n_up, B.n_blk, B.pitch, B.t_ptr, B.t_col, B.t_val, B.c_ptr, B.c_col, B.c_code, B.blockbase,
-	                                                           B.dcode, B.dict, (int64_t*)drp.p, (int32_t*)dci.p, (double*)dva.p);
+	                                                           B.dcode, B.dict, (int64_t*)drp.p, (int32_t*)dci.p, (double*)dva.p, B.dval);
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipStreamSynchronize(e->stream));
 	if (rowptr) HIP_TRY(hipMemcpy(rowptr, drp.p, sizeof(int64_t) * (size_t)(n + 1), hipMemcpyDeviceToHost));

@@ -341,7 +341,9 @@ struct PbDownArgs {
 // The two HBM loads per task this needs are only USED behind the gather loop.  Where they are issued (in front of the gathers,
 // behind the first or the second chunk: LPP_PB_RMW_POS) moved the kernel by less than 4 % (1.86 / 1.94 / 1.93 ms at BASELINE
 // config 2): it is bound by what goes through L1 -- 17 gathered lines + 3 streamed ones per line written -- not by the order.
-template <int THREADS, bool RMW = false> __global__ __launch_bounds__(THREADS) void k_pb_down(PbDownArgs a)
+// WIDE: vectors beyond 4 GiB (BASELINE config 5's sectors).  The LDS image then holds 128-byte LINE numbers instead of byte
+// offsets and every address is formed in 64 bits: (line of the source block's row + panel) << 7.
+template <int THREADS, bool RMW = false, bool WIDE = false> __global__ __launch_bounds__(THREADS) void k_pb_down(PbDownArgs a)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
 	__shared__ double dict_s[256];
@@ -365,7 +367,7 @@ template <int THREADS, bool RMW = false> __global__ __launch_bounds__(THREADS) v
 	const int nslots = (int)(gridDim.x / nx);
 	const int64_t b0 = (int64_t)slot * a.ids_per_wg;
 	const int nown = (int)max((int64_t)0, min((int64_t)a.ids_per_wg, a.n_blk - b0));
-	const uint32_t rowbytes = (uint32_t)(a.pitch * 8);
+	const uint32_t rowbytes = WIDE ? (uint32_t)(a.pitch >> 4) : (uint32_t)(a.pitch * 8); // WIDE: lines per row
 	for (int il = threadIdx.x; il < nown; il += THREADS) {
 		const int64_t b = a.order[b0 + il];
 		row_s[il] = (uint32_t)b * rowbytes;
@@ -397,7 +399,9 @@ template <int THREADS, bool RMW = false> __global__ __launch_bounds__(THREADS) v
 			}
 			__syncthreads();
 		}
-		const uint32_t colb = (uint32_t)(p * 128 + c * 16); // byte offset of this lane's two positions inside a row
+		const uint32_t colb = WIDE ? (uint32_t)(c * 16) : (uint32_t)(p * 128 + c * 16); // byte offset of this lane's two positions inside a row (WIDE: inside the panel line)
+		// byte offset of (row `r` as stored in the LDS image, this lane's two positions of panel p)
+		auto at = [=](uint32_t r) __attribute__((always_inline)) -> size_t { return WIDE ? (((size_t)(r + (uint32_t)p) << 7) + colb) : (size_t)(r + colb); };
 		for (int g = wave; g < ngroups; g += THREADS / 64) {
 			const int il = min(g * 8 + sub, nown - 1);
 			const bool valid = g * 8 + sub < nown;
@@ -411,7 +415,7 @@ template <int THREADS, bool RMW = false> __global__ __launch_bounds__(THREADS) v
 			double2 ga[4], gb[4], gc[4];
 			auto issue = [&](int ch, double2* gbuf) __attribute__((always_inline)) {
 #pragma unroll
-				for (int q = 0; q < 4; q++) gbuf[q] = *(const double2*)(ysrc + (size_t)((uint32_t)orow[ch * 4 + q] * rowbytes + colb));
+				for (int q = 0; q < 4; q++) gbuf[q] = *(const double2*)(ysrc + at((uint32_t)orow[ch * 4 + q] * rowbytes));
 			};
 			auto consume = [&](int ch, const double2* gbuf) __attribute__((always_inline)) {
 #pragma unroll
@@ -424,12 +428,12 @@ template <int THREADS, bool RMW = false> __global__ __launch_bounds__(THREADS) v
 #ifndef LPP_PB_RMW_POS
 #define LPP_PB_RMW_POS 0
 #endif
-			double2* const zp = (double2*)((char*)a.z + (size_t)row_s[il] + colb);
+			double2* const zp = (double2*)((char*)a.z + at(row_s[il]));
 			double2 uo = double2 { 0.0, 0.0 }, xo = double2 { 0.0, 0.0 };
 			if (LPP_PB_RMW_POS >= 1 && n4 > 0) issue(0, ga);
 			if (LPP_PB_RMW_POS >= 2 && n4 > 1) issue(1, gb);
 			if (RMW) { // used only behind the gather loop: no wait here
-				uo = nt_load2((const double2*)((const char*)a.u_in + (size_t)row_s[il] + colb));
+				uo = nt_load2((const double2*)((const char*)a.u_in + at(row_s[il])));
 				xo = nt_load2(zp);
 			}
 			if (LPP_PB_RMW_POS < 1 && n4 > 0) issue(0, ga);
@@ -446,7 +450,7 @@ template <int THREADS, bool RMW = false> __global__ __launch_bounds__(THREADS) v
 					consume(ch + 2, gc);
 				}
 			}
-			const double2 yown = *(const double2*)(ysrc + (size_t)(row_s[il] + colb)); // the panel is in L2
+			const double2 yown = *(const double2*)(ysrc + at(row_s[il])); // the panel is in L2
 			if (valid) {
 				acc.x = fma(alpha, acc.x, fma(beta, xo.x, uo.x));
 				acc.y = fma(alpha, acc.y, fma(beta, xo.y, uo.y));
@@ -504,6 +508,11 @@ static __global__ __launch_bounds__(kBlock) void k_pb_materialise(double2* __res
 struct PbCombineArgs {
 	double2* x;
 	const double2 *y, *u, *z;
+	// the diagonal as a plain f64 stream (more than 256 distinct values: site-dependent U / potentials): the in-block kernel then
+	// adds nothing for it (all codes 0 = +0.0) and this pass adds alpha D y; partial_dq receives the partials of sum D x_new^2,
+	// the <y | D y> of the NEXT step's a_j (the product kernels' partials no longer hold it).  null: the diagonal travels as codes
+	const double2* d;
+	double* partial_dq;
 	int64_t n2;
 	EpiScale sc; // beta
 	const double* a_ptr; // null: g = 0
@@ -515,8 +524,9 @@ struct PbCombineArgs {
 static __global__ __launch_bounds__(kBlock) void k_pb_combine(PbCombineArgs a)
 {
 	__shared__ double smem[kBlock / 64];
-	double alpha_unused, beta;
-	epi_coeffs(a.sc, alpha_unused, beta);
+	double alpha, beta;
+	epi_coeffs(a.sc, alpha, beta);
+	const bool hasd = a.d != nullptr;
 	double g = 0.0;
 	if (a.a_ptr) {
 		g = *a.a_ptr;
@@ -525,7 +535,7 @@ static __global__ __launch_bounds__(kBlock) void k_pb_combine(PbCombineArgs a)
 			if (sqrt(b2) >= 1e-10) g /= b2;
 		}
 	}
-	double s = 0.0, c = 0.0;
+	double s = 0.0, c = 0.0, q = 0.0;
 	const int64_t stride = (int64_t)gridDim.x * kBlock;
 	int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
 	constexpr int U = 4; // elements per lane and stream in flight (16 x 16-byte loads); measured with scripts/experiments/calib_combine.hip
@@ -539,11 +549,21 @@ static __global__ __launch_bounds__(kBlock) void k_pb_combine(PbCombineArgs a)
 		for (int k = 0; k < U; k++) uv[k] = nt_load2(&a.u[i + k * stride]);
 #pragma unroll
 		for (int k = 0; k < U; k++) zv[k] = nt_load2(&a.z[i + k * stride]);
+		double2 dv[U];
+		if (hasd) {
+#pragma unroll
+			for (int k = 0; k < U; k++) dv[k] = nt_load2(&a.d[i + k * stride]);
+		}
 #pragma unroll
 		for (int k = 0; k < U; k++) {
 			double2 r;
 			r.x = beta * xv[k].x + uv[k].x + zv[k].x - g * yv[k].x;
 			r.y = beta * xv[k].y + uv[k].y + zv[k].y - g * yv[k].y;
+			if (hasd) {
+				r.x = fma(alpha * dv[k].x, yv[k].x, r.x);
+				r.y = fma(alpha * dv[k].y, yv[k].y, r.y);
+				q += dv[k].x * r.x * r.x + dv[k].y * r.y * r.y;
+			}
 			nt_store2(r, &a.x[i + k * stride]);
 			s += r.x * r.x + r.y * r.y;
 			c += r.x * yv[k].x + r.y * yv[k].y;
@@ -554,6 +574,12 @@ static __global__ __launch_bounds__(kBlock) void k_pb_combine(PbCombineArgs a)
 		double2 r;
 		r.x = beta * xv.x + uv.x + zv.x - g * yv.x;
 		r.y = beta * xv.y + uv.y + zv.y - g * yv.y;
+		if (hasd) {
+			const double2 dv = a.d[i];
+			r.x = fma(alpha * dv.x, yv.x, r.x);
+			r.y = fma(alpha * dv.y, yv.y, r.y);
+			q += dv.x * r.x * r.x + dv.y * r.y * r.y;
+		}
 		a.x[i] = r;
 		s += r.x * r.x + r.y * r.y;
 		c += r.x * yv.x + r.y * yv.y;
@@ -564,6 +590,10 @@ static __global__ __launch_bounds__(kBlock) void k_pb_combine(PbCombineArgs a)
 		const double rc = block_sum(c, smem);
 		if (threadIdx.x == 0) a.partial_xy[blockIdx.x] = rc;
 	}
+	if (a.partial_dq) {
+		const double rq = block_sum(q, smem);
+		if (threadIdx.x == 0) a.partial_dq[blockIdx.x] = rq;
+	}
 }
 
 // Several GPUs, transposition exchange: the streaming pass behind the second all-to-all.  recv holds, for every rank p, the block
@@ -573,11 +603,12 @@ static __global__ __launch_bounds__(kBlock) void k_pb_combine(PbCombineArgs a)
 // beyond N_up hold zeros on both sides).
 static __global__ __launch_bounds__(kBlock) void k_pb_unpack_combine(double2* __restrict__ x, const double2* __restrict__ y, const double2* __restrict__ u,
                                                                      const double2* __restrict__ recv, int64_t nblk, int64_t pitch2, int64_t peru2, int64_t chunk2,
-                                                                     EpiScale sc, double* __restrict__ partial, const double* __restrict__ shift)
+                                                                     EpiScale sc, double* __restrict__ partial, const double* __restrict__ shift,
+                                                                     const double2* __restrict__ dplain = nullptr)
 {
 	__shared__ double smem[kBlock / 64];
-	double alpha_unused, beta;
-	epi_coeffs(sc, alpha_unused, beta);
+	double alpha, beta;
+	epi_coeffs(sc, alpha, beta);
 	const double sh = shift ? *shift : 0.0;
 	const int64_t n2 = nblk * pitch2;
 	double dot = 0.0, nrm = 0.0;
@@ -589,6 +620,11 @@ static __global__ __launch_bounds__(kBlock) void k_pb_unpack_combine(double2* __
 		double2 r;
 		r.x = beta * xv.x + uv.x + zv.x;
 		r.y = beta * xv.y + uv.y + zv.y;
+		if (dplain) { // the diagonal as a plain stream (see PbCombineArgs::d)
+			const double2 dv = dplain[i];
+			r.x = fma(alpha * dv.x, yv.x, r.x);
+			r.y = fma(alpha * dv.y, yv.y, r.y);
+		}
 		x[i] = r;
 		dot += yv.x * r.x + yv.y * r.y;
 		const double dx = r.x - sh * yv.x, dy = r.y - sh * yv.y;
@@ -600,18 +636,31 @@ static __global__ __launch_bounds__(kBlock) void k_pb_unpack_combine(double2* __
 	if (threadIdx.x == 0) partial[2 * blockIdx.x + 1] = rn;
 }
 
+// <y | D y> of a plain-stream diagonal for the vector a run starts from (afterwards the combine pass carries it along)
+static __global__ __launch_bounds__(kBlock) void k_pb_dq(const double2* __restrict__ y, const double2* __restrict__ d, int64_t n2, double* __restrict__ partial)
+{
+	__shared__ double smem[kBlock / 64];
+	double q = 0.0;
+	for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n2; i += (int64_t)gridDim.x * kBlock) {
+		const double2 yv = y[i], dv = d[i];
+		q += dv.x * yv.x * yv.x + dv.y * yv.y * yv.y;
+	}
+	const double r = block_sum(q, smem);
+	if (threadIdx.x == 0) partial[blockIdx.x] = r;
+}
+
 // a_j of the scale-free recurrence from the two product kernels' partials and the carried <y | x_old>:
 //   out = sum_p partial[p] + beta * (*xy)        (single block, fixed summation order)
 static __global__ __launch_bounds__(kBlock) void k_pb_reduce_a(const double* __restrict__ partial, int np, const double* __restrict__ xy, EpiScale sc,
                                                                double* __restrict__ out)
 {
 	__shared__ double smem[kBlock / 64];
-	double alpha_unused, beta;
-	epi_coeffs(sc, alpha_unused, beta);
+	double alpha, beta;
+	epi_coeffs(sc, alpha, beta);
 	double s = 0.0;
 	for (int p = threadIdx.x; p < np; p += kBlock) s += partial[p];
 	const double r = block_sum(s, smem);
-	if (threadIdx.x == 0) out[0] = r + beta * xy[0];
+	if (threadIdx.x == 0) out[0] = r + beta * xy[0] + alpha * xy[1]; // xy[1]: <y | D y> of a plain-stream diagonal (0 otherwise)
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -625,7 +674,7 @@ static __global__ void k_pb_rebuild(int64_t n_up, int64_t n_blk, int64_t pitch, 
                                     const double* __restrict__ t_val, const int64_t* __restrict__ c_ptr, const int32_t* __restrict__ c_col,
                                     const uint8_t* __restrict__ c_code, const int64_t* __restrict__ blockbase, const uint8_t* __restrict__ dcode,
                                     const double* __restrict__ dict, int64_t* __restrict__ rowptr_out, int32_t* __restrict__ col_out,
-                                    double* __restrict__ val_out)
+                                    double* __restrict__ val_out, const double* __restrict__ dplain = nullptr)
 {
 	const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	const int64_t n = n_up * n_blk;
@@ -648,7 +697,7 @@ static __global__ void k_pb_rebuild(int64_t n_up, int64_t n_blk, int64_t pitch, 
 		val_out[o] = t_val[q];
 	}
 	col_out[o] = (int32_t)r;
-	val_out[o] = dict[dcode[b * pitch + i]];
+	val_out[o] = dplain ? dplain[b * pitch + i] : dict[dcode[b * pitch + i]];
 	o++;
 	for (; q < q1; q++, o++) {
 		col_out[o] = (int32_t)(b * n_up + t_col[q]);

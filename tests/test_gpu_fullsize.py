@@ -111,5 +111,35 @@ def test_config5_lattice_sector_matrix_free_free_fermions():
     with LanczosEngine(max_steps=300, eps=1e-11, save_vectors=0) as e:
         e.setup_hubbard_onthefly(L, 6, 6, hop, np.zeros(L))
         assert e.rows() == 38760 * 38760 == 1502337600
+        lay = e.layout()  # rows of 38760 positions in pieces, couplings over parts of the 38760 blocks (lpp_pbig_kernels.h)
+        assert lay["kernel"] == 4 and lay["pieces"] > 1
         eg, _, st = e.lanczos(1, want_vectors=False)
     assert abs(eg[0] - exact) <= 1e-10 * abs(exact), (eg[0], exact, st["steps"])
+
+
+def test_config5_lattice_products_agree_beyond_the_lds_window(monkeypatch):
+    """x += H y where a block's row no longer fits one LDS window (4x5 lattice, 6 up / 5 down: N_up = 38760 in pieces, 15504 blocks,
+    6.0e8 states): the product-basis kernels for long rows (lpp_pbig_kernels.h) against the fused block-order kernel
+    (LPP_ONTHEFLY_KRON=1, an implementation of its own), plus linearity, the accumulate form and <u|H v> = <H u|v>."""
+    L = 20
+    hop, U = square(4, 5, -1.0, pbc=True), np.full(L, 4.0)
+    n = 38760 * 15504
+    rng = np.random.default_rng(43)
+    u = rng.standard_normal(n)
+    v = rng.standard_normal(n)
+    with LanczosEngine(save_vectors=0) as e:
+        e.setup_hubbard_onthefly(L, 6, 5, hop, U)
+        lay = e.layout()
+        assert lay["kernel"] == 4 and lay["pieces"] > 1
+        hv = e.matrixVectorProduct(np.zeros(n), v)
+        hu = e.matrixVectorProduct(np.zeros(n), u)
+        acc = e.matrixVectorProduct(u.copy(), v)
+        lin = e.matrixVectorProduct(np.zeros(n), 2.0 * u - 0.5 * v)
+    assert np.max(np.abs(acc - (u + hv))) <= 1e-12 * np.max(np.abs(hv))
+    assert np.max(np.abs(lin - (2.0 * hu - 0.5 * hv))) <= 1e-12 * np.max(np.abs(hv))
+    assert abs(np.dot(u, hv) - np.dot(hu, v)) <= 1e-11 * abs(np.dot(u, hv))
+    monkeypatch.setenv("LPP_ONTHEFLY_KRON", "1")
+    with LanczosEngine(save_vectors=0) as e:
+        e.setup_hubbard_onthefly(L, 6, 5, hop, U)
+        hv2 = e.matrixVectorProduct(np.zeros(n), v)
+    assert np.max(np.abs(hv2 - hv)) <= 1e-13 * np.max(np.abs(hv))

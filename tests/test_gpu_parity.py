@@ -653,13 +653,24 @@ PB_CASES = {
 }
 
 
+@pytest.mark.parametrize("form", ["window", "pieces", "wide"])
 @pytest.mark.parametrize("case", sorted(PB_CASES))
-def test_product_basis_layout(case, monkeypatch):
+def test_product_basis_layout(case, form, monkeypatch):
     """Device assembly of Hubbard straight into the product-basis layout (T, C, diagonal codes; lpp_pb_kernels.h): the CSR it
     stands for is the oracle's bit for bit, x += H y (two kernels, pitched vectors) matches the oracle, and every solver entry
-    point works on the pitched vectors; the general layout (LPP_PRODUCT_LAYOUT=0) gives the same numbers."""
+    point works on the pitched vectors; the general layout (LPP_PRODUCT_LAYOUT=0) gives the same numbers.
+    form "pieces": the kernels for rows beyond one LDS window and vectors beyond 4 GiB (lpp_pbig_kernels.h: BASELINE config 5's
+    sectors) forced onto the same small matrices -- rows cut into pieces of 256 positions (entries that leave a piece are read
+    from memory), couplings over 3 parts of the source range with 64-bit addresses; "wide": pieces of 320 positions and the
+    whole-panel coupling kernel with 64-bit addresses (what BASELINE config 5's sectors take on one GPU)."""
     L, nup, ndown, hop, U, V = PB_CASES[case]()
     monkeypatch.setenv("LPP_PRODUCT_LAYOUT", "1")  # these matrices are below the size from which the layout is chosen by itself
+    if form == "pieces":
+        monkeypatch.setenv("LPP_PB_PIECE_ROWS", "256")
+        monkeypatch.setenv("LPP_PB_PARTS", "3")
+    if form == "wide":
+        monkeypatch.setenv("LPP_PB_PIECE_ROWS", "320")
+        monkeypatch.setenv("LPP_PB_WIDE", "1")
     A = oracle.hubbard_csr(L, nup, ndown, hop, U, V)
     x0, y = oracle.fill_random(A.nrows, 7), oracle.fill_random(A.nrows, 8)
     xo = oracle.spmv_acc(A, x0.copy(), y)
@@ -670,6 +681,7 @@ def test_product_basis_layout(case, monkeypatch):
         e.assemble_hubbard(L, nup, ndown, hop, U, V)
         lay = e.layout()
         assert lay["kernel"] == 4 and lay["nnz"] == A.nnz and lay["resident_bytes"] < 0.05 * 12 * A.nnz
+        assert (lay["pieces"], lay["coupling_parts"]) == {"window": (1, 1), "pieces": (4, 3), "wide": (3, 1)}[form]
         st = e.stats()
         assert (st["nrows"], st["nnz"]) == (A.nrows, A.nnz)
         rp, ci, va = e.get_csr()
