@@ -424,7 +424,7 @@ def test_four_ranks_stream_ordered_collectives_are_recorded_and_correct(worker, 
             assert abs(o["e_kron"][0] - o["e_oracle"]) <= 1e-10 * abs(o["e_oracle"])
             assert abs(o["e_tx_c"] - o["e_oracle_c"]) <= 1e-10 * abs(o["e_oracle_c"])
         else:
-            for tag in ("ladder", "chain"):
+            for tag in ("disorder", "ladder", "chain"):
                 eo = res[0][tag + "_eo"]
                 assert abs(o[tag + "_e"] - eo) <= 1e-10 * abs(eo) and abs(o[tag + "_e2"] - eo) <= 1e-10 * abs(eo) and abs(o[tag + "_mf_e"] - eo) <= 1e-10 * abs(eo)
                 assert np.array_equal(o[tag + "_a"], res[0][tag + "_a"]) and np.array_equal(o[tag + "_b"], res[0][tag + "_b"])
@@ -500,7 +500,8 @@ def _worker_pb_tx(rank, world, port, q):
         dev = torch.device("cuda", 0)
         torch.cuda.set_device(dev)
         out = {}
-        for tag, (L, nup, ndown, hop, U, ninj) in (("ladder", (12, 6, 4, square(2, 6, -1.0, True), np.full(12, 4.0), None)),
+        for tag, (L, nup, ndown, hop, U, ninj) in (("disorder", (12, 6, 5, chain(12, -1.0, True), np.random.default_rng(5).uniform(1, 5, 12), None)),  # plain-stream diagonal
+                                                   ("ladder", (12, 6, 4, square(2, 6, -1.0, True), np.full(12, 4.0), None)),
                                                    ("chain", (12, 6, 6, chain(12, -1.0, False), np.where(np.arange(12) % 2 == 0, 3.0, 5.0),
                                                               chain(12, 0.5, False)))):  # HubbardOneBandExtended: Coulomb term in the diagonal codes
             from math import comb
@@ -552,7 +553,7 @@ def test_product_basis_kernels_on_the_transposition_exchange(world):
     for r in range(world):
         assert "error" not in res[r], res[r].get("error")
     from helpers import rel
-    for tag in ("ladder", "chain"):
+    for tag in ("disorder", "ladder", "chain"):
         eo, so, ao, bo = (res[0][tag + k] for k in ("_eo", "_so", "_ao", "_bo"))
         assert res[0][tag + "_res"] < 1e-5
         assert sum(res[r][tag + "_rows"] for r in range(world)) == len(ao) * 0 + sum(res[r][tag + "_rows"] for r in range(world))

@@ -650,6 +650,9 @@ PB_CASES = {
     "ladder_2x6": lambda: (12, 6, 6, square(2, 6, -1.0, True), np.full(12, 4.0), np.zeros(24)),
     "open_chain_L12": lambda: (12, 6, 6, chain(12, -1.0, False), np.full(12, 4.0), np.zeros(24)),  # one value group (no sign changes); a_j > b_j
     "two_hoppings": lambda: (12, 5, 7, chain(12, -1.0, False) + 0.5 * (np.diag(np.ones(10), 2) + np.diag(np.ones(10), -2)), np.full(12, 3.0), np.zeros(24)),
+    # site-dependent U and potentials (HubbardHelper.h:138-189 with disorder): thousands of distinct diagonal values -- the diagonal
+    # travels as a plain f64 stream added by the streaming pass, T and C are unchanged
+    "disorder": lambda: (12, 6, 5, chain(12, -1.0, True), np.random.default_rng(5).uniform(1, 5, 12), np.random.default_rng(6).uniform(-0.5, 0.5, 24)),
 }
 
 
@@ -680,7 +683,8 @@ def test_product_basis_layout(case, form, monkeypatch):
     with LanczosEngine() as e:
         e.assemble_hubbard(L, nup, ndown, hop, U, V)
         lay = e.layout()
-        assert lay["kernel"] == 4 and lay["nnz"] == A.nnz and lay["resident_bytes"] < 0.05 * 12 * A.nnz
+        assert lay["kernel"] == 4 and lay["nnz"] == A.nnz and lay["resident_bytes"] < (0.12 if case == "disorder" else 0.05) * 12 * A.nnz
+        assert (lay["diagonal_plain"], lay["diagonal_codes"], lay["chained_step"]) == ((1, 0, 0) if case == "disorder" else (0, 1, 1 if form == "window" and case != "two_hoppings" else 0))  # the chained step is built for <= 2 hopping values
         assert (lay["pieces"], lay["coupling_parts"]) == {"window": (1, 1), "pieces": (4, 3), "wide": (3, 1)}[form]
         st = e.stats()
         assert (st["nrows"], st["nnz"]) == (A.nrows, A.nnz)
@@ -728,12 +732,17 @@ def test_product_basis_layout(case, form, monkeypatch):
 
 
 def test_product_basis_layout_falls_back_when_it_does_not_apply(monkeypatch):
-    """more than 256 distinct diagonal values, or more than 8 distinct in-block values: the general layout takes over, results unchanged"""
+    """more than 8 distinct in-block values, or a many-valued diagonal with the plain stream switched off (LPP_PB_PLAIN_DIAG=0): the
+    general layout takes over, results unchanged"""
     monkeypatch.setenv("LPP_PRODUCT_LAYOUT", "1")
     L, nup, ndown = 12, 6, 6
     rng = np.random.default_rng(5)
-    for hop, U in ((chain(L, -1.0, True), rng.uniform(1, 5, L)),  # random U: 2^12 distinct diagonals
-                   (chain(L, -1.0, True) * np.triu(1 + 0.01 * np.arange(L * L).reshape(L, L), 1) + (chain(L, -1.0, True) * np.triu(1 + 0.01 * np.arange(L * L).reshape(L, L), 1)).T, np.full(L, 4.0))):
+    for k, (hop, U) in enumerate(((chain(L, -1.0, True), rng.uniform(1, 5, L)),  # random U: 2^12 distinct diagonals
+                                  (chain(L, -1.0, True) * np.triu(1 + 0.01 * np.arange(L * L).reshape(L, L), 1) + (chain(L, -1.0, True) * np.triu(1 + 0.01 * np.arange(L * L).reshape(L, L), 1)).T, np.full(L, 4.0)))):
+        if k == 0:
+            monkeypatch.setenv("LPP_PB_PLAIN_DIAG", "0")
+        else:
+            monkeypatch.delenv("LPP_PB_PLAIN_DIAG")
         A = oracle.hubbard_csr(L, nup, ndown, hop, U)
         with LanczosEngine() as e:
             e.assemble_hubbard(L, nup, ndown, hop, U)
