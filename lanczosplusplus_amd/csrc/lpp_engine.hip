@@ -844,8 +844,30 @@ lpp_status lpp_engine_destroy(lpp_engine* e)
 	return LPP_OK;
 }
 
+// A whole real matrix on one GPU that turns out to be of product-basis form (basis block = the caller's hint or the detected one)
+// is taken into the product-basis layout (pb_from_csr: T, C, D extracted and the CSR verified against them row by row) and the
+// CSR is dropped; *as_product says so.  Everything else goes on to finalize_csr.
+static lpp_status try_product_layout(lpp_engine* e, DevCsr& A, bool* as_product)
+{
+	*as_product = false;
+	if (e->is_complex || A.nrows == 0 || A.nnz == 0) return LPP_OK;
+	int64_t hb = A.hint_block;
+	if (hb == 0 && !(getenv("LPP_DETECT_BLOCK") && atoi(getenv("LPP_DETECT_BLOCK")) == 0) && (size_t)A.nrows * e->esz < ((size_t)1 << 32)) {
+		StageTimer tm("basis block detection");
+		hb = detect_row_block_t<double>(e, A, (int64_t)1 << 23);
+		if (hb && getenv("LPP_VERBOSE")) fprintf(stderr, "lpp: detected a basis block of %lld rows\n", (long long)hb);
+		if (hb > 0 && hb <= (int64_t)((156 * 1024) / e->esz)) A.hint_block = hb; // finalize_csr need not look again
+	}
+	if (hb <= 0) return LPP_OK;
+	StageTimer tm("product-basis layout from the CSR");
+	lpp_status st = pb_from_csr(e, A, hb, as_product);
+	if (st != LPP_OK) return st;
+	if (*as_product) free_csr(A);
+	return LPP_OK;
+}
+
 static lpp_status upload_csr(lpp_engine* e, DevCsr& A, int64_t nrows, const int64_t* rowptr, const int32_t* colind, const void* values,
-                             int64_t hint_block = 0)
+                             int64_t hint_block = 0, bool try_product = false)
 {
 	const int64_t keep_src = A.src_elems;
 	free_csr(A);
@@ -863,6 +885,11 @@ static lpp_status upload_csr(lpp_engine* e, DevCsr& A, int64_t nrows, const int6
 		HIP_TRY(hipMemcpyAsync(A.val, values, e->esz * (size_t)A.nnz, hipMemcpyHostToDevice, e->stream));
 	}
 	HIP_TRY(hipStreamSynchronize(e->stream));
+	if (try_product) {
+		bool as_product = false;
+		lpp_status st = try_product_layout(e, A, &as_product);
+		if (st != LPP_OK || as_product) return st;
+	}
 	return finalize_csr(e, A, true);
 }
 
@@ -896,7 +923,7 @@ lpp_status lpp_engine_set_csr(lpp_engine* e, int64_t nrows, const int64_t* rowpt
 	e->bind_scalars(e->scal_own);
 	free_csr(e->A_rem);
 	drop_product(e);
-	st = upload_csr(e, e->A_loc, nrows, rowptr, colind, values, e->row_block_hint);
+	st = upload_csr(e, e->A_loc, nrows, rowptr, colind, values, e->row_block_hint, true);
 	if (st != LPP_OK) return st;
 	e->n_local = e->n_global = nrows;
 	e->row_start = 0;
@@ -944,7 +971,10 @@ lpp_status lpp_engine_set_csr_device(lpp_engine* e, int64_t nrows, const int64_t
 		HIP_TRY(hipMemcpyAsync(A.val, d_values, e->esz * (size_t)nnz, hipMemcpyDeviceToDevice, e->stream));
 	}
 	HIP_TRY(hipStreamSynchronize(e->stream));
-	lpp_status st = finalize_csr(e, A, true);
+	bool as_product = false;
+	lpp_status st = try_product_layout(e, A, &as_product);
+	if (st != LPP_OK) return st;
+	if (!as_product) st = finalize_csr(e, A, true);
 	if (st != LPP_OK) return st;
 	e->n_local = e->n_global = nrows;
 	e->row_start = 0;

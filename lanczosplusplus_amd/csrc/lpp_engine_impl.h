@@ -255,6 +255,8 @@ int pb_launch_chain(lpp_engine* e, void* w, void* y, double* partial, const EpiS
 void pb_materialise(lpp_engine* e, void* y, const void* x, const double* g_a, const double* g_b2, double* partial);
 int pb_combine_axpy(lpp_engine* e, void* x, const void* y, const EpiScale& sc, const double* a_ptr, const double* b2_prev, double* partial);
 lpp_status pb_get_csr(lpp_engine* e, int64_t* rowptr, int32_t* colind, void* values);
+// a handed-over CSR of product-basis form -> the product-basis layout (verified row by row); *done == false: keep the general layout
+lpp_status pb_from_csr(lpp_engine* e, const DevCsr& A, int64_t n_up, bool* done);
 int64_t pb_pitch_for(int64_t n_up);
 // host <-> device vector copies that know the pitched layout
 lpp_status vec_from_host(lpp_engine* e, double* dev, const void* host);

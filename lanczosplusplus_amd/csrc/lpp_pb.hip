@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -696,6 +697,152 @@ int pb_combine_axpy(lpp_engine* e, void* x, const void* y, const EpiScale& sc, c
 	k_reduce_final<<<1, kBlock, 0, e->stream>>>(partial + nb, nb, 1, 1, B.xy); // next step's <y | x_old>
 	if (B.dval) k_reduce_final<<<1, kBlock, 0, e->stream>>>(partial + 2 * nb, nb, 1, 1, B.xy + 1); // and its <y | D y>
 	return nb;
+}
+
+// ---- a CSR that was handed over (lpp_engine_set_csr / _set_csr_device) -------------------------------------------------
+// The reference hands its matrix over as a CSR (DefaultSymmetry.h:54-57 -> InternalProductStored.h:116).  When that CSR is of
+// the product-basis form -- basis block n_up (the caller's hint or the detected one), every block's in-block part equal to
+// block 0's (= T), every leaving entry a position-preserving block coupling (= C), a stored diagonal in every row (= D) -- it
+// is taken into the same layout device assembly builds: T from block 0, C from the first row of every block, D from the
+// diagonals, then EVERY row of the CSR is compared with the row (T, C, D) stand for, entry by entry and bit by bit
+// (k_pb_csr_verify).  Only a CSR that passes is dropped; anything else keeps the general layout.  *done says which.
+lpp_status pb_from_csr(lpp_engine* e, const DevCsr& A, int64_t n_up, bool* done)
+{
+	*done = false;
+	if (e->is_complex || n_up < 512 || A.nrows <= 0 || A.nrows % n_up != 0 || !A.col || !A.val) return LPP_OK;
+	const int64_t n_blk = A.nrows / n_up;
+	if (n_blk < 2 || n_blk > 65535) return LPP_OK;
+	bool forced = false;
+	if (const char* s = getenv("LPP_PRODUCT_LAYOUT")) {
+		if (atoi(s) == 0) return LPP_OK;
+		forced = true;
+	}
+	if (!forced && (size_t)A.nrows * sizeof(double) < ((size_t)32 << 20)) return LPP_OK; // as for device assembly (assemble_hubbard_pb)
+	if (e->cfg.spmv_kernel != LPP_SPMV_AUTO || getenv("LPP_SPMV_KERNEL")) return LPP_OK;
+	int want = e->cfg.compress_values;
+	if (const char* s = getenv("LPP_COMPRESS_VALUES")) want = atoi(s);
+	if (want == 0) return LPP_OK;
+	for (const char* k : { "LPP_SHARED_OFFSETS", "LPP_LOCAL16", "LPP_DIAG_CODES", "LPP_BLOCK_TEMPLATE", "LPP_WINDOW_ROWS" })
+		if (getenv(k)) return LPP_OK; // switches of the general layout: measure that one
+	hipStream_t st = e->stream;
+	const int64_t pitch = pb_pitch_for(n_up);
+	struct Buf {
+		void* p = nullptr;
+		~Buf()
+		{
+			if (p) (void)hipFree(p);
+		}
+	} d_bad, d_clen, d_cptr, d_ccol, d_cval, d_dval, d_table, d_ov;
+	HIP_TRY_MEM(hipMalloc(&d_bad.p, sizeof(int) * 2));
+	HIP_TRY(hipMemsetAsync(d_bad.p, 0, sizeof(int) * 2, st));
+	// T: block 0's rows, columns inside the block
+	std::vector<int64_t> rp0((size_t)n_up + 1);
+	HIP_TRY(hipMemcpyAsync(rp0.data(), A.rowptr, sizeof(int64_t) * (size_t)(n_up + 1), hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipStreamSynchronize(st));
+	const int64_t n0 = rp0[(size_t)n_up];
+	if (n0 <= 0 || n0 > ((int64_t)1 << 28)) return LPP_OK;
+	std::vector<int32_t> c0((size_t)n0);
+	std::vector<double> v0((size_t)n0);
+	HIP_TRY(hipMemcpyAsync(c0.data(), A.col, sizeof(int32_t) * (size_t)n0, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipMemcpyAsync(v0.data(), A.val, sizeof(double) * (size_t)n0, hipMemcpyDeviceToHost, st));
+	// C: the first row of every block
+	HIP_TRY_MEM(hipMalloc(&d_clen.p, sizeof(int64_t) * (size_t)(n_blk + 1)));
+	const int nbb = (int)((n_blk + 255) / 256);
+	k_pb_csr_couplings<false><<<nbb, 256, 0, st>>>(n_up, n_blk, A.rowptr, A.col, (const double*)A.val, (int64_t*)d_clen.p, nullptr, nullptr, nullptr, (int*)d_bad.p);
+	std::vector<int64_t> clen((size_t)n_blk), crp((size_t)n_blk + 1, 0);
+	HIP_TRY(hipMemcpyAsync(clen.data(), d_clen.p, sizeof(int64_t) * (size_t)n_blk, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipStreamSynchronize(st));
+	for (int64_t b = 0; b < n_blk; b++) crp[(size_t)b + 1] = crp[(size_t)b] + clen[(size_t)b];
+	const int64_t cz = crp[(size_t)n_blk];
+	HIP_TRY_MEM(hipMalloc(&d_cptr.p, sizeof(int64_t) * (size_t)(n_blk + 1)));
+	HIP_TRY_MEM(hipMalloc(&d_ccol.p, sizeof(int32_t) * (size_t)std::max<int64_t>(cz, 1)));
+	HIP_TRY_MEM(hipMalloc(&d_cval.p, sizeof(double) * (size_t)std::max<int64_t>(cz, 1)));
+	HIP_TRY(hipMemcpyAsync(d_cptr.p, crp.data(), sizeof(int64_t) * (size_t)(n_blk + 1), hipMemcpyHostToDevice, st));
+	k_pb_csr_couplings<true><<<nbb, 256, 0, st>>>(n_up, n_blk, A.rowptr, A.col, (const double*)A.val, nullptr, (const int64_t*)d_cptr.p, (int32_t*)d_ccol.p,
+	                                             (double*)d_cval.p, (int*)d_bad.p);
+	std::vector<int32_t> cci((size_t)std::max<int64_t>(cz, 1));
+	std::vector<double> cva((size_t)std::max<int64_t>(cz, 1));
+	HIP_TRY(hipMemcpyAsync(cci.data(), d_ccol.p, sizeof(int32_t) * (size_t)cz, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipMemcpyAsync(cva.data(), d_cval.p, sizeof(double) * (size_t)cz, hipMemcpyDeviceToHost, st));
+	// D: the stored diagonal of every row, pitched
+	const size_t loc = (size_t)n_blk * (size_t)pitch;
+	HIP_TRY_MEM(hipMalloc(&d_dval.p, sizeof(double) * loc));
+	HIP_TRY(hipMemsetAsync(d_dval.p, 0, sizeof(double) * loc, st));
+	const int nbr = (int)std::max<int64_t>(1, std::min<int64_t>((A.nrows + 255) / 256, 1 << 16));
+	k_pb_csr_diagonal<<<nbr, 256, 0, st>>>(n_up, n_blk, pitch, A.rowptr, A.col, (const double*)A.val, (double*)d_dval.p, (int*)d_bad.p);
+	// its distinct values
+	HIP_TRY_MEM(hipMalloc(&d_table.p, sizeof(unsigned long long) * kDictTable));
+	HIP_TRY_MEM(hipMalloc(&d_ov.p, sizeof(int)));
+	HIP_TRY(hipMemsetAsync(d_table.p, 0xff, sizeof(unsigned long long) * kDictTable, st));
+	HIP_TRY(hipMemsetAsync(d_ov.p, 0, sizeof(int), st));
+	k_dict_collect<<<2048, kBlock, 0, st>>>((const double*)d_dval.p, (int64_t)loc, (unsigned long long*)d_table.p, (int*)d_ov.p);
+	std::vector<unsigned long long> host(kDictTable);
+	int ov = 0, bad[2] = { 0, 0 };
+	HIP_TRY(hipMemcpyAsync(host.data(), d_table.p, sizeof(unsigned long long) * kDictTable, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipMemcpyAsync(&ov, d_ov.p, sizeof(int), hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipMemcpyAsync(bad, d_bad.p, sizeof(int) * 2, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipStreamSynchronize(st));
+	if (bad[0]) return LPP_OK; // a coupling that does not preserve the position, or a row without a stored diagonal
+	std::vector<int64_t> trp((size_t)n_up + 1, 0);
+	std::vector<int32_t> tci;
+	std::vector<double> tva;
+	for (int64_t r = 0; r < n_up; r++) {
+		for (int64_t p = rp0[(size_t)r]; p < rp0[(size_t)r + 1]; p++)
+			if (c0[(size_t)p] >= 0 && c0[(size_t)p] < n_up) { // pb_build skips the diagonal itself
+				tci.push_back(c0[(size_t)p]);
+				tva.push_back(v0[(size_t)p]);
+			}
+		trp[(size_t)r + 1] = (int64_t)tci.size();
+	}
+	std::vector<unsigned long long> keys;
+	keys.push_back(0ull);
+	auto add_key = [&](unsigned long long k) {
+		if (std::find(keys.begin(), keys.end(), k) == keys.end()) keys.push_back(k);
+	};
+	size_t ndiag = 0;
+	for (unsigned long long k : host)
+		if (k != kDictEmpty) ndiag++;
+	bool plain_diag = ov != 0 || ndiag > 250 || (getenv("LPP_PB_PLAIN_DIAG") && atoi(getenv("LPP_PB_PLAIN_DIAG")) != 0);
+	if (plain_diag && getenv("LPP_PB_PLAIN_DIAG") && atoi(getenv("LPP_PB_PLAIN_DIAG")) == 0) return LPP_OK;
+	if (!plain_diag)
+		for (unsigned long long k : host)
+			if (k != kDictEmpty) add_key(k);
+	for (int64_t p = 0; p < cz && keys.size() <= 256; p++) {
+		unsigned long long k;
+		std::memcpy(&k, &cva[(size_t)p], 8);
+		add_key(k);
+	}
+	if (keys.size() > 256) return LPP_OK;
+	std::sort(keys.begin(), keys.end());
+	std::vector<double> dict(256);
+	for (size_t i = 0; i < 256; i++) std::memcpy(&dict[i], &keys[std::min(i, keys.size() - 1)], 8);
+	// two work vectors + the two parts of a product + the diagonal must fit once the CSR is gone (it is still resident here)
+	lpp_status rc = pb_build(e, n_up, n_blk, trp.data(), tci.data(), tva.data(), crp.data(), cci.data(), cva.data(), dict.data(), (int)keys.size());
+	if (rc == LPP_ERR_INVALID || rc == LPP_ERR_NOMEM) { // not representable, or no room beside the CSR: the general layout
+		if (getenv("LPP_VERBOSE")) fprintf(stderr, "lpp: the product-basis layout does not apply to the uploaded matrix: %s\n", lpp_last_error());
+		free_pb(e);
+		return LPP_OK;
+	}
+	if (rc != LPP_OK) return rc;
+	PbState& B = e->pb;
+	if (plain_diag) {
+		B.dval = (double*)d_dval.p; // the codes stay 0 (+0.0)
+		d_dval.p = nullptr;
+	} else {
+		k_pb_codes_from_values<<<nbr, 256, 0, st>>>((int64_t)loc, (const double*)d_dval.p, B.dict, B.ndict, B.dcode);
+	}
+	k_pb_csr_verify<<<nbr, 256, 0, st>>>(n_up, n_blk, pitch, B.t_ptr, B.t_col, B.t_val, B.c_ptr, B.c_col, B.c_code, B.blockbase, B.dcode, B.dict, B.dval, A.rowptr, A.col,
+	                                    (const double*)A.val, (int*)d_bad.p + 1);
+	HIP_TRY(hipMemcpyAsync(bad, d_bad.p, sizeof(int) * 2, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipStreamSynchronize(st));
+	if (bad[1] || B.nnz != A.nnz) { // some row is not what (T, C, D) say: not a product-basis matrix
+		free_pb(e);
+		return LPP_OK;
+	}
+	*done = true;
+	return LPP_OK;
 }
 
 lpp_status pb_get_csr(lpp_engine* e, int64_t* rowptr, int32_t* colind, void* values)

@@ -709,6 +709,88 @@ static __global__ void k_pb_rebuild(int64_t n_up, int64_t n_blk, int64_t pitch, 
 	}
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// (T, C, D) from a CSR that was handed over (lpp_engine_set_csr: DefaultSymmetry.h:54-57 -> InternalProductStored.h:116), and the
+// proof that the CSR is nothing but them
+// ---------------------------------------------------------------------------------------------
+
+// per block b: entries of its FIRST row (b, 0) that leave the block -- the couplings of block b.  FILL == false: count only.
+// bad is raised when such an entry does not land on position 0 of another block.
+template <bool FILL>
+static __global__ void k_pb_csr_couplings(int64_t n_up, int64_t n_blk, const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                          const double* __restrict__ val, int64_t* __restrict__ c_len, const int64_t* __restrict__ c_ptr,
+                                          int32_t* __restrict__ c_col, double* __restrict__ c_val, int* __restrict__ bad)
+{
+	const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (b >= n_blk) return;
+	const int64_t r = b * n_up;
+	int64_t n = 0;
+	for (int64_t p = rowptr[r]; p < rowptr[r + 1]; p++) {
+		const int64_t c = col[p];
+		if (c >= r && c < r + n_up) continue;
+		if (c % n_up != 0) *bad = 1;
+		if (FILL) {
+			c_col[c_ptr[b] + n] = (int32_t)(c / n_up);
+			c_val[c_ptr[b] + n] = val[p];
+		}
+		n++;
+	}
+	if (!FILL) c_len[b] = n;
+}
+
+// the diagonal of every row as a pitched f64 array; bad is raised for a row that stores no diagonal entry
+static __global__ void k_pb_csr_diagonal(int64_t n_up, int64_t n_blk, int64_t pitch, const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                         const double* __restrict__ val, double* __restrict__ dval, int* __restrict__ bad)
+{
+	const int64_t n = n_up * n_blk;
+	for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (int64_t)gridDim.x * blockDim.x) {
+		bool found = false;
+		for (int64_t p = rowptr[r]; p < rowptr[r + 1]; p++)
+			if ((int64_t)col[p] == r) {
+				dval[(r / n_up) * pitch + (r % n_up)] = val[p];
+				found = true;
+				break;
+			}
+		if (!found) *bad = 1;
+	}
+}
+
+static __global__ void k_pb_codes_from_values(int64_t n, const double* __restrict__ dval, const double* __restrict__ dict, int ndict, uint8_t* __restrict__ dcode)
+{
+	for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x) dcode[k] = (uint8_t)dict_code(dict, ndict, dval[k]);
+}
+
+// every row of the CSR against the row (T, C, D) stand for, entry by entry and bit by bit (the walk of k_pb_rebuild)
+static __global__ void k_pb_csr_verify(int64_t n_up, int64_t n_blk, int64_t pitch, const int64_t* __restrict__ t_ptr, const int32_t* __restrict__ t_col,
+                                       const double* __restrict__ t_val, const int64_t* __restrict__ c_ptr, const int32_t* __restrict__ c_col,
+                                       const uint8_t* __restrict__ c_code, const int64_t* __restrict__ blockbase, const uint8_t* __restrict__ dcode,
+                                       const double* __restrict__ dict, const double* __restrict__ dplain, const int64_t* __restrict__ rowptr,
+                                       const int32_t* __restrict__ col, const double* __restrict__ val, int* __restrict__ bad)
+{
+	const int64_t n = n_up * n_blk;
+	for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (int64_t)gridDim.x * blockDim.x) {
+		const int64_t b = r / n_up, i = r - b * n_up;
+		const int64_t c0 = c_ptr[b], c1 = c_ptr[b + 1];
+		int64_t o = blockbase[b] + t_ptr[i] + i * (1 + (c1 - c0));
+		const int64_t oe = o + (t_ptr[i + 1] - t_ptr[i]) + 1 + (c1 - c0);
+		bool ok = rowptr[r] == o && rowptr[r + 1] == oe;
+		if (ok) {
+			auto same = [&](int64_t at, int64_t c, double v) { return (int64_t)col[at] == c && __double_as_longlong(val[at]) == __double_as_longlong(v); };
+			int64_t p = c0;
+			for (; p < c1 && c_col[p] < b; p++, o++) ok = ok && same(o, (int64_t)c_col[p] * n_up + i, dict[c_code[p]]);
+			int64_t q = t_ptr[i];
+			const int64_t q1 = t_ptr[i + 1];
+			for (; q < q1 && t_col[q] < i; q++, o++) ok = ok && same(o, b * n_up + t_col[q], t_val[q]);
+			ok = ok && same(o, r, dplain ? dplain[b * pitch + i] : dict[dcode[b * pitch + i]]);
+			o++;
+			for (; q < q1; q++, o++) ok = ok && same(o, b * n_up + t_col[q], t_val[q]);
+			for (; p < c1; p++, o++) ok = ok && same(o, (int64_t)c_col[p] * n_up + i, dict[c_code[p]]);
+		}
+		if (!ok) *bad = 1;
+	}
+}
+
 // start vector in the pitched layout: element (b, i) takes the value the unpitched stream gives index b*rows + i
 static __global__ void k_fill_random_pitched(double* __restrict__ v, int64_t n_blk, int64_t rows, int64_t pitch, int64_t offset, uint64_t seed)
 {

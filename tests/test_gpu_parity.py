@@ -3,6 +3,8 @@
 Tolerances: indices/structure bit-exact; matrix values bit-exact; SpMV 1e-13 relative per vector
 (summation order differs); energies 1e-10 relative (BASELINE.json north_star).
 """
+from math import comb
+
 import numpy as np
 import pytest
 
@@ -642,6 +644,45 @@ def test_basis_block_is_detected_without_a_hint():
         assert e.layout()["rows_per_block"] != 924 and e.layout()["block_template"] == 0
         x0, y = oracle.fill_random(H.nrows, 3), oracle.fill_random(H.nrows, 4)
         assert rel(e.matrixVectorProduct(x0.copy(), y), oracle.spmv_acc(H, x0.copy(), y)) < SPMV_TOL
+
+
+def test_uploaded_csr_takes_the_product_basis_layout(monkeypatch):
+    """The reference hands its Hamiltonian over as a CSR (DefaultSymmetry.h:54-57 -> InternalProductStored.h:116).  A Hubbard CSR
+    uploaded through lpp_engine_set_csr -- no hint, no model knowledge -- ends in the same product-basis layout device assembly
+    builds: the basis block is detected, T, C and D are read off the matrix and EVERY row of the CSR is verified against them
+    before the CSR is dropped.  get_csr gives the uploaded arrays back bit for bit; one changed value anywhere keeps the general layout."""
+    monkeypatch.setenv("LPP_PRODUCT_LAYOUT", "1")  # below the size from which the layout is chosen by itself
+    for case in ("chain_L12", "disorder"):
+        L, nup, ndown, hop, U, V = PB_CASES[case]()
+        A = oracle.hubbard_csr(L, nup, ndown, hop, U, V)
+        x0, y = oracle.fill_random(A.nrows, 7), oracle.fill_random(A.nrows, 8)
+        xo = oracle.spmv_acc(A, x0.copy(), y)
+        eo, _, so = oracle.lanczos_solve(A, oracle.fill_random(A.nrows, 1234), want_vectors=False)
+        with LanczosEngine() as e, LanczosEngine() as d:
+            e.set_csr(A.rowptr, A.colind, A.values)
+            d.assemble_hubbard(L, nup, ndown, hop, U, V)
+            lay = e.layout()
+            assert lay["kernel"] == 4 and lay == d.layout(), (lay, d.layout())
+            assert lay["diagonal_plain"] == (1 if case == "disorder" else 0)
+            rp, ci, va = e.get_csr()
+            assert np.array_equal(rp, A.rowptr) and np.array_equal(ci, A.colind) and np.array_equal(_bits(va), _bits(A.values))
+            assert rel(e.matrixVectorProduct(x0.copy(), y), xo) < SPMV_TOL
+            eg, _, st = e.lanczos(1, want_vectors=False)
+            assert abs(eg[0] - eo[0]) <= E_TOL * abs(eo[0]) and st["steps"] == so
+            e.set_row_block(comb(L, nup))  # the shim's hint (BasisHubbardLanczos::sizeUp()): same result without the detection
+            e.set_csr(A.rowptr, A.colind, A.values)
+            assert e.layout() == lay
+        # not a product-basis matrix any more: one off-diagonal value of one row in the middle differs from its template
+        B = oracle.Csr(A.rowptr.copy(), A.colind.copy(), A.values.copy())
+        r = A.nrows // 2 + 17
+        k = A.rowptr[r] + (0 if A.colind[A.rowptr[r]] != r else 1)
+        B.values[k] *= 1.5
+        with LanczosEngine() as e:
+            e.set_csr(B.rowptr, B.colind, B.values)
+            assert e.layout()["kernel"] != 4
+            rp, ci, va = e.get_csr()
+            assert np.array_equal(ci, B.colind) and np.array_equal(_bits(va), _bits(B.values))
+            assert rel(e.matrixVectorProduct(x0.copy(), y), oracle.spmv_acc(B, x0.copy(), y)) < SPMV_TOL
 
 
 PB_CASES = {
