@@ -214,7 +214,7 @@ public:
 		}
 		const typename BasisType::PairIntType parts = model.basis().parts();
 		lppCheck(lpp_engine_setup_hubbard_onthefly_ext(engine_.get(), nullptr, (int32_t)n, parts.first, parts.second, hr.data(),
-		                                               sizeof(ComplexOrRealType) == 16 ? hi.data() : nullptr, hub->hubbardU.data(), hub->potentialV.data(),
+		                                               sizeof(ComplexOrRealType) == 16 ? hi.data() : nullptr, hub->hubbardU.data(), hub->potentialEffective.data(),
 		                                               hub->coulombCoupling()));
 	}
 	SizeType rows() const { return rows_; }

@@ -161,10 +161,10 @@ static int mainPartitioned(LppHost::InputReadable& io, int precision, bool onthe
 	for (int k = 0; k < n * n; k++) hr[(size_t)k] = hub->hoppings()[(size_t)k];
 	if (onthefly)
 		lppCheck(lpp_engine_setup_hubbard_onthefly_ext(engine.get(), lpp_rccl_comm_get(comm), n, parts.first, parts.second, hr.data(), nullptr,
-		                                               hub->hubbardU.data(), hub->potentialV.data(), hub->coulombCoupling()));
+		                                               hub->hubbardU.data(), hub->potentialEffective.data(), hub->coulombCoupling()));
 	else
 		lppCheck(lpp_engine_assemble_hubbard_super(engine.get(), lpp_rccl_comm_get(comm), n, parts.first, parts.second, hr.data(), nullptr,
-		                                           hub->hubbardU.data(), hub->potentialV.data(), hub->coulombCoupling(), hub->jCoupling()));
+		                                           hub->hubbardU.data(), hub->potentialEffective.data(), hub->coulombCoupling(), hub->jCoupling()));
 	double e0 = 0;
 	lpp_stats st;
 	lppCheck(lpp_engine_lanczos(engine.get(), nullptr, 1, &e0, nullptr, &st));

@@ -58,6 +58,8 @@ def lib():
     L.lppo_hubbard_setup.argtypes = [C.c_int] * 3 + [C.c_void_p] * 5 + [C.c_int]
     L.lppo_hubbard_setup_super.restype = C.c_void_p
     L.lppo_hubbard_setup_super.argtypes = [C.c_int] * 3 + [C.c_void_p] * 6 + [C.c_int]
+    L.lppo_hubbard_setup_time.restype = C.c_void_p
+    L.lppo_hubbard_setup_time.argtypes = [C.c_int] * 3 + [C.c_void_p] * 6 + [C.c_int, C.c_void_p, C.c_double]
     L.lppo_hubbard_otf_mvp.argtypes = [C.c_int] * 3 + [_f64p, _f64p, _f64p, _f64p, _f64p, C.c_int64, C.c_int64, C.c_int]
     L.lppo_hubbard_otf_new.restype = C.c_void_p
     L.lppo_hubbard_otf_new.argtypes = [C.c_int] * 3 + [_f64p, _f64p, _f64p, C.c_int]
@@ -169,9 +171,10 @@ def hubbard_basis_words(L, nup, ndown):
     return up, dn
 
 
-def hubbard_csr(L, nup, ndown, hop, U, V=None, ninj=None, jcoup=None):
+def hubbard_csr(L, nup, ndown, hop, U, V=None, ninj=None, jcoup=None, potentialT=None, timeFactor=0.0):
     """HubbardHelper::setupHamiltonian.  ninj: Coulomb coupling (HubbardOneBandExtended); jcoup: spin coupling, with ninj
-    Model=SuperHubbardExtended; Model=KaneMeleHubbard is hop = term 0 + term 1 (HubbardHelper.h:63-66), summed by the caller."""
+    Model=SuperHubbardExtended; Model=KaneMeleHubbard is hop = term 0 + term 1 (HubbardHelper.h:63-66), summed by the caller;
+    potentialT, timeFactor: the time-dependent potential of HubbardHelper.h:181-182."""
     hop = np.asarray(hop).reshape(L, L)
     cplx = np.iscomplexobj(hop) and np.any(hop.imag != 0)
     hr = _mat(hop.real, L)
@@ -180,7 +183,8 @@ def hubbard_csr(L, nup, ndown, hop, U, V=None, ninj=None, jcoup=None):
     V = np.zeros(L) if V is None else np.ascontiguousarray(np.asarray(V, np.float64)[:L])
     nj = _mat(ninj, L)
     jc = _mat(jcoup, L)
-    h = lib().lppo_hubbard_setup_super(L, nup, ndown, _ptr(hr), _ptr(hi), _ptr(U), _ptr(V), _ptr(nj), _ptr(jc), int(cplx))
+    pt = None if potentialT is None else np.ascontiguousarray(np.asarray(potentialT, np.float64)[:L])
+    h = lib().lppo_hubbard_setup_time(L, nup, ndown, _ptr(hr), _ptr(hi), _ptr(U), _ptr(V), _ptr(nj), _ptr(jc), int(cplx), _ptr(pt), float(timeFactor))
     return _take_csr(h)
 
 

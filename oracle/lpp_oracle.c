@@ -358,6 +358,8 @@ typedef struct {
 	const double* V; /* L: potentialV[i], i<L, used for both spins (HubbardHelper.h:180-183) */
 	const double* ninj; /* L*L Coulomb coupling (HubbardOneBandExtended, SuperHubbardExtended) or NULL */
 	const double* jcoup; /* L*L spin coupling J (SuperHubbardExtended, geometry term SUPER = 2, HubbardHelper.h:30,358-362) or NULL */
+	const double* potT; /* L: PotentialT (ParametersModelHubbard.h:95-99) or NULL */
+	double timeFactor; /* timeFactor= (0 when PotentialT is absent, ParametersModelHubbard.h:95) */
 } hub_params;
 
 /* szTerm, HubbardHelper.h:345-355 */
@@ -368,7 +370,7 @@ static double hub_sz(word_t ket1, word_t ket2, int i)
 	return 0.5 * sz;
 }
 
-/* calcDiagonalElements for one state, HubbardHelper.h:138-189 (the potentialT branch is for time-dependent runs: not restated) */
+/* calcDiagonalElements for one state, HubbardHelper.h:138-189 */
 static double hub_diag_one(const hub_params* P, word_t ket1, word_t ket2)
 {
 	int L = P->L;
@@ -394,6 +396,7 @@ static double hub_diag_one(const hub_params* P, word_t ket1, word_t ket2)
 			}
 		}
 		double tmp = P->V[i]; /* :180 */
+		if (P->potT) tmp += P->potT[i] * P->timeFactor; /* :181-182 */
 		if (tmp != 0) s += tmp * ne; /* :183 */
 	}
 	return s;
@@ -474,12 +477,22 @@ static void hub_set_jterm(const hub_params* P, const hub_basis* B, sparse_row* r
 }
 
 /* HubbardHelper::setupHamiltonian, HubbardHelper.h:75-103; jcoup != NULL: Model=SuperHubbardExtended */
+lppo_csr* lppo_hubbard_setup_time(int L, int nup, int ndown, const double* hop_re, const double* hop_im, const double* U, const double* V,
+                                  const double* ninj, const double* jcoup, int is_complex, const double* potT, double timeFactor);
+
 lppo_csr* lppo_hubbard_setup_super(int L, int nup, int ndown, const double* hop_re, const double* hop_im,
                                    const double* U, const double* V, const double* ninj, const double* jcoup, int is_complex)
 {
+	return lppo_hubbard_setup_time(L, nup, ndown, hop_re, hop_im, U, V, ninj, jcoup, is_complex, NULL, 0.0);
+}
+
+/* the same with the time-dependent potential PotentialT * timeFactor of HubbardHelper.h:181-182 (potT == NULL: none) */
+lppo_csr* lppo_hubbard_setup_time(int L, int nup, int ndown, const double* hop_re, const double* hop_im, const double* U, const double* V,
+                                  const double* ninj, const double* jcoup, int is_complex, const double* potT, double timeFactor)
+{
 	hub_basis B;
 	hub_basis_init(&B, L, nup, ndown);
-	hub_params P = { L, is_complex, hop_re, hop_im, U, V, ninj, jcoup };
+	hub_params P = { L, is_complex, hop_re, hop_im, U, V, ninj, jcoup, potT, timeFactor };
 	int64_t hilbert = B.n1 * B.n2;
 	const int nchunks = asm_chunks(hilbert);
 	lppo_csr** parts = (lppo_csr**)calloc((size_t)nchunks, sizeof(lppo_csr*));
@@ -525,7 +538,7 @@ void lppo_hubbard_otf_mvp(int L, int nup, int ndown, const double* hop_re, const
 {
 	hub_basis B;
 	hub_basis_init(&B, L, nup, ndown);
-	hub_params P = { L, 0, hop_re, NULL, U, V, NULL, NULL };
+	hub_params P = { L, 0, hop_re, NULL, U, V, NULL, NULL, NULL, 0.0 };
 	int64_t hilbert = B.n1 * B.n2;
 	if (row1 <= 0 || row1 > hilbert) row1 = hilbert;
 	/* :110-114 serial diagonal pass */

@@ -24,7 +24,7 @@ def _oracle_csr(path):
         # ModelSelector.h:76-80; HubbardHelper.h:39-66: Coulomb coupling = term 1, spin coupling = term 2, Kane-Mele hoppings = term 0 + term 1
         hop = terms[0] + terms[1] if model == "KaneMeleHubbard" else terms[0]
         return oracle.hubbard_csr(L, int(inp["TargetElectronsUp"]), int(inp["TargetElectronsDown"]), hop,
-                                  inp["hubbardU"], inp["potentialV"],
+                                  inp["hubbardU"], inp["potentialV"], potentialT=inp.get("PotentialT"), timeFactor=float(inp.get("timeFactor", 0.0)),
                                   ninj=(terms[1] if model in ("HubbardOneBandExtended", "SuperHubbardExtended") else None),
                                   jcoup=(terms[2] if model == "SuperHubbardExtended" else None))
     if model == "Heisenberg":
@@ -49,7 +49,7 @@ def _read_dump(path):
 @pytest.mark.parametrize("name", ["input0.inp", "hubbard_ladder_2x4.inp", "heisenberg_chain_L12.inp",
                                   "tj_chain_L8_complex.inp", "hubbard_chain_L12.inp", "hubbard_extended_2x4.inp",
                                   "heisenberg_spin1_L8.inp", "heisenberg_spin32_L6.inp", "super_hubbard_2x4.inp",
-                                  "kane_mele_hubbard_chain_L8.inp"])
+                                  "kane_mele_hubbard_chain_L8.inp", "hubbard_ladder_2x4_potentialT.inp"])
 def test_host_assembly_bit_exact(name, tmp_path):
     exe = os.path.join(HOST, "dump_csr")
     assert os.path.exists(exe), "run __graft_entry__.build()"

@@ -395,3 +395,23 @@ def test_config2_golden_fixture_is_self_consistent():
     assert abs(w[0] - g["e0"]) < 1e-12 * abs(g["e0"]) and h[-1] == g["e0"]
     assert abs(h[-1] - h[-2]) < g["eps"] and abs(h[-2] - h[-3]) >= g["eps"]
     assert abs(g["e0"] + 13.62185) < 2e-4
+
+
+def test_hubbard_time_dependent_potential_is_a_site_potential():
+    """HubbardHelper.h:180-183: tmp = potentialV[i]; tmp += potentialT[i]*timeFactor; s += tmp*ne -- the literal restatement equals
+    the matrix with the site potential V + T*timeFactor (formed with the same two operations), differs from the one without it,
+    and its diagonal moves by exactly sum_i T_i*timeFactor*n_i."""
+    from helpers import chain
+    L, nup, ndown = 6, 3, 2
+    hop, U = chain(L, -1.0, True), np.linspace(1.0, 3.5, L)
+    V = np.linspace(-0.5, 0.5, L)
+    T, tf = np.array([0.3, -0.1, 0.7, 0.0, 0.2, -0.6]), 0.37
+    A0 = oracle.hubbard_csr(L, nup, ndown, hop, U, V)
+    A1 = oracle.hubbard_csr(L, nup, ndown, hop, U, V, potentialT=T, timeFactor=tf)
+    A2 = oracle.hubbard_csr(L, nup, ndown, hop, U, V + T * tf)
+    assert np.array_equal(A1.rowptr, A2.rowptr) and np.array_equal(A1.colind, A2.colind)
+    assert np.array_equal(A1.values.view(np.uint64), A2.values.view(np.uint64))
+    assert not np.array_equal(A1.values, A0.values)
+    d0 = A0.to_scipy().diagonal()
+    d1 = A1.to_scipy().diagonal()
+    assert np.isclose((d1 - d0).sum(), (T * tf).sum() * (nup + ndown) / L * A0.nrows, rtol=1e-12)  # every site is occupied by (nup+ndown)/L electrons on average
