@@ -222,6 +222,14 @@ lpp_status lpp_engine_setup_hubbard_onthefly_ext(lpp_engine* e, const lpp_comm* 
                                                  const double* hop_re, const double* hop_im, const double* U, const double* V,
                                                  const double* ninj);
 
+/* The same for Model=SuperHubbardExtended (ModelSelector.h:76-80): the reference's on-the-fly product applies setJTermOffDiagonal as well
+ * (HubbardHelper.h:119-129, :282-330).  Those spin-flip terms move both species, so H is no longer H_up (x) 1 + 1 (x) H_down + D: with a
+ * non-zero jcoup every row re-derives its entries from the term list per product (k_asm_apply), storing nothing -- the literal
+ * counterpart of the reference's per-row walk, on one GPU.  jcoup == NULL (or all zero) is lpp_engine_setup_hubbard_onthefly_ext. */
+lpp_status lpp_engine_setup_hubbard_onthefly_super(lpp_engine* e, const lpp_comm* comm, int32_t nsites, int32_t nup, int32_t ndown,
+                                                   const double* hop_re, const double* hop_im, const double* U, const double* V,
+                                                   const double* ninj, const double* jcoup);
+
 /* On-device assembly of the S=1/2 Heisenberg Hamiltonian (Heisenberg.h:80-114,242-307) in the
  * BasisHeisenberg ordering (ascending words of fixed popcount, BasisHeisenberg.h:38-46). */
 lpp_status lpp_engine_assemble_heisenberg(lpp_engine* e, int32_t nsites, int32_t szPlusConst, const double* jpm,

@@ -86,6 +86,7 @@ SYMBOLS = {
     "lpp_engine_assemble_hubbard_ext": (C.c_int32, [_P, C.POINTER(Comm), C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P]),
     "lpp_engine_assemble_hubbard_super": (C.c_int32, [_P, C.POINTER(Comm), C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P]),
     "lpp_engine_setup_hubbard_onthefly_ext": (C.c_int32, [_P, C.POINTER(Comm), C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P]),
+    "lpp_engine_setup_hubbard_onthefly_super": (C.c_int32, [_P, C.POINTER(Comm), C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P]),
     "lpp_engine_assemble_heisenberg": (C.c_int32, [_P, C.c_int32, C.c_int32, _P, _P, _P, C.c_int32]),
     "lpp_engine_assemble_heisenberg_spin": (C.c_int32, [_P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, C.c_int32, _P, C.c_int32]),
     "lpp_engine_assemble_tj": (C.c_int32, [_P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P, C.c_int32]),

@@ -1121,6 +1121,102 @@ lpp_status lpp_engine_setup_hubbard_onthefly_ext(lpp_engine* e, const lpp_comm* 
 	return alloc_work(e);
 }
 
+
+lpp_status lpp_engine_setup_hubbard_onthefly_super(lpp_engine* e, const lpp_comm* comm, int32_t L, int32_t nup, int32_t ndown,
+                                                   const double* hop_re, const double* hop_im, const double* U, const double* V,
+                                                   const double* ninj, const double* jcoup)
+{
+	bool has_j = false;
+	if (jcoup && L >= 1 && L <= 31)
+		for (int k = 0; k < L * L; k++) has_j |= (jcoup[k] != 0);
+	if (!has_j) return lpp_engine_setup_hubbard_onthefly_ext(e, comm, L, nup, ndown, hop_re, hop_im, U, V, ninj);
+	if (!e || !hop_re || !U || !V || nup < 0 || ndown < 0 || nup > L || ndown > L) return fail(LPP_ERR_INVALID, "lpp_engine_setup_hubbard_onthefly_super: bad argument (1 <= L <= 31)");
+	if (comm && comm->nranks > 1) return fail(LPP_ERR_INVALID, "setup_hubbard_onthefly_super: the term-list product runs on one GPU (partition the stored matrix instead: lpp_engine_assemble_hubbard_super)");
+	const std::vector<uint64_t> comb = comb_table();
+	const int64_t n_up = (int64_t)binom(comb, L, nup), n_dn = (int64_t)binom(comb, L, ndown);
+	bool cplx_in = false;
+	if (hop_im)
+		for (int k = 0; k < L * L; k++) cplx_in |= (hop_im[k] != 0);
+	if (cplx_in && !e->is_complex) return fail(LPP_ERR_INVALID, "setup_hubbard_onthefly_super: complex hoppings need a c128 engine");
+	if (n_up <= 0 || n_dn <= 0) return fail(LPP_ERR_INVALID, "setup_hubbard_onthefly_super: empty Hilbert space");
+	HIP_TRY(hipSetDevice(e->cfg.device));
+	e->has_comm = false;
+	e->bind_scalars(e->scal_own);
+	free_csr(e->A_loc);
+	free_csr(e->A_rem);
+	drop_product(e);
+	KronState& K = e->kron;
+	std::vector<HostProc> hp;
+	hubbard_terms(L, hop_re, hop_im, hp);
+	super_terms(L, jcoup, hp);
+	std::vector<Proc> procs;
+	int nneg = 0;
+	lpp_status st = finish_procs(hp, procs, &nneg);
+	if (st != LPP_OK) return st;
+	// the device buffers live as long as the product does (K.terms_bufs, released by free_kron)
+	auto keep = [&](int slot, const void* src, size_t bytes) -> lpp_status {
+		HIP_TRY_MEM(hipMalloc(&K.terms_bufs[slot], std::max<size_t>(bytes, 8)));
+		if (bytes) HIP_TRY(hipMemcpyAsync(K.terms_bufs[slot], src, bytes, hipMemcpyHostToDevice, e->stream));
+		return LPP_OK;
+	};
+	if ((st = keep(0, procs.data(), sizeof(Proc) * procs.size())) != LPP_OK) return st;
+	if ((st = keep(1, comb.data(), sizeof(uint64_t) * comb.size())) != LPP_OK) return st;
+	if ((st = keep(2, U, sizeof(double) * L)) != LPP_OK) return st;
+	if ((st = keep(3, V, sizeof(double) * L)) != LPP_OK) return st;
+	if (ninj && (st = keep(4, ninj, sizeof(double) * L * L)) != LPP_OK) return st;
+	if ((st = keep(5, jcoup, sizeof(double) * L * L)) != LPP_OK) return st;
+	HIP_TRY(hipStreamSynchronize(e->stream)); // the host vectors above go out of scope
+	AsmParams* P = new AsmParams();
+	P->model = ASM_HUBBARD;
+	P->L = L;
+	P->nup = nup;
+	P->ndown = ndown;
+	P->nproc = (int)procs.size();
+	P->nneg = nneg;
+	P->n_up = n_up;
+	P->nrows_global = P->nloc = n_up * n_dn;
+	P->row0 = 0;
+	P->part = 0;
+	P->procs = (const Proc*)K.terms_bufs[0];
+	P->comb = (const uint64_t*)K.terms_bufs[1];
+	P->d0 = (const double*)K.terms_bufs[2];
+	P->d1 = (const double*)K.terms_bufs[3];
+	P->d2 = (const double*)K.terms_bufs[4];
+	P->d3 = (const double*)K.terms_bufs[5];
+	K.terms_params = P;
+	// entries of the CSR this product stands for (statistics only): one count pass
+	{
+		DevBuf len, sums, total;
+		const int64_t n = P->nloc + 1;
+		const int64_t nblk = (n + kScanChunk - 1) / kScanChunk;
+		HIP_TRY_MEM(hipMalloc(&len.p, sizeof(int64_t) * (size_t)n));
+		HIP_TRY(hipMemsetAsync(len.p, 0, sizeof(int64_t) * (size_t)n, e->stream));
+		HIP_TRY_MEM(hipMalloc(&sums.p, sizeof(int64_t) * (size_t)nblk));
+		HIP_TRY_MEM(hipMalloc(&total.p, sizeof(int64_t)));
+		const int nb = (int)std::max<int64_t>(1, std::min<int64_t>((P->nloc + kBlock - 1) / kBlock, 1 << 20));
+		k_asm_count<ASM_HUBBARD><<<nb, kBlock, 0, e->stream>>>(*P, (int64_t*)len.p);
+		k_scan_block_sums<<<(int)nblk, kBlock, 0, e->stream>>>((const int64_t*)len.p, n, (int64_t*)sums.p);
+		k_scan_sums<<<1, kBlock, 0, e->stream>>>((int64_t*)sums.p, nblk, (int64_t*)total.p);
+		int64_t nnz = 0;
+		HIP_TRY(hipMemcpyAsync(&nnz, total.p, sizeof(int64_t), hipMemcpyDeviceToHost, e->stream));
+		HIP_TRY(hipGetLastError());
+		HIP_TRY(hipStreamSynchronize(e->stream));
+		K.equiv_nnz = (double)nnz;
+	}
+	K.terms = true;
+	K.L = L;
+	K.n_up = n_up;
+	K.n_dn = n_dn;
+	K.id0 = 0;
+	K.nid = n_dn;
+	K.active = true;
+	e->n_local = e->n_global = n_up * n_dn;
+	e->row_start = 0;
+	e->active = false;
+	set_spmv_bytes(e);
+	return alloc_work(e);
+}
+
 } // extern "C"
 
 namespace lpp {
@@ -1146,12 +1242,25 @@ void free_kron(lpp_engine* e)
 	if (K.pk_dict) (void)hipFree(K.pk_dict);
 	for (double* q : { K.cdiag_up, K.cdiag_dn, K.cross })
 		if (q) (void)hipFree(q);
+	for (void* q : K.terms_bufs)
+		if (q) (void)hipFree(q);
+	delete (AsmParams*)K.terms_params;
 	K = KronState();
 }
 
 template <typename T> static int kron_launch_t(lpp_engine* e, const void* ywin, const void* ydown, void* x, double* partial, const EpiScale& sc, int part, int64_t b0, int64_t cnt)
 {
 	KronState& K = e->kron;
+	if (K.terms) { // term-list product (k_asm_apply): whole vector, one GPU
+		if (part != 0 || b0 != 0) return -1;
+		const AsmParams& P = *(const AsmParams*)K.terms_params;
+		const int nb = (int)std::max<int64_t>(1, std::min<int64_t>((P.nloc + kBlock - 1) / kBlock, kMaxPartials));
+		if (partial)
+			k_asm_apply<ASM_HUBBARD, T, true><<<nb, kBlock, 0, e->stream>>>(P, (const T*)ywin, (T*)x, partial, sc);
+		else
+			k_asm_apply<ASM_HUBBARD, T, false><<<nb, kBlock, 0, e->stream>>>(P, (const T*)ywin, (T*)x, nullptr, sc);
+		return partial ? nb : 0;
+	}
 	if (K.nid == 0 && part != 2) return 0;
 	if (cnt < 0) cnt = K.nid - b0; // default: every block of the slice
 	if (part != 2 && (b0 < 0 || b0 + cnt > K.nid)) return -1;

@@ -389,6 +389,60 @@ __global__ __launch_bounds__(kBlock) void k_asm_fill(AsmParams P, const int64_t*
 	}
 }
 
+
+// x = beta x + alpha H y with NOTHING stored: every row re-derives its entries from the term list, as the reference's on-the-fly
+// plug-in does (InternalProductOnTheFly.h:120-123 -> HubbardHelper::matrixVectorProduct, HubbardHelper.h:105-134: the same
+// setHoppingTerm / setJTermOffDiagonal walk per row and call).  One thread per row; O(terms) tests and an O(L) ranking per entry.
+// It serves what the structured matrix-free kernels (lpp_kron_kernels.h, lpp_pb_kernels.h) do not: terms that move both
+// species (Model=SuperHubbardExtended, HubbardHelper.h:282-330).
+template <int MODEL, typename T, bool DOT>
+__global__ __launch_bounds__(kBlock) void k_asm_apply(AsmParams P, const T* __restrict__ y, T* __restrict__ x, double* __restrict__ partial, EpiScale sc)
+{
+	__shared__ double smem[kBlock / 64];
+	double alpha, beta;
+	epi_coeffs(sc, alpha, beta);
+	double dot = 0.0;
+	for (int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x; r < P.nloc; r += (int64_t)gridDim.x * kBlock) {
+		const int64_t row = P.row0 + r;
+		const uint64_t ket = state_of<MODEL>(P, row);
+		const T yc = y[r];
+		T acc = VT<T>::zero();
+		{
+			const double d = diag_of<MODEL>(P, ket);
+			if constexpr (sizeof(T) == 16) {
+				acc.re = d * yc.re;
+				acc.im = d * yc.im;
+			} else {
+				acc = d * yc;
+			}
+		}
+		for (int p = 0; p < P.nproc; p++) {
+			const Proc& pr = P.procs[p];
+			uint64_t bra;
+			int dj;
+			if (!proc_bra<MODEL>(P, pr, ket, bra, dj)) continue;
+			const int64_t c = index_of<MODEL>(P, bra);
+			const int par = (__popcll(ket & pr.smask_ket) + __popcll(bra & pr.smask_bra) + pr.sign_const) & 1;
+			const double sg = par ? -1.0 : 1.0;
+			T v;
+			if constexpr (sizeof(T) == 16) {
+				v.re = pr.amp_re * sg;
+				v.im = pr.real_only ? 0.0 : pr.amp_im * sg;
+			} else {
+				v = pr.amp_re * sg;
+			}
+			VT<T>::mac(acc, v, y[c - P.row0]);
+		}
+		const T xv = epi_lin(beta, x[r], alpha, acc);
+		x[r] = xv;
+		if (DOT) dot += VT<T>::dot_re(yc, xv);
+	}
+	if (DOT) {
+		const double s = block_sum(dot, smem);
+		if (threadIdx.x == 0) partial[blockIdx.x] = s;
+	}
+}
+
 // ---------------------------------------------------------------------------------------------
 // Product-basis layout (lpp_pb_kernels.h): the diagonal of every row straight from the state, never through a CSR.
 // Pass 1 collects the distinct diagonal values (same open-addressing table as k_dict_collect), pass 2 writes one

@@ -677,6 +677,10 @@ void set_spmv_bytes(lpp_engine* e)
 		// matrix-free product: no matrix stream.  Vector-streaming model: x in/out and y once (3 N s) plus one
 		// coalesced pass over the source block of every connected down-configuration (H_down off-diagonals).
 		const KronState& K = e->kron;
+		if (K.terms) { // term-list product: the CSR it stands for, as the SURVEY 8(d) figure
+			e->spmv_bytes = K.equiv_nnz * (s + 4.0) + (N + 1.0) * 8.0 + 3.0 * N * s;
+			return;
+		}
 		const double avg_down = K.n_dn > 0 ? ((double)K.dn.nnz - (double)K.n_dn) / (double)K.n_dn : 0.0;
 		e->spmv_bytes = N * s * (3.0 + avg_down);
 		return;

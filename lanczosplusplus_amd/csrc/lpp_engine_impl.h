@@ -87,6 +87,11 @@ struct KronState {
 	double* pk_dict = nullptr;
 	int pk_spb = 0;
 	int pk_nchunk = 1, pk_cw = 0; // LDS window pieces of the packed H_up (N_up beyond LDS: see k_spmv_kron_chunked)
+	// term-list form (k_asm_apply): nothing but the term list and the couplings live on the device; every row re-derives its
+	// entries per product.  Serves Model=SuperHubbardExtended, whose spin-flip terms move both species.
+	bool terms = false;
+	void* terms_params = nullptr; // AsmParams (host copy; its pointers are the device buffers below)
+	void* terms_bufs[8] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
 };
 
 // product-basis stored matrix  H = 1 (x) T + C (x) 1 + D  (lpp_pb_kernels.h): everything the 5.8e9-entry CSR of BASELINE

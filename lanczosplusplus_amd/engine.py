@@ -123,8 +123,10 @@ class LanczosEngine:
         jc = None if jcoup is None else _mat(jcoup, L)
         check(self._lib.lpp_engine_assemble_hubbard_super(self._h, cs, L, nup, ndown, _vp(hr), _vp(hi), _vp(U), _vp(V), _vp(nj), _vp(jc)))
 
-    def setup_hubbard_onthefly(self, L, nup, ndown, hop, U, V=None, comm=None, ninj=None):
-        """Matrix-free Hubbard product (InternalProductOnTheFly semantics): nothing but H_up and H_down is stored."""
+    def setup_hubbard_onthefly(self, L, nup, ndown, hop, U, V=None, comm=None, ninj=None, jcoup=None):
+        """Matrix-free Hubbard product (InternalProductOnTheFly semantics): nothing but H_up and H_down is stored.
+        jcoup (Model=SuperHubbardExtended): the spin-flip terms move both species; the product then re-derives every row from the
+        term list (lpp_engine_setup_hubbard_onthefly_super)."""
         hop = np.asarray(hop).reshape(L, L)
         hr = _mat(hop.real, L)
         hi = _mat(hop.imag, L) if np.iscomplexobj(hop) else None
@@ -133,7 +135,8 @@ class LanczosEngine:
         nj = None if ninj is None else _mat(ninj, L)
         self._comm_keepalive = comm
         cs = C.byref(comm.struct) if comm is not None else None
-        check(self._lib.lpp_engine_setup_hubbard_onthefly_ext(self._h, cs, L, nup, ndown, _vp(hr), _vp(hi), _vp(U), _vp(V), _vp(nj)))
+        jc = None if jcoup is None else _mat(jcoup, L)
+        check(self._lib.lpp_engine_setup_hubbard_onthefly_super(self._h, cs, L, nup, ndown, _vp(hr), _vp(hi), _vp(U), _vp(V), _vp(nj), _vp(jc)))
 
     def assemble_heisenberg(self, L, szPlusConst, jpm, jzz, field=None, twiceS=1, anisotropy=None):
         """Heisenberg.h:80-114 on the device; twiceS > 1 or an anisotropy take the any-spin assembler (digit basis)."""

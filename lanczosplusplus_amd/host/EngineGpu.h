@@ -188,7 +188,7 @@ private:
 };
 
 // x += H y without a stored matrix: SolverOptions=InternalProductOnTheFly (src/Engine/InternalProductOnTheFly.h:93-133).
-// In scope for HubbardOneBand only (the reference's threaded HubbardHelper::matrixVectorProduct, HubbardHelper.h:105-134).
+// In scope for the HubbardOneOrbital family (the reference's threaded HubbardHelper::matrixVectorProduct, HubbardHelper.h:105-134).
 template <typename ModelType_, typename SpecialSymmetryType_> class InternalProductOnTheFly {
 public:
 	typedef ModelType_ ModelType;
@@ -205,7 +205,6 @@ public:
 	{
 		const HubbardOneOrbital<ComplexOrRealType>* hub = dynamic_cast<const HubbardOneOrbital<ComplexOrRealType>*>(&model);
 		if (!hub) throw std::runtime_error("InternalProductOnTheFly: only Model=HubbardOneBand / HubbardOneBandExtended have an on-the-fly product\n");
-		if (hub->jCoupling()) throw std::runtime_error("InternalProductOnTheFly: the spin-flip terms of Model=SuperHubbardExtended are not in the matrix-free product\n");
 		const SizeType n = model.geometry().numberOfSites();
 		std::vector<double> hr(n * n), hi(n * n);
 		for (SizeType k = 0; k < n * n; k++) {
@@ -213,9 +212,11 @@ public:
 			hi[k] = LppHost::imag(hub->hoppings()[k]);
 		}
 		const typename BasisType::PairIntType parts = model.basis().parts();
-		lppCheck(lpp_engine_setup_hubbard_onthefly_ext(engine_.get(), nullptr, (int32_t)n, parts.first, parts.second, hr.data(),
-		                                               sizeof(ComplexOrRealType) == 16 ? hi.data() : nullptr, hub->hubbardU.data(), hub->potentialEffective.data(),
-		                                               hub->coulombCoupling()));
+		// Model=SuperHubbardExtended: the reference's on-the-fly lambda applies setJTermOffDiagonal too (HubbardHelper.h:119-129); the engine
+		// then re-derives every row from the term list per product (lpp_engine_setup_hubbard_onthefly_super)
+		lppCheck(lpp_engine_setup_hubbard_onthefly_super(engine_.get(), nullptr, (int32_t)n, parts.first, parts.second, hr.data(),
+		                                                 sizeof(ComplexOrRealType) == 16 ? hi.data() : nullptr, hub->hubbardU.data(), hub->potentialEffective.data(),
+		                                                 hub->coulombCoupling(), hub->jCoupling()));
 	}
 	SizeType rows() const { return rows_; }
 	void matrixVectorProduct(VectorType& x, const VectorType& y) const

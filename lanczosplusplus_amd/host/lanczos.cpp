@@ -142,7 +142,7 @@ static int mainPartitioned(LppHost::InputReadable& io, int precision, bool onthe
 	char id[LPP_RCCL_ID_BYTES];
 	// everything that can throw on ONE rank comes before the communicator exists: afterwards a rank that leaves alone would
 	// strand its peers inside a collective
-	if (onthefly && hub->jCoupling()) throw std::runtime_error("lanczos -P: the matrix-free product has no spin-flip terms (Model=SuperHubbardExtended): use the stored engine\n");
+	if (onthefly && hub->jCoupling()) throw std::runtime_error("lanczos -P: the term-list product of Model=SuperHubbardExtended runs on one GPU: use the stored engine (SolverOptions=none) with -P\n");
 	shareUniqueId(id, rank, world);
 	lpp_config cfg;
 	lpp_config_default(&cfg);

@@ -935,6 +935,17 @@ def test_super_hubbard_extended_and_kane_mele(case):
         assert rel(e.matrixVectorProduct(x0.copy(), y), xo) < SPMV_TOL
         eg, _, st = e.lanczos(1, want_vectors=False)
         assert abs(eg[0] - eo[0]) <= E_TOL * abs(eo[0]) and st["steps"] == so
+        # SolverOptions=InternalProductOnTheFly for the same model: the reference's lambda applies setJTermOffDiagonal too
+        # (HubbardHelper.h:119-129); nothing is stored, every row re-derives its entries from the term list (k_asm_apply)
+        e.setup_hubbard_onthefly(L, nup, ndown, hop, U, V, ninj=nj, jcoup=jc)
+        assert e.stats()["nnz"] == A.nnz
+        with pytest.raises(LppError):
+            e.get_csr()
+        assert rel(e.matrixVectorProduct(x0.copy(), y), xo) < SPMV_TOL
+        eg, zg, st = e.lanczos(1, want_vectors=True)
+        assert abs(eg[0] - eo[0]) <= E_TOL * abs(eo[0]) and st["steps"] == so
+        r = oracle.spmv_acc(A, np.zeros_like(zg[0]), zg[0]) - eg[0] * zg[0]
+        assert np.linalg.norm(r) < 1e-5
 
 
 def test_recurrence_started_from_an_eigenvector(monkeypatch):

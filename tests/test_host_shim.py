@@ -66,7 +66,8 @@ def test_host_assembly_bit_exact(name, tmp_path):
 @pytest.mark.parametrize("name", ["input0.inp", "hubbard_ladder_2x4.inp", "hubbard_ladder_2x4_onthefly.inp", "heisenberg_chain_L12.inp",
                                   "tj_chain_L8_complex.inp", "hubbard_chain_L12.inp", "hubbard_extended_2x4.inp",
                                   "hubbard_extended_2x4_onthefly.inp", "heisenberg_spin1_L8.inp", "heisenberg_spin32_L6.inp",
-                                  "super_hubbard_2x4.inp", "kane_mele_hubbard_chain_L8.inp"])
+                                  "super_hubbard_2x4.inp", "super_hubbard_2x4_onthefly.inp", "kane_mele_hubbard_chain_L8.inp",
+                                  "hubbard_ladder_2x4_potentialT.inp"])
 def test_lanczos_driver_prints_reference_energy_line(name):
     # hubbard_chain_L12.inp is BASELINE config 1 (853,776 states): host assembly, upload with the N_up = 924 row-block
     # hint, i.e. the LDS-window kernel with the block template on an UPLOADED matrix
