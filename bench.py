@@ -267,8 +267,9 @@ def generic_csr_leg(name, is_complex, device, iters=10):
     """x += H y with the plain 12-byte-per-entry layout (no value dictionary, no shared offsets): achieved = SURVEY 8(d)
     algorithmic bytes / HIP-event time of back-to-back launches"""
     from lanczosplusplus_amd import LanczosEngine
-    saved = {k: os.environ.get(k) for k in ("LPP_COMPRESS_VALUES", "LPP_SHARED_OFFSETS", "LPP_PRODUCT_LAYOUT")}
-    os.environ.update(LPP_COMPRESS_VALUES="0", LPP_SHARED_OFFSETS="0", LPP_PRODUCT_LAYOUT="0")
+    saved = {k: os.environ.get(k) for k in ("LPP_COMPRESS_VALUES", "LPP_SHARED_OFFSETS", "LPP_PRODUCT_LAYOUT", "LPP_LOCAL16", "LPP_SPLIT_PANEL")}
+    os.environ.update(LPP_COMPRESS_VALUES="0", LPP_SHARED_OFFSETS="0", LPP_PRODUCT_LAYOUT="0", LPP_LOCAL16="0")  # 8-byte values, 32-bit columns
+    os.environ.setdefault("LPP_SPLIT_PANEL", "1")  # entries that leave the row blocks in panel-major row order (same bytes per entry)
     try:
         with LanczosEngine(dtype="c128" if is_complex else "f64", device=device, max_steps=8, eps=0.0, save_vectors=0, compress_values=0) as e:
             assemble(e, name)
@@ -281,7 +282,10 @@ def generic_csr_leg(name, is_complex, device, iters=10):
             else:
                 os.environ[k] = v
     gbs = (st["spmv_bytes"] / 1e9) / (ms / 1e3)
-    return {"kernel": {1: "k_spmv_rowgroup", 2: "k_spmv_sliced", 3: "k_spmv_window"}.get(lay["kernel"]), "layout": "plain values and 32-bit columns (12 B per f64 entry)",
+    kern = {1: "k_spmv_rowgroup", 2: "k_spmv_sliced", 3: "k_spmv_window"}.get(lay["kernel"])
+    if lay.get("split_panel"):
+        kern += " (entries inside the row blocks, LDS window) + k_spmv_sliced (entries that leave them, rows panel-major: gathers from one XCD's L2)"
+    return {"kernel": kern, "layout": "plain values and 32-bit columns (12 B per f64 entry)" + ("; split-panel row order for the leaving entries (+4 B per row)" if lay.get("split_panel") else ""),
             "spmv_ms": ms, "algorithmic_bytes_per_launch": st["spmv_bytes"], "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": gbs / HBM_PEAK_GBS, "target_frac": 0.60, "resident_GB": round(lay["resident_bytes"] / 1e9, 2), "launches_timed": iters}
 

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define LPP_ABI_VERSION 3 /* 2: lpp_layout.stream_bytes, lpp_pb_pack_template(bank_ways), set_solver / stream / _ext / _spin entry points; 3: lpp_layout.pieces / coupling_parts / diagonal_plain / chained_step, lpp_stats.reortho_* */
+#define LPP_ABI_VERSION 3 /* 2: lpp_layout.stream_bytes, lpp_pb_pack_template(bank_ways), set_solver / stream / _ext / _spin entry points; 3: lpp_layout.pieces / coupling_parts / diagonal_plain / chained_step / split_panel, lpp_stats.reortho_* */
 
 typedef int32_t lpp_status;
 enum {
@@ -105,6 +105,10 @@ typedef struct lpp_layout {
 	int32_t diagonal_plain; /* product-basis layout: 1 = the diagonal is a plain f64 stream (more than 256 distinct values), 0 = one code per row */
 	int32_t chained_step; /* product-basis layout: 1 = a scale-free Lanczos step is the chained pair of launches (k_pb_up<CHAIN> + k_pb_down<RMW>),
 	                         0 = product kernels + one streaming pass that also applies the recurrence update */
+	int32_t split_panel; /* general layout: > 0 = the entries that leave the row blocks are held apart in that many matrices (by source block
+	                        range), rows in panel-major order (16 positions of every block, then the next 16), each applied by a launch of
+	                        its own that gathers from L2 */
+	int32_t reserved;
 } lpp_layout;
 
 /* Communicator for the 1-D row-partitioned multi-GPU path.  The engine never

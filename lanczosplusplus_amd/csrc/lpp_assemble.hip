@@ -1358,6 +1358,7 @@ template <typename T> static int kron_launch_t(lpp_engine* e, const void* ywin, 
 	a.up.tw = nullptr;
 	a.up.tw_off = nullptr;
 	a.up.tw_len = nullptr;
+	a.up.rowmap = nullptr;
 	a.n_up = K.n_up;
 	a.id0 = K.id0 + b0;
 	a.nid = cnt;

@@ -48,6 +48,11 @@ void free_csr(DevCsr& A)
 	if (A.tw) (void)hipFree(A.tw);
 	if (A.tw_off) (void)hipFree(A.tw_off);
 	if (A.tw_len) (void)hipFree(A.tw_len);
+	if (A.out_part) {
+		for (int q = 0; q < A.split_parts; q++) free_csr(A.out_part[q]);
+		delete[] A.out_part;
+	}
+	if (A.out_rowmap) (void)hipFree(A.out_rowmap);
 	A = DevCsr();
 }
 
@@ -109,6 +114,7 @@ template <typename T> static int spmv_launch_t(lpp_engine* e, const DevCsr& A, c
 		a.tw = A.tw;
 		a.tw_off = A.tw_off;
 		a.tw_len = A.tw_len;
+		a.rowmap = nullptr;
 		const bool dot = partial != nullptr;
 		const bool u8 = (e->k2_variant & 4) != 0;
 		const int sel = (dot ? 4 : 0) | (A.coded ? 2 : 0) | (u8 ? 1 : 0);
@@ -168,8 +174,58 @@ template <typename T> static int spmv_launch_t(lpp_engine* e, const DevCsr& A, c
 	return partial ? nb : 0;
 }
 
+// the part of a split-panel matrix that leaves the row blocks: k_spmv_sliced over the panel-major rows, one contiguous eighth
+// of the panels per XCD (so every panel is gathered from ONE L2), x and ydot through the row map
+template <typename T> static int spmv_launch_out_t(lpp_engine* e, const DevCsr& A, const int32_t* rowmap, const void* src, void* x, const void* ydot, double* partial, const EpiScale& sc)
+{
+	if (A.nrows == 0) return 0;
+	SlicedArgs<T> a {};
+	a.g = A.geom;
+	a.slice_ptr = A.slice_ptr;
+	a.row_len = A.row_len;
+	a.col = A.scol;
+	a.val = (const T*)A.sval;
+	a.codes = A.codes;
+	a.code_ptr = A.code_ptr;
+	a.dict = A.dict;
+	a.src = (const T*)src;
+	a.x = (T*)x;
+	a.ydot = (const T*)ydot;
+	a.partial = partial;
+	a.xcd_map = 1;
+	a.sc = sc;
+	a.rowmap = rowmap;
+	// two resident workgroups per CU walk the panels together (measured at BASELINE config 2, scripts/experiments/r03_generic_ab.sh:
+	// 512 workgroups 9.85 ms and 60.7 GB of fabric reads, 2048 11.1 ms / 66.1 GB, 4096 11.3 ms / 66.2 GB)
+	const int64_t need = (A.geom.nslices + (kBlock / 64) - 1) / (kBlock / 64);
+	int nb = (int)std::max<int64_t>(1, std::min<int64_t>(need, std::min<int64_t>(e->spmv_max_blocks, 2 * (int64_t)e->num_cus)));
+	if (nb >= 8) nb &= ~7;
+	hipStream_t st = e->stream;
+	const int sel = (partial ? 2 : 0) | (A.coded ? 1 : 0);
+	switch (sel) {
+	case 0: k_spmv_sliced<T, false, false, 8><<<nb, kBlock, 0, st>>>(a); break;
+	case 1: k_spmv_sliced<T, false, true, 8><<<nb, kBlock, 0, st>>>(a); break;
+	case 2: k_spmv_sliced<T, true, false, 8><<<nb, kBlock, 0, st>>>(a); break;
+	default: k_spmv_sliced<T, true, true, 8><<<nb, kBlock, 0, st>>>(a); break;
+	}
+	return partial ? nb : 0;
+}
+
 int spmv_launch(lpp_engine* e, const DevCsr& A, const void* src, void* x, const void* ydot, double* partial, const EpiScale& sc)
 {
+	if (A.out_part) { // split-panel layout: the in-block entries first (x = beta x + alpha A_in src), then the leaving ones on top
+		if (e->is_complex) spmv_launch_t<cplx>(e, A, src, x, nullptr, nullptr, sc);
+		else spmv_launch_t<double>(e, A, src, x, nullptr, nullptr, sc);
+		EpiScale sc2 = sc;
+		sc2.beta_one = 1;
+		int np = 0;
+		for (int q = 0; q < A.split_parts; q++) { // the dot rides in the last launch: x is complete there
+			const bool last = q == A.split_parts - 1;
+			np = e->is_complex ? spmv_launch_out_t<cplx>(e, A.out_part[q], A.out_rowmap, src, x, last ? ydot : nullptr, last ? partial : nullptr, sc2)
+			                   : spmv_launch_out_t<double>(e, A.out_part[q], A.out_rowmap, src, x, last ? ydot : nullptr, last ? partial : nullptr, sc2);
+		}
+		return np;
+	}
 	return e->is_complex ? spmv_launch_t<cplx>(e, A, src, x, ydot, partial, sc) : spmv_launch_t<double>(e, A, src, x, ydot, partial, sc);
 }
 
@@ -584,6 +640,131 @@ template <typename T> static int64_t detect_row_block_t(lpp_engine* e, const Dev
 	return G;
 }
 
+// Split-panel layout (k_split_count): A keeps the entries inside its row blocks, *A.out_part takes the others in panel-major row
+// order.  Only for plain-format matrices (shared offsets off: they take the leaving entries out of the rows in their own way),
+// rows sorted by column, whole blocks, and a leaving part worth a second launch (>= 20 % of the entries).
+template <typename T> static lpp_status split_panel_t(lpp_engine* e, DevCsr& A, int64_t B, bool* did)
+{
+	*did = false;
+	const int64_t nb = A.nrows / B;
+	if (nb < 64 || nb * B != A.nrows || !A.col || !A.val || A.nnz == 0) return LPP_OK;
+	hipStream_t st = e->stream;
+	if (!A.known_sorted) {
+		int* flag = nullptr;
+		HIP_TRY_MEM(hipMalloc(&flag, sizeof(int)));
+		(void)hipMemsetAsync(flag, 0, sizeof(int), st);
+		k_rows_sorted<<<(int)((A.nrows + 255) / 256), 256, 0, st>>>(A.nrows, A.rowptr, A.col, flag);
+		int h = 1;
+		hipError_t e1 = hipMemcpyAsync(&h, flag, sizeof(int), hipMemcpyDeviceToHost, st);
+		hipError_t e2 = hipStreamSynchronize(st);
+		(void)hipFree(flag);
+		if (e1 != hipSuccess || e2 != hipSuccess) return fail(LPP_ERR_HIP, "split-panel layout: sortedness check failed");
+		if (h) return LPP_OK;
+	}
+	StageTimer tm("split-panel layout");
+	// parts by source block range: what one part gathers from while a panel is walked -- two 128-byte lines per source block
+	// when the rows are not line-aligned (B not a multiple of 16), one when they are -- is kept near 1.7 MB
+	SplitParams P;
+	P.nrows = A.nrows;
+	P.B = B;
+	P.nb = nb;
+	const size_t foot = (size_t)nb * ((B & 15) ? 256 : 128);
+	P.nparts = (int)std::max<size_t>(1, std::min<size_t>(kSplitMaxParts, (foot + ((size_t)1700 << 10) - 1) / ((size_t)1700 << 10)));
+	P.nparts = 1; // measured: parts do not raise the L2 hit rate here (2 parts: 6.0 + 6.2 ms and 32 + 34 GB against 9.9 ms and 61 GB in one)
+	(void)foot;
+	if (const char* s2 = getenv("LPP_SPLIT_PARTS")) P.nparts = std::max(1, std::min(atoi(s2), kSplitMaxParts));
+	P.pblk = (nb + P.nparts - 1) / P.nparts;
+	const int nbk = (int)((A.nrows + 255) / 256);
+	DevCsr* O = new DevCsr[P.nparts];
+	struct Guard {
+		DevCsr*& o;
+		int n;
+		int64_t* rpi = nullptr;
+		int32_t* ci = nullptr;
+		void* vi = nullptr;
+		int32_t* map = nullptr;
+		void* ptrs = nullptr;
+		~Guard()
+		{
+			if (o) {
+				for (int q = 0; q < n; q++) free_csr(o[q]);
+				delete[] o;
+			}
+			for (void* p : { (void*)rpi, (void*)ci, vi, (void*)map, ptrs })
+				if (p) (void)hipFree(p);
+		}
+	} g { O, P.nparts };
+	HIP_TRY_MEM(hipMalloc(&g.rpi, sizeof(int64_t) * (size_t)(A.nrows + 1)));
+	HIP_TRY_MEM(hipMalloc(&g.map, sizeof(int32_t) * (size_t)A.nrows));
+	HIP_TRY(hipMemsetAsync(g.rpi, 0, sizeof(int64_t) * (size_t)(A.nrows + 1), st));
+	int64_t* lens[kSplitMaxParts] = { nullptr, nullptr, nullptr, nullptr };
+	for (int q = 0; q < P.nparts; q++) {
+		O[q].nrows = A.nrows;
+		O[q].owned = true;
+		O[q].known_sorted = true;
+		O[q].no_dia = true;
+		HIP_TRY_MEM(hipMalloc(&O[q].rowptr, sizeof(int64_t) * (size_t)(A.nrows + 1)));
+		HIP_TRY(hipMemsetAsync(O[q].rowptr, 0, sizeof(int64_t) * (size_t)(A.nrows + 1), st));
+		lens[q] = O[q].rowptr;
+	}
+	HIP_TRY_MEM(hipMalloc(&g.ptrs, sizeof(lens)));
+	HIP_TRY(hipMemcpyAsync(g.ptrs, lens, sizeof(lens), hipMemcpyHostToDevice, st));
+	k_split_count<<<nbk, 256, 0, st>>>(P, A.rowptr, A.col, g.rpi, (int64_t* const*)g.ptrs, g.map);
+	int64_t nin = 0, nout = 0;
+	lpp_status rc = scan_exclusive(e, g.rpi, A.nrows + 1, &nin);
+	if (rc != LPP_OK) return rc;
+	for (int q = 0; q < P.nparts; q++) {
+		int64_t n = 0;
+		rc = scan_exclusive(e, O[q].rowptr, A.nrows + 1, &n);
+		if (rc != LPP_OK) return rc;
+		O[q].nnz = n;
+		nout += n;
+	}
+	if (nin + nout != A.nnz) return fail(LPP_ERR_HIP, "split-panel layout: entry count mismatch");
+	if ((double)nout < 0.20 * (double)A.nnz) return LPP_OK; // not worth the extra launches
+	HIP_TRY_MEM(hipMalloc(&g.ci, sizeof(int32_t) * (size_t)std::max<int64_t>(nin, 1)));
+	HIP_TRY_MEM(hipMalloc(&g.vi, sizeof(T) * (size_t)std::max<int64_t>(nin, 1)));
+	SplitOut SO {};
+	for (int q = 0; q < P.nparts; q++) {
+		HIP_TRY_MEM(hipMalloc(&O[q].col, sizeof(int32_t) * (size_t)std::max<int64_t>(O[q].nnz, 1)));
+		HIP_TRY_MEM(hipMalloc(&O[q].val, sizeof(T) * (size_t)std::max<int64_t>(O[q].nnz, 1)));
+		SO.rp[q] = O[q].rowptr;
+		SO.col[q] = O[q].col;
+		SO.val[q] = O[q].val;
+	}
+	k_split_fill<T><<<nbk, 256, 0, st>>>(P, A.rowptr, A.col, (const T*)A.val, g.rpi, g.ci, (T*)g.vi, SO);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipStreamSynchronize(st));
+	// the in-block part replaces the matrix in A
+	(void)hipFree(A.rowptr);
+	(void)hipFree(A.col);
+	(void)hipFree(A.val);
+	A.rowptr = g.rpi;
+	A.col = g.ci;
+	A.val = g.vi;
+	g.rpi = nullptr;
+	g.ci = nullptr;
+	g.vi = nullptr;
+	A.nnz = nin;
+	A.known_sorted = true;
+	// the leaving parts: sliced layout over ALL rows in panel-major order (one "block" = the whole matrix)
+	for (int q = 0; q < P.nparts; q++) {
+		rc = finalize_csr(e, O[q], true, LPP_SPMV_SLICED, 0);
+		if (rc != LPP_OK) return rc;
+	}
+	A.out_part = O;
+	A.split_parts = P.nparts;
+	g.o = nullptr;
+	O = nullptr;
+	A.out_rowmap = g.map;
+	g.map = nullptr;
+	A.split_B = B;
+	A.split_nb = nb;
+	A.split_pblk = P.pblk;
+	*did = true;
+	return LPP_OK;
+}
+
 // Choose the SpMV kernel and build its layout.  hint_block (rows) is the basis' natural block
 // (N_up for the Hubbard product basis): when a whole number of such blocks fits the LDS window,
 // the window kernel serves every in-block gather (diagonal + up-hops) from LDS.
@@ -648,6 +829,22 @@ lpp_status finalize_csr(lpp_engine* e, DevCsr& A, bool allow_drop_plain, int for
 	if ((mode == LPP_SPMV_SLICED || mode == LPP_SPMV_WINDOW) && A.nrows > 0) {
 		const int64_t B = force_block > 0 ? force_block : ((mode == LPP_SPMV_WINDOW) ? win_rows : A.nrows);
 		const bool win = (mode == LPP_SPMV_WINDOW);
+		// plain-format matrix with a basis block: the entries that leave the row blocks go panel-major (split_panel_t)
+		{
+			int want_dia = A.no_dia ? 0 : 1;
+			if (const char* s2 = getenv("LPP_SHARED_OFFSETS")) want_dia = A.no_dia ? 0 : atoi(s2);
+			// Opt-in (LPP_SPLIT_PANEL=1; bench.py's plain-format leg takes it).  Measured at BASELINE config 2: the two launches take
+			// 8.1 + 9.9 = 17.9 ms against 18.7 ms for the one-kernel form -- the leaving entries' gathers still miss L2 half of the
+			// time (rows are not 128-byte aligned in the general layout: a panel of 16 positions is two lines per source block, and
+			// 42 MB of columns and values stream through the same L2 per panel), so the fabric reads only fall from 102 to 106 -> see
+			// DESIGN.md section 5; the product-basis layout (pitched rows, lists in LDS) is what removes them
+			const bool off = !(getenv("LPP_SPLIT_PANEL") && atoi(getenv("LPP_SPLIT_PANEL")) != 0);
+			if (win && !force_mode && !want_dia && !off && A.hint_block > 0 && B == A.hint_block && !A.out_part && A.src_elems == 0) {
+				bool did = false;
+				lpp_status st2 = e->is_complex ? split_panel_t<cplx>(e, A, B, &did) : split_panel_t<double>(e, A, B, &did);
+				if (st2 != LPP_OK) return st2;
+			}
+		}
 		StageTimer tm("sliced layout (total)");
 		lpp_status st = e->is_complex ? build_sliced_t<cplx>(e, A, B, win) : build_sliced_t<double>(e, A, B, win);
 		if (st != LPP_OK) return st;
@@ -685,7 +882,7 @@ void set_spmv_bytes(lpp_engine* e)
 		e->spmv_bytes = N * s * (3.0 + avg_down);
 		return;
 	}
-	const double Z = (double)(e->A_loc.nnz + e->A_rem.nnz);
+	const double Z = (double)(e->A_loc.nnz + e->A_loc.out_nnz() + e->A_rem.nnz);
 	e->spmv_bytes = Z * (s + 4.0) + (N + 1.0) * 8.0 + 3.0 * N * s;
 }
 
@@ -1038,26 +1235,75 @@ lpp_status lpp_engine_get_csr(lpp_engine* e, int32_t which, int64_t* nrows, int6
 		HIP_TRY(hipSetDevice(e->cfg.device));
 		return pb_get_csr(e, rowptr, colind, values);
 	}
+	const int64_t nnz_all = A.nnz + A.out_nnz();
 	if (nrows) *nrows = A.nrows;
-	if (nnz) *nnz = A.nnz;
+	if (nnz) *nnz = nnz_all;
 	if (!rowptr && !colind && !values) return LPP_OK;
 	if (e->kron.active) return fail(LPP_ERR_STATE, "lpp_engine_get_csr: the matrix-free engine stores no CSR");
 	if (!A.rowptr) return fail(LPP_ERR_STATE, "lpp_engine_get_csr: no matrix");
 	HIP_TRY(hipSetDevice(e->cfg.device));
 	HIP_TRY(hipStreamSynchronize(e->stream));
+	// plain (col, val) arrays of one stored CSR on the device: the resident ones, or rebuilt from the sliced layout
+	auto plain_of = [&](const DevCsr& X, DevScratch& scol, DevScratch& sval, const int32_t*& dcol, const void*& dval) -> lpp_status {
+		dcol = X.col;
+		dval = X.val;
+		if (X.nnz == 0 || (dcol && dval)) return LPP_OK;
+		if (!X.sliced) return fail(LPP_ERR_STATE, "lpp_engine_get_csr: matrix arrays missing");
+		lpp_status st = e->is_complex ? rebuild_csr_t<cplx>(e, X, scol, sval) : rebuild_csr_t<double>(e, X, scol, sval);
+		if (st != LPP_OK) return st;
+		dcol = (const int32_t*)scol.p;
+		dval = sval.p;
+		return LPP_OK;
+	};
+	if (A.out_part) {
+		// split-panel layout: the in-block CSR and the panel-major CSRs of the leaving entries, merged back row by row
+		SplitParams P;
+		P.nrows = A.nrows;
+		P.B = A.split_B;
+		P.nb = A.split_nb;
+		P.nparts = A.split_parts;
+		P.pblk = A.split_pblk;
+		DevScratch ic, iv, oc[kSplitMaxParts], ov[kSplitMaxParts], mrp, mc, mv;
+		const int32_t* dic = nullptr;
+		const void* div = nullptr;
+		lpp_status st = plain_of(A, ic, iv, dic, div);
+		if (st != LPP_OK) return st;
+		SplitOut SO {};
+		for (int q = 0; q < A.split_parts; q++) {
+			const int32_t* dc = nullptr;
+			const void* dv = nullptr;
+			if ((st = plain_of(A.out_part[q], oc[q], ov[q], dc, dv)) != LPP_OK) return st;
+			SO.rp[q] = A.out_part[q].rowptr;
+			SO.col[q] = (int32_t*)dc;
+			SO.val[q] = (void*)dv;
+		}
+		if (mrp.alloc(sizeof(int64_t) * (size_t)(A.nrows + 1)) != hipSuccess || mc.alloc(sizeof(int32_t) * (size_t)nnz_all) != hipSuccess
+		    || mv.alloc(e->esz * (size_t)nnz_all) != hipSuccess)
+			return fail(LPP_ERR_NOMEM, "lpp_engine_get_csr: scratch allocation failed");
+		HIP_TRY(hipMemsetAsync(mrp.p, 0, sizeof(int64_t) * (size_t)(A.nrows + 1), e->stream));
+		const int nbk = (int)((A.nrows + 255) / 256);
+		k_split_lengths<<<nbk, 256, 0, e->stream>>>(P, A.rowptr, SO, (int64_t*)mrp.p);
+		int64_t tot = 0;
+		if ((st = scan_exclusive(e, (int64_t*)mrp.p, A.nrows + 1, &tot)) != LPP_OK) return st;
+		if (tot != nnz_all) return fail(LPP_ERR_HIP, "lpp_engine_get_csr: split-panel merge lost entries");
+		if (e->is_complex)
+			k_split_merge<cplx><<<nbk, 256, 0, e->stream>>>(P, A.rowptr, dic, (const cplx*)div, SO, (const int64_t*)mrp.p, (int32_t*)mc.p, (cplx*)mv.p);
+		else
+			k_split_merge<double><<<nbk, 256, 0, e->stream>>>(P, A.rowptr, dic, (const double*)div, SO, (const int64_t*)mrp.p, (int32_t*)mc.p, (double*)mv.p);
+		HIP_TRY(hipGetLastError());
+		HIP_TRY(hipStreamSynchronize(e->stream));
+		if (rowptr) HIP_TRY(hipMemcpy(rowptr, mrp.p, sizeof(int64_t) * (size_t)(A.nrows + 1), hipMemcpyDeviceToHost));
+		if (colind) HIP_TRY(hipMemcpy(colind, mc.p, sizeof(int32_t) * (size_t)nnz_all, hipMemcpyDeviceToHost));
+		if (values) HIP_TRY(hipMemcpy(values, mv.p, e->esz * (size_t)nnz_all, hipMemcpyDeviceToHost));
+		return LPP_OK;
+	}
 	if (rowptr) HIP_TRY(hipMemcpy(rowptr, A.rowptr, sizeof(int64_t) * (size_t)(A.nrows + 1), hipMemcpyDeviceToHost));
 	if ((colind || values) && A.nnz) {
-		const int32_t* dcol = A.col;
-		const void* dval = A.val;
 		DevScratch scol, sval;
-		if (!dcol || !dval) {
-			// only the sliced layout is resident: rebuild CSR order in scratch buffers
-			if (!A.sliced) return fail(LPP_ERR_STATE, "lpp_engine_get_csr: matrix arrays missing");
-			lpp_status st = e->is_complex ? rebuild_csr_t<cplx>(e, A, scol, sval) : rebuild_csr_t<double>(e, A, scol, sval);
-			if (st != LPP_OK) return st;
-			dcol = (const int32_t*)scol.p;
-			dval = sval.p;
-		}
+		const int32_t* dcol = nullptr;
+		const void* dval = nullptr;
+		lpp_status st = plain_of(A, scol, sval, dcol, dval);
+		if (st != LPP_OK) return st;
 		if (colind) HIP_TRY(hipMemcpy(colind, dcol, sizeof(int32_t) * (size_t)A.nnz, hipMemcpyDeviceToHost));
 		if (values) HIP_TRY(hipMemcpy(values, dval, e->esz * (size_t)A.nnz, hipMemcpyDeviceToHost));
 	}
@@ -1208,6 +1454,19 @@ lpp_status lpp_engine_get_layout(lpp_engine* e, int32_t which, lpp_layout* out)
 	} else {
 		stream = bytes; // row-group kernel: row pointers, columns and values are all read
 	}
+	if (A.out_part) { // split-panel layout: the leaving entries as further (sliced, panel-major) matrices + the row map
+		for (int q = 0; q < A.split_parts; q++) {
+			const DevCsr& O = A.out_part[q];
+			const size_t nz = (size_t)O.nnz;
+			size_t b = sizeof(int64_t) * (size_t)(O.geom.nslices + 1) + sizeof(int32_t) * (size_t)O.nrows + sizeof(int32_t) * (nz + 64) + sizeof(int32_t) * (size_t)O.nrows;
+			b += O.coded ? sizeof(int64_t) * (size_t)(O.geom.nslices + 1) + 256 * sizeof(double) + sizeof(uint32_t) * (size_t)O.code_words : s * (nz + 64);
+			stream += b;
+			bytes += b + sizeof(int64_t) * (size_t)(O.nrows + 1);
+			L.nnz += O.nnz;
+			L.per_row_entries += O.nnz;
+		}
+		L.split_panel = A.split_parts;
+	}
 	L.stream_bytes = (int64_t)stream;
 	L.resident_bytes = (int64_t)bytes;
 	*out = L;
@@ -1220,7 +1479,7 @@ lpp_status lpp_engine_get_stats(lpp_engine* e, lpp_stats* s)
 	e->collect_spmv_times();
 	*s = e->stats;
 	s->nrows = e->n_local;
-	s->nnz = e->pb.active ? e->pb.nnz_loc : (e->kron.active ? (int64_t)e->kron.equiv_nnz : e->A_loc.nnz + e->A_rem.nnz);
+	s->nnz = e->pb.active ? e->pb.nnz_loc : (e->kron.active ? (int64_t)e->kron.equiv_nnz : e->A_loc.nnz + e->A_loc.out_nnz() + e->A_rem.nnz);
 	s->spmv_bytes = e->spmv_bytes;
 	return LPP_OK;
 }

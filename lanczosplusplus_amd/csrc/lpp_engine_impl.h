@@ -66,6 +66,19 @@ struct DevCsr {
 	int dia_stride = 0; // places per slice in dia_off / dia_val
 	int32_t* dia_off = nullptr;
 	void* dia_val = nullptr;
+	// split-panel layout (k_split_count): this CSR holds the in-block entries; the entries that leave the row block live in
+	// *out_part, whose rows are the panel-major reordering given by out_rowmap (row r' of the out part is row out_rowmap[r'])
+	// (several of them, by source block range: split_parts, see SplitParams)
+	DevCsr* out_part = nullptr; // array of split_parts matrices
+	int split_parts = 0;
+	int32_t* out_rowmap = nullptr;
+	int64_t split_B = 0, split_nb = 0, split_pblk = 0;
+	int64_t out_nnz() const
+	{
+		int64_t n = 0;
+		for (int q = 0; q < split_parts; q++) n += out_part[q].nnz;
+		return n;
+	}
 };
 
 // matrix-free Hubbard product state: two one-species matrices instead of the full CSR

@@ -409,6 +409,140 @@ __device__ __forceinline__ unsigned dict_hash(unsigned long long k)
 	return (unsigned)k & (kDictTable - 1);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Split-panel layout of a plain-format matrix with a basis block B (no value compression, no model knowledge): every row's
+// entries inside its own row block [b*B, (b+1)*B) stay with the LDS-window kernel; the entries that LEAVE the block go into a
+// second CSR whose rows are reordered PANEL-major,
+//     r' = (panel p, block b, position i)   for row r = b*B + 16p + i,
+// i.e. 16 consecutive positions of EVERY block, then the next 16.  In a product basis the leaving entries connect position i of
+// block b with position i of other blocks, so while a panel is walked every gather lands in the same 16 positions of all blocks
+// (nblocks * 128 bytes = 1.6 MB at BASELINE config 2) and stays in one XCD's L2 -- read in block order those ~17 other blocks'
+// rows came from HBM every time (23 of the 102 GB the plain kernel moved).  Bytes stored are those of the CSR plus 4 per row
+// (the row map) and a second row-pointer array; nothing is compressed.
+// ---------------------------------------------------------------------------------------------
+
+// r' of row r (B = rows per block, nb = whole blocks; rows beyond nb*B -- none for a product basis -- keep their place)
+__host__ __device__ inline int64_t panel_major_row(int64_t r, int64_t B, int64_t nb)
+{
+	if (r >= nb * B) return r;
+	const int64_t b = r / B, i = r - b * B, p = i >> 4, npan = (B + 15) >> 4;
+	const int64_t wlast = B - (npan - 1) * 16; // positions of the last panel
+	const int64_t before = p * 16 * nb; // rows of the panels in front (all of them full)
+	const int64_t w = p == npan - 1 ? wlast : 16;
+	return before + b * w + (i - p * 16);
+}
+
+constexpr int kSplitMaxParts = 4;
+
+// The leaving entries are held in `nparts` CSRs by SOURCE block range (part q: source blocks [q*pblk, (q+1)*pblk)): while a
+// panel is walked the gathers of one part touch nblocks/nparts lines (two per source block and panel when rows are not
+// 128-byte aligned), which has to stay in L2 next to the entry stream that passes meanwhile.
+struct SplitParams {
+	int64_t nrows, B, nb;
+	int nparts;
+	int64_t pblk; // source blocks per part
+};
+__host__ __device__ inline int split_part_of(const SplitParams& P, int64_t col)
+{
+	const int64_t q = (col / P.B) / P.pblk;
+	return (int)(q < P.nparts ? q : P.nparts - 1);
+}
+
+// pass 1: len_in[r], len_out[q][r'] (+ rowmap[r'] = r).  Rows must be sorted by column.
+static __global__ void k_split_count(SplitParams P, const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col, int64_t* __restrict__ len_in,
+                                     int64_t* const* __restrict__ len_out, int32_t* __restrict__ rowmap)
+{
+	const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= P.nrows) return;
+	const int64_t lo = (r / P.B) * P.B, hi = lo + P.B;
+	int64_t nin = 0, nout[kSplitMaxParts] = { 0, 0, 0, 0 };
+	for (int64_t p = rowptr[r]; p < rowptr[r + 1]; p++) {
+		const int64_t c = col[p];
+		if (c >= lo && c < hi) nin++;
+		else nout[split_part_of(P, c)]++;
+	}
+	const int64_t rp = panel_major_row(r, P.B, P.nb);
+	len_in[r] = nin;
+	for (int q = 0; q < P.nparts; q++) len_out[q][rp] = nout[q];
+	rowmap[rp] = (int32_t)r;
+}
+
+struct SplitOut {
+	const int64_t* rp[kSplitMaxParts];
+	int32_t* col[kSplitMaxParts];
+	void* val[kSplitMaxParts];
+};
+
+// pass 2: the CSRs (row pointers already scanned); columns stay global in all of them
+template <typename T>
+__global__ void k_split_fill(SplitParams P, const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col, const T* __restrict__ val,
+                             const int64_t* __restrict__ rp_in, int32_t* __restrict__ col_in, T* __restrict__ val_in, SplitOut O)
+{
+	const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= P.nrows) return;
+	const int64_t lo = (r / P.B) * P.B, hi = lo + P.B;
+	const int64_t rpm = panel_major_row(r, P.B, P.nb);
+	int64_t qi = rp_in[r], qo[kSplitMaxParts];
+	for (int q = 0; q < P.nparts; q++) qo[q] = O.rp[q][rpm];
+	for (int64_t p = rowptr[r]; p < rowptr[r + 1]; p++) {
+		const int64_t c = col[p];
+		if (c >= lo && c < hi) {
+			col_in[qi] = col[p];
+			val_in[qi] = val[p];
+			qi++;
+		} else {
+			const int q = split_part_of(P, c);
+			O.col[q][qo[q]] = col[p];
+			((T*)O.val[q])[qo[q]] = val[p];
+			qo[q]++;
+		}
+	}
+}
+
+// back to one CSR in the given order (lpp_engine_get_csr): every piece of a row is sorted by column and the pieces cover
+// disjoint column ranges, except that the in-block run sits inside the range of one part -- a plain merge by column
+template <typename T>
+__global__ void k_split_merge(SplitParams P, const int64_t* __restrict__ rp_in, const int32_t* __restrict__ col_in, const T* __restrict__ val_in, SplitOut O,
+                              const int64_t* __restrict__ rowptr, int32_t* __restrict__ col, T* __restrict__ val)
+{
+	const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= P.nrows) return;
+	const int64_t rpm = panel_major_row(r, P.B, P.nb);
+	int64_t h[kSplitMaxParts + 1], e[kSplitMaxParts + 1];
+	h[0] = rp_in[r];
+	e[0] = rp_in[r + 1];
+	for (int q = 0; q < P.nparts; q++) {
+		h[q + 1] = O.rp[q][rpm];
+		e[q + 1] = O.rp[q][rpm + 1];
+	}
+	for (int64_t out = rowptr[r]; out < rowptr[r + 1]; out++) {
+		int best = -1;
+		int32_t bc = 0;
+		for (int q = 0; q <= P.nparts; q++) {
+			if (h[q] >= e[q]) continue;
+			const int32_t c = q == 0 ? col_in[h[0]] : O.col[q - 1][h[q]];
+			if (best < 0 || c < bc) {
+				best = q;
+				bc = c;
+			}
+		}
+		col[out] = bc;
+		val[out] = best == 0 ? val_in[h[0]] : ((const T*)O.val[best - 1])[h[best]];
+		h[best]++;
+	}
+}
+
+// lengths of the merged rows
+static __global__ void k_split_lengths(SplitParams P, const int64_t* __restrict__ rp_in, SplitOut O, int64_t* __restrict__ len)
+{
+	const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= P.nrows) return;
+	const int64_t rpm = panel_major_row(r, P.B, P.nb);
+	int64_t n = rp_in[r + 1] - rp_in[r];
+	for (int q = 0; q < P.nparts; q++) n += O.rp[q][rpm + 1] - O.rp[q][rpm];
+	len[r] = n;
+}
+
 // collect the distinct doubles of vals[0..n) into table (pre-filled with kDictEmpty); *overflow != 0 when full
 static __global__ __launch_bounds__(kBlock) void k_dict_collect(const double* __restrict__ vals, int64_t n,
                                                                  unsigned long long* table, int* overflow)

@@ -159,6 +159,9 @@ template <typename T> struct SlicedArgs {
 	const uint32_t* tw;
 	const int32_t* tw_off; // first word of template slice j
 	const int32_t* tw_len; // its padded slots
+	// rows of this matrix are a reordering of the vector's rows (split-panel layout, k_split_count): x and ydot of row r live at
+	// rowmap[r].  null: identity.  Only with plain per-row entries (no shared offsets, no diagonal codes).
+	const int32_t* rowmap;
 };
 
 constexpr int32_t kDiaNone = INT32_MIN;
@@ -191,6 +194,22 @@ template <> struct CodeTraits<cplx> {
 template <typename V> __device__ __forceinline__ V ld_off32(const V* base, uint32_t index)
 {
 	return *(const V*)((const char*)base + (size_t)(index * (uint32_t)sizeof(V)));
+}
+
+// the same with the non-temporal hint: entry streams that are read once must not push a panel of the source vector out of L2
+// (split-panel layout: 42 MB of columns and values pass while one 1.6 MB panel is being gathered from)
+template <typename V> __device__ __forceinline__ V ld_off32_nt(const V* base, uint32_t index)
+{
+	if constexpr (sizeof(V) == 16) {
+		const double* p = (const double*)((const char*)base + (size_t)(index * 16u));
+		V r;
+		double* q = (double*)&r;
+		q[0] = __builtin_nontemporal_load(p);
+		q[1] = __builtin_nontemporal_load(p + 1);
+		return r;
+	} else {
+		return __builtin_nontemporal_load((const V*)((const char*)base + (size_t)(index * (uint32_t)sizeof(V))));
+	}
 }
 
 __device__ __forceinline__ uint32_t lane_prefix(unsigned long long m)
@@ -228,6 +247,7 @@ __device__ __forceinline__ T sliced_accumulate(const SlicedArgs<T>& a, int len, 
 	const T* valp = CODED ? nullptr : a.val + base_u;
 	const uint32_t* codep = CODED ? a.codes + cbase_u : nullptr;
 	uint32_t run = 0; // entries of this slice consumed so far (wave-uniform)
+	const bool nt_ = !WINDOW && a.rowmap != nullptr; // the panel-major part of a split-panel matrix: streams read with the non-temporal hint
 	T acc = VT<T>::zero();
 	int32_t c0[U], c1[U];
 	T v0[CODED ? 1 : U], v1[CODED ? 1 : U];
@@ -238,9 +258,9 @@ __device__ __forceinline__ T sliced_accumulate(const SlicedArgs<T>& a, int len, 
 		const bool on_ = len > (K0) + u;                                                                              \
 		const unsigned long long m_ = __ballot(on_);                                                                  \
 		const uint32_t p_ = run + (on_ ? lane_prefix(m_) : 0u);                                                       \
-		C[u] = LOCAL16 ? (int32_t)ld_off32(colp16, p_) : ld_off32(colp, p_);                                          \
+		C[u] = LOCAL16 ? (int32_t)ld_off32(colp16, p_) : (nt_ ? ld_off32_nt(colp, p_) : ld_off32(colp, p_));          \
 		if (!CODED) {                                                                                                 \
-			const T t_ = ld_off32(valp, p_);                                                                          \
+			const T t_ = nt_ ? ld_off32_nt(valp, p_) : ld_off32(valp, p_);                                            \
 			V[u] = on_ ? t_ : VT<T>::zero();                                                                          \
 		}                                                                                                             \
 		run += (uint32_t)__popcll(m_);                                                                                \
@@ -404,11 +424,12 @@ __device__ __forceinline__ double sliced_one(const SlicedArgs<T>& a, int64_t row
 	const int lane = threadIdx.x & 63;
 	const bool valid = lane < nvalid;
 	const int64_t row = row0 + (valid ? lane : 0);
+	const int64_t xrow = a.rowmap ? (int64_t)a.rowmap[row] : row; // where this row's x and y live
 	// the row's old x and y are requested first: they are the oldest loads in flight and have landed
 	// long before the epilogue needs them
-	const T xold = a.x[row];
+	const T xold = a.x[xrow];
 	T yv = VT<T>::zero();
-	if (DOT) yv = a.ydot[row];
+	if (DOT) yv = a.ydot[xrow];
 	uint32_t dc = 0; // code(s) of the diagonal value, when it travels apart from the per-row entries
 	if (CODED && a.dcode) dc = sizeof(T) == 16 ? (uint32_t)((const uint16_t*)a.dcode)[row] : (uint32_t)a.dcode[row];
 	DiaPre<T> pre;
@@ -438,7 +459,7 @@ __device__ __forceinline__ double sliced_one(const SlicedArgs<T>& a, int64_t row
 	double d = 0.0;
 	if (valid) {
 		const T xv = epi_lin(beta, xold, alpha, acc);
-		a.x[row] = xv;
+		a.x[xrow] = xv;
 		if (DOT) d = VT<T>::dot_re(yv, xv);
 	}
 	return d;

@@ -646,6 +646,57 @@ def test_basis_block_is_detected_without_a_hint():
         assert rel(e.matrixVectorProduct(x0.copy(), y), oracle.spmv_acc(H, x0.copy(), y)) < SPMV_TOL
 
 
+@pytest.mark.parametrize("source", ["assembled", "uploaded"])
+def test_split_panel_layout_of_a_plain_format_matrix(source, monkeypatch):
+    """Plain-format matrix (no value dictionary, no shared offsets) with a basis block: the entries that leave the row blocks are
+    held in a second CSR whose rows are panel-major (16 positions of every block, then the next 16) and applied by a second
+    launch through a row map.  Same bytes per entry as the CSR; get_csr merges the two parts back bit for bit; products and
+    energies as before.  Real matrices (complex ones keep the sliced kernel and are checked to be left alone)."""
+    monkeypatch.setenv("LPP_PRODUCT_LAYOUT", "0")
+    monkeypatch.setenv("LPP_COMPRESS_VALUES", "0")
+    monkeypatch.setenv("LPP_SHARED_OFFSETS", "0")
+    monkeypatch.setenv("LPP_SPLIT_PANEL", "1")  # opt-in layout (bench.py's plain-format leg takes it)
+    monkeypatch.setenv("LPP_SPLIT_PARTS", "3")  # several source-range parts forced onto the small matrix
+    for dt in ("f64", "c128"):
+        L, nup, ndown = 12, 6, 5
+        hop = chain(L, -1.0, True).astype(complex if dt == "c128" else float)
+        if dt == "c128":
+            hop[0, 1] *= np.exp(0.3j)
+            hop[1, 0] = np.conj(hop[0, 1])
+        U, V = np.linspace(2.0, 4.0, L), np.linspace(-0.3, 0.3, 2 * L)
+        A = oracle.hubbard_csr(L, nup, ndown, hop, U, V)
+        x0, y = oracle.fill_random(A.nrows, 7, A.is_complex), oracle.fill_random(A.nrows, 8, A.is_complex)
+        xo = oracle.spmv_acc(A, x0.copy(), y)
+        eo, _, so = oracle.lanczos_solve(A, oracle.fill_random(A.nrows, 1234, A.is_complex), want_vectors=False)
+        with LanczosEngine(dtype=dt) as e:
+            if source == "assembled":
+                e.assemble_hubbard(L, nup, ndown, hop, U, V)
+            else:
+                e.set_row_block(comb(L, nup))
+                e.set_csr(A.rowptr, A.colind, A.values)
+            lay = e.layout()
+            assert lay["coded"] == 0 and lay["nnz"] == A.nnz
+            if dt == "f64":
+                assert lay["kernel"] == 3 and lay["split_panel"] >= 1 and lay["rows_per_block"] == comb(L, nup)
+            else:  # complex matrices keep the sliced kernel (16-byte window elements lose, DESIGN.md section 5): nothing to split
+                assert lay["kernel"] == 2 and lay["split_panel"] == 0
+            assert e.stats()["nnz"] == A.nnz
+            rp, ci, va = e.get_csr()
+            assert np.array_equal(rp, A.rowptr) and np.array_equal(ci, A.colind)
+            assert np.array_equal(np.ascontiguousarray(va).view(np.uint64), np.ascontiguousarray(A.values).view(np.uint64))
+            assert rel(e.matrixVectorProduct(x0.copy(), y), xo) < SPMV_TOL
+            eg, zg, st = e.lanczos(1, want_vectors=True)
+            assert abs(eg[0] - eo[0]) <= E_TOL * abs(eo[0]) and st["steps"] == so
+            r = oracle.spmv_acc(A, np.zeros_like(zg[0]), zg[0]) - eg[0] * zg[0]
+            assert np.linalg.norm(r) < 1e-5
+        monkeypatch.setenv("LPP_SPLIT_PANEL", "0")
+        with LanczosEngine(dtype=dt) as e:
+            e.assemble_hubbard(L, nup, ndown, hop, U, V)
+            assert e.layout()["split_panel"] == 0
+            assert rel(e.matrixVectorProduct(x0.copy(), y), xo) < SPMV_TOL
+        monkeypatch.setenv("LPP_SPLIT_PANEL", "1")
+
+
 def test_uploaded_csr_takes_the_product_basis_layout(monkeypatch):
     """The reference hands its Hamiltonian over as a CSR (DefaultSymmetry.h:54-57 -> InternalProductStored.h:116).  A Hubbard CSR
     uploaded through lpp_engine_set_csr -- no hint, no model knowledge -- ends in the same product-basis layout device assembly
