@@ -151,6 +151,7 @@ struct PbState {
 	const double* pend_b2 = nullptr;
 	// rows beyond one LDS window / vectors beyond 4 GiB (lpp_pbig_kernels.h)
 	bool big = false; // in-block part by pieces of W positions (k_pb_up_big)
+	bool big2 = false; // ... two blocks per workgroup and template read (k_pb_up_big2)
 	int W = 0, npieces = 1;
 	uint32_t* fw = nullptr; // entries that leave their piece
 	int32_t* f_off = nullptr;

@@ -77,8 +77,11 @@ lpp_status pb_build(lpp_engine* e, int64_t n_up, int64_t n_blk, const int64_t* t
 	// Rows beyond one LDS window are cut into pieces (k_pb_up_big): two 512-thread workgroups of <= 80 KB per CU.  LPP_PB_PIECE_ROWS
 	// forces pieces of (at most) that many positions on any matrix (tests run the small cases of the suite through them).
 	int64_t wmax = 0;
-	if ((size_t)(pitch + kPbZeroSlots) * sizeof(double) > (size_t)156 * 1024) wmax = 8768;
-	if (const char* s = getenv("LPP_PB_PIECE_ROWS")) wmax = std::max<int64_t>(64, std::min<int64_t>(atoll(s), 16384)) & ~(int64_t)63;
+	// pieces of <= 8128 positions: two blocks' windows share a workgroup (k_pb_up_big2) and the second one stays within the 64 KB an
+	// LDS instruction's offset reaches; LPP_PB_BIG2=0: one block per workgroup, two 512-thread workgroups per CU (k_pb_up_big, <= 8768)
+	const bool big2 = !(getenv("LPP_PB_BIG2") && atoi(getenv("LPP_PB_BIG2")) == 0);
+	if ((size_t)(pitch + kPbZeroSlots) * sizeof(double) > (size_t)156 * 1024) wmax = big2 ? 8128 : 8768;
+	if (const char* s = getenv("LPP_PB_PIECE_ROWS")) wmax = std::max<int64_t>(64, std::min<int64_t>(atoll(s), big2 ? 8128 : 16384)) & ~(int64_t)63;
 	int64_t W = 0;
 	if (wmax > 0) {
 		const int64_t np = (n_up + wmax - 1) / wmax;
@@ -119,6 +122,7 @@ lpp_status pb_build(lpp_engine* e, int64_t n_up, int64_t n_blk, const int64_t* t
 	if ((rc = to_device(&B.tw_off, T.off, st)) != LPP_OK) return rc;
 	if ((rc = to_device(&B.tw_len, T.len, st)) != LPP_OK) return rc;
 	B.big = W > 0;
+	B.big2 = B.big && big2 && (T.G == 1 || T.G == 2) && pb_big2_lds_bytes((int)W) <= (size_t)160 * 1024 - 64 && (W + kPbZeroSlots) * 8 < 65536;
 	B.W = (int)W;
 	B.npieces = W > 0 ? (int)((n_up + W - 1) / W) : 1;
 	if (B.big) {
@@ -302,6 +306,11 @@ template <bool DOT, bool LEAN> static void launch_up(const PbState& B, const PbU
 static int big_grid(const lpp_engine* e, int64_t cnt)
 {
 	const PbState& B = e->pb;
+	if (B.big2) { // one 1024-thread workgroup per CU, items = (pair of blocks of one XCD, piece)
+		int nb = (int)std::max<int64_t>(1, std::min<int64_t>(((cnt + 1) / 2) * B.npieces, (int64_t)e->num_cus));
+		if (nb >= 8) nb &= ~7;
+		return nb;
+	}
 	const size_t lds = pb_big_lds_bytes(B.W);
 	const int per_cu = std::max(1, std::min(2, (int)(((size_t)160 * 1024) / (lds + 512))));
 	int nb = (int)std::max<int64_t>(1, std::min<int64_t>(cnt * B.npieces, (int64_t)e->num_cus * per_cu));
@@ -333,8 +342,25 @@ static int launch_up_big(lpp_engine* e, const double* y, double* u, const uint8_
 	a.u = u;
 	a.partial = partial;
 	a.sc = sc;
-	const size_t lds = pb_big_lds_bytes(B.W);
 	const int nb = big_grid(e, cnt);
+	if (B.big2) {
+		const size_t lds2 = pb_big2_lds_bytes(B.W);
+#define LPP_PB_BIG2(DOT_, GT_)                                                                                         \
+	do {                                                                                                              \
+		(void)hipFuncSetAttribute((const void*)k_pb_up_big2<DOT_, GT_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2); \
+		k_pb_up_big2<DOT_, GT_><<<nb, kPbBig2Threads, lds2, st>>>(a);                                                   \
+	} while (0)
+		if (partial) {
+			if (B.G == 1) LPP_PB_BIG2(true, 1);
+			else LPP_PB_BIG2(true, 2);
+		} else {
+			if (B.G == 1) LPP_PB_BIG2(false, 1);
+			else LPP_PB_BIG2(false, 2);
+		}
+#undef LPP_PB_BIG2
+		return partial ? nb : 0;
+	}
+	const size_t lds = pb_big_lds_bytes(B.W);
 	int gt = B.G <= 2 ? B.G : 0;
 	if (getenv("LPP_PB_UP_GENERIC")) gt = 0;
 #define LPP_PB_BIG(DOT_, GT_)                                                                                          \

@@ -294,6 +294,242 @@ template <bool DOT, int GT> __global__ __launch_bounds__(kPbBigThreads, 4) void 
 }
 
 // ---------------------------------------------------------------------------------------------
+// The same with TWO blocks per template read.  The template of a long row is large (80 bytes per position: 6.2 MB at N_up = 77520)
+// and every (block, piece) streams its share of it: 240 GB of the 374 GB k_pb_up_big reads per product at 3.0e9 states are template
+// words, which cannot stay in L2 beside the rows.  Here a 1024-thread workgroup stages the same piece of two blocks (two windows; the
+// second one within the 64 KB reach of an LDS instruction's offset field, so a template entry still is the address) and applies every
+// word it loads to both: half the template traffic and half the word decoding per output row.
+// ---------------------------------------------------------------------------------------------
+constexpr int kPbBig2Threads = 1024;
+constexpr int kBig2FarPre = 4;
+
+__host__ __device__ inline size_t pb_big2_lds_bytes(int W)
+{
+	return ((2 * sizeof(double) * (size_t)(W + kPbZeroSlots) + 2 * (size_t)W + 15) & ~(size_t)15) + sizeof(double) * (256 + kPbMaxGroups + 1 + kPbBig2Threads / 64) + 16;
+}
+
+template <int GG> struct Big2Words {
+	uint2 w[GG][kBigPre];
+	uint32_t f[kBig2FarPre];
+};
+
+template <bool DOT, int GT> __global__ __launch_bounds__(kPbBig2Threads) void k_pb_up_big2(PbUpBigArgs a)
+{
+	static_assert(GT == 1 || GT == 2, "unrolled value groups only");
+	extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+	double* win = (double*)lds_raw; // window of block 0 at LDS address 0, of block 1 at (W + 32) * 8
+	const int WS = a.W + kPbZeroSlots; // window stride in elements
+	uint8_t* dcode_s = (uint8_t*)(win + 2 * WS); // [2][W]
+	double* dict_s = (double*)(lds_raw + ((2 * sizeof(double) * (size_t)WS + 2 * (size_t)a.W + 15) & ~(size_t)15));
+	double* gv_s = dict_s + 256;
+	double* smem = gv_s + kPbMaxGroups + 1;
+	for (int i = threadIdx.x; i < 256; i += kPbBig2Threads) dict_s[i] = a.dict[i];
+	if (threadIdx.x <= kPbMaxGroups) gv_s[threadIdx.x] = threadIdx.x <= (unsigned)a.G ? a.gval[threadIdx.x] : 0.0;
+	if (threadIdx.x < 2 * kPbZeroSlots) win[(threadIdx.x >> 5) * WS + a.W + (threadIdx.x & 31)] = 0.0;
+	double alpha, beta_unused;
+	epi_coeffs(a.sc, alpha, beta_unused);
+	constexpr int NW = kPbBig2Threads / 64;
+	constexpr int GG = GT;
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const uint2* const tw2 = (const uint2*)a.tw;
+	const uint32_t* const fw = a.fw;
+	const int32_t* const tw_off = a.tw_off;
+	const uint16_t* const tw_len = a.tw_len;
+	const int32_t* const f_off = a.f_off;
+	const uint16_t* const f_len = a.f_len;
+	const int W = a.W, npieces = a.npieces, n_up = (int)a.n_up;
+	const uint32_t wbytes = (uint32_t)WS * 8u; // byte distance of the two windows (< 65536: pb_build)
+	double* const uout = a.u;
+	double gv[GG];
+#pragma unroll
+	for (int g = 0; g < GG; g++) gv[g] = a.gval[g];
+	double dot = 0.0;
+	const int nx = (gridDim.x & 7) == 0 ? 8 : 1;
+	const int xcd = nx == 8 ? (int)(blockIdx.x & 7) : 0;
+	const int64_t slot = nx == 8 ? (int64_t)(blockIdx.x >> 3) : (int64_t)blockIdx.x, nslots = gridDim.x / nx;
+	const int64_t nbx = (a.n_blk - xcd + nx - 1) / nx; // blocks of this XCD: xcd, xcd + nx, ...
+	const int64_t npairs = (nbx + 1) >> 1;
+	auto gather4x2 = [=](const uint2& w, double& a0, double& a1, double& b0, double& b1) __attribute__((always_inline)) {
+		const uint32_t p0 = pb_lo8(w.x), p1 = pb_hi8(w.x), p2 = pb_lo8(w.y), p3 = pb_hi8(w.y);
+		a0 += pb_lds_abs(p0);
+		b0 += pb_lds_abs(p0 + wbytes);
+		a1 += pb_lds_abs(p1);
+		b1 += pb_lds_abs(p1 + wbytes);
+		a0 += pb_lds_abs(p2);
+		b0 += pb_lds_abs(p2 + wbytes);
+		a1 += pb_lds_abs(p3);
+		b1 += pb_lds_abs(p3 + wbytes);
+	};
+	for (int64_t seq = slot; seq < npairs * npieces; seq += nslots) {
+		const int64_t pr = seq / npieces;
+		const int q = (int)(seq - pr * npieces);
+		const int64_t blk0 = (2 * pr) * nx + xcd;
+		const bool two = 2 * pr + 1 < nbx; // the last pair of an odd count holds one block: its twin re-reads it and stores nothing
+		const int64_t blk1 = two ? (2 * pr + 1) * nx + xcd : blk0;
+		const int c0 = q * W;
+		const int wlen = min(W, (int)a.pitch - c0);
+		const int64_t rowbase0 = blk0 * a.pitch, rowbase1 = blk1 * a.pitch;
+		const double* const yrow0 = a.y + rowbase0;
+		const double* const yrow1 = a.y + rowbase1;
+		__syncthreads(); // everyone is done with the previous windows
+		{
+			constexpr int NS = 4;
+			const int p2 = wlen >> 1;
+			for (int i0 = threadIdx.x; i0 < 2 * p2; i0 += NS * kPbBig2Threads) { // [0, p2): block 0, [p2, 2 p2): block 1
+				double2 t[NS];
+				int idx[NS];
+#pragma unroll
+				for (int k = 0; k < NS; k++) idx[k] = min(i0 + k * kPbBig2Threads, 2 * p2 - 1);
+#pragma unroll
+				for (int k = 0; k < NS; k++) {
+					const bool second = idx[k] >= p2;
+					t[k] = ((const double2*)((second ? yrow1 : yrow0) + c0))[second ? idx[k] - p2 : idx[k]];
+				}
+#pragma unroll
+				for (int k = 0; k < NS; k++) {
+					const bool second = idx[k] >= p2;
+					((double2*)(win + (second ? WS : 0)))[second ? idx[k] - p2 : idx[k]] = t[k];
+				}
+			}
+			const int p16 = wlen >> 4;
+			for (int i0 = threadIdx.x; i0 < 2 * p16; i0 += kPbBig2Threads) {
+				const bool second = i0 >= p16;
+				const int k = second ? i0 - p16 : i0;
+				((uint4*)(dcode_s + (second ? W : 0)))[k] = ((const uint4*)(a.dcode + (second ? rowbase1 : rowbase0) + c0))[k];
+			}
+		}
+		__syncthreads();
+		const int j0 = c0 >> 6, nsl = (min(c0 + W, n_up) - c0 + 63) >> 6;
+		auto epilogue = [=, &dot](int jj, double acc0, double acc1) __attribute__((always_inline)) {
+			const int il_raw = jj * 64 + lane;
+			const bool valid = c0 + il_raw < n_up;
+			const int il = valid ? il_raw : n_up - 1 - c0;
+			const double y0 = win[il], y1 = win[WS + il];
+			acc0 = fma(dict_s[dcode_s[il]], y0, acc0);
+			acc1 = fma(dict_s[dcode_s[W + il]], y1, acc1);
+			if (valid) {
+				const double u0 = alpha * acc0, u1 = alpha * acc1;
+				__builtin_nontemporal_store(u0, &uout[rowbase0 + c0 + il]);
+				if (DOT) dot += y0 * u0;
+				if (two) {
+					__builtin_nontemporal_store(u1, &uout[rowbase1 + c0 + il]);
+					if (DOT) dot += y1 * u1;
+				}
+			}
+		};
+		auto load_heads = [=](int jj, BigHeads<GG>& h) __attribute__((always_inline)) {
+			const int j = __builtin_amdgcn_readfirstlane(j0 + min(jj, nsl - 1));
+#pragma unroll
+			for (int g = 0; g < GG; g++) {
+				h.nc[g] = tw_len[j * GG + g];
+				h.off[g] = tw_off[j * GG + g];
+			}
+			h.nf = f_len[j];
+			h.foff = f_off[j];
+		};
+		auto load_words = [=](const BigHeads<GG>& h, Big2Words<GG>& s) __attribute__((always_inline)) {
+#pragma unroll
+			for (int g = 0; g < GG; g++) {
+				const uint2* wp = tw2 + (size_t)h.off[g] * 64 + lane;
+#pragma unroll
+				for (int c = 0; c < kBigPre; c++) s.w[g][c] = wp[c * 64];
+			}
+			const uint32_t* fp = fw + (size_t)h.foff * 64 + lane;
+#pragma unroll
+			for (int k = 0; k < kBig2FarPre; k++) s.f[k] = fp[k * 64];
+		};
+		auto compute = [=](int jj, const BigHeads<GG>& h, const Big2Words<GG>& s) __attribute__((always_inline)) {
+			if (jj >= nsl) return; // wave-uniform
+			const int nf = h.nf;
+			double fv0[kBig2FarPre], fv1[kBig2FarPre];
+			if (nf > 0) { // lists are whole groups of 4 slots
+#pragma unroll
+				for (int t = 0; t < kBig2FarPre; t++) {
+					const uint32_t c = s.f[t] & 0xffffffu;
+					fv0[t] = yrow0[c];
+					fv1[t] = yrow1[c];
+				}
+			}
+			double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+			for (int g = 0; g < GG; g++) {
+				const int nc = h.nc[g];
+				double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
+				if (nc >= 2) {
+					gather4x2(s.w[g][0], a0, a1, b0, b1);
+					gather4x2(s.w[g][1], a0, a1, b0, b1);
+				} else if (nc == 1) {
+					gather4x2(s.w[g][0], a0, a1, b0, b1);
+				}
+				if (nc >= 4) {
+					gather4x2(s.w[g][2], a0, a1, b0, b1);
+					gather4x2(s.w[g][3], a0, a1, b0, b1);
+				} else if (nc == 3) {
+					gather4x2(s.w[g][2], a0, a1, b0, b1);
+				}
+				if (nc > kBigPre) {
+					const uint2* wp = tw2 + (size_t)h.off[g] * 64 + lane;
+					for (int c = kBigPre; c < nc; c++) {
+						const uint2 wr = wp[c * 64];
+						gather4x2(wr, a0, a1, b0, b1);
+					}
+				}
+				acc0 = fma(gv[g], a0 + a1, acc0);
+				acc1 = fma(gv[g], b0 + b1, acc1);
+			}
+			if (nf > kBig2FarPre) { // the rest of the far list, streamed
+				const uint32_t* fp = fw + (size_t)h.foff * 64 + lane;
+				for (int k = kBig2FarPre; k < nf; k += 4) {
+					uint32_t w[4];
+#pragma unroll
+					for (int t = 0; t < 4; t++) w[t] = fp[(k + t) * 64];
+					double v0[4], v1[4];
+#pragma unroll
+					for (int t = 0; t < 4; t++) {
+						v0[t] = yrow0[w[t] & 0xffffffu];
+						v1[t] = yrow1[w[t] & 0xffffffu];
+					}
+#pragma unroll
+					for (int t = 0; t < 4; t++) {
+						const double gq = gv_s[w[t] >> 24];
+						acc0 = fma(gq, v0[t], acc0);
+						acc1 = fma(gq, v1[t], acc1);
+					}
+				}
+			}
+			if (nf > 0) {
+#pragma unroll
+				for (int t = 0; t < kBig2FarPre; t++) {
+					const double gq = gv_s[s.f[t] >> 24];
+					acc0 = fma(gq, fv0[t], acc0);
+					acc1 = fma(gq, fv1[t], acc1);
+				}
+			}
+			epilogue(jj, acc0, acc1);
+		};
+		BigHeads<GG> h0, h1, h2, h3;
+		Big2Words<GG> wa, wb;
+		load_heads(wave, h0);
+		load_heads(wave + NW, h1);
+		load_words(h0, wa);
+		for (int jj = wave; jj < nsl; jj += 2 * NW) {
+			load_heads(jj + 2 * NW, h2);
+			load_words(h1, wb);
+			compute(jj, h0, wa);
+			load_heads(jj + 3 * NW, h3);
+			load_words(h2, wa);
+			compute(jj + NW, h1, wb);
+			h0 = h2;
+			h1 = h3;
+		}
+	}
+	if (DOT) {
+		const double r = block_sum_n<kPbBig2Threads / 64>(dot, smem);
+		if (threadIdx.x == 0) a.partial[blockIdx.x] = r;
+	}
+}
+
+// ---------------------------------------------------------------------------------------------
 // block couplings over parts of the source range:  z[b][i] = alpha sum_k C[b][b'_k] y[b'_k][i]   (+ Re<y|z> partial)
 // ---------------------------------------------------------------------------------------------
 struct PbDownPartsArgs {

@@ -766,6 +766,7 @@ def test_product_basis_layout(case, form, monkeypatch):
     if form == "wide":
         monkeypatch.setenv("LPP_PB_PIECE_ROWS", "320")
         monkeypatch.setenv("LPP_PB_WIDE", "1")
+        monkeypatch.setenv("LPP_PB_BIG2", "0")  # one block per workgroup (k_pb_up_big); "pieces" runs two per workgroup (k_pb_up_big2)
     A = oracle.hubbard_csr(L, nup, ndown, hop, U, V)
     x0, y = oracle.fill_random(A.nrows, 7), oracle.fill_random(A.nrows, 8)
     xo = oracle.spmv_acc(A, x0.copy(), y)
