@@ -269,7 +269,8 @@ def generic_csr_leg(name, is_complex, device, iters=10):
     from lanczosplusplus_amd import LanczosEngine
     saved = {k: os.environ.get(k) for k in ("LPP_COMPRESS_VALUES", "LPP_SHARED_OFFSETS", "LPP_PRODUCT_LAYOUT", "LPP_LOCAL16", "LPP_SPLIT_PANEL")}
     os.environ.update(LPP_COMPRESS_VALUES="0", LPP_SHARED_OFFSETS="0", LPP_PRODUCT_LAYOUT="0", LPP_LOCAL16="0")  # 8-byte values, 32-bit columns
-    os.environ.setdefault("LPP_SPLIT_PANEL", "1")  # entries that leave the row blocks in panel-major row order (same bytes per entry)
+    # (LPP_SPLIT_PANEL=1 would take the split-panel row order for the leaving entries: measured 8.1 + 9.9 ms in two launches, 19.3 ms
+    #  back to back against 18.7 ms in one kernel -- DESIGN.md section 5 -- so the leg keeps the one-kernel form)
     try:
         with LanczosEngine(dtype="c128" if is_complex else "f64", device=device, max_steps=8, eps=0.0, save_vectors=0, compress_values=0) as e:
             assemble(e, name)
