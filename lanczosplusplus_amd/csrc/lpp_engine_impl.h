@@ -157,6 +157,9 @@ struct PbState {
 	int32_t* f_off = nullptr;
 	uint16_t* f_len = nullptr;
 	int64_t f_words = 0, f_entries = 0;
+	bool down2 = false; // k_pb_down2: the workgroup's own lines of a panel staged in LDS (couplings inside its block range are LDS reads)
+	size_t down2_lds = 0;
+	int down2_ent = 0;
 	bool wide = false; // vector beyond 4 GiB: k_pb_down<WIDE> (64-bit addresses from line numbers)
 	bool parts = false; // couplings over parts of the source range (k_pb_down_parts; 64-bit addresses too)
 	int nparts = 1, ent_cap = 0, pace_stride = 0, maxr = 0;

@@ -190,6 +190,20 @@ lpp_status pb_build(lpp_engine* e, int64_t n_up, int64_t n_blk, const int64_t* t
 	if (n_blk > 65535) return fail(LPP_ERR_INVALID, "pb_build: more than 65535 blocks");
 	B.parts = parts;
 	B.wide = wide;
+	// k_pb_down2 (own lines of the panel in LDS): opt-in (LPP_PB_DOWN2=1).  Measured at BASELINE config 2 (profiles/README.md, round 3):
+	// it halves the couplings that go through L1 (8.6 of 17.1 per block leave the workgroup's range) but the far lists padded per
+	// task (12 instead of 8.6), the selects of the compact lists and twice the VALU / LDS instructions leave it at 1.57 ms against
+	// 1.43 ms (plain) and 2.08 against 1.80 ms (chained form) for k_pb_down
+	if (!parts && !wide && B.ids_per_wg >= 8 && getenv("LPP_PB_DOWN2") && atoi(getenv("LPP_PB_DOWN2")) != 0) {
+		int64_t ent_cap = 0;
+		for (int64_t lo = 0; lo < n_blk; lo += B.ids_per_wg) ent_cap = std::max(ent_cap, cp[(size_t)std::min<int64_t>(lo + B.ids_per_wg, n_blk)] - cp[(size_t)lo]);
+		const size_t need = pb_down2_lds_bytes(B.ids_per_wg, (int)std::min<int64_t>(ent_cap, 1 << 20));
+		if (ent_cap < 65000 && need <= (size_t)156 * 1024 && (int64_t)B.ids_per_wg * 8 <= 4 * 1024) { // 4 x 16 bytes per thread stage a panel
+			B.down2 = true;
+			B.down2_ent = (int)ent_cap;
+			B.down2_lds = need;
+		}
+	}
 	if (parts) {
 		// per block and part: where the part's entries start in the (ascending) list; per part: the longest list, in whole chunks of 4
 		B.nparts = nparts;
@@ -246,6 +260,15 @@ lpp_status pb_build(lpp_engine* e, int64_t n_up, int64_t n_blk, const int64_t* t
 						if (px[q] != py[q]) return px[q] > py[q];
 					return false;
 				});
+			} else if (B.down2) {
+				// tasks of 8 consecutive blocks gather as long as their longest list of couplings that LEAVE the workgroup's range
+				// (the others are LDS reads): blocks of equal far length belong together
+				auto far_len = [&](int32_t b) {
+					int64_t n = 0;
+					for (int64_t p = cp[(size_t)b]; p < cp[(size_t)b + 1]; p++) n += (cc[(size_t)p] < lo || cc[(size_t)p] >= hi) ? 1 : 0;
+					return n;
+				};
+				std::stable_sort(order.begin() + lo, order.begin() + hi, [&](int32_t x, int32_t y) { return far_len(x) > far_len(y); });
 			} else
 			std::stable_sort(order.begin() + lo, order.begin() + hi, [&](int32_t x, int32_t y) { return cp[(size_t)x + 1] - cp[(size_t)x] > cp[(size_t)y + 1] - cp[(size_t)y]; });
 		}
@@ -420,6 +443,39 @@ static int launch_down_parts(lpp_engine* e, const double* y, double* z, int64_t 
 	return partial ? B.down_grid : 0;
 }
 
+// block couplings with the workgroup's own lines of the panel staged in LDS (k_pb_down2); rmw: the chained form (u_in, shift, pairs of partials)
+static int launch_down2(lpp_engine* e, const double* y, double* z, int64_t pitch, const double* u_in, const double* shift, double* partial, const EpiScale& sc, bool rmw, hipStream_t st)
+{
+	const PbState& B = e->pb;
+	PbDown2Args d;
+	d.pitch = pitch;
+	d.n_blk = B.n_blk;
+	d.npanels = (int)(pitch / 16);
+	d.ids_per_wg = B.ids_per_wg;
+	d.ent_cap = B.down2_ent;
+	d.c_ptr = B.c_ptr;
+	d.c_col = B.c_col;
+	d.c_code = B.c_code;
+	d.order = B.order;
+	d.dict = B.dict;
+	d.y = y;
+	d.z = z;
+	d.u_in = u_in;
+	d.shift = shift;
+	d.partial = partial;
+	d.sc = sc;
+	d.pace = B.pace;
+	if (d.pace) (void)hipMemsetAsync(d.pace, 0, sizeof(int) * 8 * (size_t)d.npanels, st);
+	if (rmw) {
+		(void)hipFuncSetAttribute((const void*)k_pb_down2<1024, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B.down2_lds);
+		k_pb_down2<1024, true><<<B.down_grid, 1024, B.down2_lds, st>>>(d);
+	} else {
+		(void)hipFuncSetAttribute((const void*)k_pb_down2<1024, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B.down2_lds);
+		k_pb_down2<1024, false><<<B.down_grid, 1024, B.down2_lds, st>>>(d);
+	}
+	return partial ? B.down_grid : 0;
+}
+
 // 8192 blocks x 4 elements in flight: 5.2 TB/s for the 4-read 1-write mix (4.7 with 2048 x 2), scripts/experiments/calib_combine.hip
 static int combine_blocks(int64_t n2) { return (int)std::max<int64_t>(1, std::min<int64_t>((n2 + 4 * kBlock - 1) / (4 * kBlock), 8192)); }
 
@@ -447,6 +503,9 @@ int pb_launch(lpp_engine* e, const void* y, void* x, double* partial, const EpiS
 	}
 	if (both && B.parts) {
 		const int n = launch_down_parts(e, (const double*)y, B.z, B.pitch, partial ? partial + nb : nullptr, sc, sd);
+		if (partial) np += n;
+	} else if (both && B.down2 && !concurrent && !getenv("LPP_PB_DOWN_THREADS")) {
+		const int n = launch_down2(e, (const double*)y, B.z, B.pitch, nullptr, nullptr, partial ? partial + nb : nullptr, sc, false, sd);
 		if (partial) np += n;
 	} else if (both) {
 		PbDownArgs d;
@@ -586,6 +645,10 @@ void pb_tx_down(lpp_engine* e, const void* gath, void* send2, const EpiScale& sc
 		launch_down_parts(e, (const double*)gath, (double*)send2, B.pitch_dn, nullptr, sc, e->stream);
 		return;
 	}
+	if (B.down2) {
+		launch_down2(e, (const double*)gath, (double*)send2, B.pitch_dn, nullptr, nullptr, nullptr, sc, false, e->stream);
+		return;
+	}
 	PbDownArgs d;
 	d.pitch = B.pitch_dn;
 	d.n_blk = B.n_blk;
@@ -668,6 +731,7 @@ int pb_launch_chain(lpp_engine* e, void* w, void* y, double* partial, const EpiS
 	const size_t lds = pb_up_lds_bytes(B.pitch, B.spb, B.G);
 	if (B.G == 1) launch_up_chain<1>(u, nb, lds, st);
 	else launch_up_chain<2>(u, nb, lds, st);
+	if (B.down2) return launch_down2(e, (const double*)w, (double*)y, B.pitch, B.u, shift, partial, sc, true, st);
 	PbDownArgs d;
 	d.pitch = B.pitch;
 	d.n_blk = B.n_blk;

@@ -478,6 +478,282 @@ template <int THREADS, bool RMW = false, bool WIDE = false> __global__ __launch_
 	}
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_pb_down2: the coupling kernel with the workgroup's OWN lines of the panel in LDS.
+// k_pb_down moves 17 gathered lines (+ its own, + u and x in the chained form) through L1 per line written and sits at the
+// L2 -> L1 fill rate.  But a workgroup owns a contiguous range of ~400 blocks, and -- basis words being ascending, the high
+// sites the major key -- half of every block's couplings end inside its workgroup's own range (49.6 % at BASELINE config 2,
+// 54 % on the 4x5 lattice).  So the last wave of the workgroup stages the range's 16-position lines of the NEXT panel in LDS
+// (one line per block: the only time they pass through L1) while the other waves work on the current one: couplings inside
+// the range are LDS reads, only the others are gathered through L1 (8.6 instead of 17.1 per block).
+// Lists are kept compact in LDS (no padding): [far entries | local entries] per block, places beyond a list are switched off
+// by a select (own line, +0.0).  Tasks (8 blocks x 16 positions) take the blocks in the order of decreasing FAR length.
+// ---------------------------------------------------------------------------------------------
+struct PbDown2Args {
+	int64_t pitch, n_blk;
+	int npanels; // pitch / 16
+	int ids_per_wg; // blocks owned by one workgroup = the range whose lines are staged
+	int ent_cap; // list entries a workgroup holds at most (LDS sizing)
+	const int64_t* c_ptr; // couplings: CSR over blocks, off-diagonal, ascending
+	const int32_t* c_col;
+	const uint8_t* c_code;
+	const int32_t* order; // blocks of every workgroup's range by decreasing number of couplings that leave the range
+	const double* dict;
+	const double* y;
+	double* z;
+	const double* u_in; // RMW: the in-block part of the product (k_pb_up's u)
+	const double* shift; // RMW: s of the second partial |w - s y|^2 (k_b2_from_w)
+	double* partial; // per-workgroup Re<y|z>; RMW: pairs (Re<y|w>, |w - s y|^2)
+	EpiScale sc;
+	int* pace; // [8][npanels] finished-workgroup counters (zeroed before the launch); null: free-running
+};
+
+constexpr int kPbLineStride = 18; // doubles per staged line in LDS: 16 + 2 (144 bytes: 16-byte reads of neighbouring lines fall on different banks)
+
+// LDS: line[ids] u32 | fo[ids+1] u16 | lo[ids+1] u16 | n4f[tasks] u8 | nl[tasks] u8 | idx[ent] u16 | code[ent] u8 | 2 panel buffers
+__host__ __device__ inline size_t pb_down2_lists_bytes(int ids_per_wg, int ent_cap)
+{
+	const size_t tasks = (size_t)(ids_per_wg + 7) / 8;
+	return (((size_t)ids_per_wg * 4 + ((size_t)ids_per_wg + 1) * 4 + tasks * 2 + (size_t)(ent_cap + 8) * 3) + 15) & ~(size_t)15;
+}
+__host__ __device__ inline size_t pb_down2_lds_bytes(int ids_per_wg, int ent_cap)
+{
+	return pb_down2_lists_bytes(ids_per_wg, ent_cap) + 2 * (size_t)ids_per_wg * kPbLineStride * sizeof(double) + 64;
+}
+
+template <int THREADS, bool RMW> __global__ __launch_bounds__(THREADS) void k_pb_down2(PbDown2Args a)
+{
+	extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+	__shared__ double dict_s[256];
+	__shared__ double smem_d[THREADS / 64];
+	const int ngmax = (a.ids_per_wg + 7) >> 3;
+	uint32_t* line_s = (uint32_t*)lds_raw; // [ids] byte offset of the block's row
+	uint16_t* fo_s = (uint16_t*)(line_s + a.ids_per_wg); // [ids+1] first place of the block's far entries; its local entries follow them
+	uint16_t* lo_s = fo_s + a.ids_per_wg + 1; // [ids+1] first place of the local entries (lo_s[il] .. fo_s[il+1])
+	uint8_t* n4f_s = (uint8_t*)(lo_s + a.ids_per_wg + 1); // [tasks] far trip count (chunks of 4)
+	uint8_t* nl_s = n4f_s + ngmax; // [tasks] local trip count
+	// (offsets from lds_raw only: a pointer that went through an integer cast is no longer known to be LDS and is read with flat loads)
+	const size_t idx_off = ((size_t)a.ids_per_wg * 4 + ((size_t)a.ids_per_wg + 1) * 4 + (size_t)ngmax * 2 + 1) & ~(size_t)1;
+	uint16_t* idx_s = (uint16_t*)(lds_raw + idx_off); // [ent] far: source block; local: source block - b0
+	uint8_t* code_s = (uint8_t*)(idx_s + a.ent_cap + 8);
+	double* pan_s = (double*)(lds_raw + pb_down2_lists_bytes(a.ids_per_wg, a.ent_cap)); // [2][ids][kPbLineStride]
+	for (int i = threadIdx.x; i < 256; i += THREADS) dict_s[i] = a.dict[i];
+	double alpha, beta;
+	epi_coeffs(a.sc, alpha, beta);
+	double dot = 0.0, nrm = 0.0;
+	const double sh = RMW ? *a.shift : 0.0;
+	constexpr int NW = THREADS / 64, NWC = NW; // every wave computes; the next panel's lines are requested into registers and stored at the end
+	constexpr int NPF = 4; // 16-byte loads per thread that stage a panel (THREADS * NPF * 16 bytes >= ids_per_wg * 128: pb_build)
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = lane >> 3, c = lane & 7;
+	const int nx = (gridDim.x & 7) == 0 ? 8 : 1;
+	const int grp = nx == 8 ? (int)(blockIdx.x & 7) : 0;
+	const int slot = nx == 8 ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+	const int nslots = (int)(gridDim.x / nx);
+	const int64_t b0 = (int64_t)slot * a.ids_per_wg;
+	const int nown = (int)max((int64_t)0, min((int64_t)a.ids_per_wg, a.n_blk - b0));
+	const uint32_t rowbytes = (uint32_t)(a.pitch * 8);
+	// places: per block (in `order`) its far entries, then its local ones; wave 0 scans the lengths
+	if (wave == 0) {
+		int run = 0;
+		for (int i0 = 0; i0 < nown; i0 += 64) {
+			const int il = i0 + lane;
+			const int64_t b = il < nown ? (int64_t)a.order[b0 + il] : 0;
+			int len = 0, nloc = 0;
+			if (il < nown) {
+				len = (int)(a.c_ptr[b + 1] - a.c_ptr[b]);
+				for (int64_t p = a.c_ptr[b]; p < a.c_ptr[b + 1]; p++) nloc += (a.c_col[p] >= b0 && a.c_col[p] < b0 + nown) ? 1 : 0;
+			}
+			int incl = len;
+#pragma unroll
+			for (int off = 1; off < 64; off <<= 1) {
+				const int t = __shfl_up(incl, off, 64);
+				if (lane >= off) incl += t;
+			}
+			if (il < nown) {
+				const int first = run + incl - len;
+				line_s[il] = (uint32_t)b * rowbytes;
+				fo_s[il] = (uint16_t)first;
+				lo_s[il] = (uint16_t)(first + len - nloc);
+			}
+			run += __shfl(incl, 63, 64);
+		}
+		if (lane == 0) fo_s[nown] = (uint16_t)run;
+	}
+	__syncthreads();
+	for (int il = wave; il < nown; il += NW) { // one wave per list
+		const int64_t b = a.order[b0 + il];
+		const int64_t p0 = a.c_ptr[b];
+		const int len = (int)(a.c_ptr[b + 1] - p0);
+		// rows are ascending and the own range is contiguous: the local entries are one run [l0, l1) of the list
+		for (int k = lane; k < len; k += 64) {
+			const int32_t src = a.c_col[p0 + k];
+			const bool loc = src >= b0 && src < b0 + nown;
+			int below = 0, lbelow = 0; // entries in front of k, and local ones among them
+			for (int t = 0; t < k; t++) {
+				const int32_t s2 = a.c_col[p0 + t];
+				lbelow += (s2 >= b0 && s2 < b0 + nown) ? 1 : 0;
+			}
+			below = k - lbelow; // far entries in front of k
+			const int place = loc ? (int)lo_s[il] + lbelow : (int)fo_s[il] + below;
+			idx_s[place] = (uint16_t)(loc ? src - b0 : src);
+			code_s[place] = a.c_code[p0 + k];
+		}
+	}
+	__syncthreads();
+	const int ngroups = (nown + 7) >> 3;
+	for (int i = threadIdx.x; i < ngmax; i += THREADS) {
+		int mf = 0, ml = 0;
+		for (int t = 0; t < 8; t++)
+			if (i * 8 + t < nown) {
+				mf = max(mf, (int)lo_s[i * 8 + t] - (int)fo_s[i * 8 + t]);
+				ml = max(ml, (int)fo_s[i * 8 + t + 1] - (int)lo_s[i * 8 + t]);
+			}
+		n4f_s[i] = (uint8_t)((mf + 3) >> 2);
+		nl_s[i] = (uint8_t)ml;
+	}
+	// own block of a place in the panel buffer: buffer row = block - b0 (NOT the position in `order`)
+	const char* ysrc = (const char*)a.y;
+	// this thread's share of a panel's lines: element e = threadIdx.x + k * THREADS covers line e >> 3, 16-byte piece e & 7
+	const int nel = nown * 8;
+	// (four named registers: as an array the values went through scratch memory)
+	auto pf_addr = [=](int p, int k) __attribute__((always_inline)) -> const double2* {
+		const int el = min((int)threadIdx.x + k * THREADS, nel - 1);
+		return (const double2*)(ysrc + (size_t)((uint32_t)(b0 + (el >> 3)) * rowbytes + (uint32_t)(p * 128) + (uint32_t)(el & 7) * 16u));
+	};
+	auto pf_put = [=](double* buf, int k, double2 v) __attribute__((always_inline)) {
+		const int el = (int)threadIdx.x + k * THREADS;
+		if (el < nel) *(double2*)(buf + (el >> 3) * kPbLineStride + (el & 7) * 2) = v;
+	};
+	static_assert(NPF == 4, "four staging registers");
+	const size_t bstride = (size_t)a.ids_per_wg * kPbLineStride; // the two buffers (an indexed array of pointers would live in scratch)
+	int cur = 0;
+	if (nown > 0 && grp < a.npanels) {
+		const double2 s0 = *pf_addr(grp, 0), s1 = *pf_addr(grp, 1), s2 = *pf_addr(grp, 2), s3 = *pf_addr(grp, 3);
+		pf_put(pan_s, 0, s0);
+		pf_put(pan_s, 1, s1);
+		pf_put(pan_s, 2, s2);
+		pf_put(pan_s, 3, s3);
+	}
+	__syncthreads();
+	for (int p = grp; p < a.npanels; p += nx) {
+		if (a.pace && p >= grp + 2 * nx) {
+			if (threadIdx.x == 0) {
+				const int* cnt = a.pace + (int64_t)grp * a.npanels + (p - 2 * nx);
+				for (int spin = 0; spin < 8192 && __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nslots; spin++)
+					__builtin_amdgcn_s_sleep(8);
+			}
+			__syncthreads();
+		}
+		const double* pan = pan_s + (size_t)cur * bstride;
+		// the next panel's lines: requested now (HBM / L2 first touch), stored behind the tasks -- the only loads of this kernel that
+		// are not L2 hits or LDS reads, so nothing else waits for them
+		const bool more = p + nx < a.npanels && nown > 0;
+		const int pnext = more ? p + nx : p; // loads unconditional (of a panel that exists)
+		const double2 tn0 = *pf_addr(pnext, 0), tn1 = *pf_addr(pnext, 1), tn2 = *pf_addr(pnext, 2), tn3 = *pf_addr(pnext, 3);
+		{
+			const uint32_t colb = (uint32_t)(p * 128 + c * 16);
+			for (int g = wave; g < ngroups; g += NWC) {
+				const int il = min(g * 8 + sub, nown - 1);
+				const bool valid = g * 8 + sub < nown;
+				const int n4 = __builtin_amdgcn_readfirstlane((int)n4f_s[g]);
+				const int nl = __builtin_amdgcn_readfirstlane((int)nl_s[g]);
+				const int f0 = fo_s[il], l0 = lo_s[il], e0 = fo_s[il + 1];
+				const int nfar = l0 - f0, nloc = e0 - l0;
+				const int own = (int)(line_s[il] / rowbytes - (uint32_t)b0); // buffer row of this lane's block
+				double2 acc = double2 { 0.0, 0.0 };
+				double2 ga[4], gb[4], gc[4];
+				auto issue = [&](int ch, double2* gbuf) __attribute__((always_inline)) {
+#pragma unroll
+					for (int q = 0; q < 4; q++) {
+						const int k = ch * 4 + q;
+						const uint32_t off = k < nfar ? (uint32_t)idx_s[f0 + k] * rowbytes : line_s[il]; // beyond the list: the own line
+						gbuf[q] = *(const double2*)(ysrc + (size_t)(off + colb));
+					}
+				};
+				auto consume = [&](int ch, const double2* gbuf) __attribute__((always_inline)) {
+#pragma unroll
+					for (int q = 0; q < 4; q++) {
+						const int k = ch * 4 + q;
+						const double v = k < nfar ? dict_s[code_s[f0 + k]] : 0.0;
+						acc.x = fma(v, gbuf[q].x, acc.x);
+						acc.y = fma(v, gbuf[q].y, acc.y);
+					}
+				};
+				double2* const zp = (double2*)((char*)a.z + (size_t)line_s[il] + colb);
+				double2 uo = double2 { 0.0, 0.0 }, xo = double2 { 0.0, 0.0 };
+				if (RMW) { // used only behind the gathers: no wait here
+					uo = nt_load2((const double2*)((const char*)a.u_in + (size_t)line_s[il] + colb));
+					xo = nt_load2(zp);
+				}
+				if (n4 > 0) issue(0, ga);
+				if (n4 > 1) issue(1, gb);
+				// couplings inside the workgroup's range: the staged lines, while the gathers above are in flight
+				double2 accl = double2 { 0.0, 0.0 };
+				for (int k0 = 0; k0 < nl; k0 += 4) { // wave-uniform trip count; four independent read chains per round
+					int src[4];
+					double v[4];
+#pragma unroll
+					for (int q = 0; q < 4; q++) {
+						const bool on = k0 + q < nloc;
+						src[q] = on ? (int)idx_s[l0 + k0 + q] : own;
+						v[q] = on ? dict_s[code_s[l0 + k0 + q]] : 0.0;
+					}
+					double2 t[4];
+#pragma unroll
+					for (int q = 0; q < 4; q++) t[q] = *(const double2*)(pan + src[q] * kPbLineStride + c * 2);
+#pragma unroll
+					for (int q = 0; q < 4; q++) {
+						accl.x = fma(v[q], t[q].x, accl.x);
+						accl.y = fma(v[q], t[q].y, accl.y);
+					}
+				}
+				for (int ch = 0; ch < n4; ch += 3) { // wave-uniform conditions
+					if (ch + 2 < n4) issue(ch + 2, gc);
+					consume(ch, ga);
+					if (ch + 1 < n4) {
+						if (ch + 3 < n4) issue(ch + 3, ga);
+						consume(ch + 1, gb);
+					}
+					if (ch + 2 < n4) {
+						if (ch + 4 < n4) issue(ch + 4, gb);
+						consume(ch + 2, gc);
+					}
+				}
+				const double2 yown = *(const double2*)(pan + own * kPbLineStride + c * 2);
+				if (valid) {
+					acc.x = fma(alpha, acc.x + accl.x, fma(beta, xo.x, uo.x));
+					acc.y = fma(alpha, acc.y + accl.y, fma(beta, xo.y, uo.y));
+					__builtin_nontemporal_store(acc.x, &zp->x);
+					__builtin_nontemporal_store(acc.y, &zp->y);
+					dot += yown.x * acc.x + yown.y * acc.y;
+					if (RMW) {
+						const double dx = acc.x - sh * yown.x, dy = acc.y - sh * yown.y;
+						nrm += dx * dx + dy * dy;
+					}
+				}
+			}
+		}
+		if (more) {
+			double* nb = pan_s + (size_t)(cur ^ 1) * bstride;
+			pf_put(nb, 0, tn0);
+			pf_put(nb, 1, tn1);
+			pf_put(nb, 2, tn2);
+			pf_put(nb, 3, tn3);
+		}
+		__syncthreads(); // the next panel is staged, this one is consumed
+		cur ^= 1;
+		if (a.pace && threadIdx.x == 0) __hip_atomic_fetch_add(a.pace + (int64_t)grp * a.npanels + p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	}
+	if (a.partial) {
+		const double r = block_sum_n<THREADS / 64>(dot, smem_d);
+		if (threadIdx.x == 0) a.partial[RMW ? 2 * blockIdx.x : blockIdx.x] = r;
+		if (RMW) {
+			const double q = block_sum_n<THREADS / 64>(nrm, smem_d);
+			if (threadIdx.x == 0) a.partial[2 * blockIdx.x + 1] = q;
+		}
+	}
+}
+
 // leaving the chained form: the pending pass  y = y - g x  (g = *g_a / *g_b2), with the partials of Re<y_new|x> that the
 // three-kernel form carries as <y | x_old>
 static __global__ __launch_bounds__(kBlock) void k_pb_materialise(double2* __restrict__ y, const double2* __restrict__ x, const double* __restrict__ g_a,
