@@ -465,6 +465,7 @@ static int launch_down2(lpp_engine* e, const double* y, double* z, int64_t pitch
 	d.partial = partial;
 	d.sc = sc;
 	d.pace = B.pace;
+	d.u_has_beta = rmw ? 1 : 0; // the chained form's u comes from k_pb_up<CHAIN>, which has added beta r_{j-1}
 	if (d.pace) (void)hipMemsetAsync(d.pace, 0, sizeof(int) * 8 * (size_t)d.npanels, st);
 	if (rmw) {
 		(void)hipFuncSetAttribute((const void*)k_pb_down2<1024, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B.down2_lds);
@@ -526,6 +527,7 @@ int pb_launch(lpp_engine* e, const void* y, void* x, double* partial, const EpiS
 		d.sc = sc;
 		d.pace = B.pace;
 		d.order = B.order;
+		d.u_has_beta = 0;
 		if (d.pace) (void)hipMemsetAsync(d.pace, 0, sizeof(int) * 8 * (size_t)d.npanels, sd);
 		int threads = concurrent ? 512 : 1024;
 		if (const char* s = getenv("LPP_PB_DOWN_THREADS")) threads = atoi(s);
@@ -667,6 +669,7 @@ void pb_tx_down(lpp_engine* e, const void* gath, void* send2, const EpiScale& sc
 	d.sc = sc;
 	d.pace = B.pace;
 	d.order = B.order;
+	d.u_has_beta = 0;
 	if (d.pace) (void)hipMemsetAsync(d.pace, 0, sizeof(int) * 8 * (size_t)d.npanels, e->stream);
 	if (B.wide) {
 		(void)hipFuncSetAttribute((const void*)k_pb_down<1024, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B.down_lds);
@@ -750,6 +753,7 @@ int pb_launch_chain(lpp_engine* e, void* w, void* y, double* partial, const EpiS
 	d.sc = sc;
 	d.pace = B.pace;
 	d.order = B.order;
+	d.u_has_beta = 1; // k_pb_up<CHAIN> has put beta r_{j-1} into u
 	if (d.pace) (void)hipMemsetAsync(d.pace, 0, sizeof(int) * 8 * (size_t)d.npanels, st);
 	(void)hipFuncSetAttribute((const void*)k_pb_down<1024, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B.down_lds);
 	k_pb_down<1024, true><<<B.down_grid, 1024, B.down_lds, st>>>(d);

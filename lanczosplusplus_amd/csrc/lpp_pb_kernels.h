@@ -65,6 +65,7 @@ constexpr int kPbPre = 4; // chunks (of 4 slots) of every (slice, group) request
 template <int GT> struct PbWords {
 	uint2 w[GT][kPbPre];
 	int nc[GT];
+	double yo; // chained form: the previous Lanczos vector at this lane's row (its beta term rides in u)
 };
 
 // index * 8 of the low / high 16 bits of w in ONE instruction (the compiler emits and + shift)
@@ -120,8 +121,8 @@ template <bool DOT, int GT, bool LEAN, bool CHAIN = false> __global__ __launch_b
 		off_s[i] = a.tw_off[i];
 		len_s[i] = a.tw_len[i];
 	}
-	double alpha, beta_unused;
-	epi_coeffs(a.sc, alpha, beta_unused);
+	double alpha, beta;
+	epi_coeffs(a.sc, alpha, beta);
 	double gco = 0.0; // chained form: r_next = w - gco r
 	if (CHAIN && a.g_a) {
 		gco = *a.g_a;
@@ -204,14 +205,16 @@ template <bool DOT, int GT, bool LEAN, bool CHAIN = false> __global__ __launch_b
 		}
 		if (threadIdx.x < kPbZeroSlots) win[a.pitch + threadIdx.x] = 0.0;
 		__syncthreads();
-		auto epilogue = [=, &dot](int j, double acc) __attribute__((always_inline)) {
+		const double* const yold = CHAIN ? a.ybuf + rowbase : nullptr;
+		auto epilogue = [=, &dot](int j, double acc, double yo = 0.0) __attribute__((always_inline)) {
 			const int iu_raw = j * 64 + lane;
 			const bool valid = iu_raw < n_up;
 			const int iu = valid ? iu_raw : n_up - 1;
 			const double yc = win[iu];
 			acc = fma(dict_s[dcode_s[iu]], yc, acc);
 			if (valid) {
-				const double uv = alpha * acc;
+				// chained form: u = alpha (T + D) r_j + beta r_{j-1}, so that the coupling kernel needs neither r_{j-1} nor beta
+				const double uv = CHAIN ? fma(beta, yo, alpha * acc) : alpha * acc;
 				__builtin_nontemporal_store(uv, &uout[rowbase + iu]);
 				if (DOT) dot += yc * uv;
 			}
@@ -226,6 +229,9 @@ template <bool DOT, int GT, bool LEAN, bool CHAIN = false> __global__ __launch_b
 #pragma unroll
 					for (int c = 0; c < kPbPre; c++) s.w[g][c] = wp[c * 64]; // chunks beyond the list belong to the next list (or the slack): never used
 				}
+				// chained form: r_{j-1} at this row, re-read one slice ahead with the words.  The row was read during staging a
+				// few microseconds ago: an L2 hit, like the template words in front of and behind it in the return queue
+				if (CHAIN) s.yo = yold[min(j * 64 + lane, n_up - 1)];
 			};
 			// one value group of a slice: sum of the window elements its (look-ahead) chunks index, longer lists streamed
 			auto group_sum = [=](int j, int g, int nc, const uint2* w) __attribute__((always_inline)) {
@@ -256,7 +262,7 @@ template <bool DOT, int GT, bool LEAN, bool CHAIN = false> __global__ __launch_b
 				double acc = 0.0;
 #pragma unroll
 				for (int g = 0; g < GG; g++) acc = fma(gv[g], group_sum(j, g, s.nc[g], s.w[g]), acc);
-				epilogue(j, acc);
+				epilogue(j, acc, CHAIN ? s.yo : 0.0);
 			};
 			if (LEAN) { // one group's words at a time: 8 registers instead of 2 x 8 x GG
 				for (int j = wave; j < spb; j += NW) {
@@ -334,6 +340,7 @@ struct PbDownArgs {
 	double* partial; // per-workgroup Re<y|z> (null: not wanted); RMW: pairs (Re<y|z>, |z|^2) of the finished z
 	EpiScale sc; // only alpha is used: z = alpha * C y
 	int* pace; // [8][npanels] finished-workgroup counters (zeroed before the launch); null: free-running
+	int u_has_beta; // RMW: u_in already holds beta * (old z) (k_pb_up<CHAIN> adds it): z is written only, one stream less
 };
 
 // RMW (chained Lanczos step, see k_pb_up): z holds the previous Lanczos vector r' and receives the finished
@@ -434,7 +441,7 @@ template <int THREADS, bool RMW = false, bool WIDE = false> __global__ __launch_
 			if (LPP_PB_RMW_POS >= 2 && n4 > 1) issue(1, gb);
 			if (RMW) { // used only behind the gather loop: no wait here
 				uo = nt_load2((const double2*)((const char*)a.u_in + at(row_s[il])));
-				xo = nt_load2(zp);
+				if (!a.u_has_beta) xo = nt_load2(zp); // wave-uniform
 			}
 			if (LPP_PB_RMW_POS < 1 && n4 > 0) issue(0, ga);
 			if (LPP_PB_RMW_POS < 2 && n4 > 1) issue(1, gb);
@@ -506,6 +513,7 @@ struct PbDown2Args {
 	double* partial; // per-workgroup Re<y|z>; RMW: pairs (Re<y|w>, |w - s y|^2)
 	EpiScale sc;
 	int* pace; // [8][npanels] finished-workgroup counters (zeroed before the launch); null: free-running
+	int u_has_beta; // RMW: as in PbDownArgs
 };
 
 constexpr int kPbLineStride = 18; // doubles per staged line in LDS: 16 + 2 (144 bytes: 16-byte reads of neighbouring lines fall on different banks)
@@ -683,7 +691,7 @@ template <int THREADS, bool RMW> __global__ __launch_bounds__(THREADS) void k_pb
 				double2 uo = double2 { 0.0, 0.0 }, xo = double2 { 0.0, 0.0 };
 				if (RMW) { // used only behind the gathers: no wait here
 					uo = nt_load2((const double2*)((const char*)a.u_in + (size_t)line_s[il] + colb));
-					xo = nt_load2(zp);
+					if (!a.u_has_beta) xo = nt_load2(zp);
 				}
 				if (n4 > 0) issue(0, ga);
 				if (n4 > 1) issue(1, gb);
