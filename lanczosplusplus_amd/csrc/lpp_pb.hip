@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "lpp_engine_impl.h"
+#include "lpp_pbws_kernels.h"
 
 using namespace lpp;
 
@@ -190,6 +191,8 @@ lpp_status pb_build(lpp_engine* e, int64_t n_up, int64_t n_blk, const int64_t* t
 	if (n_blk > 65535) return fail(LPP_ERR_INVALID, "pb_build: more than 65535 blocks");
 	B.parts = parts;
 	B.wide = wide;
+	B.ws = getenv("LPP_PB_WS") && atoi(getenv("LPP_PB_WS")) == 1 && !B.big && pitch <= kPbWsMaxPitch && pb_ws_lds_bytes(pitch, T.spb, T.G) <= (size_t)160 * 1024 - 64;
+	B.ws_beta = !(getenv("LPP_PB_WS_BETA") && atoi(getenv("LPP_PB_WS_BETA")) == 0);
 	// k_pb_down2 (own lines of the panel in LDS): opt-in (LPP_PB_DOWN2=1).  Measured at BASELINE config 2 (profiles/README.md, round 3):
 	// it halves the couplings that go through L1 (8.6 of 17.1 per block leave the workgroup's range) but the far lists padded per
 	// task (12 instead of 8.6), the selects of the compact lists and twice the VALU / LDS instructions leave it at 1.57 ms against
@@ -444,7 +447,7 @@ static int launch_down_parts(lpp_engine* e, const double* y, double* z, int64_t 
 }
 
 // block couplings with the workgroup's own lines of the panel staged in LDS (k_pb_down2); rmw: the chained form (u_in, shift, pairs of partials)
-static int launch_down2(lpp_engine* e, const double* y, double* z, int64_t pitch, const double* u_in, const double* shift, double* partial, const EpiScale& sc, bool rmw, hipStream_t st)
+static int launch_down2(lpp_engine* e, const double* y, double* z, int64_t pitch, const double* u_in, const double* shift, double* partial, const EpiScale& sc, bool rmw, bool beta_in_u, hipStream_t st)
 {
 	const PbState& B = e->pb;
 	PbDown2Args d;
@@ -465,7 +468,7 @@ static int launch_down2(lpp_engine* e, const double* y, double* z, int64_t pitch
 	d.partial = partial;
 	d.sc = sc;
 	d.pace = B.pace;
-	d.u_has_beta = rmw ? 1 : 0; // the chained form's u comes from k_pb_up<CHAIN>, which has added beta r_{j-1}
+	d.u_has_beta = rmw && beta_in_u ? 1 : 0; // the chained form's in-block kernel has added beta r_{j-1}
 	if (d.pace) (void)hipMemsetAsync(d.pace, 0, sizeof(int) * 8 * (size_t)d.npanels, st);
 	if (rmw) {
 		(void)hipFuncSetAttribute((const void*)k_pb_down2<1024, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B.down2_lds);
@@ -506,7 +509,7 @@ int pb_launch(lpp_engine* e, const void* y, void* x, double* partial, const EpiS
 		const int n = launch_down_parts(e, (const double*)y, B.z, B.pitch, partial ? partial + nb : nullptr, sc, sd);
 		if (partial) np += n;
 	} else if (both && B.down2 && !concurrent && !getenv("LPP_PB_DOWN_THREADS")) {
-		const int n = launch_down2(e, (const double*)y, B.z, B.pitch, nullptr, nullptr, partial ? partial + nb : nullptr, sc, false, sd);
+		const int n = launch_down2(e, (const double*)y, B.z, B.pitch, nullptr, nullptr, partial ? partial + nb : nullptr, sc, false, false, sd);
 		if (partial) np += n;
 	} else if (both) {
 		PbDownArgs d;
@@ -546,7 +549,7 @@ int pb_launch(lpp_engine* e, const void* y, void* x, double* partial, const EpiS
 	if (B.big) {
 		launch_up_big(e, (const double*)y, B.u, B.dcode, B.n_blk, partial, sc, st); // nb partials, in front of the couplings'
 	} else {
-	PbUpArgs u;
+	PbUpArgs u = {};
 	u.tw = B.tw;
 	u.tw_off = B.tw_off;
 	u.tw_len = B.tw_len;
@@ -629,7 +632,7 @@ void pb_tx_up(lpp_engine* e, const void* y, const EpiScale& sc, int64_t b0, int6
 		launch_up_big(e, (const double*)y + b0 * B.pitch, B.u + b0 * B.pitch, B.dcode + b0 * B.pitch, cnt, nullptr, sc, e->stream);
 		return;
 	}
-	PbUpArgs u;
+	PbUpArgs u = {};
 	fill_up_args(B, u);
 	u.dcode = B.dcode + b0 * B.pitch;
 	u.n_blk = cnt;
@@ -648,7 +651,7 @@ void pb_tx_down(lpp_engine* e, const void* gath, void* send2, const EpiScale& sc
 		return;
 	}
 	if (B.down2) {
-		launch_down2(e, (const double*)gath, (double*)send2, B.pitch_dn, nullptr, nullptr, nullptr, sc, false, e->stream);
+		launch_down2(e, (const double*)gath, (double*)send2, B.pitch_dn, nullptr, nullptr, nullptr, sc, false, false, e->stream);
 		return;
 	}
 	PbDownArgs d;
@@ -711,7 +714,7 @@ int pb_launch_chain(lpp_engine* e, void* w, void* y, double* partial, const EpiS
 	PbState& B = e->pb;
 	hipStream_t st = e->stream;
 	const int nb = (int)std::max<int64_t>(1, std::min<int64_t>(B.n_blk, (int64_t)e->num_cus));
-	PbUpArgs u;
+	PbUpArgs u = {};
 	u.tw = B.tw;
 	u.tw_off = B.tw_off;
 	u.tw_len = B.tw_len;
@@ -731,10 +734,27 @@ int pb_launch_chain(lpp_engine* e, void* w, void* y, double* partial, const EpiS
 	u.ybuf = (double*)y;
 	u.g_a = g_a;
 	u.g_b2 = g_b2;
-	const size_t lds = pb_up_lds_bytes(B.pitch, B.spb, B.G);
-	if (B.G == 1) launch_up_chain<1>(u, nb, lds, st);
-	else launch_up_chain<2>(u, nb, lds, st);
-	if (B.down2) return launch_down2(e, (const double*)w, (double*)y, B.pitch, B.u, shift, partial, sc, true, st);
+	// LPP_PB_WS=1: rows that fit five waves' registers are staged beside the gathers (k_pb_up_ws).  Measured slower than the
+	// two-phase kernel (1.63-1.99 against 1.56 ms at config 2: the gathers need all 16 waves), so it is not the default
+	const size_t lds_ws = pb_ws_lds_bytes(B.pitch, B.spb, B.G);
+	bool beta_in_u = true;
+	u.beta_in_u = 1;
+	if (B.ws) {
+		beta_in_u = B.ws_beta;
+		u.beta_in_u = beta_in_u ? 1 : 0;
+		if (B.G == 1) {
+			(void)hipFuncSetAttribute((const void*)k_pb_up_ws<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ws);
+			k_pb_up_ws<1><<<nb, kPbUpThreads, lds_ws, st>>>(u);
+		} else {
+			(void)hipFuncSetAttribute((const void*)k_pb_up_ws<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ws);
+			k_pb_up_ws<2><<<nb, kPbUpThreads, lds_ws, st>>>(u);
+		}
+	} else {
+		const size_t lds = pb_up_lds_bytes(B.pitch, B.spb, B.G);
+		if (B.G == 1) launch_up_chain<1>(u, nb, lds, st);
+		else launch_up_chain<2>(u, nb, lds, st);
+	}
+	if (B.down2) return launch_down2(e, (const double*)w, (double*)y, B.pitch, B.u, shift, partial, sc, true, beta_in_u, st);
 	PbDownArgs d;
 	d.pitch = B.pitch;
 	d.n_blk = B.n_blk;
@@ -753,7 +773,7 @@ int pb_launch_chain(lpp_engine* e, void* w, void* y, double* partial, const EpiS
 	d.sc = sc;
 	d.pace = B.pace;
 	d.order = B.order;
-	d.u_has_beta = 1; // k_pb_up<CHAIN> has put beta r_{j-1} into u
+	d.u_has_beta = beta_in_u ? 1 : 0; // the in-block kernel has put beta r_{j-1} into u
 	if (d.pace) (void)hipMemsetAsync(d.pace, 0, sizeof(int) * 8 * (size_t)d.npanels, st);
 	(void)hipFuncSetAttribute((const void*)k_pb_down<1024, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B.down_lds);
 	k_pb_down<1024, true><<<B.down_grid, 1024, B.down_lds, st>>>(d);

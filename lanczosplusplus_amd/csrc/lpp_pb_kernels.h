@@ -48,6 +48,7 @@ struct PbUpArgs {
 	double* ybuf;
 	const double* g_a; // raw_{j-1} (null: the vector in wbuf is r_j already, nothing to subtract)
 	const double* g_b2; // b_{j-2}^2
+	int beta_in_u; // k_pb_up_ws: add beta r_{j-1} to u (k_pb_up<CHAIN> always does)
 };
 
 constexpr int kPbPre = 4; // chunks (of 4 slots) of every (slice, group) requested one slice ahead
