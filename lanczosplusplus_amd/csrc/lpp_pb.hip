@@ -101,6 +101,13 @@ lpp_status pb_build(lpp_engine* e, int64_t n_up, int64_t n_blk, const int64_t* t
 	if (const char* s = getenv("LPP_PB_PARTS")) nparts = std::max(1, std::min(atoi(s), kPbMaxParts));
 	const bool parts = nparts > 1 || getenv("LPP_PB_PARTS") != nullptr;
 	const bool wide = vec_bytes >= ((size_t)1 << 32) || getenv("LPP_PB_WIDE") != nullptr;
+	// LPP_PB_HALF=1: panels of 8 positions (64-byte half lines), so that a panel of 38,760 blocks is 2.5 MB instead of 5.  Measured
+	// at the (7,6) sector (scripts/experiments/r03_half_ab.sh): 53 ms against 38 ms per product with whole lines -- the kernel
+	// is bound by line requests through L1, a half line costs a whole request and there are twice as many; the fabric reads
+	// it saves were Infinity-Cache hits already.  Opt-in, kept with its parity form.
+	bool half = false;
+	if (const char* s = getenv("LPP_PB_HALF")) half = wide && !parts && atoi(s) != 0;
+	if ((size_t)nblk_padded * (size_t)(pitch_dn >> 3) >= ((size_t)1 << 32)) half = false; // 32-bit half-line numbers
 	PbTemplate T;
 	int ways = 2;
 	if (const char* s = getenv("LPP_PB_BANK_WAYS")) ways = std::max(1, std::min(atoi(s), 4));
@@ -191,6 +198,7 @@ lpp_status pb_build(lpp_engine* e, int64_t n_up, int64_t n_blk, const int64_t* t
 	if (n_blk > 65535) return fail(LPP_ERR_INVALID, "pb_build: more than 65535 blocks");
 	B.parts = parts;
 	B.wide = wide;
+	B.half = half;
 	B.ws = getenv("LPP_PB_WS") && atoi(getenv("LPP_PB_WS")) == 1 && !B.big && pitch <= kPbWsMaxPitch && pb_ws_lds_bytes(pitch, T.spb, T.G) <= (size_t)160 * 1024 - 64;
 	B.ws_beta = !(getenv("LPP_PB_WS_BETA") && atoi(getenv("LPP_PB_WS_BETA")) == 0);
 	// k_pb_down2 (own lines of the panel in LDS): opt-in (LPP_PB_DOWN2=1).  Measured at BASELINE config 2 (profiles/README.md, round 3):
@@ -278,7 +286,7 @@ lpp_status pb_build(lpp_engine* e, int64_t n_up, int64_t n_blk, const int64_t* t
 		if ((rc = to_device(&B.order, order, st)) != LPP_OK) return rc;
 	}
 	if (!(getenv("LPP_PB_PACE") && atoi(getenv("LPP_PB_PACE")) == 0))
-		HIP_TRY_MEM(hipMalloc(&B.pace, sizeof(int) * 8 * (parts ? (size_t)B.pace_stride : (size_t)(std::max(pitch, pitch_dn) / 16))));
+		HIP_TRY_MEM(hipMalloc(&B.pace, sizeof(int) * 8 * (parts ? (size_t)B.pace_stride : (size_t)(std::max(pitch, pitch_dn) / (half ? 8 : 16)))));
 	// the two parts of a product (padding stays zero) and the carried scalar; with the transposition exchange the couplings'
 	// part is written straight into the exchange buffer
 	const size_t loc = (size_t)std::max<int64_t>(nblk_loc, 1) * (size_t)pitch;
@@ -515,7 +523,7 @@ int pb_launch(lpp_engine* e, const void* y, void* x, double* partial, const EpiS
 		PbDownArgs d;
 		d.pitch = B.pitch;
 		d.n_blk = B.n_blk;
-		d.npanels = (int)(B.pitch / 16);
+		d.npanels = (int)(B.pitch / (B.half ? 8 : 16));
 		d.ids_per_wg = B.ids_per_wg;
 		d.rowcap = B.rowcap;
 		d.c_ptr = B.c_ptr;
@@ -537,6 +545,9 @@ int pb_launch(lpp_engine* e, const void* y, void* x, double* partial, const EpiS
 		if (threads == 512) {
 			(void)hipFuncSetAttribute((const void*)k_pb_down<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B.down_lds);
 			k_pb_down<512><<<B.down_grid, 512, B.down_lds, sd>>>(d);
+		} else if (B.wide && B.half) {
+			(void)hipFuncSetAttribute((const void*)k_pb_down<1024, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B.down_lds);
+			k_pb_down<1024, false, true, true><<<B.down_grid, 1024, B.down_lds, sd>>>(d);
 		} else if (B.wide) {
 			(void)hipFuncSetAttribute((const void*)k_pb_down<1024, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B.down_lds);
 			k_pb_down<1024, false, true><<<B.down_grid, 1024, B.down_lds, sd>>>(d);
@@ -657,7 +668,7 @@ void pb_tx_down(lpp_engine* e, const void* gath, void* send2, const EpiScale& sc
 	PbDownArgs d;
 	d.pitch = B.pitch_dn;
 	d.n_blk = B.n_blk;
-	d.npanels = (int)(B.pitch_dn / 16);
+	d.npanels = (int)(B.pitch_dn / (B.half ? 8 : 16));
 	d.ids_per_wg = B.ids_per_wg;
 	d.rowcap = B.rowcap;
 	d.c_ptr = B.c_ptr;
@@ -674,6 +685,11 @@ void pb_tx_down(lpp_engine* e, const void* gath, void* send2, const EpiScale& sc
 	d.order = B.order;
 	d.u_has_beta = 0;
 	if (d.pace) (void)hipMemsetAsync(d.pace, 0, sizeof(int) * 8 * (size_t)d.npanels, e->stream);
+	if (B.wide && B.half) {
+		(void)hipFuncSetAttribute((const void*)k_pb_down<1024, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B.down_lds);
+		k_pb_down<1024, false, true, true><<<B.down_grid, 1024, B.down_lds, e->stream>>>(d);
+		return;
+	}
 	if (B.wide) {
 		(void)hipFuncSetAttribute((const void*)k_pb_down<1024, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B.down_lds);
 		k_pb_down<1024, false, true><<<B.down_grid, 1024, B.down_lds, e->stream>>>(d);

@@ -326,7 +326,7 @@ template <bool DOT, int GT, bool LEAN, bool CHAIN = false> __global__ __launch_b
 // ---------------------------------------------------------------------------------------------
 struct PbDownArgs {
 	int64_t pitch, n_blk;
-	int npanels; // pitch / 16
+	int npanels; // pitch / 16 (HALF: pitch / 8)
 	int ids_per_wg; // blocks owned by one workgroup
 	int rowcap; // longest coupling list rounded up to a multiple of 4
 	const int64_t* c_ptr; // couplings: CSR over blocks, off-diagonal, ascending
@@ -351,7 +351,10 @@ struct PbDownArgs {
 // config 2): it is bound by what goes through L1 -- 17 gathered lines + 3 streamed ones per line written -- not by the order.
 // WIDE: vectors beyond 4 GiB (BASELINE config 5's sectors).  The LDS image then holds 128-byte LINE numbers instead of byte
 // offsets and every address is formed in 64 bits: (line of the source block's row + panel) << 7.
-template <int THREADS, bool RMW = false, bool WIDE = false> __global__ __launch_bounds__(THREADS) void k_pb_down(PbDownArgs a)
+// HALF: panels of 8 positions (64-byte half lines; a wave task is 16 blocks x 8 positions, npanels = pitch / 8): with 38,760 or
+// 77,520 blocks (BASELINE config 5's sectors) a panel of whole lines is 5-10 MB and does not stay in an XCD's 4 MiB L2 --
+// every one of the ~17 gathers of a line then comes from the fabric (measured at the (7,6) sector: 88 GB read for a 24 GB vector).
+template <int THREADS, bool RMW = false, bool WIDE = false, bool HALF = false> __global__ __launch_bounds__(THREADS) void k_pb_down(PbDownArgs a)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
 	__shared__ double dict_s[256];
@@ -368,14 +371,17 @@ template <int THREADS, bool RMW = false, bool WIDE = false> __global__ __launch_
 	epi_coeffs(a.sc, alpha, beta);
 	double dot = 0.0, nrm = 0.0;
 	const double sh = RMW ? *a.shift : 0.0;
-	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = lane >> 3, c = lane & 7;
+	constexpr int LPL = HALF ? 4 : 8; // 16-byte lanes per panel line
+	constexpr int BPT = 64 / LPL; // blocks of a wave task
+	constexpr int LSH = HALF ? 6 : 7; // log2 of the panel line's bytes
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = lane / LPL, c = lane & (LPL - 1);
 	const int nx = (gridDim.x & 7) == 0 ? 8 : 1; // groups the panels are dealt over
 	const int grp = nx == 8 ? (int)(blockIdx.x & 7) : 0;
 	const int slot = nx == 8 ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
 	const int nslots = (int)(gridDim.x / nx);
 	const int64_t b0 = (int64_t)slot * a.ids_per_wg;
 	const int nown = (int)max((int64_t)0, min((int64_t)a.ids_per_wg, a.n_blk - b0));
-	const uint32_t rowbytes = WIDE ? (uint32_t)(a.pitch >> 4) : (uint32_t)(a.pitch * 8); // WIDE: lines per row
+	const uint32_t rowbytes = WIDE ? (uint32_t)((a.pitch * 8) >> LSH) : (uint32_t)(a.pitch * 8); // WIDE: panel lines per row
 	for (int il = threadIdx.x; il < nown; il += THREADS) {
 		const int64_t b = a.order[b0 + il];
 		row_s[il] = (uint32_t)b * rowbytes;
@@ -388,14 +394,14 @@ template <int THREADS, bool RMW = false, bool WIDE = false> __global__ __launch_
 		const bool in = k < (int)(a.c_ptr[b + 1] - p0);
 		// places beyond the list carry code 0 (+0.0) and the address the task's first block (the longest list) reads at this
 		// place, so the filling lanes of a gather ask for a line that is requested anyway; no per-lane conditions in the loop
-		const int64_t bl = a.order[b0 + (il & ~7)];
+		const int64_t bl = a.order[b0 + (il & ~(BPT - 1))];
 		const int64_t pl = a.c_ptr[bl];
 		const int32_t fill = k < (int)(a.c_ptr[bl + 1] - pl) ? a.c_col[pl + k] : (int32_t)bl;
 		idx_s[il * stride + k] = (uint16_t)(in ? a.c_col[p0 + k] : fill);
 		code_s[il * stride + k] = in ? a.c_code[p0 + k] : (uint8_t)0;
 	}
 	__syncthreads();
-	const int ngroups = (nown + 7) >> 3;
+	const int ngroups = (nown + BPT - 1) / BPT;
 	const char* ysrc = (const char*)a.y;
 	for (int p = grp; p < a.npanels; p += nx) {
 		if (a.pace && p >= grp + 2 * nx) {
@@ -407,14 +413,14 @@ template <int THREADS, bool RMW = false, bool WIDE = false> __global__ __launch_
 			}
 			__syncthreads();
 		}
-		const uint32_t colb = WIDE ? (uint32_t)(c * 16) : (uint32_t)(p * 128 + c * 16); // byte offset of this lane's two positions inside a row (WIDE: inside the panel line)
+		const uint32_t colb = WIDE ? (uint32_t)(c * 16) : (uint32_t)((p << LSH) + c * 16); // byte offset of this lane's two positions inside a row (WIDE: inside the panel line)
 		// byte offset of (row `r` as stored in the LDS image, this lane's two positions of panel p)
-		auto at = [=](uint32_t r) __attribute__((always_inline)) -> size_t { return WIDE ? (((size_t)(r + (uint32_t)p) << 7) + colb) : (size_t)(r + colb); };
+		auto at = [=](uint32_t r) __attribute__((always_inline)) -> size_t { return WIDE ? (((size_t)(r + (uint32_t)p) << LSH) + colb) : (size_t)(r + colb); };
 		for (int g = wave; g < ngroups; g += THREADS / 64) {
-			const int il = min(g * 8 + sub, nown - 1);
-			const bool valid = g * 8 + sub < nown;
+			const int il = min(g * BPT + sub, nown - 1);
+			const bool valid = g * BPT + sub < nown;
 			// trip count of the task: the longest list is the first one (decreasing order), in chunks of 4
-			const int n4 = (__builtin_amdgcn_readfirstlane(len_s[g * 8]) + 3) >> 2;
+			const int n4 = (__builtin_amdgcn_readfirstlane(len_s[g * BPT]) + 3) >> 2;
 			const uint16_t* orow = idx_s + il * stride;
 			const uint8_t* crow = code_s + il * stride;
 			double2 acc = double2 { 0.0, 0.0 };

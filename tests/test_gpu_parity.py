@@ -748,7 +748,7 @@ PB_CASES = {
 }
 
 
-@pytest.mark.parametrize("form", ["window", "pieces", "wide", "down2", "ws"])
+@pytest.mark.parametrize("form", ["window", "pieces", "wide", "half", "down2", "ws"])
 @pytest.mark.parametrize("case", sorted(PB_CASES))
 def test_product_basis_layout(case, form, monkeypatch):
     """Device assembly of Hubbard straight into the product-basis layout (T, C, diagonal codes; lpp_pb_kernels.h): the CSR it
@@ -767,7 +767,8 @@ def test_product_basis_layout(case, form, monkeypatch):
         monkeypatch.setenv("LPP_PB_DOWN2", "1")  # coupling kernel with the workgroup's own lines of a panel staged in LDS (opt-in experiment)
     if form == "ws":
         monkeypatch.setenv("LPP_PB_WS", "1")  # chained step with the next row staged by loader waves (k_pb_up_ws, opt-in experiment)
-    if form == "wide":
+    if form in ("wide", "half"):
+        monkeypatch.setenv("LPP_PB_HALF", "1" if form == "half" else "0")  # coupling panels of 8 positions (64-byte half lines) / of 16
         monkeypatch.setenv("LPP_PB_PIECE_ROWS", "320")
         monkeypatch.setenv("LPP_PB_WIDE", "1")
         monkeypatch.setenv("LPP_PB_BIG2", "0")  # one block per workgroup (k_pb_up_big); "pieces" runs two per workgroup (k_pb_up_big2)
@@ -782,7 +783,7 @@ def test_product_basis_layout(case, form, monkeypatch):
         lay = e.layout()
         assert lay["kernel"] == 4 and lay["nnz"] == A.nnz and lay["resident_bytes"] < (0.12 if case == "disorder" else 0.05) * 12 * A.nnz
         assert (lay["diagonal_plain"], lay["diagonal_codes"], lay["chained_step"]) == ((1, 0, 0) if case == "disorder" else (0, 1, 1 if form in ("window", "down2", "ws") and case != "two_hoppings" else 0))  # the chained step is built for <= 2 hopping values
-        assert (lay["pieces"], lay["coupling_parts"]) == {"window": (1, 1), "pieces": (4, 3), "wide": (3, 1), "down2": (1, 1), "ws": (1, 1)}[form]
+        assert (lay["pieces"], lay["coupling_parts"]) == {"window": (1, 1), "pieces": (4, 3), "wide": (3, 1), "half": (3, 1), "down2": (1, 1), "ws": (1, 1)}[form]
         st = e.stats()
         assert (st["nrows"], st["nnz"]) == (A.nrows, A.nnz)
         rp, ci, va = e.get_csr()
