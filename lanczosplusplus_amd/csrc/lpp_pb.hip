@@ -253,6 +253,12 @@ lpp_status pb_build(lpp_engine* e, int64_t n_up, int64_t n_blk, const int64_t* t
 		// every workgroup takes its blocks in the order of decreasing list length (tasks of 8 blocks with equal trip counts)
 		std::vector<int32_t> order((size_t)n_blk);
 		for (int64_t b = 0; b < n_blk; b++) order[(size_t)b] = (int32_t)b;
+		// ... inside windows of 64 consecutive blocks: neighbouring blocks gather many of the same lines (hops among the low sites
+		// keep the high part of the word -- a run of <= 70 consecutive blocks at config 2), so the tasks that are in flight together
+		// share them in L1.  Measured at config 2 (scripts/experiments/r03_order_ab.sh): k_pb_down<RMW> 1.711 ms sorted over the
+		// whole range of ~400 blocks, 1.655-1.662 ms with windows of 48-64, 1.73 ms with windows of 32 (tasks of unequal lists)
+		int64_t order_window = 64;
+		if (const char* s = getenv("LPP_PB_ORDER_WINDOW")) order_window = std::max(0, atoi(s)) / 16 * 16;
 		for (int sl = 0; sl < slots; sl++) {
 			const int64_t lo = std::min<int64_t>((int64_t)sl * B.ids_per_wg, n_blk), hi = std::min<int64_t>(lo + B.ids_per_wg, n_blk);
 			if (parts) {
@@ -280,8 +286,12 @@ lpp_status pb_build(lpp_engine* e, int64_t n_up, int64_t n_blk, const int64_t* t
 					return n;
 				};
 				std::stable_sort(order.begin() + lo, order.begin() + hi, [&](int32_t x, int32_t y) { return far_len(x) > far_len(y); });
-			} else
-			std::stable_sort(order.begin() + lo, order.begin() + hi, [&](int32_t x, int32_t y) { return cp[(size_t)x + 1] - cp[(size_t)x] > cp[(size_t)y + 1] - cp[(size_t)y]; });
+			} else {
+				// sorted inside windows of `ow` consecutive blocks (a multiple of 16; 0: the whole range at once)
+				const int64_t ow = order_window > 0 ? order_window : hi - lo;
+				for (int64_t w0 = lo; w0 < hi; w0 += ow)
+					std::stable_sort(order.begin() + w0, order.begin() + std::min(w0 + ow, hi), [&](int32_t x, int32_t y) { return cp[(size_t)x + 1] - cp[(size_t)x] > cp[(size_t)y + 1] - cp[(size_t)y]; });
+			}
 		}
 		if ((rc = to_device(&B.order, order, st)) != LPP_OK) return rc;
 	}
