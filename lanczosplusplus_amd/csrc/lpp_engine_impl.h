@@ -160,6 +160,7 @@ struct PbState {
 	bool down2 = false; // k_pb_down2: the workgroup's own lines of a panel staged in LDS (couplings inside its block range are LDS reads)
 	size_t down2_lds = 0;
 	int down2_ent = 0;
+	int pre0 = 4; // chained step, two value groups: chunks of group 0 requested one slice ahead (group 1: 8 - pre0)
 	bool half = false; // k_pb_down<WIDE, HALF>: panels of 8 positions (64-byte half lines), for panels beyond an XCD's L2
 	bool ws = false; // k_pb_up_ws in the chained step (LPP_PB_WS=1): the next row staged by loader waves beside the gathers
 	bool ws_beta = true; // ... with the beta term in u (0: left to the coupling kernel)

@@ -129,6 +129,20 @@ lpp_status pb_build(lpp_engine* e, int64_t n_up, int64_t n_blk, const int64_t* t
 	if ((rc = to_device(&B.tw, T.words, st)) != LPP_OK) return rc;
 	if ((rc = to_device(&B.tw_off, T.off, st)) != LPP_OK) return rc;
 	if ((rc = to_device(&B.tw_len, T.len, st)) != LPP_OK) return rc;
+	B.pre0 = kPbPre;
+	if (T.G == 2 && W == 0) {
+		// look-ahead split of the chained kernel: the depth pair (3,5), (4,4) or (5,3) that leaves the fewest chunks beyond it
+		int64_t best = -1;
+		for (int p0 = 3; p0 <= 5; p0++) {
+			int64_t beyond = 0;
+			for (int j = 0; j < T.spb; j++) beyond += std::max(0, (int)T.len[(size_t)j * 2] - p0) + std::max(0, (int)T.len[(size_t)j * 2 + 1] - (2 * kPbPre - p0));
+			if (best < 0 || beyond < best || (beyond == best && p0 == kPbPre)) {
+				best = beyond;
+				B.pre0 = p0;
+			}
+		}
+		if (const char* s = getenv("LPP_PB_PRE0")) B.pre0 = std::max(3, std::min(atoi(s), 5));
+	}
 	B.big = W > 0;
 	B.big2 = B.big && big2 && (T.G == 1 || T.G == 2) && pb_big2_lds_bytes((int)W) <= (size_t)160 * 1024 - 64 && (W + kPbZeroSlots) * 8 < 65536;
 	B.W = (int)W;
@@ -727,10 +741,10 @@ bool pb_chain_ok(const lpp_engine* e)
 	return B.active && !B.tx && !B.big && !B.parts && !B.wide && !B.dval && B.c_nnz > 0 && (B.G == 1 || B.G == 2);
 }
 
-template <int GT> static void launch_up_chain(const PbUpArgs& u, int nb, size_t lds, hipStream_t st)
+template <int GT, int PRE0 = kPbPre> static void launch_up_chain(const PbUpArgs& u, int nb, size_t lds, hipStream_t st)
 {
-	(void)hipFuncSetAttribute((const void*)k_pb_up<false, GT, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-	k_pb_up<false, GT, false, true><<<nb, kPbUpThreads, lds, st>>>(u);
+	(void)hipFuncSetAttribute((const void*)k_pb_up<false, GT, false, true, PRE0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+	k_pb_up<false, GT, false, true, PRE0><<<nb, kPbUpThreads, lds, st>>>(u);
 }
 
 // One scale-free Lanczos step in two launches.  In: w (= w_{j-1}, or r_j itself when g_a is null) and y (= r_{j-1}).
@@ -778,6 +792,8 @@ int pb_launch_chain(lpp_engine* e, void* w, void* y, double* partial, const EpiS
 	} else {
 		const size_t lds = pb_up_lds_bytes(B.pitch, B.spb, B.G);
 		if (B.G == 1) launch_up_chain<1>(u, nb, lds, st);
+		else if (B.pre0 == 3) launch_up_chain<2, 3>(u, nb, lds, st);
+		else if (B.pre0 == 5) launch_up_chain<2, 5>(u, nb, lds, st);
 		else launch_up_chain<2>(u, nb, lds, st);
 	}
 	if (B.down2) return launch_down2(e, (const double*)w, (double*)y, B.pitch, B.u, shift, partial, sc, true, beta_in_u, st);

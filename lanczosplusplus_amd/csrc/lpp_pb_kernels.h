@@ -63,8 +63,9 @@ constexpr int kPbPre = 4; // chunks (of 4 slots) of every (slice, group) request
 // address, the window sits at LDS address 0), one ds_read_b64, one v_add_f64.  Both ends of that were measured: with a
 // plain and/shift/add unpacking the kernel was VALU-bound (10 vector instructions per pair of entries); with ready-made
 // 32-bit addresses the template words (19 GB per product through a ~57 GB/s-per-CU L2->L1 path) bound it instead.
+constexpr int kPbPreMax = 6; // deepest look-ahead of one value group (k_pb_up's PRE0)
 template <int GT> struct PbWords {
-	uint2 w[GT][kPbPre];
+	uint2 w[GT][kPbPreMax]; // only the first `depth(g)` chunks of group g are ever touched (the others take no register)
 	int nc[GT];
 	double yo; // chained form: the previous Lanczos vector at this lane's row (its beta term rides in u)
 };
@@ -108,7 +109,11 @@ __host__ __device__ inline size_t pb_up_lds_bytes(int64_t pitch, int spb, int G)
 // A step is 8 passes over the vector (here: 2 reads, 2 writes; there: the gathers, 2 reads, 1 write) in two launches, instead of
 // 9 in three with the separate combine pass (2 + 2 + 5).  (Keeping the old row in registers for the beta term here would save
 // one more pass, but 2 x 13 registers on top of the look-ahead words spill: 476 bytes of scratch per lane at KC = 14.)
-template <bool DOT, int GT, bool LEAN, bool CHAIN = false> __global__ __launch_bounds__(kPbUpThreads, LEAN ? 8 : 4) void k_pb_up(PbUpArgs a)
+// PRE0 (two value groups): chunks of group 0 requested one slice ahead; group 1 gets 2 kPbPre - PRE0.  The lists of the two
+// groups are not equally long (config 2: hops with sign + average 11.7 entries per row, 4-5 chunks; sign -: 5.4 entries, 2-3
+// chunks), and a chunk beyond the look-ahead is a load with a full L2 round trip in the middle of a slice.  The host picks
+// PRE0 from the template's list lengths (pb_build).
+template <bool DOT, int GT, bool LEAN, bool CHAIN = false, int PRE0 = kPbPre> __global__ __launch_bounds__(kPbUpThreads, LEAN ? 8 : 4) void k_pb_up(PbUpArgs a)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
 	double* win = (double*)lds_raw; // pitch + kPbZeroSlots elements, at LDS address 0
@@ -207,51 +212,69 @@ template <bool DOT, int GT, bool LEAN, bool CHAIN = false> __global__ __launch_b
 		if (threadIdx.x < kPbZeroSlots) win[a.pitch + threadIdx.x] = 0.0;
 		__syncthreads();
 		const double* const yold = CHAIN ? a.ybuf + rowbase : nullptr;
-		auto epilogue = [=, &dot](int j, double acc, double yo = 0.0) __attribute__((always_inline)) {
-			const int iu_raw = j * 64 + lane;
-			const bool valid = iu_raw < n_up;
-			const int iu = valid ? iu_raw : n_up - 1;
-			const double yc = win[iu];
-			acc = fma(dict_s[dcode_s[iu]], yc, acc);
-			if (valid) {
+		// the row's own element and its diagonal value (code -> dictionary: two dependent LDS reads): asked for in FRONT of a slice's
+		// gathers by the look-ahead path, so that their latency passes under the gathers instead of behind them
+		auto own = [=](int j, double& yc, double& dv) __attribute__((always_inline)) {
+			const int iu = min(j * 64 + lane, n_up - 1);
+			yc = win[iu];
+			dv = dict_s[dcode_s[iu]];
+		};
+		auto finish = [=, &dot](int j, double acc, double yc, double dv, double yo) __attribute__((always_inline)) {
+			const int iu = j * 64 + lane;
+			acc = fma(dv, yc, acc);
+			if (iu < n_up) {
 				// chained form: u = alpha (T + D) r_j + beta r_{j-1}, so that the coupling kernel needs neither r_{j-1} nor beta
 				const double uv = CHAIN ? fma(beta, yo, alpha * acc) : alpha * acc;
 				__builtin_nontemporal_store(uv, &uout[rowbase + iu]);
 				if (DOT) dot += yc * uv;
 			}
 		};
+		auto epilogue = [=](int j, double acc, double yo = 0.0) __attribute__((always_inline)) {
+			double yc, dv;
+			own(j, yc, dv);
+			finish(j, acc, yc, dv, yo);
+		};
 		if (GT > 0) {
 			auto load_words = [=](int j, PbWords<GG>& s) __attribute__((always_inline)) {
 				if (j >= spb) return; // wave-uniform
 #pragma unroll
 				for (int g = 0; g < GG; g++) {
-					s.nc[g] = len_s[j * GG + g];
+					s.nc[g] = __builtin_amdgcn_readfirstlane((int)len_s[j * GG + g]); // uniform: scalar branches below
 					const uint2* wp = tw2 + (size_t)off_s[j * GG + g] * 64 + lane;
+					const int depth = GG == 2 ? (g == 0 ? PRE0 : 2 * kPbPre - PRE0) : kPbPre;
 #pragma unroll
-					for (int c = 0; c < kPbPre; c++) s.w[g][c] = wp[c * 64]; // chunks beyond the list belong to the next list (or the slack): never used
+					for (int c = 0; c < kPbPreMax; c++)
+						if (c < depth) s.w[g][c] = wp[c * 64]; // chunks beyond the list belong to the next list (or the slack): never used
 				}
 				// chained form: r_{j-1} at this row, re-read one slice ahead with the words.  The row was read during staging a
 				// few microseconds ago: an L2 hit, like the template words in front of and behind it in the return queue
 				if (CHAIN) s.yo = yold[min(j * 64 + lane, n_up - 1)];
 			};
 			// one value group of a slice: sum of the window elements its (look-ahead) chunks index, longer lists streamed
-			auto group_sum = [=](int j, int g, int nc, const uint2* w) __attribute__((always_inline)) {
+			auto group_sum = [=](int j, int g, int nc, const uint2* w, int depth) __attribute__((always_inline)) {
 				double s0 = 0.0, s1 = 0.0;
-				if (nc >= 2) { // 8 LDS gathers in flight
-					gather4(w[0], s0, s1);
-					gather4(w[1], s0, s1);
-				} else if (nc == 1) {
-					gather4(w[0], s0, s1);
+#ifndef LPP_PB_BATCH
+#define LPP_PB_BATCH 2
+#endif
+				constexpr int BT = LPP_PB_BATCH; // chunks per batch: 4 BT LDS gathers in flight
+#pragma unroll
+				for (int c = 0; c < kPbPreMax; c += BT) {
+					if (c >= depth) continue;
+					// the branch taken is the largest k <= BT with nc >= c + k (and c + k <= depth)
+					if (BT >= 3 && c + 3 <= depth && nc >= c + 3) {
+						gather4(w[c], s0, s1);
+						gather4(w[c + 1], s0, s1);
+						gather4(w[c + 2], s0, s1);
+					} else if (c + 2 <= depth && nc >= c + 2) {
+						gather4(w[c], s0, s1);
+						gather4(w[c + 1], s0, s1);
+					} else if (nc >= c + 1) {
+						gather4(w[c], s0, s1);
+					}
 				}
-				if (nc >= 4) {
-					gather4(w[2], s0, s1);
-					gather4(w[3], s0, s1);
-				} else if (nc == 3) {
-					gather4(w[2], s0, s1);
-				}
-				if (nc > kPbPre) {
+				if (nc > depth) {
 					const uint2* wp = tw2 + (size_t)off_s[j * GG + g] * 64 + lane;
-					for (int c = kPbPre; c < nc; c++) {
+					for (int c = depth; c < nc; c++) {
 						const uint2 wr = wp[c * 64];
 						gather4(wr, s0, s1);
 					}
@@ -260,10 +283,12 @@ template <bool DOT, int GT, bool LEAN, bool CHAIN = false> __global__ __launch_b
 			};
 			auto compute = [=](int j, const PbWords<GG>& s) __attribute__((always_inline)) {
 				if (j >= spb) return; // wave-uniform
+				double yc, dv;
+				own(j, yc, dv);
 				double acc = 0.0;
 #pragma unroll
-				for (int g = 0; g < GG; g++) acc = fma(gv[g], group_sum(j, g, s.nc[g], s.w[g]), acc);
-				epilogue(j, acc, CHAIN ? s.yo : 0.0);
+				for (int g = 0; g < GG; g++) acc = fma(gv[g], group_sum(j, g, s.nc[g], s.w[g], GG == 2 ? (g == 0 ? PRE0 : 2 * kPbPre - PRE0) : kPbPre), acc);
+				finish(j, acc, yc, dv, CHAIN ? s.yo : 0.0);
 			};
 			if (LEAN) { // one group's words at a time: 8 registers instead of 2 x 8 x GG
 				for (int j = wave; j < spb; j += NW) {
@@ -272,10 +297,10 @@ template <bool DOT, int GT, bool LEAN, bool CHAIN = false> __global__ __launch_b
 					for (int g = 0; g < GG; g++) {
 						const int nc = len_s[j * GG + g];
 						const uint2* wp = tw2 + (size_t)off_s[j * GG + g] * 64 + lane;
-						uint2 w[kPbPre];
+						uint2 w[kPbPreMax];
 #pragma unroll
 						for (int c = 0; c < kPbPre; c++) w[c] = wp[c * 64];
-						acc = fma(gv[g], group_sum(j, g, nc, w), acc);
+						acc = fma(gv[g], group_sum(j, g, nc, w, kPbPre), acc);
 					}
 					epilogue(j, acc);
 				}
