@@ -353,9 +353,17 @@ template <bool DOT, bool LEAN> static void launch_up(const PbState& B, const PbU
 		(void)hipFuncSetAttribute((const void*)k_pb_up<DOT, GT_, LEAN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
 		k_pb_up<DOT, GT_, LEAN><<<nb, kPbUpThreads, lds, st>>>(u);                                                      \
 	} while (0)
+#define LPP_PB_UP2(PRE_)                                                                                              \
+	do {                                                                                                              \
+		(void)hipFuncSetAttribute((const void*)k_pb_up<DOT, 2, LEAN, false, PRE_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+		k_pb_up<DOT, 2, LEAN, false, PRE_><<<nb, kPbUpThreads, lds, st>>>(u);                                           \
+	} while (0)
 	if (gt == 1) LPP_PB_UP(1);
+	else if (gt == 2 && !LEAN && B.pre0 == 3) LPP_PB_UP2(3); // look-ahead split of the two value groups (pb_build)
+	else if (gt == 2 && !LEAN && B.pre0 == 5) LPP_PB_UP2(5);
 	else if (gt == 2) LPP_PB_UP(2);
 	else LPP_PB_UP(0);
+#undef LPP_PB_UP2
 #undef LPP_PB_UP
 }
 

@@ -1,11 +1,17 @@
 #!/bin/bash
 # copy the round's profile sets from gpurun_out/ into profiles/ and stamp profiles/traffic.json with the current source hash
-# usage: bash scripts/stamp_round.sh r02      (after scripts/profile_others.sh <tag> and scripts/profile_round.sh <tag>_c2_stored ...)
-T=${1:-r02}
-for t in c2_stored c2_stored_3k c3 c4 c2otf c2otf_kron c1; do
+# usage: bash scripts/stamp_round.sh r03         after `scripts/profile_set.sh r03 counters` (summaries + traffic stamp)
+#        bash scripts/stamp_round.sh r03 lines   after `scripts/profile_set.sh r03 lines`    (only the bench lines, now with traffic)
+T=${1:-r03}
+for t in c2_stored c2_stored_3k c3 c4 c2otf c2otf_kron c1 reortho; do
   [ -d gpurun_out/profile_${T}_$t ] || continue
-  for f in bench.json kernel_stats.csv pmc_summary.csv; do cp gpurun_out/profile_${T}_$t/$f profiles/${T}_${t}_$f; done
+  for f in bench.json kernel_stats.csv pmc_summary.csv; do
+    [ "$2" = lines ] && [ $f != bench.json ] && continue
+    [ "$2" = lines ] && [ $t = reortho ] && continue
+    [ -f gpurun_out/profile_${T}_$t/$f ] && cp gpurun_out/profile_${T}_$t/$f profiles/${T}_${t}_$f
+  done
 done
+[ "$2" = lines ] && { grep -l '"stale' profiles/${T}_*_bench.json && echo "STALE LINES ABOVE"; exit 0; }
 python scripts/traffic_stamp.py stored hubbard_4x4_half_filling_pbc_U4 profiles/${T}_c2_stored_pmc_summary.csv "k_pb_up,k_pb_down" &&
 python scripts/traffic_stamp.py onthefly hubbard_4x4_half_filling_pbc_U4 profiles/${T}_c2otf_pmc_summary.csv "k_pb_up,k_pb_down" &&
 python scripts/traffic_stamp.py stored heisenberg_chain_L28_sz0_obc profiles/${T}_c3_pmc_summary.csv k_spmv_window &&
