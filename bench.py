@@ -446,7 +446,12 @@ def main():
         """An attempt in stages; the ranks compare notes (all_agree) after every stage, and only the stages marked COLLECTIVE
         enqueue anything another rank waits for -- a rank that fails alone (an allocation, a missing library) is noticed by
         all of them before anyone blocks inside a collective it will never join."""
-        nd, nu, w = (n_dn, n_up, world) if world > 1 else (__import__("math").comb(p["L"], p["ndown"]), __import__("math").comb(p["L"], p["nup"]), 1)
+        if world > 1:
+            nd, nu, w = n_dn, n_up, world
+        elif "ndown" in p and "nup" in p:
+            nd, nu, w = __import__("math").comb(p["L"], p["ndown"]), __import__("math").comb(p["L"], p["nup"]), 1
+        else:
+            nd, nu, w = 0, 0, 1  # no species blocks (Heisenberg, t-J): only the one-rank form, no exchange buffer
 
         def create():  # local
             # up indices per rank rounded up to a multiple of 16 (= lpp_xchg_chunk): real Hubbard matrices then take the

@@ -111,3 +111,19 @@ def test_config5_7up6down_sector_matrix_free_free_fermions():
         assert e.rows() == 77520 * 38760 == 3004675200
         eg, _, st = e.lanczos(1, want_vectors=False)
     assert abs(eg[0] - exact) <= E_TOL * abs(exact), (eg[0], exact, st["steps"])
+
+
+@pytest.mark.parametrize("workload", ["hubbard_chain_L12_half_filling_U4", "heisenberg_chain_L24_sz0_obc", "tj_chain_L12_5up5down_complex", "hubbard_chain_L14_complex_U4"])
+def test_bench_line_of_the_other_model_families(workload):
+    """`bench.py --workload W` prints its one JSON line for every model family (a Hubbard-only assumption in the attempt loop
+    once broke the Heisenberg and t-J lines while the default line stayed green)."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", workload, "--steps", "5", "--warmup", "1", "--no-cpu-baseline",
+                          "--no-generic-csr", "--no-reortho-leg"], capture_output=True, text=True, timeout=400)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["config"]["workload"] == workload and line["steps"] == 5 and line["value"] > 0
+    assert line["roofline"]["achieved"] > 0 and 0 < line["roofline"]["frac"] <= 1.0
