@@ -108,7 +108,9 @@ typedef struct lpp_layout {
 	int32_t split_panel; /* general layout: > 0 = the entries that leave the row blocks are held apart in that many matrices (by source block
 	                        range), rows in panel-major order (16 positions of every block, then the next 16), each applied by a launch of
 	                        its own that gathers from L2 */
-	int32_t reserved;
+	int32_t rows_by_list_length; /* product-basis layout (was `reserved`, always 0, until round 3): 1 = inside a block the positions are stored in the
+	                                order of their in-block list lengths, not in the basis order (slices of rows with equal lists: fewer template
+	                                slots).  Internal: vectors, lpp_engine_get_csr and the start vector keep the basis order at the boundary */
 } lpp_layout;
 
 /* Communicator for the 1-D row-partitioned multi-GPU path.  The engine never

@@ -348,9 +348,9 @@ lpp_status assemble_hubbard_pb(lpp_engine* e, AsmParams P, int nup, int ndown, i
 		const size_t loc = (size_t)std::max<int64_t>(e->pb.nblk_loc, 1) * (size_t)e->pb.pitch;
 		HIP_TRY_MEM(hipMalloc(&e->pb.dval, sizeof(double) * loc));
 		HIP_TRY(hipMemsetAsync(e->pb.dval, 0, sizeof(double) * loc, st));
-		if (Pf.nloc > 0) k_pb_diag_values<ASM_HUBBARD><<<nb, kBlock, 0, st>>>(Pf, e->pb.pitch, e->pb.dval, blk0); // the codes stay 0 (+0.0)
+		if (Pf.nloc > 0) k_pb_diag_values<ASM_HUBBARD><<<nb, kBlock, 0, st>>>(Pf, e->pb.pitch, e->pb.dval, blk0, e->pb.inv); // the codes stay 0 (+0.0)
 	} else if (Pf.nloc > 0)
-		k_pb_diag_codes<ASM_HUBBARD><<<nb, kBlock, 0, st>>>(Pf, e->pb.pitch, e->pb.dict, e->pb.ndict, e->pb.dcode, blk0);
+		k_pb_diag_codes<ASM_HUBBARD><<<nb, kBlock, 0, st>>>(Pf, e->pb.pitch, e->pb.dict, e->pb.ndict, e->pb.dcode, blk0, e->pb.inv);
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipStreamSynchronize(st));
 	*done = true;

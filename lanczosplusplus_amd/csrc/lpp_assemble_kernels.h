@@ -475,25 +475,27 @@ __global__ __launch_bounds__(kBlock) void k_pb_diag_collect(AsmParams P, unsigne
 
 template <int MODEL>
 __global__ __launch_bounds__(kBlock) void k_pb_diag_codes(AsmParams P, int64_t pitch, const double* __restrict__ dict, int ndict,
-                                                           uint8_t* __restrict__ dcode, int64_t blk0 = 0)
+                                                           uint8_t* __restrict__ dcode, int64_t blk0 = 0, const int32_t* __restrict__ inv = nullptr)
 {
 	for (int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x; r < P.nloc; r += (int64_t)gridDim.x * kBlock) {
 		const int64_t row = P.row0 + r;
 		const uint64_t ket = state_of<MODEL>(P, row);
 		const int64_t b = row / P.n_up, i = row - b * P.n_up;
-		dcode[(b - blk0) * pitch + i] = (uint8_t)dict_code(dict, ndict, diag_of<MODEL>(P, ket)); // blk0: first block this rank holds
+		// blk0: first block this rank holds; inv: where the layout stores position i of a block (PbState::inv)
+		dcode[(b - blk0) * pitch + (inv ? inv[i] : i)] = (uint8_t)dict_code(dict, ndict, diag_of<MODEL>(P, ket));
 	}
 }
 
 // the diagonal as plain doubles (more than 256 distinct values), pitched like the vectors
 template <int MODEL>
-__global__ __launch_bounds__(kBlock) void k_pb_diag_values(AsmParams P, int64_t pitch, double* __restrict__ dval, int64_t blk0 = 0)
+__global__ __launch_bounds__(kBlock) void k_pb_diag_values(AsmParams P, int64_t pitch, double* __restrict__ dval, int64_t blk0 = 0,
+                                                            const int32_t* __restrict__ inv = nullptr)
 {
 	for (int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x; r < P.nloc; r += (int64_t)gridDim.x * kBlock) {
 		const int64_t row = P.row0 + r;
 		const uint64_t ket = state_of<MODEL>(P, row);
 		const int64_t b = row / P.n_up, i = row - b * P.n_up;
-		dval[(b - blk0) * pitch + i] = diag_of<MODEL>(P, ket);
+		dval[(b - blk0) * pitch + (inv ? inv[i] : i)] = diag_of<MODEL>(P, ket);
 	}
 }
 

@@ -1402,6 +1402,7 @@ lpp_status lpp_engine_get_layout(lpp_engine* e, int32_t which, lpp_layout* out)
 		L.pieces = B.npieces;
 		L.coupling_parts = B.parts ? B.nparts : 1;
 		L.chained_step = pb_chain_ok(e) ? 1 : 0;
+		L.rows_by_list_length = e->pb.perm ? 1 : 0;
 		L.diagonal_plain = B.dval ? 1 : 0;
 		const size_t small = sizeof(uint32_t) * (size_t)B.f_words + sizeof(uint32_t) * (size_t)B.tw_words + (sizeof(int32_t) + sizeof(uint16_t)) * (size_t)B.spb * (size_t)B.G
 		    + (size_t)B.t_entries * 12 + sizeof(int64_t) * (size_t)(B.n_up + 1) + (size_t)B.c_nnz * 5 + sizeof(int64_t) * 2 * (size_t)(B.n_blk + 1) + 256 * sizeof(double);

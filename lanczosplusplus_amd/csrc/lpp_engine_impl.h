@@ -160,6 +160,11 @@ struct PbState {
 	bool down2 = false; // k_pb_down2: the workgroup's own lines of a panel staged in LDS (couplings inside its block range are LDS reads)
 	size_t down2_lds = 0;
 	int down2_ent = 0;
+	// positions of a block stored in the order of their list lengths (single-GPU, one-window form): stored position p holds the
+	// basis state perm[p] of the species, inv[perm[p]] = p.  Null: natural order.  Only the boundary knows (vec_from_host / _to_host,
+	// the start vector, the diagonal's assembly, lpp_engine_get_csr); every kernel of a step is position-blind.
+	int32_t* perm = nullptr;
+	int32_t* inv = nullptr;
 	int pre0 = 4; // chained step, two value groups: chunks of group 0 requested one slice ahead (group 1: 8 - pre0)
 	bool half = false; // k_pb_down<WIDE, HALF>: panels of 8 positions (64-byte half lines), for panels beyond an XCD's L2
 	bool ws = false; // k_pb_up_ws in the chained step (LPP_PB_WS=1): the next row staged by loader waves beside the gathers

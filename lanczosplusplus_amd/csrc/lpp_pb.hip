@@ -21,7 +21,7 @@ void free_pb(lpp_engine* e)
 	PbState& B = e->pb;
 	for (void* p : { (void*)B.tw, (void*)B.tw_off, (void*)B.tw_len, (void*)B.t_ptr, (void*)B.t_col, (void*)B.t_val, (void*)B.c_ptr, (void*)B.c_col,
 	                 (void*)B.c_code, (void*)B.order, (void*)B.pace, (void*)B.z, (void*)B.u, (void*)B.xy, (void*)B.dict, (void*)B.dcode, (void*)B.blockbase,
-	                 (void*)B.fw, (void*)B.f_off, (void*)B.f_len, (void*)B.c_pstart, (void*)B.dval })
+	                 (void*)B.fw, (void*)B.f_off, (void*)B.f_len, (void*)B.c_pstart, (void*)B.dval, (void*)B.perm, (void*)B.inv })
 		if (p) (void)hipFree(p);
 	if (B.stream2) {
 		(void)hipStreamSynchronize(B.stream2);
@@ -111,8 +111,71 @@ lpp_status pb_build(lpp_engine* e, int64_t n_up, int64_t n_blk, const int64_t* t
 	PbTemplate T;
 	int ways = 2;
 	if (const char* s = getenv("LPP_PB_BANK_WAYS")) ways = std::max(1, std::min(atoi(s), 4));
-	lpp_status rc = pb_pack_template(n_up, pitch, t_rp, t_ci, t_va, T, ways, W);
+	// Row order inside a block.  A slice of 64 rows walks as many template chunks per value group as its LONGEST list needs, and in
+	// the basis order neighbouring rows have lists of very different lengths: at config 2 17.1 entries per row occupy 28.9 slots.
+	// Stored in the order of their chunk counts (stable, so neighbours stay neighbours among equals) they occupy 20.2: 30 % fewer
+	// template words through L1, LDS gathers and adds.  One-window, single-GPU form only: the pieces form lives on the locality of
+	// the basis order and the exchange kernels address positions by their basis index.  LPP_PB_PERM=0 switches it off.
+	std::vector<int32_t> perm, inv;
+	std::vector<int64_t> p_rp;
+	std::vector<int32_t> p_ci;
+	std::vector<double> p_va;
+	const bool want_perm = W == 0 && !tx && nblk_loc == n_blk && n_up >= 128 && !(getenv("LPP_PB_PERM") && atoi(getenv("LPP_PB_PERM")) == 0);
+	if (want_perm) {
+		std::vector<unsigned long long> vals; // distinct values, ascending bit pattern (the order pb_pack_template numbers its groups in does not matter here)
+		for (int64_t i = 0; i < n_up && vals.size() <= (size_t)kPbGroupsMax; i++)
+			for (int64_t q = t_rp[i]; q < t_rp[i + 1] && vals.size() <= (size_t)kPbGroupsMax; q++) {
+				if (t_ci[q] == i) continue; // the diagonal is not part of the template (it lives in D)
+				unsigned long long k;
+				std::memcpy(&k, &t_va[q], 8);
+				if (std::find(vals.begin(), vals.end(), k) == vals.end()) vals.push_back(k);
+			}
+		if (vals.size() <= (size_t)kPbGroupsMax && !vals.empty()) {
+			const int G = (int)vals.size();
+			std::vector<uint8_t> key((size_t)n_up * (size_t)G, 0); // chunks of 4 per group
+			for (int64_t i = 0; i < n_up; i++) {
+				int cnt[kPbGroupsMax] = { 0 };
+				for (int64_t q = t_rp[i]; q < t_rp[i + 1]; q++) {
+					if (t_ci[q] == i) continue;
+					unsigned long long k;
+					std::memcpy(&k, &t_va[q], 8);
+					cnt[std::find(vals.begin(), vals.end(), k) - vals.begin()]++;
+				}
+				for (int g = 0; g < G; g++) key[(size_t)i * G + g] = (uint8_t)std::min(255, (cnt[g] + 3) / 4);
+			}
+			perm.resize((size_t)n_up);
+			for (int64_t i = 0; i < n_up; i++) perm[(size_t)i] = (int32_t)i;
+			std::stable_sort(perm.begin(), perm.end(), [&](int32_t x, int32_t y) { return std::lexicographical_compare(&key[(size_t)x * G], &key[(size_t)x * G] + G, &key[(size_t)y * G], &key[(size_t)y * G] + G); });
+			inv.resize((size_t)n_up);
+			for (int64_t q = 0; q < n_up; q++) inv[(size_t)perm[(size_t)q]] = (int32_t)q;
+			// T' = P T P^T, columns ascending inside a row
+			p_rp.assign((size_t)n_up + 1, 0);
+			p_ci.resize((size_t)t_rp[n_up]);
+			p_va.resize((size_t)t_rp[n_up]);
+			std::vector<std::pair<int32_t, double>> row;
+			for (int64_t q = 0; q < n_up; q++) {
+				const int64_t i = perm[(size_t)q];
+				row.clear();
+				for (int64_t k = t_rp[i]; k < t_rp[i + 1]; k++) row.emplace_back(inv[(size_t)t_ci[k]], t_va[k]);
+				std::sort(row.begin(), row.end(), [](const std::pair<int32_t, double>& a, const std::pair<int32_t, double>& b) { return a.first < b.first; });
+				int64_t o = p_rp[(size_t)q];
+				for (const auto& en : row) {
+					p_ci[(size_t)o] = en.first;
+					p_va[(size_t)o] = en.second;
+					o++;
+				}
+				p_rp[(size_t)q + 1] = o;
+			}
+		}
+	}
+	const bool permuted = !perm.empty();
+	if (getenv("LPP_VERBOSE")) fprintf(stderr, "lpp: product-basis rows %s (pieces %d, exchange %d, blocks %lld of %lld, %lld positions)\n", permuted ? "stored by list length" : "in basis order", W > 0 ? 1 : 0, tx ? 1 : 0, (long long)nblk_loc, (long long)n_blk, (long long)n_up);
+	lpp_status rc = permuted ? pb_pack_template(n_up, pitch, p_rp.data(), p_ci.data(), p_va.data(), T, ways, W) : pb_pack_template(n_up, pitch, t_rp, t_ci, t_va, T, ways, W);
 	if (rc != LPP_OK) return rc;
+	if (permuted) {
+		if ((rc = to_device(&B.perm, perm, st)) != LPP_OK) return rc;
+		if ((rc = to_device(&B.inv, inv, st)) != LPP_OK) return rc;
+	}
 	B.n_up = n_up;
 	B.n_blk = n_blk;
 	B.pitch = pitch;
@@ -990,6 +1053,10 @@ lpp_status pb_from_csr(lpp_engine* e, const DevCsr& A, int64_t n_up, bool* done)
 	}
 	if (rc != LPP_OK) return rc;
 	PbState& B = e->pb;
+	if (B.perm) { // the diagonal was read off the CSR in the basis order: into the stored order (pb.u is free until the first product)
+		k_pb_permute<true><<<nbr, 256, 0, st>>>(B.u, (const double*)d_dval.p, B.perm, n_blk, n_up, pitch);
+		HIP_TRY(hipMemcpyAsync(d_dval.p, B.u, sizeof(double) * loc, hipMemcpyDeviceToDevice, st));
+	}
 	if (plain_diag) {
 		B.dval = (double*)d_dval.p; // the codes stay 0 (+0.0)
 		d_dval.p = nullptr;
@@ -997,7 +1064,7 @@ lpp_status pb_from_csr(lpp_engine* e, const DevCsr& A, int64_t n_up, bool* done)
 		k_pb_codes_from_values<<<nbr, 256, 0, st>>>((int64_t)loc, (const double*)d_dval.p, B.dict, B.ndict, B.dcode);
 	}
 	k_pb_csr_verify<<<nbr, 256, 0, st>>>(n_up, n_blk, pitch, B.t_ptr, B.t_col, B.t_val, B.c_ptr, B.c_col, B.c_code, B.blockbase, B.dcode, B.dict, B.dval, A.rowptr, A.col,
-	                                    (const double*)A.val, (int*)d_bad.p + 1);
+	                                    (const double*)A.val, (int*)d_bad.p + 1, B.inv);
 	HIP_TRY(hipMemcpyAsync(bad, d_bad.p, sizeof(int) * 2, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipStreamSynchronize(st));
@@ -1026,7 +1093,7 @@ lpp_status pb_get_csr(lpp_engine* e, int64_t* rowptr, int32_t* colind, void* val
 		HIP_TRY_MEM(hipMalloc(&dva.p, sizeof(double) * (size_t)std::max<int64_t>(B.nnz, 1)));
 	}
 	k_pb_rebuild<<<(int)((n + 255) / 256), 256, 0, e->stream>>>(B.n_up, B.n_blk, B.pitch, B.t_ptr, B.t_col, B.t_val, B.c_ptr, B.c_col, B.c_code, B.blockbase,
-	                                                           B.dcode, B.dict, (int64_t*)drp.p, (int32_t*)dci.p, (double*)dva.p, B.dval);
+	                                                           B.dcode, B.dict, (int64_t*)drp.p, (int32_t*)dci.p, (double*)dva.p, B.dval, B.inv);
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipStreamSynchronize(e->stream));
 	if (rowptr) HIP_TRY(hipMemcpy(rowptr, drp.p, sizeof(int64_t) * (size_t)(n + 1), hipMemcpyDeviceToHost));
@@ -1039,9 +1106,16 @@ lpp_status pb_get_csr(lpp_engine* e, int64_t* rowptr, int32_t* colind, void* val
 lpp_status vec_from_host(lpp_engine* e, double* dev, const void* host)
 {
 	if (e->pitch > 0) {
-		HIP_TRY(hipMemsetAsync(dev, 0, sizeof(double) * (size_t)e->nd_pad, e->stream));
-		HIP_TRY(hipMemcpy2DAsync(dev, e->esz * (size_t)e->pitch, host, e->esz * (size_t)e->pitch_rows, e->esz * (size_t)e->pitch_rows, (size_t)e->pitch_blocks,
+		const PbState& B = e->pb;
+		// stored order of the positions (PbState::perm): the copy lands in pb.u in the basis order and is gathered from there
+		double* const land = B.perm ? B.u : dev;
+		HIP_TRY(hipMemsetAsync(land, 0, sizeof(double) * (size_t)e->nd_pad, e->stream));
+		HIP_TRY(hipMemcpy2DAsync(land, e->esz * (size_t)e->pitch, host, e->esz * (size_t)e->pitch_rows, e->esz * (size_t)e->pitch_rows, (size_t)e->pitch_blocks,
 		                         hipMemcpyHostToDevice, e->stream));
+		if (B.perm) {
+			k_pb_permute<true><<<2048, 256, 0, e->stream>>>(dev, land, B.perm, e->pitch_blocks, e->pitch_rows, e->pitch);
+			HIP_TRY(hipGetLastError());
+		}
 		return LPP_OK;
 	}
 	HIP_TRY(hipMemcpyAsync(dev, host, e->esz * (size_t)e->n_local, hipMemcpyHostToDevice, e->stream));
@@ -1051,7 +1125,14 @@ lpp_status vec_from_host(lpp_engine* e, double* dev, const void* host)
 lpp_status vec_to_host(lpp_engine* e, void* host, const double* dev)
 {
 	if (e->pitch > 0) {
-		HIP_TRY(hipMemcpy2DAsync(host, e->esz * (size_t)e->pitch_rows, dev, e->esz * (size_t)e->pitch, e->esz * (size_t)e->pitch_rows, (size_t)e->pitch_blocks,
+		const PbState& B = e->pb;
+		const double* from = dev;
+		if (B.perm) { // back into the basis order, through pb.u (free between products)
+			k_pb_permute<false><<<2048, 256, 0, e->stream>>>(B.u, dev, B.perm, e->pitch_blocks, e->pitch_rows, e->pitch);
+			HIP_TRY(hipGetLastError());
+			from = B.u;
+		}
+		HIP_TRY(hipMemcpy2DAsync(host, e->esz * (size_t)e->pitch_rows, from, e->esz * (size_t)e->pitch, e->esz * (size_t)e->pitch_rows, (size_t)e->pitch_blocks,
 		                         hipMemcpyDeviceToHost, e->stream));
 		return LPP_OK;
 	}
@@ -1062,7 +1143,7 @@ lpp_status vec_to_host(lpp_engine* e, void* host, const double* dev)
 void vec_fill_random(lpp_engine* e, double* dev, uint64_t seed)
 {
 	if (e->pitch > 0) {
-		k_fill_random_pitched<<<1024, 256, 0, e->stream>>>(dev, e->pitch_blocks, e->pitch_rows, e->pitch, e->row_start, seed);
+		k_fill_random_pitched<<<1024, 256, 0, e->stream>>>(dev, e->pitch_blocks, e->pitch_rows, e->pitch, e->row_start, seed, e->pb.perm);
 		return;
 	}
 	if (e->nd > 0) k_fill_random<<<1024, 256, 0, e->stream>>>(dev, e->nd, e->row_start * (e->is_complex ? 2 : 1), seed);

@@ -64,6 +64,10 @@ constexpr int kPbPre = 4; // chunks (of 4 slots) of every (slice, group) request
 // plain and/shift/add unpacking the kernel was VALU-bound (10 vector instructions per pair of entries); with ready-made
 // 32-bit addresses the template words (19 GB per product through a ~57 GB/s-per-CU L2->L1 path) bound it instead.
 constexpr int kPbPreMax = 6; // deepest look-ahead of one value group (k_pb_up's PRE0)
+#ifndef LPP_PB_PRE_MIN
+#define LPP_PB_PRE_MIN 1
+#endif
+constexpr int kPbPreMin = LPP_PB_PRE_MIN; // chunks of a group requested whatever its list length (no branch)
 template <int GT> struct PbWords {
 	uint2 w[GT][kPbPreMax]; // only the first `depth(g)` chunks of group g are ever touched (the others take no register)
 	int nc[GT];
@@ -105,10 +109,11 @@ __host__ __device__ inline size_t pb_up_lds_bytes(int64_t pitch, int spb, int G)
 // in wbuf and its own vector r in ybuf, but did NOT run the pass  r_next = w - g r  (g = raw / b^2): this kernel does it while it
 // stages the row -- it reads both rows, keeps r_next in the LDS window and writes it back over w (k_pb_down gathers from there).
 // Its result u = alpha (T r_next + D r_next) goes to the buffer u as always; k_pb_down<RMW> then forms the new
-//   w = u + beta r + alpha C r_next   over r in ybuf.
-// A step is 8 passes over the vector (here: 2 reads, 2 writes; there: the gathers, 2 reads, 1 write) in two launches, instead of
-// 9 in three with the separate combine pass (2 + 2 + 5).  (Keeping the old row in registers for the beta term here would save
-// one more pass, but 2 x 13 registers on top of the look-ahead words spill: 476 bytes of scratch per lane at KC = 14.)
+//   w = u + alpha C r_next   over r in ybuf  (u = alpha (T + D) r_next + beta r).
+// A step is 8 passes over the vector (here: 3 reads -- w, r and r again for the beta term, which rides in u --, 2 writes; there: the
+// gathers, 1 read, 1 write) in two launches, instead of 9 in three with the separate combine pass (2 + 2 + 5).  (Keeping the old row in
+// registers for the beta term here would save the re-read, but 2 x 13 registers on top of the look-ahead words spill: 476 bytes of
+// scratch per lane at KC = 14.)
 // PRE0 (two value groups): chunks of group 0 requested one slice ahead; group 1 gets 2 kPbPre - PRE0.  The lists of the two
 // groups are not equally long (config 2: hops with sign + average 11.7 entries per row, 4-5 chunks; sign -: 5.4 entries, 2-3
 // chunks), and a chunk beyond the look-ahead is a load with a full L2 round trip in the middle of a slice.  The host picks
@@ -149,10 +154,14 @@ template <bool DOT, int GT, bool LEAN, bool CHAIN = false, int PRE0 = kPbPre> __
 #pragma unroll
 	for (int g = 0; g < GG; g++) gv[g] = a.gval[g];
 	auto gather4 = [=](const uint2& w, double& s0, double& s1) __attribute__((always_inline)) {
+#ifdef LPP_PB_TIMING_NOGATHER
+		asm volatile("" ::"v"(w.x), "v"(w.y)); // timing-only build: the words are loaded, nothing is gathered
+#else
 		s0 += pb_lds_abs(pb_lo8(w.x));
 		s1 += pb_lds_abs(pb_hi8(w.x));
 		s0 += pb_lds_abs(pb_lo8(w.y));
 		s1 += pb_lds_abs(pb_hi8(w.y));
+#endif
 	};
 	for (int64_t blk = blockIdx.x; blk < a.n_blk; blk += gridDim.x) {
 		const double2* yb = (const double2*)(a.y + blk * a.pitch);
@@ -177,7 +186,11 @@ template <bool DOT, int GT, bool LEAN, bool CHAIN = false, int PRE0 = kPbPre> __
 				for (int q = 0; q < NS; q++) idx[q] = min(i0 + q * kPbUpThreads, p2 - 1);
 #pragma unroll
 				for (int q = 0; q < NS; q++) wv[q] = wb[idx[q]];
+#ifdef LPP_PB_TIMING_NOSTAGE
+				if (gco == 1.2345e300) { // timing-only build: one row read, nothing written back
+#else
 				if (gco != 0.0) {
+#endif
 #pragma unroll
 					for (int q = 0; q < NS; q++) yv[q] = yo[idx[q]];
 #pragma unroll
@@ -225,6 +238,9 @@ template <bool DOT, int GT, bool LEAN, bool CHAIN = false, int PRE0 = kPbPre> __
 			if (iu < n_up) {
 				// chained form: u = alpha (T + D) r_j + beta r_{j-1}, so that the coupling kernel needs neither r_{j-1} nor beta
 				const double uv = CHAIN ? fma(beta, yo, alpha * acc) : alpha * acc;
+#ifdef LPP_PB_TIMING_NOSTORE
+				if (uv == 1.2345e300) // timing-only build (wrong results): what the store in the slice loop costs
+#endif
 				__builtin_nontemporal_store(uv, &uout[rowbase + iu]);
 				if (DOT) dot += yc * uv;
 			}
@@ -244,11 +260,20 @@ template <bool DOT, int GT, bool LEAN, bool CHAIN = false, int PRE0 = kPbPre> __
 					const int depth = GG == 2 ? (g == 0 ? PRE0 : 2 * kPbPre - PRE0) : kPbPre;
 #pragma unroll
 					for (int c = 0; c < kPbPreMax; c++)
-						if (c < depth) s.w[g][c] = wp[c * 64]; // chunks beyond the list belong to the next list (or the slack): never used
+#ifdef LPP_PB_TIMING_NOWORDS
+						if (c < depth) s.w[g][c] = uint2 { (uint32_t)(lane * 2 + c) | ((uint32_t)(lane * 2 + 1 + c) << 16), (uint32_t)(lane * 2 + 128 + c) | ((uint32_t)(lane * 2 + 129) << 16) }; // timing-only build
+#else
+						if (c < depth && (c < kPbPreMin || c < s.nc[g])) s.w[g][c] = wp[c * 64]; // beyond the first chunks only what the list holds (scalar branch)
+#endif
 				}
-				// chained form: r_{j-1} at this row, re-read one slice ahead with the words.  The row was read during staging a
-				// few microseconds ago: an L2 hit, like the template words in front of and behind it in the return queue
+				// chained form: r_{j-1} at this row, re-read one slice ahead with the words.  By the counters the re-read does NOT hit L2
+				// (the XCD streams ~10 MB between staging and here): 1.33 GB more fabric reads per step at config 2, served one slice
+				// before it is used; k_pb_up pays 0.05 ms for it, k_pb_down<RMW> saves 0.14 ms by not reading r_{j-1} at all
+#ifndef LPP_PB_TIMING_NOYOLD
 				if (CHAIN) s.yo = yold[min(j * 64 + lane, n_up - 1)];
+#else
+				if (CHAIN) s.yo = 0.0; // timing-only build (wrong results): what the re-read costs
+#endif
 			};
 			// one value group of a slice: sum of the window elements its (look-ahead) chunks index, longer lists streamed
 			auto group_sum = [=](int j, int g, int nc, const uint2* w, int depth) __attribute__((always_inline)) {
@@ -990,7 +1015,7 @@ static __global__ void k_pb_rebuild(int64_t n_up, int64_t n_blk, int64_t pitch, 
                                     const double* __restrict__ t_val, const int64_t* __restrict__ c_ptr, const int32_t* __restrict__ c_col,
                                     const uint8_t* __restrict__ c_code, const int64_t* __restrict__ blockbase, const uint8_t* __restrict__ dcode,
                                     const double* __restrict__ dict, int64_t* __restrict__ rowptr_out, int32_t* __restrict__ col_out,
-                                    double* __restrict__ val_out, const double* __restrict__ dplain = nullptr)
+                                    double* __restrict__ val_out, const double* __restrict__ dplain = nullptr, const int32_t* __restrict__ inv = nullptr)
 {
 	const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	const int64_t n = n_up * n_blk;
@@ -1013,7 +1038,8 @@ static __global__ void k_pb_rebuild(int64_t n_up, int64_t n_blk, int64_t pitch, 
 		val_out[o] = t_val[q];
 	}
 	col_out[o] = (int32_t)r;
-	val_out[o] = dplain ? dplain[b * pitch + i] : dict[dcode[b * pitch + i]];
+	const int64_t at = b * pitch + (inv ? inv[i] : i); // where the layout keeps (b, i)
+	val_out[o] = dplain ? dplain[at] : dict[dcode[at]];
 	o++;
 	for (; q < q1; q++, o++) {
 		col_out[o] = (int32_t)(b * n_up + t_col[q]);
@@ -1082,11 +1108,13 @@ static __global__ void k_pb_csr_verify(int64_t n_up, int64_t n_blk, int64_t pitc
                                        const double* __restrict__ t_val, const int64_t* __restrict__ c_ptr, const int32_t* __restrict__ c_col,
                                        const uint8_t* __restrict__ c_code, const int64_t* __restrict__ blockbase, const uint8_t* __restrict__ dcode,
                                        const double* __restrict__ dict, const double* __restrict__ dplain, const int64_t* __restrict__ rowptr,
-                                       const int32_t* __restrict__ col, const double* __restrict__ val, int* __restrict__ bad)
+                                       const int32_t* __restrict__ col, const double* __restrict__ val, int* __restrict__ bad,
+                                       const int32_t* __restrict__ inv = nullptr)
 {
 	const int64_t n = n_up * n_blk;
 	for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (int64_t)gridDim.x * blockDim.x) {
 		const int64_t b = r / n_up, i = r - b * n_up;
+		const int64_t dat = b * pitch + (inv ? inv[i] : i);
 		const int64_t c0 = c_ptr[b], c1 = c_ptr[b + 1];
 		int64_t o = blockbase[b] + t_ptr[i] + i * (1 + (c1 - c0));
 		const int64_t oe = o + (t_ptr[i + 1] - t_ptr[i]) + 1 + (c1 - c0);
@@ -1098,7 +1126,7 @@ static __global__ void k_pb_csr_verify(int64_t n_up, int64_t n_blk, int64_t pitc
 			int64_t q = t_ptr[i];
 			const int64_t q1 = t_ptr[i + 1];
 			for (; q < q1 && t_col[q] < i; q++, o++) ok = ok && same(o, b * n_up + t_col[q], t_val[q]);
-			ok = ok && same(o, r, dplain ? dplain[b * pitch + i] : dict[dcode[b * pitch + i]]);
+			ok = ok && same(o, r, dplain ? dplain[dat] : dict[dcode[dat]]);
 			o++;
 			for (; q < q1; q++, o++) ok = ok && same(o, b * n_up + t_col[q], t_val[q]);
 			for (; p < c1; p++, o++) ok = ok && same(o, (int64_t)c_col[p] * n_up + i, dict[c_code[p]]);
@@ -1107,15 +1135,34 @@ static __global__ void k_pb_csr_verify(int64_t n_up, int64_t n_blk, int64_t pitc
 	}
 }
 
+// pitched vector between the natural order of positions and the stored one: dst[b][p] = src[b][perm[p]] (TO_STORED) or
+// dst[b][perm[p]] = src[b][p]; padding positions are written as zero
+template <bool TO_STORED>
+static __global__ void k_pb_permute(double* __restrict__ dst, const double* __restrict__ src, const int32_t* __restrict__ perm, int64_t n_blk, int64_t rows,
+                                    int64_t pitch)
+{
+	const int64_t n = n_blk * pitch;
+	for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x) {
+		const int64_t b = k / pitch, p = k - b * pitch;
+		if (p >= rows) {
+			dst[k] = 0.0;
+			continue;
+		}
+		if (TO_STORED) dst[k] = src[b * pitch + perm[p]];
+		else dst[b * pitch + perm[p]] = src[k];
+	}
+}
+
 // start vector in the pitched layout: element (b, i) takes the value the unpitched stream gives index b*rows + i
-static __global__ void k_fill_random_pitched(double* __restrict__ v, int64_t n_blk, int64_t rows, int64_t pitch, int64_t offset, uint64_t seed)
+static __global__ void k_fill_random_pitched(double* __restrict__ v, int64_t n_blk, int64_t rows, int64_t pitch, int64_t offset, uint64_t seed,
+                                             const int32_t* __restrict__ perm = nullptr)
 {
 	const int64_t n = n_blk * pitch;
 	for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x) {
 		const int64_t b = k / pitch, i = k - b * pitch;
 		double val = 0.0;
 		if (i < rows) {
-			const uint64_t r = splitmix64(seed * 0x2545F4914F6CDD1DULL + (uint64_t)(b * rows + i + offset));
+			const uint64_t r = splitmix64(seed * 0x2545F4914F6CDD1DULL + (uint64_t)(b * rows + (perm ? perm[i] : i) + offset));
 			val = (double)(r >> 11) * (1.0 / 9007199254740992.0) - 0.5;
 		}
 		v[k] = val;

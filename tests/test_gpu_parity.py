@@ -748,7 +748,7 @@ PB_CASES = {
 }
 
 
-@pytest.mark.parametrize("form", ["window", "pieces", "wide", "half", "down2", "ws"])
+@pytest.mark.parametrize("form", ["window", "natural", "pieces", "wide", "half", "down2", "ws"])
 @pytest.mark.parametrize("case", sorted(PB_CASES))
 def test_product_basis_layout(case, form, monkeypatch):
     """Device assembly of Hubbard straight into the product-basis layout (T, C, diagonal codes; lpp_pb_kernels.h): the CSR it
@@ -765,6 +765,8 @@ def test_product_basis_layout(case, form, monkeypatch):
         monkeypatch.setenv("LPP_PB_PARTS", "3")
     if form == "down2":
         monkeypatch.setenv("LPP_PB_DOWN2", "1")  # coupling kernel with the workgroup's own lines of a panel staged in LDS (opt-in experiment)
+    if form == "natural":
+        monkeypatch.setenv("LPP_PB_PERM", "0")  # positions of a block in the basis order ("window": stored in the order of their list lengths)
     if form == "ws":
         monkeypatch.setenv("LPP_PB_WS", "1")  # chained step with the next row staged by loader waves (k_pb_up_ws, opt-in experiment)
     if form in ("wide", "half"):
@@ -782,8 +784,9 @@ def test_product_basis_layout(case, form, monkeypatch):
         e.assemble_hubbard(L, nup, ndown, hop, U, V)
         lay = e.layout()
         assert lay["kernel"] == 4 and lay["nnz"] == A.nnz and lay["resident_bytes"] < (0.12 if case == "disorder" else 0.05) * 12 * A.nnz
-        assert (lay["diagonal_plain"], lay["diagonal_codes"], lay["chained_step"]) == ((1, 0, 0) if case == "disorder" else (0, 1, 1 if form in ("window", "down2", "ws") and case != "two_hoppings" else 0))  # the chained step is built for <= 2 hopping values
-        assert (lay["pieces"], lay["coupling_parts"]) == {"window": (1, 1), "pieces": (4, 3), "wide": (3, 1), "half": (3, 1), "down2": (1, 1), "ws": (1, 1)}[form]
+        assert (lay["diagonal_plain"], lay["diagonal_codes"], lay["chained_step"]) == ((1, 0, 0) if case == "disorder" else (0, 1, 1 if form in ("window", "natural", "down2", "ws") and case != "two_hoppings" else 0))  # the chained step is built for <= 2 hopping values
+        assert (lay["pieces"], lay["coupling_parts"]) == {"window": (1, 1), "pieces": (4, 3), "natural": (1, 1), "wide": (3, 1), "half": (3, 1), "down2": (1, 1), "ws": (1, 1)}[form]
+        assert lay["rows_by_list_length"] == (1 if form in ("window", "down2", "ws") else 0)  # one-window form only; internal: every check below is in the basis order
         st = e.stats()
         assert (st["nrows"], st["nnz"]) == (A.nrows, A.nnz)
         rp, ci, va = e.get_csr()
