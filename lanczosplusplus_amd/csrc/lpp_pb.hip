@@ -271,7 +271,7 @@ lpp_status pb_build(lpp_engine* e, int64_t n_up, int64_t n_blk, const int64_t* t
 	B.rowcap = (int)std::max<int64_t>(4, (longest_list + 3) & ~(int64_t)3);
 	B.ids_per_wg = (int)((n_blk + slots - 1) / slots);
 	B.down_grid = grid;
-	B.down_lds = (size_t)B.ids_per_wg * ((size_t)(B.rowcap + 1) * 3 + 8) + 16;
+	B.down_lds = pb_down_lds_bytes(B.ids_per_wg, B.rowcap);
 	if (n_blk > 65535) return fail(LPP_ERR_INVALID, "pb_build: more than 65535 blocks");
 	B.parts = parts;
 	B.wide = wide;

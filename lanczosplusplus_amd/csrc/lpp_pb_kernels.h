@@ -374,6 +374,14 @@ template <bool DOT, int GT, bool LEAN, bool CHAIN = false, int PRE0 = kPbPre> __
 // The kernel only READS y (L2 hits after the first touch of a line) and WRITES z (non-temporal): no HBM load sits in the
 // in-order return queue in front of the gathers (an x read-modify-write here cost an HBM round trip per task).
 // ---------------------------------------------------------------------------------------------
+// LDS image of k_pb_down: one 32-bit word per place of a block's coupling list (source block | value code << 16), rows of
+// `stride` words.  A lane reads the 4 places of a chunk with ONE 16-byte LDS read (the 8 blocks of a task sit `stride` words
+// apart: stride / 4 odd puts their 16-byte segments on different bank groups); separate 2-byte index and 1-byte code arrays
+// cost 8 LDS instructions per chunk instead, and the LDS pipeline was what the kernel's instruction skeleton waited for
+// (0.8 of its 0.875 ms at config 2: scripts/experiments/r03_down_parts_ab.sh).
+__host__ __device__ inline int pb_down_stride(int rowcap) { return ((rowcap >> 2) & 1) ? rowcap : rowcap + 4; }
+__host__ __device__ inline size_t pb_down_lds_bytes(int ids_per_wg, int rowcap) { return (((size_t)ids_per_wg * 8 + 15) & ~(size_t)15) + (size_t)ids_per_wg * (size_t)pb_down_stride(rowcap) * 4 + 16; }
+
 struct PbDownArgs {
 	int64_t pitch, n_blk;
 	int npanels; // pitch / 16 (HALF: pitch / 8)
@@ -410,11 +418,10 @@ template <int THREADS, bool RMW = false, bool WIDE = false, bool HALF = false> _
 	__shared__ double dict_s[256];
 	// LDS image of this workgroup's coupling lists in `order` (block numbers and value codes, 3 bytes per place: a workgroup of
 	// k_pb_up must fit next to this one)
-	const int stride = a.rowcap + 1;
+	const int stride = pb_down_stride(a.rowcap);
 	uint32_t* row_s = (uint32_t*)lds_raw; // [ids_per_wg] byte offset of the block itself
 	int32_t* len_s = (int32_t*)(row_s + a.ids_per_wg); // [ids_per_wg] list length
-	uint16_t* idx_s = (uint16_t*)(len_s + a.ids_per_wg); // [ids_per_wg][stride] source block (n_blk < 65536: the lists must fit LDS anyway)
-	uint8_t* code_s = (uint8_t*)(idx_s + (size_t)a.ids_per_wg * stride); // [ids_per_wg][stride]
+	uint32_t* place_s = (uint32_t*)(lds_raw + (((size_t)a.ids_per_wg * 8 + 15) & ~(size_t)15)); // [ids_per_wg][stride] source block (n_blk < 65536: the lists must fit LDS anyway) | code << 16
 	__shared__ double smem_d[THREADS / 64];
 	for (int i = threadIdx.x; i < 256; i += THREADS) dict_s[i] = a.dict[i];
 	double alpha, beta;
@@ -447,8 +454,7 @@ template <int THREADS, bool RMW = false, bool WIDE = false, bool HALF = false> _
 		const int64_t bl = a.order[b0 + (il & ~(BPT - 1))];
 		const int64_t pl = a.c_ptr[bl];
 		const int32_t fill = k < (int)(a.c_ptr[bl + 1] - pl) ? a.c_col[pl + k] : (int32_t)bl;
-		idx_s[il * stride + k] = (uint16_t)(in ? a.c_col[p0 + k] : fill);
-		code_s[il * stride + k] = in ? a.c_code[p0 + k] : (uint8_t)0;
+		place_s[il * stride + k] = (uint32_t)(uint16_t)(in ? a.c_col[p0 + k] : fill) | ((uint32_t)(in ? a.c_code[p0 + k] : (uint8_t)0) << 16);
 	}
 	__syncthreads();
 	const int ngroups = (nown + BPT - 1) / BPT;
@@ -471,20 +477,29 @@ template <int THREADS, bool RMW = false, bool WIDE = false, bool HALF = false> _
 			const bool valid = g * BPT + sub < nown;
 			// trip count of the task: the longest list is the first one (decreasing order), in chunks of 4
 			const int n4 = (__builtin_amdgcn_readfirstlane(len_s[g * BPT]) + 3) >> 2;
-			const uint16_t* orow = idx_s + il * stride;
-			const uint8_t* crow = code_s + il * stride;
+			const uint4* const prow = (const uint4*)(place_s + il * stride); // a chunk = 4 places = one 16-byte read
 			double2 acc = double2 { 0.0, 0.0 };
 			// three chunks of 4 gathers in flight; the chunk loop is unrolled by three with one fixed buffer per stage (a buffer
 			// rotated by register copies would wait for the loads it holds)
 			double2 ga[4], gb[4], gc[4];
-			auto issue = [&](int ch, double2* gbuf) __attribute__((always_inline)) {
-#pragma unroll
-				for (int q = 0; q < 4; q++) gbuf[q] = *(const double2*)(ysrc + at((uint32_t)orow[ch * 4 + q] * rowbytes));
-			};
-			auto consume = [&](int ch, const double2* gbuf) __attribute__((always_inline)) {
+			uint4 pa, pb, pc; // the chunks' places (their codes are needed when the gathers have come back)
+			auto issue = [&](int ch, double2* gbuf, uint4& pw) __attribute__((always_inline)) {
+				pw = prow[ch];
+				const uint32_t w4[4] = { pw.x, pw.y, pw.z, pw.w };
 #pragma unroll
 				for (int q = 0; q < 4; q++) {
-					const double v = dict_s[crow[ch * 4 + q]];
+#ifdef LPP_PB_TIMING_DOWN_OWNLINES
+					gbuf[q] = *(const double2*)(ysrc + at(row_s[il] + 0 * (w4[q] & 0xffffu))); // timing-only build: every gather asks for the block's own line (an L1 hit)
+#else
+					gbuf[q] = *(const double2*)(ysrc + at((w4[q] & 0xffffu) * rowbytes));
+#endif
+				}
+			};
+			auto consume = [&](const double2* gbuf, const uint4& pw) __attribute__((always_inline)) {
+				const uint32_t w4[4] = { pw.x, pw.y, pw.z, pw.w };
+#pragma unroll
+				for (int q = 0; q < 4; q++) {
+					const double v = dict_s[w4[q] >> 16];
 					acc.x = fma(v, gbuf[q].x, acc.x);
 					acc.y = fma(v, gbuf[q].y, acc.y);
 				}
@@ -494,32 +509,39 @@ template <int THREADS, bool RMW = false, bool WIDE = false, bool HALF = false> _
 #endif
 			double2* const zp = (double2*)((char*)a.z + at(row_s[il]));
 			double2 uo = double2 { 0.0, 0.0 }, xo = double2 { 0.0, 0.0 };
-			if (LPP_PB_RMW_POS >= 1 && n4 > 0) issue(0, ga);
-			if (LPP_PB_RMW_POS >= 2 && n4 > 1) issue(1, gb);
+			if (LPP_PB_RMW_POS >= 1 && n4 > 0) issue(0, ga, pa);
+			if (LPP_PB_RMW_POS >= 2 && n4 > 1) issue(1, gb, pb);
 			if (RMW) { // used only behind the gather loop: no wait here
+#ifndef LPP_PB_TIMING_DOWN_NOU
 				uo = nt_load2((const double2*)((const char*)a.u_in + at(row_s[il])));
+#endif
 				if (!a.u_has_beta) xo = nt_load2(zp); // wave-uniform
 			}
-			if (LPP_PB_RMW_POS < 1 && n4 > 0) issue(0, ga);
-			if (LPP_PB_RMW_POS < 2 && n4 > 1) issue(1, gb);
+			if (LPP_PB_RMW_POS < 1 && n4 > 0) issue(0, ga, pa);
+			if (LPP_PB_RMW_POS < 2 && n4 > 1) issue(1, gb, pb);
 			for (int ch = 0; ch < n4; ch += 3) { // wave-uniform conditions
-				if (ch + 2 < n4) issue(ch + 2, gc);
-				consume(ch, ga);
+				if (ch + 2 < n4) issue(ch + 2, gc, pc);
+				consume(ga, pa);
 				if (ch + 1 < n4) {
-					if (ch + 3 < n4) issue(ch + 3, ga);
-					consume(ch + 1, gb);
+					if (ch + 3 < n4) issue(ch + 3, ga, pa);
+					consume(gb, pb);
 				}
 				if (ch + 2 < n4) {
-					if (ch + 4 < n4) issue(ch + 4, gb);
-					consume(ch + 2, gc);
+					if (ch + 4 < n4) issue(ch + 4, gb, pb);
+					consume(gc, pc);
 				}
 			}
 			const double2 yown = *(const double2*)(ysrc + at(row_s[il])); // the panel is in L2
 			if (valid) {
 				acc.x = fma(alpha, acc.x, fma(beta, xo.x, uo.x));
 				acc.y = fma(alpha, acc.y, fma(beta, xo.y, uo.y));
-				__builtin_nontemporal_store(acc.x, &zp->x);
-				__builtin_nontemporal_store(acc.y, &zp->y);
+#ifdef LPP_PB_TIMING_DOWN_NOSTORE
+				if (acc.x == 1.2345e300) // timing-only build
+#endif
+				{
+					__builtin_nontemporal_store(acc.x, &zp->x);
+					__builtin_nontemporal_store(acc.y, &zp->y);
+				}
 				dot += yown.x * acc.x + yown.y * acc.y;
 				if (RMW) {
 					const double dx = acc.x - sh * yown.x, dy = acc.y - sh * yown.y;
