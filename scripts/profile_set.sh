@@ -15,9 +15,10 @@ cfg() { # name, bench args, env
     c3) echo "--workload heisenberg_chain_L28_sz0_obc" ;;
     c4) echo "--workload tj_4x5_9up9down_complex" ;;
     c1) echo "--workload hubbard_chain_L12_half_filling_U4" ;;
+    c5_76) echo "--engine onthefly --workload hubbard_4x5_7up6down_pbc_U4 --no-generic-csr" ;;
   esac
 }
-for c in c2_stored c2otf c3 c4 c1; do
+for c in c2_stored c2otf c3 c4 c1 c5_76; do
   if [ $MODE = counters ]; then
     SQ_PASS=$([ $c = c2_stored ] && echo 1) BENCH_ARGS="$(cfg $c)" bash scripts/profile_round.sh ${T}_$c > gpurun_out/ps_$c.out 2>&1 || { tail -5 gpurun_out/ps_$c.out; exit 1; }
   else
