@@ -172,6 +172,15 @@ lpp_status pb_build(lpp_engine* e, int64_t n_up, int64_t n_blk, const int64_t* t
 	if (getenv("LPP_VERBOSE")) fprintf(stderr, "lpp: product-basis rows %s (pieces %d, exchange %d, blocks %lld of %lld, %lld positions)\n", permuted ? "stored by list length" : "in basis order", W > 0 ? 1 : 0, tx ? 1 : 0, (long long)nblk_loc, (long long)n_blk, (long long)n_up);
 	lpp_status rc = permuted ? pb_pack_template(n_up, pitch, p_rp.data(), p_ci.data(), p_va.data(), T, ways, W) : pb_pack_template(n_up, pitch, t_rp, t_ci, t_va, T, ways, W);
 	if (rc != LPP_OK) return rc;
+	if (getenv("LPP_VERBOSE")) { // list lengths of the packed template: chunks of 4 slots per (slice, group), far slots per slice
+		int hist[kPbGroupsMax][9] = { { 0 } }, fh[9] = { 0 };
+		for (int j = 0; j < T.spb; j++) {
+			for (int g = 0; g < T.G; g++) hist[g][std::min<int>(T.len[(size_t)j * T.G + g], 8)]++;
+			if (!T.flen.empty()) fh[std::min<int>((T.flen[(size_t)j] + 3) / 4, 8)]++;
+		}
+		for (int g = 0; g < T.G; g++) fprintf(stderr, "lpp: template group %d: slices with 0..8+ chunks: %d %d %d %d %d %d %d %d %d\n", g, hist[g][0], hist[g][1], hist[g][2], hist[g][3], hist[g][4], hist[g][5], hist[g][6], hist[g][7], hist[g][8]);
+		if (!T.flen.empty()) fprintf(stderr, "lpp: template far slots / 4 per slice 0..8+: %d %d %d %d %d %d %d %d %d; %lld entries in pieces, %lld far\n", fh[0], fh[1], fh[2], fh[3], fh[4], fh[5], fh[6], fh[7], fh[8], (long long)T.entries, (long long)T.far_entries);
+	}
 	if (permuted) {
 		if ((rc = to_device(&B.perm, perm, st)) != LPP_OK) return rc;
 		if ((rc = to_device(&B.inv, inv, st)) != LPP_OK) return rc;
@@ -193,8 +202,8 @@ lpp_status pb_build(lpp_engine* e, int64_t n_up, int64_t n_blk, const int64_t* t
 	if ((rc = to_device(&B.tw_off, T.off, st)) != LPP_OK) return rc;
 	if ((rc = to_device(&B.tw_len, T.len, st)) != LPP_OK) return rc;
 	B.pre0 = kPbPre;
-	if (T.G == 2 && W == 0) {
-		// look-ahead split of the chained kernel: the depth pair (3,5), (4,4) or (5,3) that leaves the fewest chunks beyond it
+	if (T.G == 2) {
+		// look-ahead split of the in-block kernels: the depth pair (3,5), (4,4) or (5,3) that leaves the fewest chunks beyond it
 		int64_t best = -1;
 		for (int p0 = 3; p0 <= 5; p0++) {
 			int64_t beyond = 0;
@@ -474,17 +483,21 @@ static int launch_up_big(lpp_engine* e, const double* y, double* u, const uint8_
 	const int nb = big_grid(e, cnt);
 	if (B.big2) {
 		const size_t lds2 = pb_big2_lds_bytes(B.W);
-#define LPP_PB_BIG2(DOT_, GT_)                                                                                         \
+#define LPP_PB_BIG2(DOT_, GT_, PRE_)                                                                                   \
 	do {                                                                                                              \
-		(void)hipFuncSetAttribute((const void*)k_pb_up_big2<DOT_, GT_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2); \
-		k_pb_up_big2<DOT_, GT_><<<nb, kPbBig2Threads, lds2, st>>>(a);                                                   \
+		(void)hipFuncSetAttribute((const void*)k_pb_up_big2<DOT_, GT_, PRE_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2); \
+		k_pb_up_big2<DOT_, GT_, PRE_><<<nb, kPbBig2Threads, lds2, st>>>(a);                                             \
 	} while (0)
 		if (partial) {
-			if (B.G == 1) LPP_PB_BIG2(true, 1);
-			else LPP_PB_BIG2(true, 2);
+			if (B.G == 1) LPP_PB_BIG2(true, 1, 4);
+			else if (B.pre0 == 3) LPP_PB_BIG2(true, 2, 3);
+			else if (B.pre0 == 5) LPP_PB_BIG2(true, 2, 5);
+			else LPP_PB_BIG2(true, 2, 4);
 		} else {
-			if (B.G == 1) LPP_PB_BIG2(false, 1);
-			else LPP_PB_BIG2(false, 2);
+			if (B.G == 1) LPP_PB_BIG2(false, 1, 4);
+			else if (B.pre0 == 3) LPP_PB_BIG2(false, 2, 3);
+			else if (B.pre0 == 5) LPP_PB_BIG2(false, 2, 5);
+			else LPP_PB_BIG2(false, 2, 4);
 		}
 #undef LPP_PB_BIG2
 		return partial ? nb : 0;

@@ -309,11 +309,13 @@ __host__ __device__ inline size_t pb_big2_lds_bytes(int W)
 }
 
 template <int GG> struct Big2Words {
-	uint2 w[GG][kBigPre];
+	uint2 w[GG][kPbPreMax]; // only the first depth(g) chunks of group g are touched
 	uint32_t f[kBig2FarPre];
 };
 
-template <bool DOT, int GT> __global__ __launch_bounds__(kPbBig2Threads) void k_pb_up_big2(PbUpBigArgs a)
+// PRE0: look-ahead chunks of value group 0 (group 1: 2 kBigPre - PRE0), as in k_pb_up; the words of a chunk are requested only if the
+// list holds it (at the (7,6) sector of the 4x5 lattice the lists are 2 and 3-4 chunks long: 64 bytes per row were requested for 45)
+template <bool DOT, int GT, int PRE0 = kBigPre> __global__ __launch_bounds__(kPbBig2Threads) void k_pb_up_big2(PbUpBigArgs a)
 {
 	static_assert(GT == 1 || GT == 2, "unrolled value groups only");
 	extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -431,8 +433,11 @@ template <bool DOT, int GT> __global__ __launch_bounds__(kPbBig2Threads) void k_
 #pragma unroll
 			for (int g = 0; g < GG; g++) {
 				const uint2* wp = tw2 + (size_t)h.off[g] * 64 + lane;
+				const int depth = GG == 2 ? (g == 0 ? PRE0 : 2 * kBigPre - PRE0) : kBigPre;
+				const int nc = __builtin_amdgcn_readfirstlane(h.nc[g]); // scalar branches
 #pragma unroll
-				for (int c = 0; c < kBigPre; c++) s.w[g][c] = wp[c * 64];
+				for (int c = 0; c < kPbPreMax; c++)
+					if (c < depth && (c < 1 || c < nc)) s.w[g][c] = wp[c * 64];
 			}
 			const uint32_t* fp = fw + (size_t)h.foff * 64 + lane;
 #pragma unroll
@@ -453,23 +458,25 @@ template <bool DOT, int GT> __global__ __launch_bounds__(kPbBig2Threads) void k_
 			double acc0 = 0.0, acc1 = 0.0;
 #pragma unroll
 			for (int g = 0; g < GG; g++) {
-				const int nc = h.nc[g];
+				const int nc = __builtin_amdgcn_readfirstlane(h.nc[g]);
+				const int depth = GG == 2 ? (g == 0 ? PRE0 : 2 * kBigPre - PRE0) : kBigPre;
 				double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
-				if (nc >= 2) {
-					gather4x2(s.w[g][0], a0, a1, b0, b1);
-					gather4x2(s.w[g][1], a0, a1, b0, b1);
-				} else if (nc == 1) {
-					gather4x2(s.w[g][0], a0, a1, b0, b1);
+#pragma unroll
+				for (int c = 0; c < kPbPreMax; c += 2) { // pairs of chunks
+					if (c + 1 < depth) {
+						if (nc >= c + 2) {
+							gather4x2(s.w[g][c], a0, a1, b0, b1);
+							gather4x2(s.w[g][c + 1], a0, a1, b0, b1);
+						} else if (nc == c + 1) {
+							gather4x2(s.w[g][c], a0, a1, b0, b1);
+						}
+					} else if (c < depth) {
+						if (nc >= c + 1) gather4x2(s.w[g][c], a0, a1, b0, b1);
+					}
 				}
-				if (nc >= 4) {
-					gather4x2(s.w[g][2], a0, a1, b0, b1);
-					gather4x2(s.w[g][3], a0, a1, b0, b1);
-				} else if (nc == 3) {
-					gather4x2(s.w[g][2], a0, a1, b0, b1);
-				}
-				if (nc > kBigPre) {
+				if (nc > depth) {
 					const uint2* wp = tw2 + (size_t)h.off[g] * 64 + lane;
-					for (int c = kBigPre; c < nc; c++) {
+					for (int c = depth; c < nc; c++) {
 						const uint2 wr = wp[c * 64];
 						gather4x2(wr, a0, a1, b0, b1);
 					}
