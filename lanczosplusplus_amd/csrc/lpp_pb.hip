@@ -901,6 +901,12 @@ int pb_launch_chain(lpp_engine* e, void* w, void* y, double* partial, const EpiS
 	d.order = B.order;
 	d.u_has_beta = beta_in_u ? 1 : 0; // the in-block kernel has put beta r_{j-1} into u
 	if (d.pace) (void)hipMemsetAsync(d.pace, 0, sizeof(int) * 8 * (size_t)d.npanels, st);
+	static const int down_threads = getenv("LPP_PB_DOWN_THREADS") ? atoi(getenv("LPP_PB_DOWN_THREADS")) : 1024; // experiment: fewer waves, fewer lines in flight per L1
+	if (down_threads == 512) {
+		(void)hipFuncSetAttribute((const void*)k_pb_down<512, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B.down_lds);
+		k_pb_down<512, true><<<B.down_grid, 512, B.down_lds, st>>>(d);
+		return B.down_grid;
+	}
 	(void)hipFuncSetAttribute((const void*)k_pb_down<1024, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B.down_lds);
 	k_pb_down<1024, true><<<B.down_grid, 1024, B.down_lds, st>>>(d);
 	return B.down_grid;

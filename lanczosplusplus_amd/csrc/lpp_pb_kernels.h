@@ -491,7 +491,11 @@ template <int THREADS, bool RMW = false, bool WIDE = false, bool HALF = false> _
 #ifdef LPP_PB_TIMING_DOWN_OWNLINES
 					gbuf[q] = *(const double2*)(ysrc + at(row_s[il] + 0 * (w4[q] & 0xffffu))); // timing-only build: every gather asks for the block's own line (an L1 hit)
 #else
+#ifdef LPP_PB_TIMING_DOWN_NTGATHER
+					gbuf[q] = nt_load2((const double2*)(ysrc + at((w4[q] & 0xffffu) * rowbytes))); // experiment: the gathers bypass L1
+#else
 					gbuf[q] = *(const double2*)(ysrc + at((w4[q] & 0xffffu) * rowbytes));
+#endif
 #endif
 				}
 			};

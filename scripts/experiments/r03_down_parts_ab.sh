@@ -2,7 +2,7 @@
 # Timing-only builds (WRONG results) of k_pb_down<RMW>: what each part costs -- the gathered lines (replaced by the block's own line:
 # same instructions, L1 hits), the read of u, the store.  Rebuilds on the box; kernel trace only.
 R=$GRAFT_REPO_ROOT; export TMPDIR=/tmp
-VARS=("" "-DLPP_PB_TIMING_DOWN_OWNLINES" "-DLPP_PB_TIMING_DOWN_NOU" "-DLPP_PB_TIMING_DOWN_NOSTORE" "-DLPP_PB_TIMING_DOWN_OWNLINES@-DLPP_PB_TIMING_DOWN_NOU@-DLPP_PB_TIMING_DOWN_NOSTORE")
+[ -n "$ONLY" ] && VARS=($ONLY) || VARS=("" "-DLPP_PB_TIMING_DOWN_NTGATHER" "-DLPP_PB_TIMING_DOWN_OWNLINES" "-DLPP_PB_TIMING_DOWN_NOU" "-DLPP_PB_TIMING_DOWN_NOSTORE" "-DLPP_PB_TIMING_DOWN_OWNLINES@-DLPP_PB_TIMING_DOWN_NOU@-DLPP_PB_TIMING_DOWN_NOSTORE")
 for d in "${VARS[@]}"; do
   d=${d//@/ }
   cd $R/lanczosplusplus_amd/csrc && rm -f lpp_pb.o && make CXXFLAGS="-O3 -std=c++17 -fPIC -Wno-unused-result --offload-arch=gfx950 -I../../include $d" liblpp_engine.so > /tmp/mk.log 2>&1 || { tail -5 /tmp/mk.log; continue; }

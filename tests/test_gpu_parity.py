@@ -751,6 +751,8 @@ PB_CASES = {
 @pytest.mark.parametrize("form", ["window", "natural", "pieces", "wide", "half", "down2", "ws"])
 @pytest.mark.parametrize("case", sorted(PB_CASES))
 def test_product_basis_layout(case, form, monkeypatch):
+    if form in ("half", "down2", "ws") and case not in ("chain_L12", "two_hoppings"):
+        pytest.skip("opt-in experiment forms run on two of the cases (suite time)")
     """Device assembly of Hubbard straight into the product-basis layout (T, C, diagonal codes; lpp_pb_kernels.h): the CSR it
     stands for is the oracle's bit for bit, x += H y (two kernels, pitched vectors) matches the oracle, and every solver entry
     point works on the pitched vectors; the general layout (LPP_PRODUCT_LAYOUT=0) gives the same numbers.
