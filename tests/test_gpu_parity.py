@@ -751,8 +751,6 @@ PB_CASES = {
 @pytest.mark.parametrize("form", ["window", "natural", "pieces", "wide", "half", "down2", "ws"])
 @pytest.mark.parametrize("case", sorted(PB_CASES))
 def test_product_basis_layout(case, form, monkeypatch):
-    if form in ("half", "down2", "ws") and case not in ("chain_L12", "two_hoppings"):
-        pytest.skip("opt-in experiment forms run on two of the cases (suite time)")
     """Device assembly of Hubbard straight into the product-basis layout (T, C, diagonal codes; lpp_pb_kernels.h): the CSR it
     stands for is the oracle's bit for bit, x += H y (two kernels, pitched vectors) matches the oracle, and every solver entry
     point works on the pitched vectors; the general layout (LPP_PRODUCT_LAYOUT=0) gives the same numbers.
@@ -760,6 +758,8 @@ def test_product_basis_layout(case, form, monkeypatch):
     sectors) forced onto the same small matrices -- rows cut into pieces of 256 positions (entries that leave a piece are read
     from memory), couplings over 3 parts of the source range with 64-bit addresses; "wide": pieces of 320 positions and the
     whole-panel coupling kernel with 64-bit addresses (what BASELINE config 5's sectors take on one GPU)."""
+    if form in ("half", "down2", "ws") and case not in ("chain_L12", "two_hoppings"):
+        pytest.skip("opt-in experiment forms run on two of the cases (suite time)")
     L, nup, ndown, hop, U, V = PB_CASES[case]()
     monkeypatch.setenv("LPP_PRODUCT_LAYOUT", "1")  # these matrices are below the size from which the layout is chosen by itself
     if form == "pieces":
