@@ -106,6 +106,9 @@ WORKLOADS = {
     "hubbard_chain_L14_half_filling_U4": ("hubbard", dict(L=14, nup=7, ndown=7, hop=lambda: chain(14, -1.0), U=4.0)),
     # complex hoppings (Peierls phase on every bond): the reference's SolverOptions=useComplex path
     "hubbard_chain_L14_complex_U4": ("hubbard", dict(L=14, nup=7, ndown=7, hop=lambda: chain(14, -1.0) * np.where(np.triu(np.ones((14, 14)), 1) > 0, np.exp(0.2j), np.exp(-0.2j)), U=4.0)),
+    # 6.4e7 states, complex: the largest 4x4 sector whose one-species space (8008 complex positions = 125 KB) fits the LDS window of the
+    # product-basis layout for complex hoppings
+    "hubbard_4x4_6up6down_complex_U4": ("hubbard", dict(L=16, nup=6, ndown=6, hop=lambda: square_lattice(4, 4, -1.0) * np.where(np.triu(np.ones((16, 16)), 1) > 0, np.exp(0.2j), np.exp(-0.2j)), U=4.0)),
     "heisenberg_chain_L28_sz0_obc": ("heisenberg", dict(L=28, sz=14, j=1.0, pbc=False)),
     "heisenberg_chain_L24_sz0_obc": ("heisenberg", dict(L=24, sz=12, j=1.0, pbc=False)),
     "tj_4x5_9up9down_complex": ("tj", dict(L=20, nup=9, ndown=9, lx=5, ly=4, t=-1.0, j=0.4)),

@@ -206,15 +206,15 @@ lpp_status common_setup(lpp_engine* e, int64_t nrows, int is_complex_input, bool
 }
 
 // plain host copy of a small device CSR
-lpp_status fetch_csr(const DevCsr& A, std::vector<int64_t>& rp, std::vector<int32_t>& ci, std::vector<double>& va)
+lpp_status fetch_csr(const DevCsr& A, std::vector<int64_t>& rp, std::vector<int32_t>& ci, std::vector<double>& va, int doubles_per_value = 1)
 {
 	rp.resize((size_t)A.nrows + 1);
 	ci.resize((size_t)std::max<int64_t>(A.nnz, 1));
-	va.resize((size_t)std::max<int64_t>(A.nnz, 1));
+	va.resize((size_t)std::max<int64_t>(A.nnz, 1) * (size_t)doubles_per_value);
 	HIP_TRY(hipMemcpy(rp.data(), A.rowptr, sizeof(int64_t) * (size_t)(A.nrows + 1), hipMemcpyDeviceToHost));
 	if (A.nnz) {
 		HIP_TRY(hipMemcpy(ci.data(), A.col, sizeof(int32_t) * (size_t)A.nnz, hipMemcpyDeviceToHost));
-		HIP_TRY(hipMemcpy(va.data(), A.val, sizeof(double) * (size_t)A.nnz, hipMemcpyDeviceToHost));
+		HIP_TRY(hipMemcpy(va.data(), A.val, sizeof(double) * (size_t)A.nnz * (size_t)doubles_per_value, hipMemcpyDeviceToHost));
 	}
 	return LPP_OK;
 }
@@ -229,7 +229,10 @@ lpp_status assemble_hubbard_pb(lpp_engine* e, AsmParams P, int nup, int ndown, i
                                int64_t blk0 = 0, int64_t nblk_loc = -1, int64_t pitch_dn = 0, int64_t nblk_padded = 0)
 {
 	*done = false;
-	if (e->is_complex || n_up < 512) return LPP_OK;
+	if (n_up < 512) return LPP_OK;
+	const bool cplx = e->is_complex != 0;
+	// complex hoppings (Peierls phases, KaneMele): one-window single-GPU form with the realified in-block matrix (PbState::cplx)
+	if (cplx && (nblk_loc >= 0 || pitch_dn > 0 || (getenv("LPP_PB_COMPLEX") && atoi(getenv("LPP_PB_COMPLEX")) == 0))) return LPP_OK;
 	if (P.d3) return LPP_OK; // spin-flip terms move both species: not of the form 1 (x) T + C (x) 1
 	// LPP_PRODUCT_LAYOUT = 0: never, 1: whenever it applies; unset: from 32 MB per vector on.  Below that everything sits in
 	// L2 / Infinity Cache anyway and the step is launch-bound: measured on Hubbard chains (scripts/experiments/pb_threshold.sh),
@@ -240,13 +243,16 @@ lpp_status assemble_hubbard_pb(lpp_engine* e, AsmParams P, int nup, int ndown, i
 		forced = true;
 	}
 	if (!forced && (size_t)n_up * (size_t)n_dn * sizeof(double) < ((size_t)32 << 20)) return LPP_OK;
+	// complex hoppings run the three-kernel form with the generic-groups in-block kernel: measured 1570 against 1649 iterations/s (general
+	// layout) at 1.2e7 states (0.19 GB per vector), 211 against 170 at 6.4e7 states (1.0 GB per vector, 0.14 against 8.6 GB resident)
+	if (!forced && cplx && (size_t)n_up * (size_t)n_dn * 2 * sizeof(double) < ((size_t)512 << 20)) return LPP_OK;
 	if (e->cfg.spmv_kernel != LPP_SPMV_AUTO || getenv("LPP_SPMV_KERNEL")) return LPP_OK;
 	int want = e->cfg.compress_values;
 	if (const char* s = getenv("LPP_COMPRESS_VALUES")) want = atoi(s);
 	if (want == 0) return LPP_OK;
 	for (const char* k : { "LPP_SHARED_OFFSETS", "LPP_LOCAL16", "LPP_DIAG_CODES", "LPP_BLOCK_TEMPLATE", "LPP_WINDOW_ROWS" })
 		if (getenv(k)) return LPP_OK; // switches of the general layout: measure that one
-	const int64_t pitch = pb_pitch_for(n_up);
+	const int64_t pitch = pb_pitch_for(cplx ? 2 * n_up : n_up); // in doubles
 	// rows beyond one LDS window and vectors beyond 4 GiB take the pieces / parts kernels (lpp_pbig_kernels.h); what the layout
 	// cannot hold at all (more than 65535 blocks, coupling lists beyond LDS) comes back from pb_build as "does not apply"
 	if (n_dn > 65535 || n_up >= ((int64_t)1 << 24)) return LPP_OK;
@@ -286,8 +292,8 @@ lpp_status assemble_hubbard_pb(lpp_engine* e, AsmParams P, int nup, int ndown, i
 	std::vector<int64_t> trp, crp;
 	std::vector<int32_t> tci, cci;
 	std::vector<double> tva, cva;
-	if ((rc = fetch_csr(Tm, trp, tci, tva)) != LPP_OK) return rc;
-	if ((rc = fetch_csr(Cm, crp, cci, cva)) != LPP_OK) return rc;
+	if ((rc = fetch_csr(Tm, trp, tci, tva, cplx ? 2 : 1)) != LPP_OK) return rc;
+	if ((rc = fetch_csr(Cm, crp, cci, cva, cplx ? 2 : 1)) != LPP_OK) return rc;
 	// distinct diagonal values over all rows
 	DevBuf table, overflow;
 	HIP_TRY_MEM(hipMalloc(&table.p, sizeof(unsigned long long) * kDictTable));
@@ -321,17 +327,50 @@ lpp_status assemble_hubbard_pb(lpp_engine* e, AsmParams P, int nup, int ndown, i
 	if (!plain_diag)
 		for (unsigned long long k : host)
 			if (k != kDictEmpty) add_key(k);
-	for (int64_t b = 0; b < n_dn; b++)
-		for (int64_t p = crp[(size_t)b]; p < crp[(size_t)b + 1] && keys.size() <= 256; p++)
-			if (cci[(size_t)p] != b) {
-				unsigned long long k;
-				std::memcpy(&k, &cva[(size_t)p], 8);
-				add_key(k);
-			}
+	if (!cplx) // (complex couplings have a dictionary of their own: pb_build)
+		for (int64_t b = 0; b < n_dn; b++)
+			for (int64_t p = crp[(size_t)b]; p < crp[(size_t)b + 1] && keys.size() <= 256; p++)
+				if (cci[(size_t)p] != b) {
+					unsigned long long k;
+					std::memcpy(&k, &cva[(size_t)p], 8);
+					add_key(k);
+				}
 	if (keys.size() > 256) return LPP_OK;
 	std::sort(keys.begin(), keys.end());
 	std::vector<double> dict(256);
 	for (size_t i = 0; i < 256; i++) std::memcpy(&dict[i], &keys[std::min(i, keys.size() - 1)], 8);
+	if (cplx) {
+		// the realified in-block matrix: complex entry (i, c, t) -> row 2i: (2c, Re t), (2c+1, -Im t); row 2i+1: (2c, Im t), (2c+1, Re t);
+		// zero parts are dropped (a real hop costs two entries, not four); columns stay ascending
+		std::vector<int64_t> rrp((size_t)(2 * n_up) + 1, 0);
+		std::vector<int32_t> rci;
+		std::vector<double> rva;
+		for (int64_t i = 0; i < n_up; i++)
+			for (int half = 0; half < 2; half++) {
+				for (int64_t p = trp[(size_t)i]; p < trp[(size_t)i + 1]; p++) {
+					const int64_t c = tci[(size_t)p];
+					if (c == i) continue; // the diagonal lives in D
+					const double re = tva[2 * (size_t)p], im = tva[2 * (size_t)p + 1];
+					const double v0 = half == 0 ? re : im, v1 = half == 0 ? -im : re; // coefficients of (Re y_c, Im y_c)
+					if (v0 != 0.0) {
+						rci.push_back((int32_t)(2 * c));
+						rva.push_back(v0);
+					}
+					if (v1 != 0.0) {
+						rci.push_back((int32_t)(2 * c + 1));
+						rva.push_back(v1);
+					}
+				}
+				rrp[(size_t)(2 * i + half) + 1] = (int64_t)rci.size();
+			}
+		PbCplxInput cx;
+		cx.n_c = n_up;
+		cx.t_rp = trp.data();
+		cx.t_ci = tci.data();
+		cx.t_va = tva.data();
+		cx.c_va = cva.data();
+		rc = pb_build(e, 2 * n_up, n_dn, rrp.data(), rci.data(), rva.data(), crp.data(), cci.data(), nullptr, dict.data(), (int)keys.size(), 0, -1, 0, 0, &cx);
+	} else
 	rc = pb_build(e, n_up, n_dn, trp.data(), tci.data(), tva.data(), crp.data(), cci.data(), cva.data(), dict.data(), (int)keys.size(), blk0, nblk_loc, pitch_dn,
 	              nblk_padded);
 	if (rc == LPP_ERR_INVALID) { // not representable (e.g. more than 8 distinct in-block values): general path
@@ -348,9 +387,9 @@ lpp_status assemble_hubbard_pb(lpp_engine* e, AsmParams P, int nup, int ndown, i
 		const size_t loc = (size_t)std::max<int64_t>(e->pb.nblk_loc, 1) * (size_t)e->pb.pitch;
 		HIP_TRY_MEM(hipMalloc(&e->pb.dval, sizeof(double) * loc));
 		HIP_TRY(hipMemsetAsync(e->pb.dval, 0, sizeof(double) * loc, st));
-		if (Pf.nloc > 0) k_pb_diag_values<ASM_HUBBARD><<<nb, kBlock, 0, st>>>(Pf, e->pb.pitch, e->pb.dval, blk0, e->pb.inv); // the codes stay 0 (+0.0)
+		if (Pf.nloc > 0) k_pb_diag_values<ASM_HUBBARD><<<nb, kBlock, 0, st>>>(Pf, e->pb.pitch, e->pb.dval, blk0, e->pb.inv, cplx ? 1 : 0); // the codes stay 0 (+0.0)
 	} else if (Pf.nloc > 0)
-		k_pb_diag_codes<ASM_HUBBARD><<<nb, kBlock, 0, st>>>(Pf, e->pb.pitch, e->pb.dict, e->pb.ndict, e->pb.dcode, blk0, e->pb.inv);
+		k_pb_diag_codes<ASM_HUBBARD><<<nb, kBlock, 0, st>>>(Pf, e->pb.pitch, e->pb.dict, e->pb.ndict, e->pb.dcode, blk0, e->pb.inv, cplx ? 1 : 0);
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipStreamSynchronize(st));
 	*done = true;

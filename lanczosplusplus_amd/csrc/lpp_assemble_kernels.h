@@ -475,27 +475,37 @@ __global__ __launch_bounds__(kBlock) void k_pb_diag_collect(AsmParams P, unsigne
 
 template <int MODEL>
 __global__ __launch_bounds__(kBlock) void k_pb_diag_codes(AsmParams P, int64_t pitch, const double* __restrict__ dict, int ndict,
-                                                           uint8_t* __restrict__ dcode, int64_t blk0 = 0, const int32_t* __restrict__ inv = nullptr)
+                                                           uint8_t* __restrict__ dcode, int64_t blk0 = 0, const int32_t* __restrict__ inv = nullptr, int dup = 0)
 {
 	for (int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x; r < P.nloc; r += (int64_t)gridDim.x * kBlock) {
 		const int64_t row = P.row0 + r;
 		const uint64_t ket = state_of<MODEL>(P, row);
 		const int64_t b = row / P.n_up, i = row - b * P.n_up;
 		// blk0: first block this rank holds; inv: where the layout stores position i of a block (PbState::inv)
-		dcode[(b - blk0) * pitch + (inv ? inv[i] : i)] = (uint8_t)dict_code(dict, ndict, diag_of<MODEL>(P, ket));
+		const uint8_t code = (uint8_t)dict_code(dict, ndict, diag_of<MODEL>(P, ket));
+		if (dup) { // complex hoppings: a position is two doubles (re, im), both carry the code
+			dcode[(b - blk0) * pitch + 2 * i] = code;
+			dcode[(b - blk0) * pitch + 2 * i + 1] = code;
+		} else
+			dcode[(b - blk0) * pitch + (inv ? inv[i] : i)] = code;
 	}
 }
 
 // the diagonal as plain doubles (more than 256 distinct values), pitched like the vectors
 template <int MODEL>
 __global__ __launch_bounds__(kBlock) void k_pb_diag_values(AsmParams P, int64_t pitch, double* __restrict__ dval, int64_t blk0 = 0,
-                                                            const int32_t* __restrict__ inv = nullptr)
+                                                            const int32_t* __restrict__ inv = nullptr, int dup = 0)
 {
 	for (int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x; r < P.nloc; r += (int64_t)gridDim.x * kBlock) {
 		const int64_t row = P.row0 + r;
 		const uint64_t ket = state_of<MODEL>(P, row);
 		const int64_t b = row / P.n_up, i = row - b * P.n_up;
-		dval[(b - blk0) * pitch + (inv ? inv[i] : i)] = diag_of<MODEL>(P, ket);
+		const double dv = diag_of<MODEL>(P, ket);
+		if (dup) {
+			dval[(b - blk0) * pitch + 2 * i] = dv;
+			dval[(b - blk0) * pitch + 2 * i + 1] = dv;
+		} else
+			dval[(b - blk0) * pitch + (inv ? inv[i] : i)] = dv;
 	}
 }
 

@@ -165,6 +165,13 @@ struct PbState {
 	// the start vector, the diagonal's assembly, lpp_engine_get_csr); every kernel of a step is position-blind.
 	int32_t* perm = nullptr;
 	int32_t* inv = nullptr;
+	// complex hoppings: the vectors are complex, a block holds 2 n_c real positions (re, im interleaved; n_up, pitch count doubles), T is
+	// stored REALIFIED (row 2i: (2c, Re t), (2c+1, -Im t); row 2i+1: (2c, Im t), (2c+1, Re t)) so that k_pb_up is the real kernel, the couplings
+	// keep complex values (cdict, k_pb_down<CPLX>), the diagonal code of a position is stored for both of its doubles.  t_ptr / t_col / t_val
+	// keep the complex T of n_c rows ((re, im) pairs) for lpp_engine_get_csr.
+	bool cplx = false;
+	int64_t n_c = 0; // complex positions per block
+	double* cdict = nullptr; // 256 complex coupling values
 	int pre0 = 4; // chained step, two value groups: chunks of group 0 requested one slice ahead (group 1: 8 - pre0)
 	bool half = false; // k_pb_down<WIDE, HALF>: panels of 8 positions (64-byte half lines), for panels beyond an XCD's L2
 	bool ws = false; // k_pb_up_ws in the chained step (LPP_PB_WS=1): the next row staged by loader waves beside the gathers
@@ -271,11 +278,20 @@ lpp_status alloc_work(lpp_engine* e);
 int spmv_launch(lpp_engine* e, const DevCsr& A, const void* src, void* x, const void* ydot, double* partial, const EpiScale& sc = EpiScale { nullptr, nullptr, 0 });
 // product-basis layout (lpp_pb.hip)
 void free_pb(lpp_engine* e);
+// complex hoppings (PbState::cplx): pb_build then gets the REALIFIED in-block matrix (2 n_c rows) as t_rp / t_ci / t_va and the couplings'
+// structure as c_rp / c_ci (c_va unused); the complex matrices themselves come through this
+struct PbCplxInput {
+	int64_t n_c; // complex positions per block
+	const int64_t* t_rp; // the complex in-block matrix, n_c rows, values as (re, im) pairs
+	const int32_t* t_ci;
+	const double* t_va;
+	const double* c_va; // complex coupling values, (re, im) pairs, aligned with c_ci
+};
 // T and C as host CSRs over one species each (diagonal entries are ignored), sorted 256-entry dictionary holding every coupling
 // value; the caller fills pb.dcode (n_blk*pitch codes) afterwards
 lpp_status pb_build(lpp_engine* e, int64_t n_up, int64_t n_blk, const int64_t* t_rp, const int32_t* t_ci, const double* t_va,
                     const int64_t* c_rp, const int32_t* c_ci, const double* c_va, const double* dict256, int ndict,
-                    int64_t blk0 = 0, int64_t nblk_loc = -1, int64_t pitch_dn = 0, int64_t nblk_padded = 0);
+                    int64_t blk0 = 0, int64_t nblk_loc = -1, int64_t pitch_dn = 0, int64_t nblk_padded = 0, const struct PbCplxInput* cx = nullptr);
 int pb_launch(lpp_engine* e, const void* y, void* x, double* partial, const EpiScale& sc = EpiScale { nullptr, nullptr, 0 }, bool defer_combine = false);
 // the streaming pass of the scale-free Lanczos step on a product-basis matrix: x = beta x + u + z - (a/b2_prev) y, |x|^2 partials
 bool pb_chain_ok(const lpp_engine* e);

@@ -21,7 +21,7 @@ void free_pb(lpp_engine* e)
 	PbState& B = e->pb;
 	for (void* p : { (void*)B.tw, (void*)B.tw_off, (void*)B.tw_len, (void*)B.t_ptr, (void*)B.t_col, (void*)B.t_val, (void*)B.c_ptr, (void*)B.c_col,
 	                 (void*)B.c_code, (void*)B.order, (void*)B.pace, (void*)B.z, (void*)B.u, (void*)B.xy, (void*)B.dict, (void*)B.dcode, (void*)B.blockbase,
-	                 (void*)B.fw, (void*)B.f_off, (void*)B.f_len, (void*)B.c_pstart, (void*)B.dval, (void*)B.perm, (void*)B.inv })
+	                 (void*)B.fw, (void*)B.f_off, (void*)B.f_len, (void*)B.c_pstart, (void*)B.dval, (void*)B.perm, (void*)B.inv, (void*)B.cdict })
 		if (p) (void)hipFree(p);
 	if (B.stream2) {
 		(void)hipStreamSynchronize(B.stream2);
@@ -62,7 +62,7 @@ uint8_t code_of(const double* dict, int ndict, double v)
 
 lpp_status pb_build(lpp_engine* e, int64_t n_up, int64_t n_blk, const int64_t* t_rp, const int32_t* t_ci, const double* t_va,
                     const int64_t* c_rp, const int32_t* c_ci, const double* c_va, const double* dict256, int ndict,
-                    int64_t blk0, int64_t nblk_loc, int64_t pitch_dn, int64_t nblk_padded)
+                    int64_t blk0, int64_t nblk_loc, int64_t pitch_dn, int64_t nblk_padded, const PbCplxInput* cx)
 {
 	free_pb(e);
 	PbState& B = e->pb;
@@ -120,7 +120,8 @@ lpp_status pb_build(lpp_engine* e, int64_t n_up, int64_t n_blk, const int64_t* t
 	std::vector<int64_t> p_rp;
 	std::vector<int32_t> p_ci;
 	std::vector<double> p_va;
-	const bool want_perm = W == 0 && !tx && nblk_loc == n_blk && n_up >= 128 && !(getenv("LPP_PB_PERM") && atoi(getenv("LPP_PB_PERM")) == 0);
+	if (cx && (W > 0 || tx || parts || wide)) return fail(LPP_ERR_INVALID, "pb_build: complex hoppings are held in the one-window single-GPU form only");
+	const bool want_perm = !cx && W == 0 && !tx && nblk_loc == n_blk && n_up >= 128 && !(getenv("LPP_PB_PERM") && atoi(getenv("LPP_PB_PERM")) == 0);
 	if (want_perm) {
 		std::vector<unsigned long long> vals; // distinct values, ascending bit pattern (the order pb_pack_template numbers its groups in does not matter here)
 		for (int64_t i = 0; i < n_up && vals.size() <= (size_t)kPbGroupsMax; i++)
@@ -232,23 +233,49 @@ lpp_status pb_build(lpp_engine* e, int64_t n_up, int64_t n_blk, const int64_t* t
 	std::vector<int32_t> tc, cc;
 	std::vector<double> tv;
 	std::vector<uint8_t> ccode;
-	for (int64_t r = 0; r < n_up; r++) {
-		for (int64_t p = t_rp[r]; p < t_rp[r + 1]; p++) {
-			if (t_ci[p] == r) continue;
-			if (!tc.empty() && (int64_t)tc.size() > tp[(size_t)r] && tc.back() >= t_ci[p]) return fail(LPP_ERR_INVALID, "pb_build: in-block rows must be sorted by column");
-			tc.push_back(t_ci[p]);
-			tv.push_back(t_va[p]);
+	const int64_t n_rows_t = cx ? cx->n_c : n_up; // rows of the matrix lpp_engine_get_csr walks
+	if (cx) tp.assign((size_t)n_rows_t + 1, 0);
+	{
+		const int64_t* rp = cx ? cx->t_rp : t_rp;
+		const int32_t* ci = cx ? cx->t_ci : t_ci;
+		const double* va = cx ? cx->t_va : t_va;
+		for (int64_t r = 0; r < n_rows_t; r++) {
+			for (int64_t p = rp[r]; p < rp[r + 1]; p++) {
+				if (ci[p] == r) continue;
+				if (!tc.empty() && (int64_t)tc.size() > tp[(size_t)r] && tc.back() >= ci[p]) return fail(LPP_ERR_INVALID, "pb_build: in-block rows must be sorted by column");
+				tc.push_back(ci[p]);
+				if (cx) {
+					tv.push_back(va[2 * p]);
+					tv.push_back(va[2 * p + 1]);
+				} else
+					tv.push_back(va[p]);
+			}
+			tp[(size_t)r + 1] = (int64_t)tc.size();
 		}
-		tp[(size_t)r + 1] = (int64_t)tc.size();
 	}
+	std::vector<double> cdict; // complex hoppings: the couplings' own dictionary; code 0 = 0 (the padding places of k_pb_down)
+	if (cx) cdict.assign(2, 0.0);
 	int64_t longest = 1;
 	for (int64_t b = 0; b < n_blk; b++) {
 		for (int64_t p = c_rp[b]; p < c_rp[b + 1]; p++) {
 			if (c_ci[p] == b) continue;
 			if (c_ci[p] < 0 || c_ci[p] >= n_blk) return fail(LPP_ERR_INVALID, "pb_build: block coupling out of range");
 			if ((int64_t)cc.size() > cp[(size_t)b] && cc.back() >= c_ci[p]) return fail(LPP_ERR_INVALID, "pb_build: block couplings must be sorted");
-			const uint8_t code = code_of(dict256, ndict, c_va[p]);
-			if (std::memcmp(&dict256[code], &c_va[p], 8) != 0) return fail(LPP_ERR_INVALID, "pb_build: coupling value missing from the dictionary");
+			uint8_t code = 0;
+			if (cx) {
+				size_t k = 0;
+				for (; k < cdict.size() / 2; k++)
+					if (std::memcmp(&cdict[2 * k], &cx->c_va[2 * p], 16) == 0) break;
+				if (k == cdict.size() / 2) {
+					if (k >= 256) return fail(LPP_ERR_INVALID, "pb_build: more than 256 distinct complex coupling values");
+					cdict.push_back(cx->c_va[2 * p]);
+					cdict.push_back(cx->c_va[2 * p + 1]);
+				}
+				code = (uint8_t)k;
+			} else {
+				code = code_of(dict256, ndict, c_va[p]);
+				if (std::memcmp(&dict256[code], &c_va[p], 8) != 0) return fail(LPP_ERR_INVALID, "pb_build: coupling value missing from the dictionary");
+			}
 			cc.push_back(c_ci[p]);
 			ccode.push_back(code);
 		}
@@ -266,10 +293,16 @@ lpp_status pb_build(lpp_engine* e, int64_t n_up, int64_t n_blk, const int64_t* t
 	std::vector<double> dict(dict256, dict256 + 256);
 	if ((rc = to_device(&B.dict, dict, st)) != LPP_OK) return rc;
 	B.ndict = ndict;
+	if (cx) {
+		cdict.resize(512, 0.0);
+		if ((rc = to_device(&B.cdict, cdict, st)) != LPP_OK) return rc;
+		B.cplx = true;
+		B.n_c = cx->n_c;
+	}
 	// first CSR entry of every block: a block holds Z_T + n_up*(1 + couplings of the block) entries
 	std::vector<int64_t> base((size_t)n_blk + 1, 0);
-	const int64_t zt = tp[(size_t)n_up];
-	for (int64_t b = 0; b < n_blk; b++) base[(size_t)b + 1] = base[(size_t)b] + zt + n_up * (1 + cp[(size_t)b + 1] - cp[(size_t)b]);
+	const int64_t zt = tp[(size_t)n_rows_t];
+	for (int64_t b = 0; b < n_blk; b++) base[(size_t)b + 1] = base[(size_t)b] + zt + n_rows_t * (1 + cp[(size_t)b + 1] - cp[(size_t)b]);
 	B.nnz = base[(size_t)n_blk];
 	B.nnz_loc = base[(size_t)(blk0 + nblk_loc)] - base[(size_t)blk0];
 	if ((rc = to_device(&B.blockbase, base, st)) != LPP_OK) return rc;
@@ -285,13 +318,13 @@ lpp_status pb_build(lpp_engine* e, int64_t n_up, int64_t n_blk, const int64_t* t
 	B.parts = parts;
 	B.wide = wide;
 	B.half = half;
-	B.ws = getenv("LPP_PB_WS") && atoi(getenv("LPP_PB_WS")) == 1 && !B.big && pitch <= kPbWsMaxPitch && pb_ws_lds_bytes(pitch, T.spb, T.G) <= (size_t)160 * 1024 - 64;
+	B.ws = !cx && getenv("LPP_PB_WS") && atoi(getenv("LPP_PB_WS")) == 1 && !B.big && pitch <= kPbWsMaxPitch && pb_ws_lds_bytes(pitch, T.spb, T.G) <= (size_t)160 * 1024 - 64;
 	B.ws_beta = !(getenv("LPP_PB_WS_BETA") && atoi(getenv("LPP_PB_WS_BETA")) == 0);
 	// k_pb_down2 (own lines of the panel in LDS): opt-in (LPP_PB_DOWN2=1).  Measured at BASELINE config 2 (profiles/README.md, round 3):
 	// it halves the couplings that go through L1 (8.6 of 17.1 per block leave the workgroup's range) but the far lists padded per
 	// task (12 instead of 8.6), the selects of the compact lists and twice the VALU / LDS instructions leave it at 1.57 ms against
 	// 1.43 ms (plain) and 2.08 against 1.80 ms (chained form) for k_pb_down
-	if (!parts && !wide && B.ids_per_wg >= 8 && getenv("LPP_PB_DOWN2") && atoi(getenv("LPP_PB_DOWN2")) != 0) {
+	if (!cx && !parts && !wide && B.ids_per_wg >= 8 && getenv("LPP_PB_DOWN2") && atoi(getenv("LPP_PB_DOWN2")) != 0) {
 		int64_t ent_cap = 0;
 		for (int64_t lo = 0; lo < n_blk; lo += B.ids_per_wg) ent_cap = std::max(ent_cap, cp[(size_t)std::min<int64_t>(lo + B.ids_per_wg, n_blk)] - cp[(size_t)lo]);
 		const size_t need = pb_down2_lds_bytes(B.ids_per_wg, (int)std::min<int64_t>(ent_cap, 1 << 20));
@@ -403,8 +436,8 @@ lpp_status pb_build(lpp_engine* e, int64_t n_up, int64_t n_blk, const int64_t* t
 		(void)hipStreamDestroy(B.stream2);
 		B.stream2 = nullptr;
 	}
-	e->pitch = pitch;
-	e->pitch_rows = n_up;
+	e->pitch = cx ? pitch / 2 : pitch; // in vector elements
+	e->pitch_rows = cx ? cx->n_c : n_up;
 	e->pitch_blocks = nblk_loc;
 	B.active = true;
 	return LPP_OK;
@@ -628,7 +661,7 @@ int pb_launch(lpp_engine* e, const void* y, void* x, double* partial, const EpiS
 		const int n = launch_down2(e, (const double*)y, B.z, B.pitch, nullptr, nullptr, partial ? partial + nb : nullptr, sc, false, false, sd);
 		if (partial) np += n;
 	} else if (both) {
-		PbDownArgs d;
+		PbDownArgs d = {};
 		d.pitch = B.pitch;
 		d.n_blk = B.n_blk;
 		d.npanels = (int)(B.pitch / (B.half ? 8 : 16));
@@ -650,7 +683,11 @@ int pb_launch(lpp_engine* e, const void* y, void* x, double* partial, const EpiS
 		if (d.pace) (void)hipMemsetAsync(d.pace, 0, sizeof(int) * 8 * (size_t)d.npanels, sd);
 		int threads = concurrent ? 512 : 1024;
 		if (const char* s = getenv("LPP_PB_DOWN_THREADS")) threads = atoi(s);
-		if (threads == 512) {
+		d.cdict = (const double2*)B.cdict;
+		if (B.cplx) {
+			(void)hipFuncSetAttribute((const void*)k_pb_down<1024, false, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B.down_lds);
+			k_pb_down<1024, false, false, false, true><<<B.down_grid, 1024, B.down_lds, sd>>>(d);
+		} else if (threads == 512) {
 			(void)hipFuncSetAttribute((const void*)k_pb_down<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B.down_lds);
 			k_pb_down<512><<<B.down_grid, 512, B.down_lds, sd>>>(d);
 		} else if (B.wide && B.half) {
@@ -773,7 +810,7 @@ void pb_tx_down(lpp_engine* e, const void* gath, void* send2, const EpiScale& sc
 		launch_down2(e, (const double*)gath, (double*)send2, B.pitch_dn, nullptr, nullptr, nullptr, sc, false, false, e->stream);
 		return;
 	}
-	PbDownArgs d;
+	PbDownArgs d = {};
 	d.pitch = B.pitch_dn;
 	d.n_blk = B.n_blk;
 	d.npanels = (int)(B.pitch_dn / (B.half ? 8 : 16));
@@ -822,7 +859,7 @@ bool pb_chain_ok(const lpp_engine* e)
 {
 	const PbState& B = e->pb;
 	if (getenv("LPP_PB_CHAIN") && atoi(getenv("LPP_PB_CHAIN")) == 0) return false;
-	return B.active && !B.tx && !B.big && !B.parts && !B.wide && !B.dval && B.c_nnz > 0 && (B.G == 1 || B.G == 2);
+	return B.active && !B.cplx && !B.tx && !B.big && !B.parts && !B.wide && !B.dval && B.c_nnz > 0 && (B.G == 1 || B.G == 2);
 }
 
 template <int GT, int PRE0 = kPbPre> static void launch_up_chain(const PbUpArgs& u, int nb, size_t lds, hipStream_t st)
@@ -881,7 +918,7 @@ int pb_launch_chain(lpp_engine* e, void* w, void* y, double* partial, const EpiS
 		else launch_up_chain<2>(u, nb, lds, st);
 	}
 	if (B.down2) return launch_down2(e, (const double*)w, (double*)y, B.pitch, B.u, shift, partial, sc, true, beta_in_u, st);
-	PbDownArgs d;
+	PbDownArgs d = {};
 	d.pitch = B.pitch;
 	d.n_blk = B.n_blk;
 	d.npanels = (int)(B.pitch / 16);
@@ -1098,7 +1135,8 @@ lpp_status pb_from_csr(lpp_engine* e, const DevCsr& A, int64_t n_up, bool* done)
 lpp_status pb_get_csr(lpp_engine* e, int64_t* rowptr, int32_t* colind, void* values)
 {
 	const PbState& B = e->pb;
-	const int64_t n = B.n_up * B.n_blk;
+	const int64_t n = (B.cplx ? B.n_c : B.n_up) * B.n_blk;
+	const size_t vsz = B.cplx ? 2 * sizeof(double) : sizeof(double);
 	struct Buf {
 		void* p = nullptr;
 		~Buf()
@@ -1109,15 +1147,19 @@ lpp_status pb_get_csr(lpp_engine* e, int64_t* rowptr, int32_t* colind, void* val
 	if (rowptr) HIP_TRY_MEM(hipMalloc(&drp.p, sizeof(int64_t) * (size_t)(n + 1)));
 	if (colind || values) {
 		HIP_TRY_MEM(hipMalloc(&dci.p, sizeof(int32_t) * (size_t)std::max<int64_t>(B.nnz, 1)));
-		HIP_TRY_MEM(hipMalloc(&dva.p, sizeof(double) * (size_t)std::max<int64_t>(B.nnz, 1)));
+		HIP_TRY_MEM(hipMalloc(&dva.p, vsz * (size_t)std::max<int64_t>(B.nnz, 1)));
 	}
+	if (B.cplx)
+		k_pb_rebuild_c<<<(int)((n + 255) / 256), 256, 0, e->stream>>>(B.n_c, B.n_blk, B.pitch, B.t_ptr, B.t_col, (const double2*)B.t_val, B.c_ptr, B.c_col, B.c_code,
+		                                                             B.blockbase, B.dcode, B.dict, (const double2*)B.cdict, (int64_t*)drp.p, (int32_t*)dci.p, (double2*)dva.p, B.dval);
+	else
 	k_pb_rebuild<<<(int)((n + 255) / 256), 256, 0, e->stream>>>(B.n_up, B.n_blk, B.pitch, B.t_ptr, B.t_col, B.t_val, B.c_ptr, B.c_col, B.c_code, B.blockbase,
 	                                                           B.dcode, B.dict, (int64_t*)drp.p, (int32_t*)dci.p, (double*)dva.p, B.dval, B.inv);
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipStreamSynchronize(e->stream));
 	if (rowptr) HIP_TRY(hipMemcpy(rowptr, drp.p, sizeof(int64_t) * (size_t)(n + 1), hipMemcpyDeviceToHost));
 	if (colind) HIP_TRY(hipMemcpy(colind, dci.p, sizeof(int32_t) * (size_t)B.nnz, hipMemcpyDeviceToHost));
-	if (values) HIP_TRY(hipMemcpy(values, dva.p, sizeof(double) * (size_t)B.nnz, hipMemcpyDeviceToHost));
+	if (values) HIP_TRY(hipMemcpy(values, dva.p, vsz * (size_t)B.nnz, hipMemcpyDeviceToHost));
 	return LPP_OK;
 }
 
@@ -1162,7 +1204,10 @@ lpp_status vec_to_host(lpp_engine* e, void* host, const double* dev)
 void vec_fill_random(lpp_engine* e, double* dev, uint64_t seed)
 {
 	if (e->pitch > 0) {
-		k_fill_random_pitched<<<1024, 256, 0, e->stream>>>(dev, e->pitch_blocks, e->pitch_rows, e->pitch, e->row_start, seed, e->pb.perm);
+		if (e->pb.cplx) // complex elements: the stream is indexed by doubles (2 per element), rows and pitch counted in doubles
+			k_fill_random_pitched<<<1024, 256, 0, e->stream>>>(dev, e->pitch_blocks, e->pb.n_up, e->pb.pitch, e->row_start * 2, seed, nullptr);
+		else
+			k_fill_random_pitched<<<1024, 256, 0, e->stream>>>(dev, e->pitch_blocks, e->pitch_rows, e->pitch, e->row_start, seed, e->pb.perm);
 		return;
 	}
 	if (e->nd > 0) k_fill_random<<<1024, 256, 0, e->stream>>>(dev, e->nd, e->row_start * (e->is_complex ? 2 : 1), seed);

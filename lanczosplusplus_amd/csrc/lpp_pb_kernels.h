@@ -400,6 +400,7 @@ struct PbDownArgs {
 	EpiScale sc; // only alpha is used: z = alpha * C y
 	int* pace; // [8][npanels] finished-workgroup counters (zeroed before the launch); null: free-running
 	int u_has_beta; // RMW: u_in already holds beta * (old z) (k_pb_up<CHAIN> adds it): z is written only, one stream less
+	const double2* cdict; // CPLX: 256 complex coupling values (the codes of c_code index it; `dict` then only serves the diagonal)
 };
 
 // RMW (chained Lanczos step, see k_pb_up): z holds the previous Lanczos vector r' and receives the finished
@@ -412,10 +413,13 @@ struct PbDownArgs {
 // HALF: panels of 8 positions (64-byte half lines; a wave task is 16 blocks x 8 positions, npanels = pitch / 8): with 38,760 or
 // 77,520 blocks (BASELINE config 5's sectors) a panel of whole lines is 5-10 MB and does not stay in an XCD's 4 MiB L2 --
 // every one of the ~17 gathers of a line then comes from the fabric (measured at the (7,6) sector: 88 GB read for a 24 GB vector).
-template <int THREADS, bool RMW = false, bool WIDE = false, bool HALF = false> __global__ __launch_bounds__(THREADS) void k_pb_down(PbDownArgs a)
+// CPLX: complex hoppings.  The vector is complex, one element per 16-byte lane (a line = 8 positions; pitch and npanels still count
+// doubles), the coupling values are complex (cdict) and a gather is multiplied as a complex number; everything else -- lines, panels,
+// pacing, the partial sums (Re<y|z> is the real dot product of the doubles) -- is the real kernel.
+template <int THREADS, bool RMW = false, bool WIDE = false, bool HALF = false, bool CPLX = false> __global__ __launch_bounds__(THREADS) void k_pb_down(PbDownArgs a)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-	__shared__ double dict_s[256];
+	__shared__ double dict_s[CPLX ? 512 : 256]; // CPLX: (re, im) pairs
 	// LDS image of this workgroup's coupling lists in `order` (block numbers and value codes, 3 bytes per place: a workgroup of
 	// k_pb_up must fit next to this one)
 	const int stride = pb_down_stride(a.rowcap);
@@ -423,7 +427,7 @@ template <int THREADS, bool RMW = false, bool WIDE = false, bool HALF = false> _
 	int32_t* len_s = (int32_t*)(row_s + a.ids_per_wg); // [ids_per_wg] list length
 	uint32_t* place_s = (uint32_t*)(lds_raw + (((size_t)a.ids_per_wg * 8 + 15) & ~(size_t)15)); // [ids_per_wg][stride] source block (n_blk < 65536: the lists must fit LDS anyway) | code << 16
 	__shared__ double smem_d[THREADS / 64];
-	for (int i = threadIdx.x; i < 256; i += THREADS) dict_s[i] = a.dict[i];
+	for (int i = threadIdx.x; i < (CPLX ? 512 : 256); i += THREADS) dict_s[i] = CPLX ? ((const double*)a.cdict)[i] : a.dict[i];
 	double alpha, beta;
 	epi_coeffs(a.sc, alpha, beta);
 	double dot = 0.0, nrm = 0.0;
@@ -503,9 +507,15 @@ template <int THREADS, bool RMW = false, bool WIDE = false, bool HALF = false> _
 				const uint32_t w4[4] = { pw.x, pw.y, pw.z, pw.w };
 #pragma unroll
 				for (int q = 0; q < 4; q++) {
-					const double v = dict_s[w4[q] >> 16];
-					acc.x = fma(v, gbuf[q].x, acc.x);
-					acc.y = fma(v, gbuf[q].y, acc.y);
+					if (CPLX) {
+						const double2 v = ((const double2*)dict_s)[w4[q] >> 16];
+						acc.x = fma(v.x, gbuf[q].x, fma(-v.y, gbuf[q].y, acc.x));
+						acc.y = fma(v.x, gbuf[q].y, fma(v.y, gbuf[q].x, acc.y));
+					} else {
+						const double v = dict_s[w4[q] >> 16];
+						acc.x = fma(v, gbuf[q].x, acc.x);
+						acc.y = fma(v, gbuf[q].y, acc.y);
+					}
 				}
 			};
 #ifndef LPP_PB_RMW_POS
@@ -1074,6 +1084,49 @@ static __global__ void k_pb_rebuild(int64_t n_up, int64_t n_blk, int64_t pitch, 
 	for (; p < c1; p++, o++) {
 		col_out[o] = (int32_t)((int64_t)c_col[p] * n_up + i);
 		val_out[o] = dict[c_code[p]];
+	}
+}
+
+
+// the same walk for complex hoppings: T and the couplings carry complex values (t_val: (re, im) pairs; cdict), the layout keeps a block as
+// 2 n_up real positions (pitch counts doubles), the diagonal is real
+static __global__ void k_pb_rebuild_c(int64_t n_up, int64_t n_blk, int64_t pitch, const int64_t* __restrict__ t_ptr, const int32_t* __restrict__ t_col,
+                                    const double2* __restrict__ t_val, const int64_t* __restrict__ c_ptr, const int32_t* __restrict__ c_col,
+                                    const uint8_t* __restrict__ c_code, const int64_t* __restrict__ blockbase, const uint8_t* __restrict__ dcode,
+                                    const double* __restrict__ dict, const double2* __restrict__ cdict, int64_t* __restrict__ rowptr_out, int32_t* __restrict__ col_out,
+                                    double2* __restrict__ val_out, const double* __restrict__ dplain = nullptr, const int32_t* __restrict__ inv = nullptr)
+{
+	const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	const int64_t n = n_up * n_blk;
+	if (r == 0 && rowptr_out) rowptr_out[n] = blockbase[n_blk];
+	if (r >= n) return;
+	const int64_t b = r / n_up, i = r - b * n_up;
+	const int64_t c0 = c_ptr[b], c1 = c_ptr[b + 1];
+	int64_t o = blockbase[b] + t_ptr[i] + i * (1 + (c1 - c0));
+	if (rowptr_out) rowptr_out[r] = o;
+	if (!col_out) return;
+	int64_t p = c0;
+	for (; p < c1 && c_col[p] < b; p++, o++) {
+		col_out[o] = (int32_t)((int64_t)c_col[p] * n_up + i);
+		val_out[o] = cdict[c_code[p]];
+	}
+	int64_t q = t_ptr[i];
+	const int64_t q1 = t_ptr[i + 1];
+	for (; q < q1 && t_col[q] < i; q++, o++) {
+		col_out[o] = (int32_t)(b * n_up + t_col[q]);
+		val_out[o] = t_val[q];
+	}
+	col_out[o] = (int32_t)r;
+	const int64_t at = b * pitch + 2 * i; // the real part's position (the imaginary part carries the same code)
+	val_out[o] = double2 { dplain ? dplain[at] : dict[dcode[at]], 0.0 };
+	o++;
+	for (; q < q1; q++, o++) {
+		col_out[o] = (int32_t)(b * n_up + t_col[q]);
+		val_out[o] = t_val[q];
+	}
+	for (; p < c1; p++, o++) {
+		col_out[o] = (int32_t)((int64_t)c_col[p] * n_up + i);
+		val_out[o] = cdict[c_code[p]];
 	}
 }
 

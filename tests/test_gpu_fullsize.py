@@ -143,3 +143,34 @@ def test_config5_lattice_products_agree_beyond_the_lds_window(monkeypatch):
         e.setup_hubbard_onthefly(L, 6, 5, hop, U)
         hv2 = e.matrixVectorProduct(np.zeros(n), v)
     assert np.max(np.abs(hv2 - hv)) <= 1e-13 * np.max(np.abs(hv))
+
+
+def test_complex_hoppings_take_the_product_basis_layout_free_fermions():
+    """4x4 lattice with a Peierls phase on every bond, 6 up 6 down (6.4e7 complex states, 1 GB per vector): large enough for the
+    product-basis layout to be chosen by itself (realified in-block matrix + complex couplings, 0.14 GB instead of 8.6 GB); the exact
+    free-fermion energy of the Hermitian hopping matrix to 1e-10, and x += H y against the general layout."""
+    L = 16
+    hop = square(4, 4, -1.0, pbc=True) * np.where(np.triu(np.ones((L, L)), 1) > 0, np.exp(0.2j), np.exp(-0.2j))
+    assert np.allclose(hop, hop.conj().T)
+    exact = _exact(hop, 6)
+    rng = np.random.default_rng(3)
+    n = 8008 * 8008
+    y = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+    with LanczosEngine(dtype="c128", max_steps=300, eps=1e-11, save_vectors=0) as e:
+        e.assemble_hubbard(L, 6, 6, hop, np.zeros(L))
+        lay = e.layout()
+        assert lay["kernel"] == 4 and lay["resident_bytes"] < 0.2e9 and e.stats()["nrows"] == n
+        xp = e.matrixVectorProduct(np.zeros(n, dtype=complex), y)
+        eg, _, st = e.lanczos(1, want_vectors=False)
+        assert abs(eg[0] - exact) <= 1e-10 * abs(exact), (eg[0], exact, st["steps"])
+    import os
+
+    os.environ["LPP_PB_COMPLEX"] = "0"
+    try:
+        with LanczosEngine(dtype="c128") as e:
+            e.assemble_hubbard(L, 6, 6, hop, np.zeros(L))
+            assert e.layout()["kernel"] != 4
+            xg = e.matrixVectorProduct(np.zeros(n, dtype=complex), y)
+    finally:
+        del os.environ["LPP_PB_COMPLEX"]
+    assert np.linalg.norm(xp - xg) <= 1e-13 * np.linalg.norm(xg)

@@ -834,6 +834,59 @@ def test_product_basis_layout(case, form, monkeypatch):
         assert rel(xw, xg) < SPMV_TOL
 
 
+@pytest.mark.parametrize("case", ["peierls_ring", "kane_mele_like", "disorder"])
+def test_product_basis_layout_with_complex_hoppings(case, monkeypatch):
+    """Complex hoppings (SolverOptions=useComplex, HubbardHelper.h:63-66; Peierls phases, KaneMele's imaginary second-neighbour hops) in the
+    product-basis layout: the in-block matrix is held realified over (re, im) pairs, so k_pb_up is the real kernel, the couplings keep
+    complex values (k_pb_down<CPLX>).  Same checks as the real layout test: CSR bit-exact, x += H y, solves, a/b, Ritz vector, reortho."""
+    monkeypatch.setenv("LPP_PRODUCT_LAYOUT", "1")
+    L, nup, ndown = 12, 6, 5
+    ring = chain(L, -1.0, True).astype(complex)
+    up = np.triu(np.ones((L, L)), 1) > 0
+    if case == "kane_mele_like":  # real first-neighbour hops, imaginary second-neighbour hops
+        nnn = (np.diag(np.ones(L - 2), 2) + np.diag(np.ones(L - 2), -2)).astype(complex)
+        hop = ring + 0.3j * np.where(up, nnn, -nnn)
+    else:  # a phase on every bond
+        hop = ring * np.where(up, np.exp(0.37j), np.exp(-0.37j))
+    assert np.allclose(hop, hop.conj().T)
+    U = np.full(L, 4.0) if case != "disorder" else np.random.default_rng(5).uniform(1, 5, L)
+    V = np.zeros(2 * L) if case != "disorder" else np.random.default_rng(6).uniform(-0.5, 0.5, 2 * L)
+    A = oracle.hubbard_csr(L, nup, ndown, hop, U, V)
+    assert A.is_complex
+    x0, y = oracle.fill_random(A.nrows, 7, True), oracle.fill_random(A.nrows, 8, True)
+    xo = oracle.spmv_acc(A, x0.copy(), y)
+    init = oracle.fill_random(A.nrows, 4321, True)
+    eo, zo, so = oracle.lanczos_solve(A, oracle.fill_random(A.nrows, 1234, True), nstates=1)
+    steps_o, ao, bo, _, _ = oracle.lanczos_decomposition(A, init)
+    with LanczosEngine(dtype="c128") as e:
+        e.assemble_hubbard(L, nup, ndown, hop, U, V)
+        lay = e.layout()
+        assert lay["kernel"] == 4 and lay["nnz"] == A.nnz and lay["chained_step"] == 0 and lay["rows_by_list_length"] == 0
+        assert lay["diagonal_plain"] == (1 if case == "disorder" else 0)
+        rp, ci, va = e.get_csr()
+        assert np.array_equal(rp, A.rowptr) and np.array_equal(ci, A.colind)
+        assert np.array_equal(np.ascontiguousarray(va).view(np.uint64), np.ascontiguousarray(A.values).view(np.uint64))
+        xg = e.matrixVectorProduct(x0.copy(), y)
+        assert rel(xg, xo) < SPMV_TOL
+        eg, zg, st = e.lanczos(1, want_vectors=True)
+        assert abs(eg[0] - eo[0]) <= E_TOL * abs(eo[0]) and st["steps"] == so
+        r = oracle.spmv_acc(A, np.zeros_like(zg[0]), zg[0]) - eg[0] * zg[0]
+        assert np.linalg.norm(r) < 1e-5 and abs(np.linalg.norm(zg[0]) - 1) < 1e-8
+        ag, bg, _ = e.decomposition(init)
+        assert len(ag) == steps_o and rel(ag, ao) < 1e-8 and rel(bg, bo) < 1e-8
+    with LanczosEngine(dtype="c128", save_vectors=0) as e:  # scale-free recurrence + two-pass Ritz vector
+        e.assemble_hubbard(L, nup, ndown, hop, U, V)
+        eg2, zg2, st2 = e.lanczos(1, want_vectors=True)
+        assert st2["vectors_saved"] == 0 and abs(eg2[0] - eo[0]) <= E_TOL * abs(eo[0])
+        r = oracle.spmv_acc(A, np.zeros_like(zg2[0]), zg2[0]) - eg2[0] * zg2[0]
+        assert np.linalg.norm(r) < 1e-5
+    monkeypatch.setenv("LPP_PB_COMPLEX", "0")  # the general layout gives the same numbers
+    with LanczosEngine(dtype="c128") as e:
+        e.assemble_hubbard(L, nup, ndown, hop, U, V)
+        assert e.layout()["kernel"] != 4
+        assert rel(e.matrixVectorProduct(x0.copy(), y), xo) < SPMV_TOL
+
+
 def test_product_basis_layout_falls_back_when_it_does_not_apply(monkeypatch):
     """more than 8 distinct in-block values, or a many-valued diagonal with the plain stream switched off (LPP_PB_PLAIN_DIAG=0): the
     general layout takes over, results unchanged"""
