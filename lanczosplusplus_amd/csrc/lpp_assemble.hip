@@ -340,29 +340,10 @@ lpp_status assemble_hubbard_pb(lpp_engine* e, AsmParams P, int nup, int ndown, i
 	std::vector<double> dict(256);
 	for (size_t i = 0; i < 256; i++) std::memcpy(&dict[i], &keys[std::min(i, keys.size() - 1)], 8);
 	if (cplx) {
-		// the realified in-block matrix: complex entry (i, c, t) -> row 2i: (2c, Re t), (2c+1, -Im t); row 2i+1: (2c, Im t), (2c+1, Re t);
-		// zero parts are dropped (a real hop costs two entries, not four); columns stay ascending
-		std::vector<int64_t> rrp((size_t)(2 * n_up) + 1, 0);
+		std::vector<int64_t> rrp;
 		std::vector<int32_t> rci;
 		std::vector<double> rva;
-		for (int64_t i = 0; i < n_up; i++)
-			for (int half = 0; half < 2; half++) {
-				for (int64_t p = trp[(size_t)i]; p < trp[(size_t)i + 1]; p++) {
-					const int64_t c = tci[(size_t)p];
-					if (c == i) continue; // the diagonal lives in D
-					const double re = tva[2 * (size_t)p], im = tva[2 * (size_t)p + 1];
-					const double v0 = half == 0 ? re : im, v1 = half == 0 ? -im : re; // coefficients of (Re y_c, Im y_c)
-					if (v0 != 0.0) {
-						rci.push_back((int32_t)(2 * c));
-						rva.push_back(v0);
-					}
-					if (v1 != 0.0) {
-						rci.push_back((int32_t)(2 * c + 1));
-						rva.push_back(v1);
-					}
-				}
-				rrp[(size_t)(2 * i + half) + 1] = (int64_t)rci.size();
-			}
+		pb_realify(n_up, trp.data(), tci.data(), tva.data(), rrp, rci, rva);
 		PbCplxInput cx;
 		cx.n_c = n_up;
 		cx.t_rp = trp.data();

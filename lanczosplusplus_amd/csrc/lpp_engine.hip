@@ -1045,17 +1045,17 @@ lpp_status lpp_engine_destroy(lpp_engine* e)
 	return LPP_OK;
 }
 
-// A whole real matrix on one GPU that turns out to be of product-basis form (basis block = the caller's hint or the detected one)
+// A whole matrix (real, or complex Hermitian with a real diagonal) on one GPU that turns out to be of product-basis form (basis block = the caller's hint or the detected one)
 // is taken into the product-basis layout (pb_from_csr: T, C, D extracted and the CSR verified against them row by row) and the
 // CSR is dropped; *as_product says so.  Everything else goes on to finalize_csr.
 static lpp_status try_product_layout(lpp_engine* e, DevCsr& A, bool* as_product)
 {
 	*as_product = false;
-	if (e->is_complex || A.nrows == 0 || A.nnz == 0) return LPP_OK;
+	if (A.nrows == 0 || A.nnz == 0) return LPP_OK;
 	int64_t hb = A.hint_block;
 	if (hb == 0 && !(getenv("LPP_DETECT_BLOCK") && atoi(getenv("LPP_DETECT_BLOCK")) == 0) && (size_t)A.nrows * e->esz < ((size_t)1 << 32)) {
 		StageTimer tm("basis block detection");
-		hb = detect_row_block_t<double>(e, A, (int64_t)1 << 23);
+		hb = e->is_complex ? detect_row_block_t<cplx>(e, A, (int64_t)1 << 23) : detect_row_block_t<double>(e, A, (int64_t)1 << 23);
 		if (hb && getenv("LPP_VERBOSE")) fprintf(stderr, "lpp: detected a basis block of %lld rows\n", (long long)hb);
 		if (hb > 0 && hb <= (int64_t)((156 * 1024) / e->esz)) A.hint_block = hb; // finalize_csr need not look again
 	}

@@ -287,6 +287,8 @@ struct PbCplxInput {
 	const double* t_va;
 	const double* c_va; // complex coupling values, (re, im) pairs, aligned with c_ci
 };
+// complex in-block matrix (n rows, (re, im) pairs, diagonal skipped) -> the realified one of 2n rows (PbState::cplx)
+void pb_realify(int64_t n, const int64_t* rp, const int32_t* ci, const double* va, std::vector<int64_t>& rrp, std::vector<int32_t>& rci, std::vector<double>& rva);
 // T and C as host CSRs over one species each (diagonal entries are ignored), sorted 256-entry dictionary holding every coupling
 // value; the caller fills pb.dcode (n_blk*pitch codes) afterwards
 lpp_status pb_build(lpp_engine* e, int64_t n_up, int64_t n_blk, const int64_t* t_rp, const int32_t* t_ci, const double* t_va,

@@ -60,6 +60,33 @@ uint8_t code_of(const double* dict, int ndict, double v)
 }
 } // namespace
 
+// the realified in-block matrix: complex entry (i, c, t) -> row 2i: (2c, Re t), (2c+1, -Im t); row 2i+1: (2c, Im t), (2c+1, Re t); zero parts
+// are dropped (a real hop costs two entries, not four); columns stay ascending
+void pb_realify(int64_t n, const int64_t* rp, const int32_t* ci, const double* va, std::vector<int64_t>& rrp, std::vector<int32_t>& rci, std::vector<double>& rva)
+{
+	rrp.assign((size_t)(2 * n) + 1, 0);
+	rci.clear();
+	rva.clear();
+	for (int64_t i = 0; i < n; i++)
+		for (int half = 0; half < 2; half++) {
+			for (int64_t p = rp[i]; p < rp[i + 1]; p++) {
+				const int64_t c = ci[p];
+				if (c == i) continue; // the diagonal lives in D
+				const double re = va[2 * p], im = va[2 * p + 1];
+				const double v0 = half == 0 ? re : im, v1 = half == 0 ? -im : re; // coefficients of (Re y_c, Im y_c)
+				if (v0 != 0.0) {
+					rci.push_back((int32_t)(2 * c));
+					rva.push_back(v0);
+				}
+				if (v1 != 0.0) {
+					rci.push_back((int32_t)(2 * c + 1));
+					rva.push_back(v1);
+				}
+			}
+			rrp[(size_t)(2 * i + half) + 1] = (int64_t)rci.size();
+		}
+}
+
 lpp_status pb_build(lpp_engine* e, int64_t n_up, int64_t n_blk, const int64_t* t_rp, const int32_t* t_ci, const double* t_va,
                     const int64_t* c_rp, const int32_t* c_ci, const double* c_va, const double* dict256, int ndict,
                     int64_t blk0, int64_t nblk_loc, int64_t pitch_dn, int64_t nblk_padded, const PbCplxInput* cx)
@@ -992,7 +1019,10 @@ int pb_combine_axpy(lpp_engine* e, void* x, const void* y, const EpiScale& sc, c
 lpp_status pb_from_csr(lpp_engine* e, const DevCsr& A, int64_t n_up, bool* done)
 {
 	*done = false;
-	if (e->is_complex || n_up < 512 || A.nrows <= 0 || A.nrows % n_up != 0 || !A.col || !A.val) return LPP_OK;
+	if (n_up < 512 || A.nrows <= 0 || A.nrows % n_up != 0 || !A.col || !A.val) return LPP_OK;
+	const bool cplx = e->is_complex != 0; // complex hoppings: realified in-block matrix, complex couplings (PbState::cplx)
+	if (cplx && getenv("LPP_PB_COMPLEX") && atoi(getenv("LPP_PB_COMPLEX")) == 0) return LPP_OK;
+	const size_t vd = cplx ? 2 : 1; // doubles per matrix value
 	const int64_t n_blk = A.nrows / n_up;
 	if (n_blk < 2 || n_blk > 65535) return LPP_OK;
 	bool forced = false;
@@ -1000,7 +1030,7 @@ lpp_status pb_from_csr(lpp_engine* e, const DevCsr& A, int64_t n_up, bool* done)
 		if (atoi(s) == 0) return LPP_OK;
 		forced = true;
 	}
-	if (!forced && (size_t)A.nrows * sizeof(double) < ((size_t)32 << 20)) return LPP_OK; // as for device assembly (assemble_hubbard_pb)
+	if (!forced && (size_t)A.nrows * vd * sizeof(double) < (cplx ? (size_t)512 << 20 : (size_t)32 << 20)) return LPP_OK; // as for device assembly (assemble_hubbard_pb)
 	if (e->cfg.spmv_kernel != LPP_SPMV_AUTO || getenv("LPP_SPMV_KERNEL")) return LPP_OK;
 	int want = e->cfg.compress_values;
 	if (const char* s = getenv("LPP_COMPRESS_VALUES")) want = atoi(s);
@@ -1008,7 +1038,7 @@ lpp_status pb_from_csr(lpp_engine* e, const DevCsr& A, int64_t n_up, bool* done)
 	for (const char* k : { "LPP_SHARED_OFFSETS", "LPP_LOCAL16", "LPP_DIAG_CODES", "LPP_BLOCK_TEMPLATE", "LPP_WINDOW_ROWS" })
 		if (getenv(k)) return LPP_OK; // switches of the general layout: measure that one
 	hipStream_t st = e->stream;
-	const int64_t pitch = pb_pitch_for(n_up);
+	const int64_t pitch = pb_pitch_for(cplx ? 2 * n_up : n_up); // in doubles
 	struct Buf {
 		void* p = nullptr;
 		~Buf()
@@ -1025,13 +1055,16 @@ lpp_status pb_from_csr(lpp_engine* e, const DevCsr& A, int64_t n_up, bool* done)
 	const int64_t n0 = rp0[(size_t)n_up];
 	if (n0 <= 0 || n0 > ((int64_t)1 << 28)) return LPP_OK;
 	std::vector<int32_t> c0((size_t)n0);
-	std::vector<double> v0((size_t)n0);
+	std::vector<double> v0((size_t)n0 * vd);
 	HIP_TRY(hipMemcpyAsync(c0.data(), A.col, sizeof(int32_t) * (size_t)n0, hipMemcpyDeviceToHost, st));
-	HIP_TRY(hipMemcpyAsync(v0.data(), A.val, sizeof(double) * (size_t)n0, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipMemcpyAsync(v0.data(), A.val, sizeof(double) * vd * (size_t)n0, hipMemcpyDeviceToHost, st));
 	// C: the first row of every block
 	HIP_TRY_MEM(hipMalloc(&d_clen.p, sizeof(int64_t) * (size_t)(n_blk + 1)));
 	const int nbb = (int)((n_blk + 255) / 256);
-	k_pb_csr_couplings<false><<<nbb, 256, 0, st>>>(n_up, n_blk, A.rowptr, A.col, (const double*)A.val, (int64_t*)d_clen.p, nullptr, nullptr, nullptr, (int*)d_bad.p);
+	if (cplx)
+		k_pb_csr_couplings<false, double2><<<nbb, 256, 0, st>>>(n_up, n_blk, A.rowptr, A.col, (const double2*)A.val, (int64_t*)d_clen.p, nullptr, nullptr, nullptr, (int*)d_bad.p);
+	else
+		k_pb_csr_couplings<false, double><<<nbb, 256, 0, st>>>(n_up, n_blk, A.rowptr, A.col, (const double*)A.val, (int64_t*)d_clen.p, nullptr, nullptr, nullptr, (int*)d_bad.p);
 	std::vector<int64_t> clen((size_t)n_blk), crp((size_t)n_blk + 1, 0);
 	HIP_TRY(hipMemcpyAsync(clen.data(), d_clen.p, sizeof(int64_t) * (size_t)n_blk, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipStreamSynchronize(st));
@@ -1039,20 +1072,27 @@ lpp_status pb_from_csr(lpp_engine* e, const DevCsr& A, int64_t n_up, bool* done)
 	const int64_t cz = crp[(size_t)n_blk];
 	HIP_TRY_MEM(hipMalloc(&d_cptr.p, sizeof(int64_t) * (size_t)(n_blk + 1)));
 	HIP_TRY_MEM(hipMalloc(&d_ccol.p, sizeof(int32_t) * (size_t)std::max<int64_t>(cz, 1)));
-	HIP_TRY_MEM(hipMalloc(&d_cval.p, sizeof(double) * (size_t)std::max<int64_t>(cz, 1)));
+	HIP_TRY_MEM(hipMalloc(&d_cval.p, sizeof(double) * vd * (size_t)std::max<int64_t>(cz, 1)));
 	HIP_TRY(hipMemcpyAsync(d_cptr.p, crp.data(), sizeof(int64_t) * (size_t)(n_blk + 1), hipMemcpyHostToDevice, st));
-	k_pb_csr_couplings<true><<<nbb, 256, 0, st>>>(n_up, n_blk, A.rowptr, A.col, (const double*)A.val, nullptr, (const int64_t*)d_cptr.p, (int32_t*)d_ccol.p,
-	                                             (double*)d_cval.p, (int*)d_bad.p);
+	if (cplx)
+		k_pb_csr_couplings<true, double2><<<nbb, 256, 0, st>>>(n_up, n_blk, A.rowptr, A.col, (const double2*)A.val, nullptr, (const int64_t*)d_cptr.p, (int32_t*)d_ccol.p,
+		                                                      (double2*)d_cval.p, (int*)d_bad.p);
+	else
+		k_pb_csr_couplings<true, double><<<nbb, 256, 0, st>>>(n_up, n_blk, A.rowptr, A.col, (const double*)A.val, nullptr, (const int64_t*)d_cptr.p, (int32_t*)d_ccol.p,
+		                                             (double*)d_cval.p, (int*)d_bad.p);
 	std::vector<int32_t> cci((size_t)std::max<int64_t>(cz, 1));
-	std::vector<double> cva((size_t)std::max<int64_t>(cz, 1));
+	std::vector<double> cva((size_t)std::max<int64_t>(cz, 1) * vd);
 	HIP_TRY(hipMemcpyAsync(cci.data(), d_ccol.p, sizeof(int32_t) * (size_t)cz, hipMemcpyDeviceToHost, st));
-	HIP_TRY(hipMemcpyAsync(cva.data(), d_cval.p, sizeof(double) * (size_t)cz, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipMemcpyAsync(cva.data(), d_cval.p, sizeof(double) * vd * (size_t)cz, hipMemcpyDeviceToHost, st));
 	// D: the stored diagonal of every row, pitched
 	const size_t loc = (size_t)n_blk * (size_t)pitch;
 	HIP_TRY_MEM(hipMalloc(&d_dval.p, sizeof(double) * loc));
 	HIP_TRY(hipMemsetAsync(d_dval.p, 0, sizeof(double) * loc, st));
 	const int nbr = (int)std::max<int64_t>(1, std::min<int64_t>((A.nrows + 255) / 256, 1 << 16));
-	k_pb_csr_diagonal<<<nbr, 256, 0, st>>>(n_up, n_blk, pitch, A.rowptr, A.col, (const double*)A.val, (double*)d_dval.p, (int*)d_bad.p);
+	if (cplx)
+		k_pb_csr_diagonal_c<<<nbr, 256, 0, st>>>(n_up, n_blk, pitch, A.rowptr, A.col, (const double2*)A.val, (double*)d_dval.p, (int*)d_bad.p);
+	else
+		k_pb_csr_diagonal<<<nbr, 256, 0, st>>>(n_up, n_blk, pitch, A.rowptr, A.col, (const double*)A.val, (double*)d_dval.p, (int*)d_bad.p);
 	// its distinct values
 	HIP_TRY_MEM(hipMalloc(&d_table.p, sizeof(unsigned long long) * kDictTable));
 	HIP_TRY_MEM(hipMalloc(&d_ov.p, sizeof(int)));
@@ -1074,7 +1114,7 @@ lpp_status pb_from_csr(lpp_engine* e, const DevCsr& A, int64_t n_up, bool* done)
 		for (int64_t p = rp0[(size_t)r]; p < rp0[(size_t)r + 1]; p++)
 			if (c0[(size_t)p] >= 0 && c0[(size_t)p] < n_up) { // pb_build skips the diagonal itself
 				tci.push_back(c0[(size_t)p]);
-				tva.push_back(v0[(size_t)p]);
+				for (size_t k = 0; k < vd; k++) tva.push_back(v0[(size_t)p * vd + k]);
 			}
 		trp[(size_t)r + 1] = (int64_t)tci.size();
 	}
@@ -1091,7 +1131,7 @@ lpp_status pb_from_csr(lpp_engine* e, const DevCsr& A, int64_t n_up, bool* done)
 	if (!plain_diag)
 		for (unsigned long long k : host)
 			if (k != kDictEmpty) add_key(k);
-	for (int64_t p = 0; p < cz && keys.size() <= 256; p++) {
+	for (int64_t p = 0; !cplx && p < cz && keys.size() <= 256; p++) { // (complex couplings: a dictionary of their own, pb_build)
 		unsigned long long k;
 		std::memcpy(&k, &cva[(size_t)p], 8);
 		add_key(k);
@@ -1101,7 +1141,21 @@ lpp_status pb_from_csr(lpp_engine* e, const DevCsr& A, int64_t n_up, bool* done)
 	std::vector<double> dict(256);
 	for (size_t i = 0; i < 256; i++) std::memcpy(&dict[i], &keys[std::min(i, keys.size() - 1)], 8);
 	// two work vectors + the two parts of a product + the diagonal must fit once the CSR is gone (it is still resident here)
-	lpp_status rc = pb_build(e, n_up, n_blk, trp.data(), tci.data(), tva.data(), crp.data(), cci.data(), cva.data(), dict.data(), (int)keys.size());
+	lpp_status rc;
+	if (cplx) {
+		std::vector<int64_t> rrp;
+		std::vector<int32_t> rci;
+		std::vector<double> rva;
+		pb_realify(n_up, trp.data(), tci.data(), tva.data(), rrp, rci, rva);
+		PbCplxInput cx;
+		cx.n_c = n_up;
+		cx.t_rp = trp.data();
+		cx.t_ci = tci.data();
+		cx.t_va = tva.data();
+		cx.c_va = cva.data();
+		rc = pb_build(e, 2 * n_up, n_blk, rrp.data(), rci.data(), rva.data(), crp.data(), cci.data(), nullptr, dict.data(), (int)keys.size(), 0, -1, 0, 0, &cx);
+	} else
+		rc = pb_build(e, n_up, n_blk, trp.data(), tci.data(), tva.data(), crp.data(), cci.data(), cva.data(), dict.data(), (int)keys.size());
 	if (rc == LPP_ERR_INVALID || rc == LPP_ERR_NOMEM) { // not representable, or no room beside the CSR: the general layout
 		if (getenv("LPP_VERBOSE")) fprintf(stderr, "lpp: the product-basis layout does not apply to the uploaded matrix: %s\n", lpp_last_error());
 		free_pb(e);
@@ -1119,6 +1173,10 @@ lpp_status pb_from_csr(lpp_engine* e, const DevCsr& A, int64_t n_up, bool* done)
 	} else {
 		k_pb_codes_from_values<<<nbr, 256, 0, st>>>((int64_t)loc, (const double*)d_dval.p, B.dict, B.ndict, B.dcode);
 	}
+	if (cplx)
+		k_pb_csr_verify_c<<<nbr, 256, 0, st>>>(n_up, n_blk, pitch, B.t_ptr, B.t_col, (const double2*)B.t_val, B.c_ptr, B.c_col, B.c_code, B.blockbase, B.dcode, B.dict,
+		                                      (const double2*)B.cdict, B.dval, A.rowptr, A.col, (const double2*)A.val, (int*)d_bad.p + 1);
+	else
 	k_pb_csr_verify<<<nbr, 256, 0, st>>>(n_up, n_blk, pitch, B.t_ptr, B.t_col, B.t_val, B.c_ptr, B.c_col, B.c_code, B.blockbase, B.dcode, B.dict, B.dval, A.rowptr, A.col,
 	                                    (const double*)A.val, (int*)d_bad.p + 1, B.inv);
 	HIP_TRY(hipMemcpyAsync(bad, d_bad.p, sizeof(int) * 2, hipMemcpyDeviceToHost, st));

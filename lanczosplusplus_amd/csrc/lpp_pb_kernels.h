@@ -1179,10 +1179,10 @@ static __global__ void k_pb_rebuild_c(int64_t n_up, int64_t n_blk, int64_t pitch
 
 // per block b: entries of its FIRST row (b, 0) that leave the block -- the couplings of block b.  FILL == false: count only.
 // bad is raised when such an entry does not land on position 0 of another block.
-template <bool FILL>
+template <bool FILL, typename V = double>
 static __global__ void k_pb_csr_couplings(int64_t n_up, int64_t n_blk, const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
-                                          const double* __restrict__ val, int64_t* __restrict__ c_len, const int64_t* __restrict__ c_ptr,
-                                          int32_t* __restrict__ c_col, double* __restrict__ c_val, int* __restrict__ bad)
+                                          const V* __restrict__ val, int64_t* __restrict__ c_len, const int64_t* __restrict__ c_ptr,
+                                          int32_t* __restrict__ c_col, V* __restrict__ c_val, int* __restrict__ bad)
 {
 	const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (b >= n_blk) return;
@@ -1211,6 +1211,27 @@ static __global__ void k_pb_csr_diagonal(int64_t n_up, int64_t n_blk, int64_t pi
 		for (int64_t p = rowptr[r]; p < rowptr[r + 1]; p++)
 			if ((int64_t)col[p] == r) {
 				dval[(r / n_up) * pitch + (r % n_up)] = val[p];
+				found = true;
+				break;
+			}
+		if (!found) *bad = 1;
+	}
+}
+
+// complex matrix: the stored diagonal must be real; both doubles of the position get it (pitch counts doubles)
+static __global__ void k_pb_csr_diagonal_c(int64_t n_c, int64_t n_blk, int64_t pitch, const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                           const double2* __restrict__ val, double* __restrict__ dval, int* __restrict__ bad)
+{
+	const int64_t n = n_c * n_blk;
+	for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (int64_t)gridDim.x * blockDim.x) {
+		bool found = false;
+		for (int64_t p = rowptr[r]; p < rowptr[r + 1]; p++)
+			if ((int64_t)col[p] == r) {
+				const double2 v = val[p];
+				if (__double_as_longlong(v.y) != 0) *bad = 1; // -0.0 would not be reproduced either
+				const int64_t at = (r / n_c) * pitch + 2 * (r % n_c);
+				dval[at] = v.x;
+				dval[at + 1] = v.x;
 				found = true;
 				break;
 			}
@@ -1250,6 +1271,37 @@ static __global__ void k_pb_csr_verify(int64_t n_up, int64_t n_blk, int64_t pitc
 			o++;
 			for (; q < q1; q++, o++) ok = ok && same(o, b * n_up + t_col[q], t_val[q]);
 			for (; p < c1; p++, o++) ok = ok && same(o, (int64_t)c_col[p] * n_up + i, dict[c_code[p]]);
+		}
+		if (!ok) *bad = 1;
+	}
+}
+
+// the same check for complex hoppings (the walk of k_pb_rebuild_c)
+static __global__ void k_pb_csr_verify_c(int64_t n_up, int64_t n_blk, int64_t pitch, const int64_t* __restrict__ t_ptr, const int32_t* __restrict__ t_col,
+                                       const double2* __restrict__ t_val, const int64_t* __restrict__ c_ptr, const int32_t* __restrict__ c_col,
+                                       const uint8_t* __restrict__ c_code, const int64_t* __restrict__ blockbase, const uint8_t* __restrict__ dcode,
+                                       const double* __restrict__ dict, const double2* __restrict__ cdict, const double* __restrict__ dplain, const int64_t* __restrict__ rowptr,
+                                       const int32_t* __restrict__ col, const double2* __restrict__ val, int* __restrict__ bad)
+{
+	const int64_t n = n_up * n_blk;
+	for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (int64_t)gridDim.x * blockDim.x) {
+		const int64_t b = r / n_up, i = r - b * n_up;
+		const int64_t dat = b * pitch + 2 * i;
+		const int64_t c0 = c_ptr[b], c1 = c_ptr[b + 1];
+		int64_t o = blockbase[b] + t_ptr[i] + i * (1 + (c1 - c0));
+		const int64_t oe = o + (t_ptr[i + 1] - t_ptr[i]) + 1 + (c1 - c0);
+		bool ok = rowptr[r] == o && rowptr[r + 1] == oe;
+		if (ok) {
+			auto same = [&](int64_t at, int64_t c, double2 v) { return (int64_t)col[at] == c && __double_as_longlong(val[at].x) == __double_as_longlong(v.x) && __double_as_longlong(val[at].y) == __double_as_longlong(v.y); };
+			int64_t p = c0;
+			for (; p < c1 && c_col[p] < b; p++, o++) ok = ok && same(o, (int64_t)c_col[p] * n_up + i, cdict[c_code[p]]);
+			int64_t q = t_ptr[i];
+			const int64_t q1 = t_ptr[i + 1];
+			for (; q < q1 && t_col[q] < i; q++, o++) ok = ok && same(o, b * n_up + t_col[q], t_val[q]);
+			ok = ok && same(o, r, double2 { dplain ? dplain[dat] : dict[dcode[dat]], 0.0 });
+			o++;
+			for (; q < q1; q++, o++) ok = ok && same(o, b * n_up + t_col[q], t_val[q]);
+			for (; p < c1; p++, o++) ok = ok && same(o, (int64_t)c_col[p] * n_up + i, cdict[c_code[p]]);
 		}
 		if (!ok) *bad = 1;
 	}

@@ -880,6 +880,23 @@ def test_product_basis_layout_with_complex_hoppings(case, monkeypatch):
         assert st2["vectors_saved"] == 0 and abs(eg2[0] - eo[0]) <= E_TOL * abs(eo[0])
         r = oracle.spmv_acc(A, np.zeros_like(zg2[0]), zg2[0]) - eg2[0] * zg2[0]
         assert np.linalg.norm(r) < 1e-5
+    # the same matrix handed over as a CSR (the reference's route, DefaultSymmetry.h:54-57): block detected, T / C / D read off it, every row verified
+    with LanczosEngine(dtype="c128") as e, LanczosEngine(dtype="c128") as d:
+        e.set_csr(A.rowptr, A.colind, A.values)
+        d.assemble_hubbard(L, nup, ndown, hop, U, V)
+        assert e.layout()["kernel"] == 4 and e.layout() == d.layout()
+        rp, ci, va = e.get_csr()
+        assert np.array_equal(rp, A.rowptr) and np.array_equal(ci, A.colind)
+        assert np.array_equal(np.ascontiguousarray(va).view(np.uint64), np.ascontiguousarray(A.values).view(np.uint64))
+        assert rel(e.matrixVectorProduct(x0.copy(), y), xo) < SPMV_TOL
+        if case == "peierls_ring":  # one changed value: not a product-basis matrix any more
+            B = oracle.Csr(A.rowptr.copy(), A.colind.copy(), A.values.copy())
+            r = A.nrows // 2 + 17
+            k = A.rowptr[r] + (0 if A.colind[A.rowptr[r]] != r else 1)
+            B.values[k] *= 1.5
+            e.set_csr(B.rowptr, B.colind, B.values)
+            assert e.layout()["kernel"] != 4
+            assert rel(e.matrixVectorProduct(x0.copy(), y), oracle.spmv_acc(B, x0.copy(), y)) < SPMV_TOL
     monkeypatch.setenv("LPP_PB_COMPLEX", "0")  # the general layout gives the same numbers
     with LanczosEngine(dtype="c128") as e:
         e.assemble_hubbard(L, nup, ndown, hop, U, V)
