@@ -243,8 +243,8 @@ lpp_status assemble_hubbard_pb(lpp_engine* e, AsmParams P, int nup, int ndown, i
 		forced = true;
 	}
 	if (!forced && (size_t)n_up * (size_t)n_dn * sizeof(double) < ((size_t)32 << 20)) return LPP_OK;
-	// complex hoppings run the three-kernel form with the any-number-of-groups in-block kernel: measured 1659 against 1687 iterations/s
-	// (general layout) at 1.2e7 states (0.19 GB per vector), 287 against 170 at 6.4e7 states (1.0 GB per vector; 0.14 against 8.6 GB resident)
+	// complex hoppings run the any-number-of-groups in-block kernel (4 groups): measured 1659 against 1687 iterations/s (general layout) at
+	// 1.2e7 states (0.19 GB per vector), 327 against 170 at 6.4e7 states (1.0 GB per vector; 0.14 against 8.6 GB resident)
 	if (!forced && cplx && (size_t)n_up * (size_t)n_dn * 2 * sizeof(double) < ((size_t)512 << 20)) return LPP_OK;
 	if (e->cfg.spmv_kernel != LPP_SPMV_AUTO || getenv("LPP_SPMV_KERNEL")) return LPP_OK;
 	int want = e->cfg.compress_values;

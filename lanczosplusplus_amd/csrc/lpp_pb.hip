@@ -345,7 +345,7 @@ lpp_status pb_build(lpp_engine* e, int64_t n_up, int64_t n_blk, const int64_t* t
 	B.parts = parts;
 	B.wide = wide;
 	B.half = half;
-	B.ws = !cx && getenv("LPP_PB_WS") && atoi(getenv("LPP_PB_WS")) == 1 && !B.big && pitch <= kPbWsMaxPitch && pb_ws_lds_bytes(pitch, T.spb, T.G) <= (size_t)160 * 1024 - 64;
+	B.ws = !cx && T.G <= 2 && getenv("LPP_PB_WS") && atoi(getenv("LPP_PB_WS")) == 1 && !B.big && pitch <= kPbWsMaxPitch && pb_ws_lds_bytes(pitch, T.spb, T.G) <= (size_t)160 * 1024 - 64;
 	B.ws_beta = !(getenv("LPP_PB_WS_BETA") && atoi(getenv("LPP_PB_WS_BETA")) == 0);
 	// k_pb_down2 (own lines of the panel in LDS): opt-in (LPP_PB_DOWN2=1).  Measured at BASELINE config 2 (profiles/README.md, round 3):
 	// it halves the couplings that go through L1 (8.6 of 17.1 per block leave the workgroup's range) but the far lists padded per
@@ -886,7 +886,7 @@ bool pb_chain_ok(const lpp_engine* e)
 {
 	const PbState& B = e->pb;
 	if (getenv("LPP_PB_CHAIN") && atoi(getenv("LPP_PB_CHAIN")) == 0) return false;
-	return B.active && !B.cplx && !B.tx && !B.big && !B.parts && !B.wide && !B.dval && B.c_nnz > 0 && (B.G == 1 || B.G == 2);
+	return B.active && !B.tx && !B.big && !B.parts && !B.wide && !B.dval && B.c_nnz > 0 && B.G >= 1 && B.G <= kPbMaxGroups; // more than two value groups (complex hoppings realified, t-t' models): the any-number-of-groups path of k_pb_up
 }
 
 template <int GT, int PRE0 = kPbPre> static void launch_up_chain(const PbUpArgs& u, int nb, size_t lds, hipStream_t st)
@@ -940,6 +940,7 @@ int pb_launch_chain(lpp_engine* e, void* w, void* y, double* partial, const EpiS
 	} else {
 		const size_t lds = pb_up_lds_bytes(B.pitch, B.spb, B.G);
 		if (B.G == 1) launch_up_chain<1>(u, nb, lds, st);
+		else if (B.G > 2) launch_up_chain<0>(u, nb, lds, st);
 		else if (B.pre0 == 3) launch_up_chain<2, 3>(u, nb, lds, st);
 		else if (B.pre0 == 5) launch_up_chain<2, 5>(u, nb, lds, st);
 		else launch_up_chain<2>(u, nb, lds, st);
@@ -966,9 +967,15 @@ int pb_launch_chain(lpp_engine* e, void* w, void* y, double* partial, const EpiS
 	d.u_has_beta = beta_in_u ? 1 : 0; // the in-block kernel has put beta r_{j-1} into u
 	if (d.pace) (void)hipMemsetAsync(d.pace, 0, sizeof(int) * 8 * (size_t)d.npanels, st);
 	static const int down_threads = getenv("LPP_PB_DOWN_THREADS") ? atoi(getenv("LPP_PB_DOWN_THREADS")) : 1024; // experiment: fewer waves, fewer lines in flight per L1
-	if (down_threads == 512) {
+	if (down_threads == 512 && !B.cplx) {
 		(void)hipFuncSetAttribute((const void*)k_pb_down<512, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B.down_lds);
 		k_pb_down<512, true><<<B.down_grid, 512, B.down_lds, st>>>(d);
+		return B.down_grid;
+	}
+	d.cdict = (const double2*)B.cdict;
+	if (B.cplx) {
+		(void)hipFuncSetAttribute((const void*)k_pb_down<1024, true, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B.down_lds);
+		k_pb_down<1024, true, false, false, true><<<B.down_grid, 1024, B.down_lds, st>>>(d);
 		return B.down_grid;
 	}
 	(void)hipFuncSetAttribute((const void*)k_pb_down<1024, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B.down_lds);

@@ -359,6 +359,7 @@ template <bool DOT, int GT, bool LEAN, bool CHAIN = false, int PRE0 = kPbPre> __
 					epilogue(j, acc);
 					continue;
 				}
+				const double yo_g = CHAIN ? yold[min(j * 64 + lane, n_up - 1)] : 0.0; // chained form: beta r_{j-1} rides in u (as in the unrolled paths)
 				uint2 wn[4];
 				int ncn = __builtin_amdgcn_readfirstlane((int)len_s[j * G]);
 				const uint2* wpn = tw2 + (size_t)off_s[j * G] * 64 + lane;
@@ -393,7 +394,7 @@ template <bool DOT, int GT, bool LEAN, bool CHAIN = false, int PRE0 = kPbPre> __
 					}
 					acc = fma(a.gval[g], s0 + s1, acc);
 				}
-				epilogue(j, acc);
+				epilogue(j, acc, yo_g);
 			}
 		}
 	}

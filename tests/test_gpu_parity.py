@@ -786,7 +786,7 @@ def test_product_basis_layout(case, form, monkeypatch):
         e.assemble_hubbard(L, nup, ndown, hop, U, V)
         lay = e.layout()
         assert lay["kernel"] == 4 and lay["nnz"] == A.nnz and lay["resident_bytes"] < (0.12 if case == "disorder" else 0.05) * 12 * A.nnz
-        assert (lay["diagonal_plain"], lay["diagonal_codes"], lay["chained_step"]) == ((1, 0, 0) if case == "disorder" else (0, 1, 1 if form in ("window", "natural", "down2", "ws") and case != "two_hoppings" else 0))  # the chained step is built for <= 2 hopping values
+        assert (lay["diagonal_plain"], lay["diagonal_codes"], lay["chained_step"]) == ((1, 0, 0) if case == "disorder" else (0, 1, 1 if form in ("window", "natural", "down2", "ws") else 0))  # the chained step: any number of hopping values (two_hoppings: the any-number-of-groups path)
         assert (lay["pieces"], lay["coupling_parts"]) == {"window": (1, 1), "pieces": (4, 3), "natural": (1, 1), "wide": (3, 1), "half": (3, 1), "down2": (1, 1), "ws": (1, 1)}[form]
         assert lay["rows_by_list_length"] == (1 if form in ("window", "down2", "ws") else 0)  # one-window form only; internal: every check below is in the basis order
         st = e.stats()
@@ -861,8 +861,8 @@ def test_product_basis_layout_with_complex_hoppings(case, monkeypatch):
     with LanczosEngine(dtype="c128") as e:
         e.assemble_hubbard(L, nup, ndown, hop, U, V)
         lay = e.layout()
-        assert lay["kernel"] == 4 and lay["nnz"] == A.nnz and lay["chained_step"] == 0 and lay["rows_by_list_length"] == 0
-        assert lay["diagonal_plain"] == (1 if case == "disorder" else 0)
+        assert lay["kernel"] == 4 and lay["nnz"] == A.nnz and lay["rows_by_list_length"] == 0
+        assert (lay["diagonal_plain"], lay["chained_step"]) == ((1, 0) if case == "disorder" else (0, 1))  # the chained pair carries complex hoppings too
         rp, ci, va = e.get_csr()
         assert np.array_equal(rp, A.rowptr) and np.array_equal(ci, A.colind)
         assert np.array_equal(np.ascontiguousarray(va).view(np.uint64), np.ascontiguousarray(A.values).view(np.uint64))
