@@ -113,7 +113,8 @@ def test_config5_7up6down_sector_matrix_free_free_fermions():
     assert abs(eg[0] - exact) <= E_TOL * abs(exact), (eg[0], exact, st["steps"])
 
 
-@pytest.mark.parametrize("workload", ["hubbard_chain_L12_half_filling_U4", "heisenberg_chain_L24_sz0_obc", "tj_chain_L12_5up5down_complex", "hubbard_chain_L14_complex_U4"])
+@pytest.mark.parametrize("workload", ["hubbard_chain_L12_half_filling_U4", "heisenberg_chain_L24_sz0_obc", "tj_chain_L12_5up5down_complex", "hubbard_chain_L14_complex_U4",
+                                      "hubbard_4x4_6up6down_complex_U4"])  # the last one: complex hoppings in the product-basis layout, chained step
 def test_bench_line_of_the_other_model_families(workload):
     """`bench.py --workload W` prints its one JSON line for every model family (a Hubbard-only assumption in the attempt loop
     once broke the Heisenberg and t-J lines while the default line stayed green)."""
@@ -127,3 +128,5 @@ def test_bench_line_of_the_other_model_families(workload):
     line = json.loads(out.stdout.strip().splitlines()[-1])
     assert line["config"]["workload"] == workload and line["steps"] == 5 and line["value"] > 0
     assert line["roofline"]["achieved"] > 0 and 0 < line["roofline"]["frac"] <= 1.0
+    if workload == "hubbard_4x4_6up6down_complex_U4":
+        assert line["config"]["layout"]["kernel"] == "product" and line["config"]["layout"]["chained_step"]
