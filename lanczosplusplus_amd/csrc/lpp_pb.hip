@@ -108,7 +108,10 @@ lpp_status pb_build(lpp_engine* e, int64_t n_up, int64_t n_blk, const int64_t* t
 	// pieces of <= 8128 positions: two blocks' windows share a workgroup (k_pb_up_big2) and the second one stays within the 64 KB an
 	// LDS instruction's offset reaches; LPP_PB_BIG2=0: one block per workgroup, two 512-thread workgroups per CU (k_pb_up_big, <= 8768)
 	const bool big2 = !(getenv("LPP_PB_BIG2") && atoi(getenv("LPP_PB_BIG2")) == 0);
-	if ((size_t)(pitch + kPbZeroSlots) * sizeof(double) > (size_t)156 * 1024) wmax = big2 ? 8128 : 8768;
+	// one window needs the row, its diagonal codes and the template's list heads in LDS (pb_up_lds_bytes; two value groups assumed here):
+	// rows of 17,400-19,500 positions pass a test of the row alone and then failed pb_build -- the 3x6 lattice's 6-electron species (18,564)
+	if ((size_t)(pitch + kPbZeroSlots) * sizeof(double) > (size_t)156 * 1024 || pb_up_lds_bytes(pitch, (int)((n_up + 63) / 64), 2) > (size_t)160 * 1024 - 64)
+		wmax = big2 ? 8128 : 8768;
 	if (const char* s = getenv("LPP_PB_PIECE_ROWS")) wmax = std::max<int64_t>(64, std::min<int64_t>(atoll(s), big2 ? 8128 : 16384)) & ~(int64_t)63;
 	int64_t W = 0;
 	if (wmax > 0) {

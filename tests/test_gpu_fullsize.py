@@ -87,9 +87,11 @@ def test_config2_shape_products_agree_and_are_hermitian(monkeypatch):
     assert np.max(np.abs(hv2 - hv)) <= 1e-13 * np.max(np.abs(hv))
 
 
-def test_3e8_states_stored_csr_free_fermions():
+def test_3e8_states_stored_csr_free_fermions(monkeypatch):
     """Twice config 2: the 3x6 cluster with 6 up / 6 down electrons -- 344,622,096 states, 1.2e10 non-zeros, 144 GB as a plain
-    CSR while it is being assembled on the device, ~8 GB once it is in the compressed layout -- through the STORED engine."""
+    CSR while it is being assembled on the device, ~8 GB once it is in the compressed layout -- through the STORED engine, general
+    layout (LPP_PRODUCT_LAYOUT=0: by itself this sector takes the product-basis form in two pieces per row, next test)."""
+    monkeypatch.setenv("LPP_PRODUCT_LAYOUT", "0")
     L = 18
     hop = square(3, 6, -1.0, pbc=True)
     exact = _exact(hop, 6)
@@ -98,6 +100,20 @@ def test_3e8_states_stored_csr_free_fermions():
         st0, lay = e.stats(), e.layout()
         assert (st0["nrows"], st0["nnz"]) == (18564 * 18564, 12021229584)
         assert lay["block_template"] == 2 and lay["resident_bytes"] < 12e9
+        eg, _, st = e.lanczos(1, want_vectors=False)
+    assert abs(eg[0] - exact) <= 1e-10 * abs(exact), (eg[0], exact, st["steps"])
+
+
+def test_3e8_states_product_basis_form_in_pieces_free_fermions():
+    """The same sector by itself: a species' row of 18,564 positions fits an LDS window alone but not with its diagonal codes and list
+    heads beside it, so it is cut into pieces (k_pb_up_big2); 0.4 GB resident, exact energy."""
+    L = 18
+    hop = square(3, 6, -1.0, pbc=True)
+    exact = _exact(hop, 6)
+    with LanczosEngine(max_steps=300, eps=1e-11, save_vectors=0) as e:
+        e.assemble_hubbard(L, 6, 6, hop, np.zeros(L))
+        lay = e.layout()
+        assert lay["kernel"] == 4 and lay["pieces"] > 1 and lay["resident_bytes"] < 1e9 and lay["nnz"] == 12021229584
         eg, _, st = e.lanczos(1, want_vectors=False)
     assert abs(eg[0] - exact) <= 1e-10 * abs(exact), (eg[0], exact, st["steps"])
 
