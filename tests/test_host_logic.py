@@ -235,3 +235,30 @@ def test_exchange_chunk_helper():
         c = L.lpp_xchg_chunk(n_up, n_dn, P)
         per = -(-n_dn // P)
         assert c % per == 0 and (c // per) % 16 == 0 and (c // per) * P >= n_up and (c // per - 16) * P < n_up + 16 * P
+
+
+def test_bench_workloads_are_well_formed():
+    """bench.py's workload table: Hermitian hopping matrices, fillings within the lattice, and every golden fixture it names exists with the
+    fields the coefficient gate and the e0 check read."""
+    import importlib.util
+    import json
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)  # imports numpy only at module level; torch and the engine are imported inside main()
+    for name, (model, p) in bench.WORKLOADS.items():
+        if model == "hubbard":
+            hop = np.asarray(p["hop"]())
+            assert hop.shape == (p["L"], p["L"]) and np.allclose(hop, hop.conj().T), name
+            assert 0 < p["nup"] <= p["L"] and 0 < p["ndown"] <= p["L"], name
+            assert ("complex" in name) == np.iscomplexobj(hop), name
+        elif model == "tj":
+            assert p["lx"] * p["ly"] == p["L"] and p["nup"] + p["ndown"] <= p["L"], name
+        elif model == "heisenberg":
+            assert 0 <= p["sz"] <= p["L"], name
+    assert bench.WORKLOADS["hubbard_4x4_half_filling_pbc_U4"][1]["nup"] == 8  # BASELINE config 2, the default line
+    for name, fixture in bench.GOLDEN.items():
+        assert name in bench.WORKLOADS
+        g = json.load(open(os.path.join(root, "tests", "golden", fixture)))
+        assert len(g["a"]) == len(g["b"]) >= 30 and "e0" in g, fixture
