@@ -3,6 +3,7 @@
 Tolerances: indices/structure bit-exact; matrix values bit-exact; SpMV 1e-13 relative per vector
 (summation order differs); energies 1e-10 relative (BASELINE.json north_star).
 """
+import os
 from math import comb
 
 import numpy as np
@@ -758,8 +759,15 @@ def test_product_basis_layout(case, form, monkeypatch):
     sectors) forced onto the same small matrices -- rows cut into pieces of 256 positions (entries that leave a piece are read
     from memory), couplings over 3 parts of the source range with 64-bit addresses; "wide": pieces of 320 positions and the
     whole-panel coupling kernel with 64-bit addresses (what BASELINE config 5's sectors take on one GPU)."""
-    if form in ("half", "down2", "ws") and case not in ("chain_L12", "two_hoppings"):
-        pytest.skip("opt-in experiment forms run on two of the cases (suite time)")
+    # suite time (the driver runs `pytest -m gpu` once per round): the full cross product runs with LPP_SLOW_TESTS=1; by default every form
+    # runs on chain_L12, the shipped forms "window" on all cases and "natural" / "pieces" / "wide" also on two_hoppings and disorder
+    if not os.environ.get("LPP_SLOW_TESTS"):
+        if form in ("half", "down2", "ws") and case != "chain_L12":
+            pytest.skip("opt-in experiment forms run on one case by default (LPP_SLOW_TESTS=1: all)")
+        if form in ("natural", "pieces", "wide") and case not in ("chain_L12", "two_hoppings", "disorder"):
+            pytest.skip("this form runs on three of the cases by default (LPP_SLOW_TESTS=1: all)")
+        if case == "ladder_2x6":
+            pytest.skip("the ladder runs with LPP_SLOW_TESTS=1 (the chains, the two-hopping model and the disordered ring by default)")
     L, nup, ndown, hop, U, V = PB_CASES[case]()
     monkeypatch.setenv("LPP_PRODUCT_LAYOUT", "1")  # these matrices are below the size from which the layout is chosen by itself
     if form == "pieces":
