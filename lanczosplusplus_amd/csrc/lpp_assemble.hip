@@ -226,7 +226,7 @@ lpp_status fetch_csr(const DevCsr& A, std::vector<int64_t>& rp, std::vector<int3
 // Several GPUs (transposition exchange): blk0 / nblk_loc = the rank's own down configurations, pitch_dn = its up-index range (the row
 // length of the transposed slice, a multiple of 16), nblk_padded = down configurations in the transposed slice, padding included.
 lpp_status assemble_hubbard_pb(lpp_engine* e, AsmParams P, int nup, int ndown, int64_t n_up, int64_t n_dn, const double* zeroU_dev, bool* done,
-                               int64_t blk0 = 0, int64_t nblk_loc = -1, int64_t pitch_dn = 0, int64_t nblk_padded = 0)
+                               int64_t blk0 = 0, int64_t nblk_loc = -1, int64_t pitch_dn = 0, int64_t nblk_padded = 0, bool stored = false)
 {
 	*done = false;
 	if (n_up < 512) return LPP_OK;
@@ -260,7 +260,16 @@ lpp_status assemble_hubbard_pb(lpp_engine* e, AsmParams P, int nup, int ndown, i
 		// two work vectors + the two parts of a product + one code per row must fit beside everything else
 		const int64_t nloc = (nblk_loc >= 0 ? nblk_loc : n_dn) * pitch;
 		size_t free_b = 0, total_b = 0;
-		if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && (size_t)nloc * 33 + ((size_t)2 << 30) > free_b) return LPP_OK;
+		// slack: an eighth of what the layout needs, at least 64 MB (a flat 2 GiB made small forced cases fall to the other layout on a
+		// nearly full GPU).  The general layout needs far more memory than this one, so there is nothing to fall back to: say so.
+		const size_t need = (size_t)nloc * 33, slack = std::max<size_t>(need / 8, (size_t)64 << 20);
+		if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && need + slack > free_b) {
+			const std::string msg = "product-basis layout: " + std::to_string((need + slack) >> 20) + " MB needed, " + std::to_string(free_b >> 20) + " MB free on the device";
+			if (getenv("LPP_VERBOSE")) fprintf(stderr, "lpp: %s\n", msg.c_str());
+			// the matrix-free engine's other kernels hold two vectors only (the (8,8) sector of the 4x5 lattice: 254 GB); a stored
+			// matrix has nothing smaller to fall back to -- the general layout needs far more -- so it fails here, with the numbers
+			return stored ? fail(LPP_ERR_NOMEM, msg) : LPP_OK;
+		}
 	}
 	hipStream_t st = e->stream;
 	// one-species matrices: hops of that species + its potential diagonal (ignored below; the true diagonal is per row)
@@ -460,7 +469,7 @@ lpp_status lpp_engine_assemble_hubbard_super(lpp_engine* e, const lpp_comm* comm
 		P.nloc = nrows;
 		P.part = 0;
 		bool as_product = false;
-		st = assemble_hubbard_pb(e, P, nup, ndown, n_up, n_dn, (const double*)d_U0.p, &as_product);
+		st = assemble_hubbard_pb(e, P, nup, ndown, n_up, n_dn, (const double*)d_U0.p, &as_product, 0, -1, 0, 0, true);
 		if (st != LPP_OK) return st;
 		if (as_product) {
 			free_csr(e->A_loc);

@@ -135,8 +135,6 @@ struct PbState {
 	int* pace = nullptr;
 	double* z = nullptr; // alpha C y of the product in flight (n_blk * pitch doubles)
 	double* u = nullptr; // alpha (T y + D y) of the product in flight
-	hipStream_t stream2 = nullptr; // k_pb_down runs here, beside k_pb_up on the engine's stream
-	hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 	double* xy = nullptr; // device scalar: Re<x|y> left by the last combine pass = the next step's <y | x_old>
 	// several GPUs, transposition exchange (pb_tx_*): this rank holds the in-block part for its own blocks [blk0, blk0 + nblk_loc)
 	// (vectors, u and dcode cover those only) and applies the block couplings to the received transposed slice: all n_blk blocks,
@@ -157,9 +155,6 @@ struct PbState {
 	int32_t* f_off = nullptr;
 	uint16_t* f_len = nullptr;
 	int64_t f_words = 0, f_entries = 0;
-	bool down2 = false; // k_pb_down2: the workgroup's own lines of a panel staged in LDS (couplings inside its block range are LDS reads)
-	size_t down2_lds = 0;
-	int down2_ent = 0;
 	// positions of a block stored in the order of their list lengths (single-GPU, one-window form): stored position p holds the
 	// basis state perm[p] of the species, inv[perm[p]] = p.  Null: natural order.  Only the boundary knows (vec_from_host / _to_host,
 	// the start vector, the diagonal's assembly, lpp_engine_get_csr); every kernel of a step is position-blind.
@@ -173,9 +168,6 @@ struct PbState {
 	int64_t n_c = 0; // complex positions per block
 	double* cdict = nullptr; // 256 complex coupling values
 	int pre0 = 4; // chained step, two value groups: chunks of group 0 requested one slice ahead (group 1: 8 - pre0)
-	bool half = false; // k_pb_down<WIDE, HALF>: panels of 8 positions (64-byte half lines), for panels beyond an XCD's L2
-	bool ws = false; // k_pb_up_ws in the chained step (LPP_PB_WS=1): the next row staged by loader waves beside the gathers
-	bool ws_beta = true; // ... with the beta term in u (0: left to the coupling kernel)
 	bool wide = false; // vector beyond 4 GiB: k_pb_down<WIDE> (64-bit addresses from line numbers)
 	bool parts = false; // couplings over parts of the source range (k_pb_down_parts; 64-bit addresses too)
 	int nparts = 1, ent_cap = 0, pace_stride = 0, maxr = 0;

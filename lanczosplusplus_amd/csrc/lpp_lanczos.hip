@@ -14,6 +14,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstring>
+#include <memory>
 #include <vector>
 
 #include "lpp_engine_impl.h"
@@ -119,10 +120,16 @@ struct SpmvTimer {
 		e->spmv_event_cols[idx] = cols;
 		(void)hipEventRecord(e->spmv_events[idx].first, e->stream);
 	}
+	bool stopped = false;
 	void stop()
 	{
-		if (on) (void)hipEventRecord(e->spmv_events[idx].second, e->stream);
+		if (on && !stopped) (void)hipEventRecord(e->spmv_events[idx].second, e->stream);
+		stopped = true;
 	}
+	// every return path closes its bracket: an event pair whose end was never recorded would fail hipEventElapsedTime later
+	~SpmvTimer() { stop(); }
+	SpmvTimer(const SpmvTimer&) = delete;
+	SpmvTimer& operator=(const SpmvTimer&) = delete;
 };
 
 // blocked classical Gram-Schmidt, two passes, of x against Krylov columns [0, ncol)
@@ -171,7 +178,7 @@ lpp_status one_step(lpp_engine* e, const double* ritz, int nst)
 	double* xcur = e->xcur;
 	int np = 0;
 	bool tx_pair = false;
-	SpmvTimer* pb_timer = nullptr;
+	std::unique_ptr<SpmvTimer> pb_timer; // closes its bracket on every return path
 	// product-basis layout, no vectors kept: two launches per step, the axpy of step j rides in the product of step j+1
 	const bool pb_chain = e->pb.active && e->scalefree && !ritz && pb_chain_ok(e);
 	// the same deferral on the transposition exchange: the update rides in the next step's pack kernel (k_pack_transpose_axpy)
@@ -280,13 +287,9 @@ lpp_status one_step(lpp_engine* e, const double* ritz, int nst)
 	} else if (e->pb.active) {
 		// scale-free: x is formed by pb_combine_axpy below, together with the recurrence update; the bracket then closes behind that
 		// pass (pb_timer), so that the timed launches are the WHOLE step as in the chained form
-		pb_timer = new SpmvTimer(e);
+		pb_timer.reset(new SpmvTimer(e));
 		np = pb_launch(e, ycur, xcur, e->partial, sc, e->scalefree);
-		if (!e->scalefree || multi(e)) {
-			pb_timer->stop();
-			delete pb_timer;
-			pb_timer = nullptr;
-		}
+		if (!e->scalefree || multi(e)) pb_timer.reset();
 	} else if (e->kron.active) {
 		// matrix-free product with the all-gather: the down part needs the whole vector, so the gather completes first
 		if (multi(e)) {
@@ -360,8 +363,7 @@ lpp_status one_step(lpp_engine* e, const double* ritz, int nst)
 		k_axpy_nrm<true><<<nb, kBlock, 0, st>>>((double2*)xcur, (const double2*)ycur, a_ptr, nullptr, nullptr, e->n2, e->partial);
 	}
 	if (pb_timer) {
-		delete pb_timer; // stopped above on every path that created it
-		pb_timer = nullptr;
+		pb_timer.reset(); // stopped above on every path that created it
 	}
 	if (!fused_ab) {
 		k_reduce_final<<<1, kBlock, 0, st>>>(e->partial, nb_nrm, 1, 1, b2_ptr);

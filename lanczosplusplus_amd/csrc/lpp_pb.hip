@@ -8,7 +8,7 @@
 #include <vector>
 
 #include "lpp_engine_impl.h"
-#include "lpp_pbws_kernels.h"
+#include "lpp_pbig_kernels.h"
 
 using namespace lpp;
 
@@ -23,12 +23,6 @@ void free_pb(lpp_engine* e)
 	                 (void*)B.c_code, (void*)B.order, (void*)B.pace, (void*)B.z, (void*)B.u, (void*)B.xy, (void*)B.dict, (void*)B.dcode, (void*)B.blockbase,
 	                 (void*)B.fw, (void*)B.f_off, (void*)B.f_len, (void*)B.c_pstart, (void*)B.dval, (void*)B.perm, (void*)B.inv, (void*)B.cdict })
 		if (p) (void)hipFree(p);
-	if (B.stream2) {
-		(void)hipStreamSynchronize(B.stream2);
-		(void)hipStreamDestroy(B.stream2);
-	}
-	if (B.ev_fork) (void)hipEventDestroy(B.ev_fork);
-	if (B.ev_join) (void)hipEventDestroy(B.ev_join);
 	B = PbState();
 	e->pitch = e->pitch_rows = e->pitch_blocks = 0;
 }
@@ -131,13 +125,6 @@ lpp_status pb_build(lpp_engine* e, int64_t n_up, int64_t n_blk, const int64_t* t
 	if (const char* s = getenv("LPP_PB_PARTS")) nparts = std::max(1, std::min(atoi(s), kPbMaxParts));
 	const bool parts = nparts > 1 || getenv("LPP_PB_PARTS") != nullptr;
 	const bool wide = vec_bytes >= ((size_t)1 << 32) || getenv("LPP_PB_WIDE") != nullptr;
-	// LPP_PB_HALF=1: panels of 8 positions (64-byte half lines), so that a panel of 38,760 blocks is 2.5 MB instead of 5.  Measured
-	// at the (7,6) sector (scripts/experiments/r03_half_ab.sh): 53 ms against 38 ms per product with whole lines -- the kernel
-	// is bound by line requests through L1, a half line costs a whole request and there are twice as many; the fabric reads
-	// it saves were Infinity-Cache hits already.  Opt-in, kept with its parity form.
-	bool half = false;
-	if (const char* s = getenv("LPP_PB_HALF")) half = wide && !parts && atoi(s) != 0;
-	if ((size_t)nblk_padded * (size_t)(pitch_dn >> 3) >= ((size_t)1 << 32)) half = false; // 32-bit half-line numbers
 	PbTemplate T;
 	int ways = 2;
 	if (const char* s = getenv("LPP_PB_BANK_WAYS")) ways = std::max(1, std::min(atoi(s), 4));
@@ -347,23 +334,6 @@ lpp_status pb_build(lpp_engine* e, int64_t n_up, int64_t n_blk, const int64_t* t
 	if (n_blk > 65535) return fail(LPP_ERR_INVALID, "pb_build: more than 65535 blocks");
 	B.parts = parts;
 	B.wide = wide;
-	B.half = half;
-	B.ws = !cx && T.G <= 2 && getenv("LPP_PB_WS") && atoi(getenv("LPP_PB_WS")) == 1 && !B.big && pitch <= kPbWsMaxPitch && pb_ws_lds_bytes(pitch, T.spb, T.G) <= (size_t)160 * 1024 - 64;
-	B.ws_beta = !(getenv("LPP_PB_WS_BETA") && atoi(getenv("LPP_PB_WS_BETA")) == 0);
-	// k_pb_down2 (own lines of the panel in LDS): opt-in (LPP_PB_DOWN2=1).  Measured at BASELINE config 2 (profiles/README.md, round 3):
-	// it halves the couplings that go through L1 (8.6 of 17.1 per block leave the workgroup's range) but the far lists padded per
-	// task (12 instead of 8.6), the selects of the compact lists and twice the VALU / LDS instructions leave it at 1.57 ms against
-	// 1.43 ms (plain) and 2.08 against 1.80 ms (chained form) for k_pb_down
-	if (!cx && !parts && !wide && B.ids_per_wg >= 8 && getenv("LPP_PB_DOWN2") && atoi(getenv("LPP_PB_DOWN2")) != 0) {
-		int64_t ent_cap = 0;
-		for (int64_t lo = 0; lo < n_blk; lo += B.ids_per_wg) ent_cap = std::max(ent_cap, cp[(size_t)std::min<int64_t>(lo + B.ids_per_wg, n_blk)] - cp[(size_t)lo]);
-		const size_t need = pb_down2_lds_bytes(B.ids_per_wg, (int)std::min<int64_t>(ent_cap, 1 << 20));
-		if (ent_cap < 65000 && need <= (size_t)156 * 1024 && (int64_t)B.ids_per_wg * 8 <= 4 * 1024) { // 4 x 16 bytes per thread stage a panel
-			B.down2 = true;
-			B.down2_ent = (int)ent_cap;
-			B.down2_lds = need;
-		}
-	}
 	if (parts) {
 		// per block and part: where the part's entries start in the (ascending) list; per part: the longest list, in whole chunks of 4
 		B.nparts = nparts;
@@ -426,15 +396,6 @@ lpp_status pb_build(lpp_engine* e, int64_t n_up, int64_t n_blk, const int64_t* t
 						if (px[q] != py[q]) return px[q] > py[q];
 					return false;
 				});
-			} else if (B.down2) {
-				// tasks of 8 consecutive blocks gather as long as their longest list of couplings that LEAVE the workgroup's range
-				// (the others are LDS reads): blocks of equal far length belong together
-				auto far_len = [&](int32_t b) {
-					int64_t n = 0;
-					for (int64_t p = cp[(size_t)b]; p < cp[(size_t)b + 1]; p++) n += (cc[(size_t)p] < lo || cc[(size_t)p] >= hi) ? 1 : 0;
-					return n;
-				};
-				std::stable_sort(order.begin() + lo, order.begin() + hi, [&](int32_t x, int32_t y) { return far_len(x) > far_len(y); });
 			} else {
 				// sorted inside windows of `ow` consecutive blocks (a multiple of 16; 0: the whole range at once)
 				const int64_t ow = order_window > 0 ? order_window : hi - lo;
@@ -445,7 +406,7 @@ lpp_status pb_build(lpp_engine* e, int64_t n_up, int64_t n_blk, const int64_t* t
 		if ((rc = to_device(&B.order, order, st)) != LPP_OK) return rc;
 	}
 	if (!(getenv("LPP_PB_PACE") && atoi(getenv("LPP_PB_PACE")) == 0))
-		HIP_TRY_MEM(hipMalloc(&B.pace, sizeof(int) * 8 * (parts ? (size_t)B.pace_stride : (size_t)(std::max(pitch, pitch_dn) / (half ? 8 : 16)))));
+		HIP_TRY_MEM(hipMalloc(&B.pace, sizeof(int) * 8 * (parts ? (size_t)B.pace_stride : (size_t)(std::max(pitch, pitch_dn) / 16))));
 	// the two parts of a product (padding stays zero) and the carried scalar; with the transposition exchange the couplings'
 	// part is written straight into the exchange buffer
 	const size_t loc = (size_t)std::max<int64_t>(nblk_loc, 1) * (size_t)pitch;
@@ -460,12 +421,6 @@ lpp_status pb_build(lpp_engine* e, int64_t n_up, int64_t n_blk, const int64_t* t
 	HIP_TRY_MEM(hipMalloc(&B.dcode, loc));
 	HIP_TRY(hipMemsetAsync(B.dcode, 0, loc, st));
 	HIP_TRY(hipStreamSynchronize(st));
-	// second stream for k_pb_down (see pb_launch); without it the two kernels simply run one after the other
-	if (hipStreamCreateWithFlags(&B.stream2, hipStreamNonBlocking) != hipSuccess) B.stream2 = nullptr;
-	if (B.stream2 && (hipEventCreateWithFlags(&B.ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&B.ev_join, hipEventDisableTiming) != hipSuccess)) {
-		(void)hipStreamDestroy(B.stream2);
-		B.stream2 = nullptr;
-	}
 	e->pitch = cx ? pitch / 2 : pitch; // in vector elements
 	e->pitch_rows = cx ? cx->n_c : n_up;
 	e->pitch_blocks = nblk_loc;
@@ -479,23 +434,22 @@ lpp_status pb_build(lpp_engine* e, int64_t n_up, int64_t n_blk, const int64_t* t
 // and a streaming pass x = beta x + u + z (k_pb_combine).  defer_combine: the caller runs that pass itself, folded into its own
 // pass over x (pb_combine_axpy of the scale-free recurrence).  Returns the number of partials written; their sum is
 // Re<y | u + z>, to which the caller adds beta Re<y | x_old> (pb.xy, left by the previous combine pass).
-template <bool DOT, bool LEAN> static void launch_up(const PbState& B, const PbUpArgs& u, int nb, size_t lds, hipStream_t st)
+template <bool DOT> static void launch_up(const PbState& B, const PbUpArgs& u, int nb, size_t lds, hipStream_t st)
 {
-	int gt = B.G <= 2 ? B.G : 0;
-	if (getenv("LPP_PB_UP_GENERIC")) gt = 0;
+	const int gt = B.G <= 2 ? B.G : 0;
 #define LPP_PB_UP(GT_)                                                                                                \
 	do {                                                                                                              \
-		(void)hipFuncSetAttribute((const void*)k_pb_up<DOT, GT_, LEAN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-		k_pb_up<DOT, GT_, LEAN><<<nb, kPbUpThreads, lds, st>>>(u);                                                      \
+		(void)hipFuncSetAttribute((const void*)k_pb_up<DOT, GT_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+		k_pb_up<DOT, GT_><<<nb, kPbUpThreads, lds, st>>>(u);                                                            \
 	} while (0)
 #define LPP_PB_UP2(PRE_)                                                                                              \
 	do {                                                                                                              \
-		(void)hipFuncSetAttribute((const void*)k_pb_up<DOT, 2, LEAN, false, PRE_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-		k_pb_up<DOT, 2, LEAN, false, PRE_><<<nb, kPbUpThreads, lds, st>>>(u);                                           \
+		(void)hipFuncSetAttribute((const void*)k_pb_up<DOT, 2, false, PRE_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+		k_pb_up<DOT, 2, false, PRE_><<<nb, kPbUpThreads, lds, st>>>(u);                                                 \
 	} while (0)
 	if (gt == 1) LPP_PB_UP(1);
-	else if (gt == 2 && !LEAN && B.pre0 == 3) LPP_PB_UP2(3); // look-ahead split of the two value groups (pb_build)
-	else if (gt == 2 && !LEAN && B.pre0 == 5) LPP_PB_UP2(5);
+	else if (gt == 2 && B.pre0 == 3) LPP_PB_UP2(3); // look-ahead split of the two value groups (pb_build)
+	else if (gt == 2 && B.pre0 == 5) LPP_PB_UP2(5);
 	else if (gt == 2) LPP_PB_UP(2);
 	else LPP_PB_UP(0);
 #undef LPP_PB_UP2
@@ -566,8 +520,7 @@ static int launch_up_big(lpp_engine* e, const double* y, double* u, const uint8_
 		return partial ? nb : 0;
 	}
 	const size_t lds = pb_big_lds_bytes(B.W);
-	int gt = B.G <= 2 ? B.G : 0;
-	if (getenv("LPP_PB_UP_GENERIC")) gt = 0;
+	const int gt = B.G <= 2 ? B.G : 0;
 #define LPP_PB_BIG(DOT_, GT_)                                                                                          \
 	do {                                                                                                              \
 		(void)hipFuncSetAttribute((const void*)k_pb_up_big<DOT_, GT_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
@@ -625,40 +578,6 @@ static int launch_down_parts(lpp_engine* e, const double* y, double* z, int64_t 
 	return partial ? B.down_grid : 0;
 }
 
-// block couplings with the workgroup's own lines of the panel staged in LDS (k_pb_down2); rmw: the chained form (u_in, shift, pairs of partials)
-static int launch_down2(lpp_engine* e, const double* y, double* z, int64_t pitch, const double* u_in, const double* shift, double* partial, const EpiScale& sc, bool rmw, bool beta_in_u, hipStream_t st)
-{
-	const PbState& B = e->pb;
-	PbDown2Args d;
-	d.pitch = pitch;
-	d.n_blk = B.n_blk;
-	d.npanels = (int)(pitch / 16);
-	d.ids_per_wg = B.ids_per_wg;
-	d.ent_cap = B.down2_ent;
-	d.c_ptr = B.c_ptr;
-	d.c_col = B.c_col;
-	d.c_code = B.c_code;
-	d.order = B.order;
-	d.dict = B.dict;
-	d.y = y;
-	d.z = z;
-	d.u_in = u_in;
-	d.shift = shift;
-	d.partial = partial;
-	d.sc = sc;
-	d.pace = B.pace;
-	d.u_has_beta = rmw && beta_in_u ? 1 : 0; // the chained form's in-block kernel has added beta r_{j-1}
-	if (d.pace) (void)hipMemsetAsync(d.pace, 0, sizeof(int) * 8 * (size_t)d.npanels, st);
-	if (rmw) {
-		(void)hipFuncSetAttribute((const void*)k_pb_down2<1024, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B.down2_lds);
-		k_pb_down2<1024, true><<<B.down_grid, 1024, B.down2_lds, st>>>(d);
-	} else {
-		(void)hipFuncSetAttribute((const void*)k_pb_down2<1024, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B.down2_lds);
-		k_pb_down2<1024, false><<<B.down_grid, 1024, B.down2_lds, st>>>(d);
-	}
-	return partial ? B.down_grid : 0;
-}
-
 // 8192 blocks x 4 elements in flight: 5.2 TB/s for the 4-read 1-write mix (4.7 with 2048 x 2), scripts/experiments/calib_combine.hip
 static int combine_blocks(int64_t n2) { return (int)std::max<int64_t>(1, std::min<int64_t>((n2 + 4 * kBlock - 1) / (4 * kBlock), 8192)); }
 
@@ -670,31 +589,18 @@ int pb_launch(lpp_engine* e, const void* y, void* x, double* partial, const EpiS
 	double* const want_dot = partial;
 	if (!defer_combine) partial = nullptr; // the combine pass below forms Re<y|x> of the finished x itself
 	int np = partial ? nb : 0;
-	// The two kernels are independent (both only read y).  LPP_PB_CONCURRENT=1 runs them side by side on the same CUs
-	// (k_pb_down on a second stream, forked and joined with events; the lean variant of k_pb_up and the 512-thread variant of
-	// k_pb_down together fit a CU's registers, LDS and wave slots).  Measured on the 4x4 cluster: 4.95 ms instead of 2.69 ms one
-	// after the other -- the in-block kernel's traffic evicts the panel from L2 and the paced workgroups are no longer all
-	// resident -- so the default is one after the other.
+	// (the two kernels only read y; side by side on the same CUs they ran 4.95 instead of 2.69 ms at config 2 -- the in-block kernel's
+	// traffic evicts the panel from L2 -- so they run one after the other: scripts/experiments/README.md)
 	const bool both = B.c_nnz > 0;
-	bool concurrent = both && B.stream2 != nullptr && getenv("LPP_PB_CONCURRENT") && atoi(getenv("LPP_PB_CONCURRENT")) != 0;
 	hipStream_t sd = st;
-	if (concurrent) {
-		if (hipEventRecord(B.ev_fork, st) == hipSuccess && hipStreamWaitEvent(B.stream2, B.ev_fork, 0) == hipSuccess)
-			sd = B.stream2;
-		else
-			concurrent = false;
-	}
 	if (both && B.parts) {
 		const int n = launch_down_parts(e, (const double*)y, B.z, B.pitch, partial ? partial + nb : nullptr, sc, sd);
-		if (partial) np += n;
-	} else if (both && B.down2 && !concurrent && !getenv("LPP_PB_DOWN_THREADS")) {
-		const int n = launch_down2(e, (const double*)y, B.z, B.pitch, nullptr, nullptr, partial ? partial + nb : nullptr, sc, false, false, sd);
 		if (partial) np += n;
 	} else if (both) {
 		PbDownArgs d = {};
 		d.pitch = B.pitch;
 		d.n_blk = B.n_blk;
-		d.npanels = (int)(B.pitch / (B.half ? 8 : 16));
+		d.npanels = (int)(B.pitch / 16);
 		d.ids_per_wg = B.ids_per_wg;
 		d.rowcap = B.rowcap;
 		d.c_ptr = B.c_ptr;
@@ -711,18 +617,10 @@ int pb_launch(lpp_engine* e, const void* y, void* x, double* partial, const EpiS
 		d.order = B.order;
 		d.u_has_beta = 0;
 		if (d.pace) (void)hipMemsetAsync(d.pace, 0, sizeof(int) * 8 * (size_t)d.npanels, sd);
-		int threads = concurrent ? 512 : 1024;
-		if (const char* s = getenv("LPP_PB_DOWN_THREADS")) threads = atoi(s);
 		d.cdict = (const double2*)B.cdict;
 		if (B.cplx) {
-			(void)hipFuncSetAttribute((const void*)k_pb_down<1024, false, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B.down_lds);
-			k_pb_down<1024, false, false, false, true><<<B.down_grid, 1024, B.down_lds, sd>>>(d);
-		} else if (threads == 512) {
-			(void)hipFuncSetAttribute((const void*)k_pb_down<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B.down_lds);
-			k_pb_down<512><<<B.down_grid, 512, B.down_lds, sd>>>(d);
-		} else if (B.wide && B.half) {
-			(void)hipFuncSetAttribute((const void*)k_pb_down<1024, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B.down_lds);
-			k_pb_down<1024, false, true, true><<<B.down_grid, 1024, B.down_lds, sd>>>(d);
+			(void)hipFuncSetAttribute((const void*)k_pb_down<1024, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B.down_lds);
+			k_pb_down<1024, false, false, true><<<B.down_grid, 1024, B.down_lds, sd>>>(d);
 		} else if (B.wide) {
 			(void)hipFuncSetAttribute((const void*)k_pb_down<1024, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B.down_lds);
 			k_pb_down<1024, false, true><<<B.down_grid, 1024, B.down_lds, sd>>>(d);
@@ -754,19 +652,8 @@ int pb_launch(lpp_engine* e, const void* y, void* x, double* partial, const EpiS
 	u.wbuf = u.ybuf = nullptr;
 	u.g_a = u.g_b2 = nullptr;
 	const size_t lds = pb_up_lds_bytes(B.pitch, B.spb, B.G);
-	bool lean = concurrent;
-	if (const char* s = getenv("LPP_PB_UP_LEAN")) lean = atoi(s) != 0;
-	if (partial) {
-		if (lean) launch_up<true, true>(B, u, nb, lds, st);
-		else launch_up<true, false>(B, u, nb, lds, st);
-	} else {
-		if (lean) launch_up<false, true>(B, u, nb, lds, st);
-		else launch_up<false, false>(B, u, nb, lds, st);
-	}
-	}
-	if (concurrent) { // join: everything later on the engine's stream sees z
-		(void)hipEventRecord(B.ev_join, B.stream2);
-		(void)hipStreamWaitEvent(st, B.ev_join, 0);
+	if (partial) launch_up<true>(B, u, nb, lds, st);
+	else launch_up<false>(B, u, nb, lds, st);
 	}
 	if (!defer_combine) {
 		PbCombineArgs c;
@@ -826,7 +713,7 @@ void pb_tx_up(lpp_engine* e, const void* y, const EpiScale& sc, int64_t b0, int6
 	u.u = B.u + b0 * B.pitch;
 	u.sc = sc;
 	const int nb = (int)std::max<int64_t>(1, std::min<int64_t>(cnt, (int64_t)e->num_cus));
-	launch_up<false, false>(B, u, nb, pb_up_lds_bytes(B.pitch, B.spb, B.G), e->stream);
+	launch_up<false>(B, u, nb, pb_up_lds_bytes(B.pitch, B.spb, B.G), e->stream);
 }
 
 void pb_tx_down(lpp_engine* e, const void* gath, void* send2, const EpiScale& sc)
@@ -836,14 +723,10 @@ void pb_tx_down(lpp_engine* e, const void* gath, void* send2, const EpiScale& sc
 		launch_down_parts(e, (const double*)gath, (double*)send2, B.pitch_dn, nullptr, sc, e->stream);
 		return;
 	}
-	if (B.down2) {
-		launch_down2(e, (const double*)gath, (double*)send2, B.pitch_dn, nullptr, nullptr, nullptr, sc, false, false, e->stream);
-		return;
-	}
 	PbDownArgs d = {};
 	d.pitch = B.pitch_dn;
 	d.n_blk = B.n_blk;
-	d.npanels = (int)(B.pitch_dn / (B.half ? 8 : 16));
+	d.npanels = (int)(B.pitch_dn / 16);
 	d.ids_per_wg = B.ids_per_wg;
 	d.rowcap = B.rowcap;
 	d.c_ptr = B.c_ptr;
@@ -860,11 +743,6 @@ void pb_tx_down(lpp_engine* e, const void* gath, void* send2, const EpiScale& sc
 	d.order = B.order;
 	d.u_has_beta = 0;
 	if (d.pace) (void)hipMemsetAsync(d.pace, 0, sizeof(int) * 8 * (size_t)d.npanels, e->stream);
-	if (B.wide && B.half) {
-		(void)hipFuncSetAttribute((const void*)k_pb_down<1024, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B.down_lds);
-		k_pb_down<1024, false, true, true><<<B.down_grid, 1024, B.down_lds, e->stream>>>(d);
-		return;
-	}
 	if (B.wide) {
 		(void)hipFuncSetAttribute((const void*)k_pb_down<1024, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B.down_lds);
 		k_pb_down<1024, false, true><<<B.down_grid, 1024, B.down_lds, e->stream>>>(d);
@@ -894,8 +772,8 @@ bool pb_chain_ok(const lpp_engine* e)
 
 template <int GT, int PRE0 = kPbPre> static void launch_up_chain(const PbUpArgs& u, int nb, size_t lds, hipStream_t st)
 {
-	(void)hipFuncSetAttribute((const void*)k_pb_up<false, GT, false, true, PRE0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-	k_pb_up<false, GT, false, true, PRE0><<<nb, kPbUpThreads, lds, st>>>(u);
+	(void)hipFuncSetAttribute((const void*)k_pb_up<false, GT, true, PRE0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+	k_pb_up<false, GT, true, PRE0><<<nb, kPbUpThreads, lds, st>>>(u);
 }
 
 // One scale-free Lanczos step in two launches.  In: w (= w_{j-1}, or r_j itself when g_a is null) and y (= r_{j-1}).
@@ -925,22 +803,8 @@ int pb_launch_chain(lpp_engine* e, void* w, void* y, double* partial, const EpiS
 	u.ybuf = (double*)y;
 	u.g_a = g_a;
 	u.g_b2 = g_b2;
-	// LPP_PB_WS=1: rows that fit five waves' registers are staged beside the gathers (k_pb_up_ws).  Measured slower than the
-	// two-phase kernel (1.63-1.99 against 1.56 ms at config 2: the gathers need all 16 waves), so it is not the default
-	const size_t lds_ws = pb_ws_lds_bytes(B.pitch, B.spb, B.G);
-	bool beta_in_u = true;
-	u.beta_in_u = 1;
-	if (B.ws) {
-		beta_in_u = B.ws_beta;
-		u.beta_in_u = beta_in_u ? 1 : 0;
-		if (B.G == 1) {
-			(void)hipFuncSetAttribute((const void*)k_pb_up_ws<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ws);
-			k_pb_up_ws<1><<<nb, kPbUpThreads, lds_ws, st>>>(u);
-		} else {
-			(void)hipFuncSetAttribute((const void*)k_pb_up_ws<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ws);
-			k_pb_up_ws<2><<<nb, kPbUpThreads, lds_ws, st>>>(u);
-		}
-	} else {
+	{
+		// beta r_{j-1} rides in u (k_pb_up<CHAIN>), so the coupling kernel reads one stream less
 		const size_t lds = pb_up_lds_bytes(B.pitch, B.spb, B.G);
 		if (B.G == 1) launch_up_chain<1>(u, nb, lds, st);
 		else if (B.G > 2) launch_up_chain<0>(u, nb, lds, st);
@@ -948,7 +812,6 @@ int pb_launch_chain(lpp_engine* e, void* w, void* y, double* partial, const EpiS
 		else if (B.pre0 == 5) launch_up_chain<2, 5>(u, nb, lds, st);
 		else launch_up_chain<2>(u, nb, lds, st);
 	}
-	if (B.down2) return launch_down2(e, (const double*)w, (double*)y, B.pitch, B.u, shift, partial, sc, true, beta_in_u, st);
 	PbDownArgs d = {};
 	d.pitch = B.pitch;
 	d.n_blk = B.n_blk;
@@ -967,18 +830,12 @@ int pb_launch_chain(lpp_engine* e, void* w, void* y, double* partial, const EpiS
 	d.sc = sc;
 	d.pace = B.pace;
 	d.order = B.order;
-	d.u_has_beta = beta_in_u ? 1 : 0; // the in-block kernel has put beta r_{j-1} into u
+	d.u_has_beta = 1; // the in-block kernel has put beta r_{j-1} into u
 	if (d.pace) (void)hipMemsetAsync(d.pace, 0, sizeof(int) * 8 * (size_t)d.npanels, st);
-	static const int down_threads = getenv("LPP_PB_DOWN_THREADS") ? atoi(getenv("LPP_PB_DOWN_THREADS")) : 1024; // experiment: fewer waves, fewer lines in flight per L1
-	if (down_threads == 512 && !B.cplx) {
-		(void)hipFuncSetAttribute((const void*)k_pb_down<512, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B.down_lds);
-		k_pb_down<512, true><<<B.down_grid, 512, B.down_lds, st>>>(d);
-		return B.down_grid;
-	}
 	d.cdict = (const double2*)B.cdict;
 	if (B.cplx) {
-		(void)hipFuncSetAttribute((const void*)k_pb_down<1024, true, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B.down_lds);
-		k_pb_down<1024, true, false, false, true><<<B.down_grid, 1024, B.down_lds, st>>>(d);
+		(void)hipFuncSetAttribute((const void*)k_pb_down<1024, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B.down_lds);
+		k_pb_down<1024, true, false, true><<<B.down_grid, 1024, B.down_lds, st>>>(d);
 		return B.down_grid;
 	}
 	(void)hipFuncSetAttribute((const void*)k_pb_down<1024, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B.down_lds);
@@ -1173,6 +1030,15 @@ lpp_status pb_from_csr(lpp_engine* e, const DevCsr& A, int64_t n_up, bool* done)
 	}
 	if (rc != LPP_OK) return rc;
 	PbState& B = e->pb;
+	// until every row has been verified the engine must not describe a product-basis matrix: any early return below drops the layout
+	struct Undo {
+		lpp_engine* e;
+		bool* done;
+		~Undo()
+		{
+			if (!*done) free_pb(e);
+		}
+	} undo { e, done };
 	if (B.perm) { // the diagonal was read off the CSR in the basis order: into the stored order (pb.u is free until the first product)
 		k_pb_permute<true><<<nbr, 256, 0, st>>>(B.u, (const double*)d_dval.p, B.perm, n_blk, n_up, pitch);
 		HIP_TRY(hipMemcpyAsync(d_dval.p, B.u, sizeof(double) * loc, hipMemcpyDeviceToDevice, st));
@@ -1192,10 +1058,7 @@ lpp_status pb_from_csr(lpp_engine* e, const DevCsr& A, int64_t n_up, bool* done)
 	HIP_TRY(hipMemcpyAsync(bad, d_bad.p, sizeof(int) * 2, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipStreamSynchronize(st));
-	if (bad[1] || B.nnz != A.nnz) { // some row is not what (T, C, D) say: not a product-basis matrix
-		free_pb(e);
-		return LPP_OK;
-	}
+	if (bad[1] || B.nnz != A.nnz) return LPP_OK; // some row is not what (T, C, D) say: not a product-basis matrix (the guard drops the layout)
 	*done = true;
 	return LPP_OK;
 }

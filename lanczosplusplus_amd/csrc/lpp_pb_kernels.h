@@ -48,7 +48,6 @@ struct PbUpArgs {
 	double* ybuf;
 	const double* g_a; // raw_{j-1} (null: the vector in wbuf is r_j already, nothing to subtract)
 	const double* g_b2; // b_{j-2}^2
-	int beta_in_u; // k_pb_up_ws: add beta r_{j-1} to u (k_pb_up<CHAIN> always does)
 };
 
 constexpr int kPbPre = 4; // chunks (of 4 slots) of every (slice, group) requested one slice ahead
@@ -64,10 +63,7 @@ constexpr int kPbPre = 4; // chunks (of 4 slots) of every (slice, group) request
 // plain and/shift/add unpacking the kernel was VALU-bound (10 vector instructions per pair of entries); with ready-made
 // 32-bit addresses the template words (19 GB per product through a ~57 GB/s-per-CU L2->L1 path) bound it instead.
 constexpr int kPbPreMax = 6; // deepest look-ahead of one value group (k_pb_up's PRE0)
-#ifndef LPP_PB_PRE_MIN
-#define LPP_PB_PRE_MIN 1
-#endif
-constexpr int kPbPreMin = LPP_PB_PRE_MIN; // chunks of a group requested whatever its list length (no branch)
+constexpr int kPbPreMin = 1; // chunks of a group requested whatever its list length (no branch)
 template <int GT> struct PbWords {
 	uint2 w[GT][kPbPreMax]; // only the first `depth(g)` chunks of group g are ever touched (the others take no register)
 	int nc[GT];
@@ -101,10 +97,6 @@ __host__ __device__ inline size_t pb_up_lds_bytes(int64_t pitch, int spb, int G)
 }
 
 // GT = number of value groups (1 or 2: unrolled, with look-ahead; 0: any G <= 8, plain loop).
-// LEAN: at most 64 registers per lane (8 waves per SIMD's worth), so that a workgroup of k_pb_down fits on the same CU and the
-// two kernels -- one bound by LDS / vector issue, the other by L2 gathers, both waiting most of the time -- fill each other's
-// stalls: no second register set for the next slice's words (the other kernel's waves cover that latency instead).
-//
 // CHAIN: the chained form of the scale-free Lanczos step (pb_launch_chain).  The previous step left w = H r/b - (b/b') r' complete
 // in wbuf and its own vector r in ybuf, but did NOT run the pass  r_next = w - g r  (g = raw / b^2): this kernel does it while it
 // stages the row -- it reads both rows, keeps r_next in the LDS window and writes it back over w (k_pb_down gathers from there).
@@ -118,7 +110,7 @@ __host__ __device__ inline size_t pb_up_lds_bytes(int64_t pitch, int spb, int G)
 // groups are not equally long (config 2: hops with sign + average 11.7 entries per row, 4-5 chunks; sign -: 5.4 entries, 2-3
 // chunks), and a chunk beyond the look-ahead is a load with a full L2 round trip in the middle of a slice.  The host picks
 // PRE0 from the template's list lengths (pb_build).
-template <bool DOT, int GT, bool LEAN, bool CHAIN = false, int PRE0 = kPbPre> __global__ __launch_bounds__(kPbUpThreads, LEAN ? 8 : 4) void k_pb_up(PbUpArgs a)
+template <bool DOT, int GT, bool CHAIN = false, int PRE0 = kPbPre> __global__ __launch_bounds__(kPbUpThreads, 4) void k_pb_up(PbUpArgs a)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
 	double* win = (double*)lds_raw; // pitch + kPbZeroSlots elements, at LDS address 0
@@ -154,14 +146,10 @@ template <bool DOT, int GT, bool LEAN, bool CHAIN = false, int PRE0 = kPbPre> __
 #pragma unroll
 	for (int g = 0; g < GG; g++) gv[g] = a.gval[g];
 	auto gather4 = [=](const uint2& w, double& s0, double& s1) __attribute__((always_inline)) {
-#ifdef LPP_PB_TIMING_NOGATHER
-		asm volatile("" ::"v"(w.x), "v"(w.y)); // timing-only build: the words are loaded, nothing is gathered
-#else
 		s0 += pb_lds_abs(pb_lo8(w.x));
 		s1 += pb_lds_abs(pb_hi8(w.x));
 		s0 += pb_lds_abs(pb_lo8(w.y));
 		s1 += pb_lds_abs(pb_hi8(w.y));
-#endif
 	};
 	for (int64_t blk = blockIdx.x; blk < a.n_blk; blk += gridDim.x) {
 		const double2* yb = (const double2*)(a.y + blk * a.pitch);
@@ -173,10 +161,7 @@ template <bool DOT, int GT, bool LEAN, bool CHAIN = false, int PRE0 = kPbPre> __
 		if (CHAIN) {
 			double2* const wb = (double2*)(a.wbuf + rowbase);
 			const double2* const yo = (const double2*)(a.ybuf + rowbase);
-#ifndef LPP_PB_CHAIN_NS
-#define LPP_PB_CHAIN_NS 4 // pairs per thread and row in flight: 2 -> 1.58 ms, 4 -> 1.57 ms, 8 spills (3.5 ms)
-#endif
-			constexpr int NS = LPP_PB_CHAIN_NS;
+			constexpr int NS = 4; // pairs per thread and row in flight: 2 -> 1.58 ms, 4 -> 1.57 ms, 8 spills (3.5 ms)
 			for (int i0 = threadIdx.x; i0 < p2; i0 += NS * kPbUpThreads) {
 				// loads unconditional and clamped (all of them in flight together); stores only from the lane that owns the pair -- a
 				// clamped lane would subtract g r a second time from a pair its owner has already updated in place
@@ -186,11 +171,7 @@ template <bool DOT, int GT, bool LEAN, bool CHAIN = false, int PRE0 = kPbPre> __
 				for (int q = 0; q < NS; q++) idx[q] = min(i0 + q * kPbUpThreads, p2 - 1);
 #pragma unroll
 				for (int q = 0; q < NS; q++) wv[q] = wb[idx[q]];
-#ifdef LPP_PB_TIMING_NOSTAGE
-				if (gco == 1.2345e300) { // timing-only build: one row read, nothing written back
-#else
 				if (gco != 0.0) {
-#endif
 #pragma unroll
 					for (int q = 0; q < NS; q++) yv[q] = yo[idx[q]];
 #pragma unroll
@@ -206,7 +187,7 @@ template <bool DOT, int GT, bool LEAN, bool CHAIN = false, int PRE0 = kPbPre> __
 			}
 			for (int i0 = threadIdx.x; i0 < p16; i0 += kPbUpThreads) ((uint4*)dcode_s)[i0] = db[i0];
 		} else {
-			constexpr int NS = LEAN ? 4 : 8; // loads per thread and pass
+			constexpr int NS = 8; // loads per thread and pass
 			for (int pass = 0; pass < 8 / NS; pass++) {
 				double2 t[NS];
 				int idx[NS];
@@ -238,9 +219,6 @@ template <bool DOT, int GT, bool LEAN, bool CHAIN = false, int PRE0 = kPbPre> __
 			if (iu < n_up) {
 				// chained form: u = alpha (T + D) r_j + beta r_{j-1}, so that the coupling kernel needs neither r_{j-1} nor beta
 				const double uv = CHAIN ? fma(beta, yo, alpha * acc) : alpha * acc;
-#ifdef LPP_PB_TIMING_NOSTORE
-				if (uv == 1.2345e300) // timing-only build (wrong results): what the store in the slice loop costs
-#endif
 				__builtin_nontemporal_store(uv, &uout[rowbase + iu]);
 				if (DOT) dot += yc * uv;
 			}
@@ -260,28 +238,17 @@ template <bool DOT, int GT, bool LEAN, bool CHAIN = false, int PRE0 = kPbPre> __
 					const int depth = GG == 2 ? (g == 0 ? PRE0 : 2 * kPbPre - PRE0) : kPbPre;
 #pragma unroll
 					for (int c = 0; c < kPbPreMax; c++)
-#ifdef LPP_PB_TIMING_NOWORDS
-						if (c < depth) s.w[g][c] = uint2 { (uint32_t)(lane * 2 + c) | ((uint32_t)(lane * 2 + 1 + c) << 16), (uint32_t)(lane * 2 + 128 + c) | ((uint32_t)(lane * 2 + 129) << 16) }; // timing-only build
-#else
 						if (c < depth && (c < kPbPreMin || c < s.nc[g])) s.w[g][c] = wp[c * 64]; // beyond the first chunks only what the list holds (scalar branch)
-#endif
 				}
 				// chained form: r_{j-1} at this row, re-read one slice ahead with the words.  By the counters the re-read does NOT hit L2
 				// (the XCD streams ~10 MB between staging and here): 1.33 GB more fabric reads per step at config 2, served one slice
 				// before it is used; k_pb_up pays 0.05 ms for it, k_pb_down<RMW> saves 0.14 ms by not reading r_{j-1} at all
-#ifndef LPP_PB_TIMING_NOYOLD
 				if (CHAIN) s.yo = yold[min(j * 64 + lane, n_up - 1)];
-#else
-				if (CHAIN) s.yo = 0.0; // timing-only build (wrong results): what the re-read costs
-#endif
 			};
 			// one value group of a slice: sum of the window elements its (look-ahead) chunks index, longer lists streamed
 			auto group_sum = [=](int j, int g, int nc, const uint2* w, int depth) __attribute__((always_inline)) {
 				double s0 = 0.0, s1 = 0.0;
-#ifndef LPP_PB_BATCH
-#define LPP_PB_BATCH 2
-#endif
-				constexpr int BT = LPP_PB_BATCH; // chunks per batch: 4 BT LDS gathers in flight
+				constexpr int BT = 2; // chunks per batch: 4 BT LDS gathers in flight (3: no faster, scripts/experiments/README.md)
 #pragma unroll
 				for (int c = 0; c < kPbPreMax; c += BT) {
 					if (c >= depth) continue;
@@ -315,29 +282,13 @@ template <bool DOT, int GT, bool LEAN, bool CHAIN = false, int PRE0 = kPbPre> __
 				for (int g = 0; g < GG; g++) acc = fma(gv[g], group_sum(j, g, s.nc[g], s.w[g], GG == 2 ? (g == 0 ? PRE0 : 2 * kPbPre - PRE0) : kPbPre), acc);
 				finish(j, acc, yc, dv, CHAIN ? s.yo : 0.0);
 			};
-			if (LEAN) { // one group's words at a time: 8 registers instead of 2 x 8 x GG
-				for (int j = wave; j < spb; j += NW) {
-					double acc = 0.0;
-#pragma unroll
-					for (int g = 0; g < GG; g++) {
-						const int nc = len_s[j * GG + g];
-						const uint2* wp = tw2 + (size_t)off_s[j * GG + g] * 64 + lane;
-						uint2 w[kPbPreMax];
-#pragma unroll
-						for (int c = 0; c < kPbPre; c++) w[c] = wp[c * 64];
-						acc = fma(gv[g], group_sum(j, g, nc, w, kPbPre), acc);
-					}
-					epilogue(j, acc);
-				}
-			} else {
-				PbWords<GG> wa, wb;
-				load_words(wave, wa);
-				for (int j0 = wave; j0 < spb; j0 += 2 * NW) {
-					load_words(j0 + NW, wb);
-					compute(j0, wa);
-					load_words(j0 + 2 * NW, wa);
-					compute(j0 + NW, wb);
-				}
+			PbWords<GG> wa, wb;
+			load_words(wave, wa);
+			for (int j0 = wave; j0 < spb; j0 += 2 * NW) {
+				load_words(j0 + NW, wb);
+				compute(j0, wa);
+				load_words(j0 + 2 * NW, wa);
+				compute(j0 + NW, wb);
 			}
 		} else {
 			for (int j = wave; j < spb; j += NW) {
@@ -345,20 +296,6 @@ template <bool DOT, int GT, bool LEAN, bool CHAIN = false, int PRE0 = kPbPre> __
 				// any number of value groups (<= 8; complex hoppings realified: 4): the words of a list are requested four chunks at a time
 				// and the first four of the NEXT group before this group's gathers (one load per chunk, each waited for, was a full L2 round
 				// trip per chunk: 2.6 ms at 6.4e7 complex states against 1.1 ms for the coupling kernel)
-				if (LEAN) { // 64 registers: one chunk at a time
-					for (int g = 0; g < G; g++) {
-						const int nc = len_s[j * G + g];
-						const uint2* wp = tw2 + (size_t)off_s[j * G + g] * 64 + lane;
-						double s0 = 0.0, s1 = 0.0;
-						for (int c = 0; c < nc; c++) {
-							const uint2 wr = wp[c * 64];
-							gather4(wr, s0, s1);
-						}
-						acc = fma(a.gval[g], s0 + s1, acc);
-					}
-					epilogue(j, acc);
-					continue;
-				}
 				const double yo_g = CHAIN ? yold[min(j * 64 + lane, n_up - 1)] : 0.0; // chained form: beta r_{j-1} rides in u (as in the unrolled paths)
 				uint2 wn[4];
 				int ncn = __builtin_amdgcn_readfirstlane((int)len_s[j * G]);
@@ -426,7 +363,7 @@ __host__ __device__ inline size_t pb_down_lds_bytes(int ids_per_wg, int rowcap) 
 
 struct PbDownArgs {
 	int64_t pitch, n_blk;
-	int npanels; // pitch / 16 (HALF: pitch / 8)
+	int npanels; // pitch / 16
 	int ids_per_wg; // blocks owned by one workgroup
 	int rowcap; // longest coupling list rounded up to a multiple of 4
 	const int64_t* c_ptr; // couplings: CSR over blocks, off-diagonal, ascending
@@ -448,17 +385,14 @@ struct PbDownArgs {
 // RMW (chained Lanczos step, see k_pb_up): z holds the previous Lanczos vector r' and receives the finished
 //   w = u_in + beta r' + alpha C y;   the partials are Re<y|w> and |w - s y|^2 (k_b2_from_w).
 // The two HBM loads per task this needs are only USED behind the gather loop.  Where they are issued (in front of the gathers,
-// behind the first or the second chunk: LPP_PB_RMW_POS) moved the kernel by less than 4 % (1.86 / 1.94 / 1.93 ms at BASELINE
+// behind the first or the second chunk) moved the kernel by less than 4 % (1.86 / 1.94 / 1.93 ms at BASELINE
 // config 2): it is bound by what goes through L1 -- 17 gathered lines + 3 streamed ones per line written -- not by the order.
 // WIDE: vectors beyond 4 GiB (BASELINE config 5's sectors).  The LDS image then holds 128-byte LINE numbers instead of byte
 // offsets and every address is formed in 64 bits: (line of the source block's row + panel) << 7.
-// HALF: panels of 8 positions (64-byte half lines; a wave task is 16 blocks x 8 positions, npanels = pitch / 8): with 38,760 or
-// 77,520 blocks (BASELINE config 5's sectors) a panel of whole lines is 5-10 MB and does not stay in an XCD's 4 MiB L2 --
-// every one of the ~17 gathers of a line then comes from the fabric (measured at the (7,6) sector: 88 GB read for a 24 GB vector).
 // CPLX: complex hoppings.  The vector is complex, one element per 16-byte lane (a line = 8 positions; pitch and npanels still count
 // doubles), the coupling values are complex (cdict) and a gather is multiplied as a complex number; everything else -- lines, panels,
 // pacing, the partial sums (Re<y|z> is the real dot product of the doubles) -- is the real kernel.
-template <int THREADS, bool RMW = false, bool WIDE = false, bool HALF = false, bool CPLX = false> __global__ __launch_bounds__(THREADS) void k_pb_down(PbDownArgs a)
+template <int THREADS, bool RMW = false, bool WIDE = false, bool CPLX = false> __global__ __launch_bounds__(THREADS) void k_pb_down(PbDownArgs a)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
 	__shared__ double dict_s[CPLX ? 512 : 256]; // CPLX: (re, im) pairs
@@ -474,9 +408,9 @@ template <int THREADS, bool RMW = false, bool WIDE = false, bool HALF = false, b
 	epi_coeffs(a.sc, alpha, beta);
 	double dot = 0.0, nrm = 0.0;
 	const double sh = RMW ? *a.shift : 0.0;
-	constexpr int LPL = HALF ? 4 : 8; // 16-byte lanes per panel line
+	constexpr int LPL = 8; // 16-byte lanes per panel line
 	constexpr int BPT = 64 / LPL; // blocks of a wave task
-	constexpr int LSH = HALF ? 6 : 7; // log2 of the panel line's bytes
+	constexpr int LSH = 7; // log2 of the panel line's bytes
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = lane / LPL, c = lane & (LPL - 1);
 	const int nx = (gridDim.x & 7) == 0 ? 8 : 1; // groups the panels are dealt over
 	const int grp = nx == 8 ? (int)(blockIdx.x & 7) : 0;
@@ -534,15 +468,7 @@ template <int THREADS, bool RMW = false, bool WIDE = false, bool HALF = false, b
 				const uint32_t w4[4] = { pw.x, pw.y, pw.z, pw.w };
 #pragma unroll
 				for (int q = 0; q < 4; q++) {
-#ifdef LPP_PB_TIMING_DOWN_OWNLINES
-					gbuf[q] = *(const double2*)(ysrc + at(row_s[il] + 0 * (w4[q] & 0xffffu))); // timing-only build: every gather asks for the block's own line (an L1 hit)
-#else
-#ifdef LPP_PB_TIMING_DOWN_NTGATHER
-					gbuf[q] = nt_load2((const double2*)(ysrc + at((w4[q] & 0xffffu) * rowbytes))); // experiment: the gathers bypass L1
-#else
 					gbuf[q] = *(const double2*)(ysrc + at((w4[q] & 0xffffu) * rowbytes));
-#endif
-#endif
 				}
 			};
 			auto consume = [&](const double2* gbuf, const uint4& pw) __attribute__((always_inline)) {
@@ -560,21 +486,14 @@ template <int THREADS, bool RMW = false, bool WIDE = false, bool HALF = false, b
 					}
 				}
 			};
-#ifndef LPP_PB_RMW_POS
-#define LPP_PB_RMW_POS 0
-#endif
 			double2* const zp = (double2*)((char*)a.z + at(row_s[il]));
 			double2 uo = double2 { 0.0, 0.0 }, xo = double2 { 0.0, 0.0 };
-			if (LPP_PB_RMW_POS >= 1 && n4 > 0) issue(0, ga, pa);
-			if (LPP_PB_RMW_POS >= 2 && n4 > 1) issue(1, gb, pb);
 			if (RMW) { // used only behind the gather loop: no wait here
-#ifndef LPP_PB_TIMING_DOWN_NOU
 				uo = nt_load2((const double2*)((const char*)a.u_in + at(row_s[il])));
-#endif
 				if (!a.u_has_beta) xo = nt_load2(zp); // wave-uniform
 			}
-			if (LPP_PB_RMW_POS < 1 && n4 > 0) issue(0, ga, pa);
-			if (LPP_PB_RMW_POS < 2 && n4 > 1) issue(1, gb, pb);
+			if (n4 > 0) issue(0, ga, pa);
+			if (n4 > 1) issue(1, gb, pb);
 			for (int ch = 0; ch < n4; ch += 3) { // wave-uniform conditions
 				if (ch + 2 < n4) issue(ch + 2, gc, pc);
 				consume(ga, pa);
@@ -591,13 +510,8 @@ template <int THREADS, bool RMW = false, bool WIDE = false, bool HALF = false, b
 			if (valid) {
 				acc.x = fma(alpha, acc.x, fma(beta, xo.x, uo.x));
 				acc.y = fma(alpha, acc.y, fma(beta, xo.y, uo.y));
-#ifdef LPP_PB_TIMING_DOWN_NOSTORE
-				if (acc.x == 1.2345e300) // timing-only build
-#endif
-				{
-					__builtin_nontemporal_store(acc.x, &zp->x);
-					__builtin_nontemporal_store(acc.y, &zp->y);
-				}
+				__builtin_nontemporal_store(acc.x, &zp->x);
+				__builtin_nontemporal_store(acc.y, &zp->y);
 				dot += yown.x * acc.x + yown.y * acc.y;
 				if (RMW) {
 					const double dx = acc.x - sh * yown.x, dy = acc.y - sh * yown.y;
@@ -609,283 +523,6 @@ template <int THREADS, bool RMW = false, bool WIDE = false, bool HALF = false, b
 			__syncthreads();
 			if (threadIdx.x == 0) __hip_atomic_fetch_add(a.pace + (int64_t)grp * a.npanels + p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		}
-	}
-	if (a.partial) {
-		const double r = block_sum_n<THREADS / 64>(dot, smem_d);
-		if (threadIdx.x == 0) a.partial[RMW ? 2 * blockIdx.x : blockIdx.x] = r;
-		if (RMW) {
-			const double q = block_sum_n<THREADS / 64>(nrm, smem_d);
-			if (threadIdx.x == 0) a.partial[2 * blockIdx.x + 1] = q;
-		}
-	}
-}
-
-// ---------------------------------------------------------------------------------------------
-// k_pb_down2: the coupling kernel with the workgroup's OWN lines of the panel in LDS.
-// k_pb_down moves 17 gathered lines (+ its own, + u and x in the chained form) through L1 per line written and sits at the
-// L2 -> L1 fill rate.  But a workgroup owns a contiguous range of ~400 blocks, and -- basis words being ascending, the high
-// sites the major key -- half of every block's couplings end inside its workgroup's own range (49.6 % at BASELINE config 2,
-// 54 % on the 4x5 lattice).  So the last wave of the workgroup stages the range's 16-position lines of the NEXT panel in LDS
-// (one line per block: the only time they pass through L1) while the other waves work on the current one: couplings inside
-// the range are LDS reads, only the others are gathered through L1 (8.6 instead of 17.1 per block).
-// Lists are kept compact in LDS (no padding): [far entries | local entries] per block, places beyond a list are switched off
-// by a select (own line, +0.0).  Tasks (8 blocks x 16 positions) take the blocks in the order of decreasing FAR length.
-// ---------------------------------------------------------------------------------------------
-struct PbDown2Args {
-	int64_t pitch, n_blk;
-	int npanels; // pitch / 16
-	int ids_per_wg; // blocks owned by one workgroup = the range whose lines are staged
-	int ent_cap; // list entries a workgroup holds at most (LDS sizing)
-	const int64_t* c_ptr; // couplings: CSR over blocks, off-diagonal, ascending
-	const int32_t* c_col;
-	const uint8_t* c_code;
-	const int32_t* order; // blocks of every workgroup's range by decreasing number of couplings that leave the range
-	const double* dict;
-	const double* y;
-	double* z;
-	const double* u_in; // RMW: the in-block part of the product (k_pb_up's u)
-	const double* shift; // RMW: s of the second partial |w - s y|^2 (k_b2_from_w)
-	double* partial; // per-workgroup Re<y|z>; RMW: pairs (Re<y|w>, |w - s y|^2)
-	EpiScale sc;
-	int* pace; // [8][npanels] finished-workgroup counters (zeroed before the launch); null: free-running
-	int u_has_beta; // RMW: as in PbDownArgs
-};
-
-constexpr int kPbLineStride = 18; // doubles per staged line in LDS: 16 + 2 (144 bytes: 16-byte reads of neighbouring lines fall on different banks)
-
-// LDS: line[ids] u32 | fo[ids+1] u16 | lo[ids+1] u16 | n4f[tasks] u8 | nl[tasks] u8 | idx[ent] u16 | code[ent] u8 | 2 panel buffers
-__host__ __device__ inline size_t pb_down2_lists_bytes(int ids_per_wg, int ent_cap)
-{
-	const size_t tasks = (size_t)(ids_per_wg + 7) / 8;
-	return (((size_t)ids_per_wg * 4 + ((size_t)ids_per_wg + 1) * 4 + tasks * 2 + (size_t)(ent_cap + 8) * 3) + 15) & ~(size_t)15;
-}
-__host__ __device__ inline size_t pb_down2_lds_bytes(int ids_per_wg, int ent_cap)
-{
-	return pb_down2_lists_bytes(ids_per_wg, ent_cap) + 2 * (size_t)ids_per_wg * kPbLineStride * sizeof(double) + 64;
-}
-
-template <int THREADS, bool RMW> __global__ __launch_bounds__(THREADS) void k_pb_down2(PbDown2Args a)
-{
-	extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-	__shared__ double dict_s[256];
-	__shared__ double smem_d[THREADS / 64];
-	const int ngmax = (a.ids_per_wg + 7) >> 3;
-	uint32_t* line_s = (uint32_t*)lds_raw; // [ids] byte offset of the block's row
-	uint16_t* fo_s = (uint16_t*)(line_s + a.ids_per_wg); // [ids+1] first place of the block's far entries; its local entries follow them
-	uint16_t* lo_s = fo_s + a.ids_per_wg + 1; // [ids+1] first place of the local entries (lo_s[il] .. fo_s[il+1])
-	uint8_t* n4f_s = (uint8_t*)(lo_s + a.ids_per_wg + 1); // [tasks] far trip count (chunks of 4)
-	uint8_t* nl_s = n4f_s + ngmax; // [tasks] local trip count
-	// (offsets from lds_raw only: a pointer that went through an integer cast is no longer known to be LDS and is read with flat loads)
-	const size_t idx_off = ((size_t)a.ids_per_wg * 4 + ((size_t)a.ids_per_wg + 1) * 4 + (size_t)ngmax * 2 + 1) & ~(size_t)1;
-	uint16_t* idx_s = (uint16_t*)(lds_raw + idx_off); // [ent] far: source block; local: source block - b0
-	uint8_t* code_s = (uint8_t*)(idx_s + a.ent_cap + 8);
-	double* pan_s = (double*)(lds_raw + pb_down2_lists_bytes(a.ids_per_wg, a.ent_cap)); // [2][ids][kPbLineStride]
-	for (int i = threadIdx.x; i < 256; i += THREADS) dict_s[i] = a.dict[i];
-	double alpha, beta;
-	epi_coeffs(a.sc, alpha, beta);
-	double dot = 0.0, nrm = 0.0;
-	const double sh = RMW ? *a.shift : 0.0;
-	constexpr int NW = THREADS / 64, NWC = NW; // every wave computes; the next panel's lines are requested into registers and stored at the end
-	constexpr int NPF = 4; // 16-byte loads per thread that stage a panel (THREADS * NPF * 16 bytes >= ids_per_wg * 128: pb_build)
-	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = lane >> 3, c = lane & 7;
-	const int nx = (gridDim.x & 7) == 0 ? 8 : 1;
-	const int grp = nx == 8 ? (int)(blockIdx.x & 7) : 0;
-	const int slot = nx == 8 ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
-	const int nslots = (int)(gridDim.x / nx);
-	const int64_t b0 = (int64_t)slot * a.ids_per_wg;
-	const int nown = (int)max((int64_t)0, min((int64_t)a.ids_per_wg, a.n_blk - b0));
-	const uint32_t rowbytes = (uint32_t)(a.pitch * 8);
-	// places: per block (in `order`) its far entries, then its local ones; wave 0 scans the lengths
-	if (wave == 0) {
-		int run = 0;
-		for (int i0 = 0; i0 < nown; i0 += 64) {
-			const int il = i0 + lane;
-			const int64_t b = il < nown ? (int64_t)a.order[b0 + il] : 0;
-			int len = 0, nloc = 0;
-			if (il < nown) {
-				len = (int)(a.c_ptr[b + 1] - a.c_ptr[b]);
-				for (int64_t p = a.c_ptr[b]; p < a.c_ptr[b + 1]; p++) nloc += (a.c_col[p] >= b0 && a.c_col[p] < b0 + nown) ? 1 : 0;
-			}
-			int incl = len;
-#pragma unroll
-			for (int off = 1; off < 64; off <<= 1) {
-				const int t = __shfl_up(incl, off, 64);
-				if (lane >= off) incl += t;
-			}
-			if (il < nown) {
-				const int first = run + incl - len;
-				line_s[il] = (uint32_t)b * rowbytes;
-				fo_s[il] = (uint16_t)first;
-				lo_s[il] = (uint16_t)(first + len - nloc);
-			}
-			run += __shfl(incl, 63, 64);
-		}
-		if (lane == 0) fo_s[nown] = (uint16_t)run;
-	}
-	__syncthreads();
-	for (int il = wave; il < nown; il += NW) { // one wave per list
-		const int64_t b = a.order[b0 + il];
-		const int64_t p0 = a.c_ptr[b];
-		const int len = (int)(a.c_ptr[b + 1] - p0);
-		// rows are ascending and the own range is contiguous: the local entries are one run [l0, l1) of the list
-		for (int k = lane; k < len; k += 64) {
-			const int32_t src = a.c_col[p0 + k];
-			const bool loc = src >= b0 && src < b0 + nown;
-			int below = 0, lbelow = 0; // entries in front of k, and local ones among them
-			for (int t = 0; t < k; t++) {
-				const int32_t s2 = a.c_col[p0 + t];
-				lbelow += (s2 >= b0 && s2 < b0 + nown) ? 1 : 0;
-			}
-			below = k - lbelow; // far entries in front of k
-			const int place = loc ? (int)lo_s[il] + lbelow : (int)fo_s[il] + below;
-			idx_s[place] = (uint16_t)(loc ? src - b0 : src);
-			code_s[place] = a.c_code[p0 + k];
-		}
-	}
-	__syncthreads();
-	const int ngroups = (nown + 7) >> 3;
-	for (int i = threadIdx.x; i < ngmax; i += THREADS) {
-		int mf = 0, ml = 0;
-		for (int t = 0; t < 8; t++)
-			if (i * 8 + t < nown) {
-				mf = max(mf, (int)lo_s[i * 8 + t] - (int)fo_s[i * 8 + t]);
-				ml = max(ml, (int)fo_s[i * 8 + t + 1] - (int)lo_s[i * 8 + t]);
-			}
-		n4f_s[i] = (uint8_t)((mf + 3) >> 2);
-		nl_s[i] = (uint8_t)ml;
-	}
-	// own block of a place in the panel buffer: buffer row = block - b0 (NOT the position in `order`)
-	const char* ysrc = (const char*)a.y;
-	// this thread's share of a panel's lines: element e = threadIdx.x + k * THREADS covers line e >> 3, 16-byte piece e & 7
-	const int nel = nown * 8;
-	// (four named registers: as an array the values went through scratch memory)
-	auto pf_addr = [=](int p, int k) __attribute__((always_inline)) -> const double2* {
-		const int el = min((int)threadIdx.x + k * THREADS, nel - 1);
-		return (const double2*)(ysrc + (size_t)((uint32_t)(b0 + (el >> 3)) * rowbytes + (uint32_t)(p * 128) + (uint32_t)(el & 7) * 16u));
-	};
-	auto pf_put = [=](double* buf, int k, double2 v) __attribute__((always_inline)) {
-		const int el = (int)threadIdx.x + k * THREADS;
-		if (el < nel) *(double2*)(buf + (el >> 3) * kPbLineStride + (el & 7) * 2) = v;
-	};
-	static_assert(NPF == 4, "four staging registers");
-	const size_t bstride = (size_t)a.ids_per_wg * kPbLineStride; // the two buffers (an indexed array of pointers would live in scratch)
-	int cur = 0;
-	if (nown > 0 && grp < a.npanels) {
-		const double2 s0 = *pf_addr(grp, 0), s1 = *pf_addr(grp, 1), s2 = *pf_addr(grp, 2), s3 = *pf_addr(grp, 3);
-		pf_put(pan_s, 0, s0);
-		pf_put(pan_s, 1, s1);
-		pf_put(pan_s, 2, s2);
-		pf_put(pan_s, 3, s3);
-	}
-	__syncthreads();
-	for (int p = grp; p < a.npanels; p += nx) {
-		if (a.pace && p >= grp + 2 * nx) {
-			if (threadIdx.x == 0) {
-				const int* cnt = a.pace + (int64_t)grp * a.npanels + (p - 2 * nx);
-				for (int spin = 0; spin < 8192 && __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nslots; spin++)
-					__builtin_amdgcn_s_sleep(8);
-			}
-			__syncthreads();
-		}
-		const double* pan = pan_s + (size_t)cur * bstride;
-		// the next panel's lines: requested now (HBM / L2 first touch), stored behind the tasks -- the only loads of this kernel that
-		// are not L2 hits or LDS reads, so nothing else waits for them
-		const bool more = p + nx < a.npanels && nown > 0;
-		const int pnext = more ? p + nx : p; // loads unconditional (of a panel that exists)
-		const double2 tn0 = *pf_addr(pnext, 0), tn1 = *pf_addr(pnext, 1), tn2 = *pf_addr(pnext, 2), tn3 = *pf_addr(pnext, 3);
-		{
-			const uint32_t colb = (uint32_t)(p * 128 + c * 16);
-			for (int g = wave; g < ngroups; g += NWC) {
-				const int il = min(g * 8 + sub, nown - 1);
-				const bool valid = g * 8 + sub < nown;
-				const int n4 = __builtin_amdgcn_readfirstlane((int)n4f_s[g]);
-				const int nl = __builtin_amdgcn_readfirstlane((int)nl_s[g]);
-				const int f0 = fo_s[il], l0 = lo_s[il], e0 = fo_s[il + 1];
-				const int nfar = l0 - f0, nloc = e0 - l0;
-				const int own = (int)(line_s[il] / rowbytes - (uint32_t)b0); // buffer row of this lane's block
-				double2 acc = double2 { 0.0, 0.0 };
-				double2 ga[4], gb[4], gc[4];
-				auto issue = [&](int ch, double2* gbuf) __attribute__((always_inline)) {
-#pragma unroll
-					for (int q = 0; q < 4; q++) {
-						const int k = ch * 4 + q;
-						const uint32_t off = k < nfar ? (uint32_t)idx_s[f0 + k] * rowbytes : line_s[il]; // beyond the list: the own line
-						gbuf[q] = *(const double2*)(ysrc + (size_t)(off + colb));
-					}
-				};
-				auto consume = [&](int ch, const double2* gbuf) __attribute__((always_inline)) {
-#pragma unroll
-					for (int q = 0; q < 4; q++) {
-						const int k = ch * 4 + q;
-						const double v = k < nfar ? dict_s[code_s[f0 + k]] : 0.0;
-						acc.x = fma(v, gbuf[q].x, acc.x);
-						acc.y = fma(v, gbuf[q].y, acc.y);
-					}
-				};
-				double2* const zp = (double2*)((char*)a.z + (size_t)line_s[il] + colb);
-				double2 uo = double2 { 0.0, 0.0 }, xo = double2 { 0.0, 0.0 };
-				if (RMW) { // used only behind the gathers: no wait here
-					uo = nt_load2((const double2*)((const char*)a.u_in + (size_t)line_s[il] + colb));
-					if (!a.u_has_beta) xo = nt_load2(zp);
-				}
-				if (n4 > 0) issue(0, ga);
-				if (n4 > 1) issue(1, gb);
-				// couplings inside the workgroup's range: the staged lines, while the gathers above are in flight
-				double2 accl = double2 { 0.0, 0.0 };
-				for (int k0 = 0; k0 < nl; k0 += 4) { // wave-uniform trip count; four independent read chains per round
-					int src[4];
-					double v[4];
-#pragma unroll
-					for (int q = 0; q < 4; q++) {
-						const bool on = k0 + q < nloc;
-						src[q] = on ? (int)idx_s[l0 + k0 + q] : own;
-						v[q] = on ? dict_s[code_s[l0 + k0 + q]] : 0.0;
-					}
-					double2 t[4];
-#pragma unroll
-					for (int q = 0; q < 4; q++) t[q] = *(const double2*)(pan + src[q] * kPbLineStride + c * 2);
-#pragma unroll
-					for (int q = 0; q < 4; q++) {
-						accl.x = fma(v[q], t[q].x, accl.x);
-						accl.y = fma(v[q], t[q].y, accl.y);
-					}
-				}
-				for (int ch = 0; ch < n4; ch += 3) { // wave-uniform conditions
-					if (ch + 2 < n4) issue(ch + 2, gc);
-					consume(ch, ga);
-					if (ch + 1 < n4) {
-						if (ch + 3 < n4) issue(ch + 3, ga);
-						consume(ch + 1, gb);
-					}
-					if (ch + 2 < n4) {
-						if (ch + 4 < n4) issue(ch + 4, gb);
-						consume(ch + 2, gc);
-					}
-				}
-				const double2 yown = *(const double2*)(pan + own * kPbLineStride + c * 2);
-				if (valid) {
-					acc.x = fma(alpha, acc.x + accl.x, fma(beta, xo.x, uo.x));
-					acc.y = fma(alpha, acc.y + accl.y, fma(beta, xo.y, uo.y));
-					__builtin_nontemporal_store(acc.x, &zp->x);
-					__builtin_nontemporal_store(acc.y, &zp->y);
-					dot += yown.x * acc.x + yown.y * acc.y;
-					if (RMW) {
-						const double dx = acc.x - sh * yown.x, dy = acc.y - sh * yown.y;
-						nrm += dx * dx + dy * dy;
-					}
-				}
-			}
-		}
-		if (more) {
-			double* nb = pan_s + (size_t)(cur ^ 1) * bstride;
-			pf_put(nb, 0, tn0);
-			pf_put(nb, 1, tn1);
-			pf_put(nb, 2, tn2);
-			pf_put(nb, 3, tn3);
-		}
-		__syncthreads(); // the next panel is staged, this one is consumed
-		cur ^= 1;
-		if (a.pace && threadIdx.x == 0) __hip_atomic_fetch_add(a.pace + (int64_t)grp * a.npanels + p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 	}
 	if (a.partial) {
 		const double r = block_sum_n<THREADS / 64>(dot, smem_d);

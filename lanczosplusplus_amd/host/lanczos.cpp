@@ -72,9 +72,10 @@ static uint64_t launchNonce()
 		for (const char* name : { "TORCHELASTIC_RUN_ID", "MASTER_ADDR", "MASTER_PORT", "SLURM_JOB_ID", "SLURM_STEP_ID" })
 			if (const char* v = getenv(name)) key += std::string(name) + "=" + v + ";";
 	}
+	if (key.empty()) return 0; // no launch identity: shareUniqueId refuses more than one rank
 	uint64_t h = 1469598103934665603ull; // FNV-1a
 	for (unsigned char c : key) h = (h ^ c) * 1099511628211ull;
-	return h;
+	return h ? h : 1;
 }
 
 static void shareUniqueId(char* id, int rank, int world)
@@ -82,6 +83,9 @@ static void shareUniqueId(char* id, int rank, int world)
 	const char* path = getenv("LPP_RCCL_ID_FILE");
 	if (world > 1 && !path) throw std::runtime_error("lanczos -P: set LPP_RCCL_ID_FILE to a path every rank can read\n");
 	const uint64_t nonce = launchNonce();
+	// without a launch identity every launch would share one nonce and a rank could join the id file a crashed run left behind
+	if (world > 1 && nonce == 0)
+		throw std::runtime_error("lanczos -P: no launch identity (set LPP_RCCL_NONCE to a value unique to this launch, or start the ranks through a launcher that exports MASTER_ADDR/MASTER_PORT, TORCHELASTIC_RUN_ID or SLURM_JOB_ID)\n");
 	if (rank == 0) {
 		rcclCheck(lpp_rccl_unique_id(id));
 		if (world == 1) return;

@@ -411,9 +411,6 @@ def test_four_ranks_stream_ordered_collectives_are_recorded_and_correct(worker, 
     joins the engine's stream with events exactly as ProcessGroupNCCL does) and every all-reduce is recorded on the engine's
     stream: the partial that went in and the value the next kernel reads.  _run_ranks fails on any record that is not the
     sum of the partials or differs between ranks; energies and coefficients are checked as in the host-staged runs."""
-    if worker == "pb_tx" and not os.environ.get("LPP_SLOW_TESTS"):
-        pytest.skip("92 s: the stream-ordered run of the product-basis exchange worker runs with LPP_SLOW_TESTS=1 (its host-staged runs and the "
-                    "stream-ordered run of the other worker are in the default suite)")
     monkeypatch.setenv("LPP_GLOO_STREAM_ORDERED", "1")
     world = 4
     res = _run_ranks(_worker_uneven if worker == "uneven" else _worker_pb_tx, world, timeout=400)
@@ -552,8 +549,6 @@ def _worker_pb_tx(rank, world, port, q):
 
 @pytest.mark.parametrize("world", [2, 4])
 def test_product_basis_kernels_on_the_transposition_exchange(world):
-    if world == 4 and not os.environ.get("LPP_SLOW_TESTS"):
-        pytest.skip("four ranks of this worker run with LPP_SLOW_TESTS=1 (two ranks, and four ranks on the 4x5 lattice, by default)")
     res = _run_ranks(_worker_pb_tx, world, timeout=400)
     for r in range(world):
         assert "error" not in res[r], res[r].get("error")

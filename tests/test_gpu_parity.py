@@ -749,7 +749,7 @@ PB_CASES = {
 }
 
 
-@pytest.mark.parametrize("form", ["window", "natural", "pieces", "wide", "half", "down2", "ws"])
+@pytest.mark.parametrize("form", ["window", "natural", "pieces", "wide"])
 @pytest.mark.parametrize("case", sorted(PB_CASES))
 def test_product_basis_layout(case, form, monkeypatch):
     """Device assembly of Hubbard straight into the product-basis layout (T, C, diagonal codes; lpp_pb_kernels.h): the CSR it
@@ -759,28 +759,14 @@ def test_product_basis_layout(case, form, monkeypatch):
     sectors) forced onto the same small matrices -- rows cut into pieces of 256 positions (entries that leave a piece are read
     from memory), couplings over 3 parts of the source range with 64-bit addresses; "wide": pieces of 320 positions and the
     whole-panel coupling kernel with 64-bit addresses (what BASELINE config 5's sectors take on one GPU)."""
-    # suite time (the driver runs `pytest -m gpu` once per round): the full cross product runs with LPP_SLOW_TESTS=1; by default every form
-    # runs on chain_L12, the shipped forms "window" on all cases and "natural" / "pieces" / "wide" also on two_hoppings and disorder
-    if not os.environ.get("LPP_SLOW_TESTS"):
-        if form in ("half", "down2", "ws") and case != "chain_L12":
-            pytest.skip("opt-in experiment forms run on one case by default (LPP_SLOW_TESTS=1: all)")
-        if form in ("natural", "pieces", "wide") and case not in ("chain_L12", "two_hoppings", "disorder"):
-            pytest.skip("this form runs on three of the cases by default (LPP_SLOW_TESTS=1: all)")
-        if case == "ladder_2x6":
-            pytest.skip("the ladder runs with LPP_SLOW_TESTS=1 (the chains, the two-hopping model and the disordered ring by default)")
     L, nup, ndown, hop, U, V = PB_CASES[case]()
     monkeypatch.setenv("LPP_PRODUCT_LAYOUT", "1")  # these matrices are below the size from which the layout is chosen by itself
     if form == "pieces":
         monkeypatch.setenv("LPP_PB_PIECE_ROWS", "256")
         monkeypatch.setenv("LPP_PB_PARTS", "3")
-    if form == "down2":
-        monkeypatch.setenv("LPP_PB_DOWN2", "1")  # coupling kernel with the workgroup's own lines of a panel staged in LDS (opt-in experiment)
     if form == "natural":
         monkeypatch.setenv("LPP_PB_PERM", "0")  # positions of a block in the basis order ("window": stored in the order of their list lengths)
-    if form == "ws":
-        monkeypatch.setenv("LPP_PB_WS", "1")  # chained step with the next row staged by loader waves (k_pb_up_ws, opt-in experiment)
-    if form in ("wide", "half"):
-        monkeypatch.setenv("LPP_PB_HALF", "1" if form == "half" else "0")  # coupling panels of 8 positions (64-byte half lines) / of 16
+    if form == "wide":
         monkeypatch.setenv("LPP_PB_PIECE_ROWS", "320")
         monkeypatch.setenv("LPP_PB_WIDE", "1")
         monkeypatch.setenv("LPP_PB_BIG2", "0")  # one block per workgroup (k_pb_up_big); "pieces" runs two per workgroup (k_pb_up_big2)
@@ -794,9 +780,9 @@ def test_product_basis_layout(case, form, monkeypatch):
         e.assemble_hubbard(L, nup, ndown, hop, U, V)
         lay = e.layout()
         assert lay["kernel"] == 4 and lay["nnz"] == A.nnz and lay["resident_bytes"] < (0.12 if case == "disorder" else 0.05) * 12 * A.nnz
-        assert (lay["diagonal_plain"], lay["diagonal_codes"], lay["chained_step"]) == ((1, 0, 0) if case == "disorder" else (0, 1, 1 if form in ("window", "natural", "down2", "ws") else 0))  # the chained step: any number of hopping values (two_hoppings: the any-number-of-groups path)
-        assert (lay["pieces"], lay["coupling_parts"]) == {"window": (1, 1), "pieces": (4, 3), "natural": (1, 1), "wide": (3, 1), "half": (3, 1), "down2": (1, 1), "ws": (1, 1)}[form]
-        assert lay["rows_by_list_length"] == (1 if form in ("window", "down2", "ws") else 0)  # one-window form only; internal: every check below is in the basis order
+        assert (lay["diagonal_plain"], lay["diagonal_codes"], lay["chained_step"]) == ((1, 0, 0) if case == "disorder" else (0, 1, 1 if form in ("window", "natural") else 0))  # the chained step: any number of hopping values (two_hoppings: the any-number-of-groups path)
+        assert (lay["pieces"], lay["coupling_parts"]) == {"window": (1, 1), "pieces": (4, 3), "natural": (1, 1), "wide": (3, 1)}[form]
+        assert lay["rows_by_list_length"] == (1 if form == "window" else 0)  # one-window form only; internal: every check below is in the basis order
         st = e.stats()
         assert (st["nrows"], st["nnz"]) == (A.nrows, A.nnz)
         rp, ci, va = e.get_csr()
