@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define LPP_ABI_VERSION 3 /* 2: lpp_layout.stream_bytes, lpp_pb_pack_template(bank_ways), set_solver / stream / _ext / _spin entry points; 3: lpp_layout.pieces / coupling_parts / diagonal_plain / chained_step / split_panel, lpp_stats.reortho_* */
+#define LPP_ABI_VERSION 4 /* 4: lpp_layout.segments, lpp_pb_seg_plan_stats; 2: lpp_layout.stream_bytes, lpp_pb_pack_template(bank_ways), set_solver / stream / _ext / _spin entry points; 3: lpp_layout.pieces / coupling_parts / diagonal_plain / chained_step / split_panel, lpp_stats.reortho_* */
 
 typedef int32_t lpp_status;
 enum {
@@ -111,6 +111,10 @@ typedef struct lpp_layout {
 	int32_t rows_by_list_length; /* product-basis layout (was `reserved`, always 0, until round 3): 1 = inside a block the positions are stored in the
 	                                order of their in-block list lengths, not in the basis order (slices of rows with equal lists: fewer template
 	                                slots).  Internal: vectors, lpp_engine_get_csr and the start vector keep the basis order at the boundary */
+	int32_t segments; /* product-basis layout, rows beyond one LDS window (ABI 4): > 0 = the in-block matrix is held decomposed by the high sites of
+	                     the species' basis word into that many segments (k_pb_up_seg; positions stored segment by segment, longest first -- internal
+	                     as above); 0 = one per-position template for the whole row */
+	int32_t reserved2;
 } lpp_layout;
 
 /* Communicator for the 1-D row-partitioned multi-GPU path.  The engine never
@@ -320,6 +324,15 @@ lpp_status lpp_tridiag_lowest(int32_t n, const double* d, const double* e, int32
 lpp_status lpp_pb_pack_template(int64_t rows, int64_t pitch, const int64_t* rowptr, const int32_t* colind, const double* values,
                                 int32_t* ngroups, double* group_values, int32_t* slices, int64_t* nwords, int32_t* off, uint16_t* len,
                                 uint32_t* words, int64_t* entries, int64_t* slots, int32_t bank_ways);
+
+/* Product-basis layout, rows beyond one LDS window, host part (ABI 4; exposed for the CPU test-suite): reads the species' basis (L sites,
+ * n particles, ascending words: BasisOneSpin.h:53-61) and the hopping amplitudes off the in-block matrix `rows` x `rows` (CSR, diagonal
+ * entries skipped; HubbardHelper.h:191-243 for one species), decomposes it by the high sites of the basis word (csrc/lpp_pbseg.h), expands
+ * the packed description again and compares it with the matrix entry by entry, bit by bit.  wcap: longest segment (64..8128).
+ * out[0] = 1 if the decomposition applies and reproduces the matrix, then out[1..13] = L, n, high sites, segments, items, item types,
+ * longest item, bytes shared by class, bytes per segment, low-low entries of the item types, their lane-slots, value groups, window stride;
+ * perm (rows int32, may be NULL): stored position -> basis index. */
+lpp_status lpp_pb_seg_plan_stats(int64_t rows, const int64_t* rowptr, const int32_t* colind, const double* values, int32_t wcap, int64_t* out, int32_t* perm);
 
 #ifdef __cplusplus
 }

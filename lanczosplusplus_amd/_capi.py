@@ -7,9 +7,10 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "liblpp_engine.so")
+# LPP_ENGINE_LIB: another build of the same library (scripts/experiments build their variants into a scratch directory, never over this one)
+LIB_PATH = os.environ.get("LPP_ENGINE_LIB") or os.path.join(_HERE, "csrc", "liblpp_engine.so")
 
-LPP_ABI_VERSION = 3
+LPP_ABI_VERSION = 4
 LPP_OK, LPP_ERR_INVALID, LPP_ERR_HIP, LPP_ERR_NOMEM, LPP_ERR_NOCONV, LPP_ERR_STATE, LPP_ERR_COMM = range(7)
 LPP_F64, LPP_C128 = 0, 1
 LPP_SPMV_AUTO, LPP_SPMV_ROWGROUP, LPP_SPMV_SLICED, LPP_SPMV_WINDOW = 0, 1, 2, 3
@@ -48,7 +49,7 @@ class Layout(C.Structure):
                 ("nnz", C.c_int64), ("per_row_entries", C.c_int64), ("shared_entries", C.c_int64),
                 ("rows_per_block", C.c_int64), ("resident_bytes", C.c_int64), ("stream_bytes", C.c_int64),
                 ("pieces", C.c_int32), ("coupling_parts", C.c_int32), ("diagonal_plain", C.c_int32), ("chained_step", C.c_int32),
-                ("split_panel", C.c_int32), ("rows_by_list_length", C.c_int32)]
+                ("split_panel", C.c_int32), ("rows_by_list_length", C.c_int32), ("segments", C.c_int32), ("reserved2", C.c_int32)]
 
     def as_dict(self):
         return {name: getattr(self, name) for name, _ in self._fields_}
@@ -108,6 +109,7 @@ SYMBOLS = {
     "lpp_tridiag_lowest": (C.c_int32, [C.c_int32, _P, _P, C.c_int32, _P, _P]),
     "lpp_pb_pack_template": (C.c_int32, [C.c_int64, C.c_int64, _P, _P, _P, C.POINTER(C.c_int32), _P, C.POINTER(C.c_int32),
                                          C.POINTER(C.c_int64), _P, _P, _P, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int32]),
+    "lpp_pb_seg_plan_stats": (C.c_int32, [C.c_int64, _P, _P, _P, C.c_int32, _P, _P]),
 }
 
 _lib = None

@@ -1402,15 +1402,16 @@ lpp_status lpp_engine_get_layout(lpp_engine* e, int32_t which, lpp_layout* out)
 		L.pieces = B.npieces;
 		L.coupling_parts = B.parts ? B.nparts : 1;
 		L.chained_step = pb_chain_ok(e) ? 1 : 0;
-		L.rows_by_list_length = e->pb.perm ? 1 : 0;
+		L.rows_by_list_length = e->pb.perm && !B.seg ? 1 : 0;
+		L.segments = B.seg ? B.seg_nsegs : 0;
 		L.diagonal_plain = B.dval ? 1 : 0;
 		const size_t small = sizeof(uint32_t) * (size_t)B.f_words + sizeof(uint32_t) * (size_t)B.tw_words + (sizeof(int32_t) + sizeof(uint16_t)) * (size_t)B.spb * (size_t)B.G
-		    + (size_t)B.t_entries * 12 + sizeof(int64_t) * (size_t)(B.n_up + 1) + (size_t)B.c_nnz * 5 + sizeof(int64_t) * 2 * (size_t)(B.n_blk + 1) + 256 * sizeof(double);
+		    + (size_t)B.seg_bytes + (size_t)B.t_entries * 12 + sizeof(int64_t) * (size_t)(B.n_up + 1) + (size_t)B.c_nnz * 5 + sizeof(int64_t) * 2 * (size_t)(B.n_blk + 1) + 256 * sizeof(double);
 		// one diagonal code per row this rank holds, or one plain double when the diagonal has more than 256 distinct values
 		const size_t codes = (size_t)(B.tx ? B.nblk_loc : B.n_blk) * (size_t)B.pitch * (B.dval ? 9 : 1);
 		L.resident_bytes = (int64_t)(small + codes);
 		// per product: one diagonal code per row; the template words and the couplings are re-read from L2 / LDS
-		L.stream_bytes = (int64_t)(codes + sizeof(uint32_t) * (size_t)(B.tw_words + B.f_words) + (size_t)B.c_nnz * 5);
+		L.stream_bytes = (int64_t)(codes + sizeof(uint32_t) * (size_t)(B.tw_words + B.f_words) + (size_t)B.seg_bytes + (size_t)B.c_nnz * 5);
 		*out = L;
 		return LPP_OK;
 	}

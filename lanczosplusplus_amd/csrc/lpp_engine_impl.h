@@ -160,6 +160,18 @@ struct PbState {
 	// the start vector, the diagonal's assembly, lpp_engine_get_csr); every kernel of a step is position-blind.
 	int32_t* perm = nullptr;
 	int32_t* inv = nullptr;
+	// rows beyond one LDS window, segmented form (lpp_pbseg.h, k_pb_up_seg): T decomposed by the high sites of the species' basis word;
+	// the stored order of the positions (perm / inv) is then the segments by length
+	bool seg = false;
+	int seg_nitems = 0, seg_nsegs = 0, seg_ws = 0, seg_wmax = 0, seg_nc = 0, seg_nh = 0, seg_pre0 = 4;
+	int64_t seg_bytes = 0; // description of T held on the device
+	void* seg_items = nullptr;
+	void* seg_segs = nullptr;
+	void* seg_cross = nullptr;
+	void* seg_hh = nullptr;
+	void* seg_slices = nullptr;
+	uint32_t* seg_tw = nullptr;
+	uint32_t* seg_xw = nullptr;
 	// complex hoppings: the vectors are complex, a block holds 2 n_c real positions (re, im interleaved; n_up, pitch count doubles), T is
 	// stored REALIFIED (row 2i: (2c, Re t), (2c+1, -Im t); row 2i+1: (2c, Im t), (2c+1, Re t)) so that k_pb_up is the real kernel, the couplings
 	// keep complex values (cdict, k_pb_down<CPLX>), the diagonal code of a position is stored for both of its doubles.  t_ptr / t_col / t_val

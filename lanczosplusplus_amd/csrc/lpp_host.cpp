@@ -241,8 +241,6 @@ lpp_status lpp_tridiag_lowest(int32_t n, const double* d, const double* e, int32
 // ---------------------------------------------------------------------------------------------
 namespace lpp {
 
-namespace {
-
 // Proper edge colouring of a bipartite multigraph (left: up to 32 rows, right: nright bank slots) with D = max degree colours
 // (Koenig's theorem; alternating-path recolouring).  edges[k] = (row, right vertex); returns the colour of every edge.
 int edge_colour(const std::vector<std::pair<int, int>>& edges, int nright, std::vector<int>& colour)
@@ -294,8 +292,6 @@ int edge_colour(const std::vector<std::pair<int, int>>& edges, int nright, std::
 	}
 	return D;
 }
-
-} // namespace
 
 lpp_status pb_pack_template(int64_t rows, int64_t pitch, const int64_t* rp, const int32_t* ci, const double* va, PbTemplate& out, int bank_ways, int64_t window)
 {

@@ -5,6 +5,7 @@
 #pragma once
 #include <stdint.h>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/lpp_engine.h"
@@ -65,5 +66,41 @@ struct PbTemplate {
 // window > 0: pieces of `window` positions (see PbTemplate::W); the zero slots then sit at window index `window`.
 lpp_status pb_pack_template(int64_t rows, int64_t pitch, const int64_t* rp, const int32_t* ci, const double* va, PbTemplate& out, int bank_ways = 2,
                             int64_t window = 0);
+
+// Proper edge colouring of a bipartite multigraph (left: up to 32 rows, right: nright bank slots) with D = max degree colours;
+// edges[k] = (row, right vertex); returns D and the colour of every edge.
+int edge_colour(const std::vector<std::pair<int, int>>& edges, int nright, std::vector<int>& colour);
+
+} // namespace lpp
+
+// ---------------------------------------------------------------------------------------------
+// Segmented in-block form for rows beyond one LDS window (lpp_pbseg.h): the host-side plan.
+// ---------------------------------------------------------------------------------------------
+#include "lpp_pbseg.h"
+namespace lpp {
+
+struct SegPlan {
+	int L = 0, n = 0, s = 0; // sites, particles of the species; high sites
+	int64_t n_up = 0;
+	int G = 1; // value groups of the low-low hops (1 or 2)
+	double gval[kPbGroupsMax] = { 0 };
+	std::vector<int32_t> perm, inv; // stored position -> basis index and back
+	std::vector<SegInst> segs;
+	std::vector<SegCross> cross;
+	std::vector<SegHh> hh;
+	std::vector<SegItem> items;
+	std::vector<SegSlice> slices;
+	std::vector<uint32_t> words; // in-window lists, as PbTemplate::words
+	std::vector<uint32_t> xwords; // cross tables: two 16-bit words (two hops of one high site) per position
+	int wmax = 0, zmax = 0, ws = 0, ntypes = 0; // longest item, largest zero_at, window stride (elements), item types
+	int max_cross = 0, max_hh = 0; // most cross / high-high hops of a segment
+	int nc_pad = 0, nh_pad = 0; // entries per segment in `cross` / `hh` (padded with value 0.0): the kernel instance's NC / NH
+	int pre0 = 4, pre1 = 4; // list chunks of value group 0 / 1 the kernel requests ahead (k_pb_up_seg's P0 / P1)
+	int64_t entries = 0, entries_lo = 0, slots_lo = 0; // rows verified; low-low entries / lane-slots of the item types
+};
+
+// T: n_up x n_up CSR (diagonal entries skipped).  *ok = false: T is not the hopping matrix of one species in the ascending-word basis,
+// or something exceeds the kernel's limits -- the caller keeps the per-position template.  wcap: longest segment / item (<= 8128).
+lpp_status pb_seg_plan(int64_t n_up, const int64_t* rp, const int32_t* ci, const double* va, int wcap, SegPlan& out, bool* ok);
 
 } // namespace lpp

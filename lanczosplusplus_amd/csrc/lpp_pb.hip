@@ -9,6 +9,7 @@
 
 #include "lpp_engine_impl.h"
 #include "lpp_pbig_kernels.h"
+#include "lpp_pbseg_kernels.h"
 
 using namespace lpp;
 
@@ -21,7 +22,8 @@ void free_pb(lpp_engine* e)
 	PbState& B = e->pb;
 	for (void* p : { (void*)B.tw, (void*)B.tw_off, (void*)B.tw_len, (void*)B.t_ptr, (void*)B.t_col, (void*)B.t_val, (void*)B.c_ptr, (void*)B.c_col,
 	                 (void*)B.c_code, (void*)B.order, (void*)B.pace, (void*)B.z, (void*)B.u, (void*)B.xy, (void*)B.dict, (void*)B.dcode, (void*)B.blockbase,
-	                 (void*)B.fw, (void*)B.f_off, (void*)B.f_len, (void*)B.c_pstart, (void*)B.dval, (void*)B.perm, (void*)B.inv, (void*)B.cdict })
+	                 (void*)B.fw, (void*)B.f_off, (void*)B.f_len, (void*)B.c_pstart, (void*)B.dval, (void*)B.perm, (void*)B.inv, (void*)B.cdict,
+	                 B.seg_items, B.seg_segs, B.seg_cross, B.seg_hh, B.seg_slices, (void*)B.seg_tw, (void*)B.seg_xw })
 		if (p) (void)hipFree(p);
 	B = PbState();
 	e->pitch = e->pitch_rows = e->pitch_blocks = 0;
@@ -186,11 +188,34 @@ lpp_status pb_build(lpp_engine* e, int64_t n_up, int64_t n_blk, const int64_t* t
 			}
 		}
 	}
+	// Rows beyond one LDS window: T decomposed by the high sites of the species' basis word (lpp_pbseg.h) when T is the hopping matrix of
+	// one species in the ascending-word basis -- read off T itself and verified against it entry by entry (pb_seg_plan); otherwise the
+	// per-position template of lpp_pbig_kernels.h.  One GPU or the transposition exchange alike: every kernel of a step is position-blind.
+	SegPlan SP;
+	bool seg = false;
+	if (W > 0 && !cx && big2 && !(getenv("LPP_PB_SEG") && atoi(getenv("LPP_PB_SEG")) == 0)) {
+		const int wcap = (int)std::min<int64_t>(wmax, 8128);
+		lpp_status rs = pb_seg_plan(n_up, t_rp, t_ci, t_va, wcap, SP, &seg);
+		if (rs != LPP_OK) return rs;
+		if (seg && pb_seg_lds_bytes(SP.ws, SP.wmax) > (size_t)160 * 1024 - 64) seg = false;
+		if (getenv("LPP_VERBOSE"))
+			fprintf(stderr, "lpp: segmented in-block form %s (L = %d, n = %d, %d high sites, %zu segments, %zu items of <= %d positions, %d types, %.2f MB)\n", seg ? "taken" : "does not apply",
+			        SP.L, SP.n, SP.s, SP.segs.size(), SP.items.size(), SP.wmax, SP.ntypes, (SP.words.size() * 4 + SP.xwords.size() * 4) / 1048576.0);
+	}
 	const bool permuted = !perm.empty();
 	if (getenv("LPP_VERBOSE")) fprintf(stderr, "lpp: product-basis rows %s (pieces %d, exchange %d, blocks %lld of %lld, %lld positions)\n", permuted ? "stored by list length" : "in basis order", W > 0 ? 1 : 0, tx ? 1 : 0, (long long)nblk_loc, (long long)n_blk, (long long)n_up);
-	lpp_status rc = permuted ? pb_pack_template(n_up, pitch, p_rp.data(), p_ci.data(), p_va.data(), T, ways, W) : pb_pack_template(n_up, pitch, t_rp, t_ci, t_va, T, ways, W);
+	lpp_status rc = LPP_OK;
+	if (seg) { // the per-position template is not built at all
+		T.G = SP.G;
+		for (int g = 0; g < kPbGroupsMax; g++) T.gval[g] = SP.gval[g];
+		T.spb = (int)((n_up + 63) / 64);
+		T.entries = SP.entries_lo;
+		T.slots = SP.slots_lo;
+		T.W = W;
+	} else
+		rc = permuted ? pb_pack_template(n_up, pitch, p_rp.data(), p_ci.data(), p_va.data(), T, ways, W) : pb_pack_template(n_up, pitch, t_rp, t_ci, t_va, T, ways, W);
 	if (rc != LPP_OK) return rc;
-	if (getenv("LPP_VERBOSE")) { // list lengths of the packed template: chunks of 4 slots per (slice, group), far slots per slice
+	if (getenv("LPP_VERBOSE") && !seg) { // list lengths of the packed template: chunks of 4 slots per (slice, group), far slots per slice
 		int hist[kPbGroupsMax][9] = { { 0 } }, fh[9] = { 0 };
 		for (int j = 0; j < T.spb; j++) {
 			for (int g = 0; g < T.G; g++) hist[g][std::min<int>(T.len[(size_t)j * T.G + g], 8)]++;
@@ -202,6 +227,26 @@ lpp_status pb_build(lpp_engine* e, int64_t n_up, int64_t n_blk, const int64_t* t
 	if (permuted) {
 		if ((rc = to_device(&B.perm, perm, st)) != LPP_OK) return rc;
 		if ((rc = to_device(&B.inv, inv, st)) != LPP_OK) return rc;
+	}
+	if (seg) {
+		if ((rc = to_device(&B.perm, SP.perm, st)) != LPP_OK) return rc;
+		if ((rc = to_device(&B.inv, SP.inv, st)) != LPP_OK) return rc;
+		if ((rc = to_device((SegItem**)&B.seg_items, SP.items, st)) != LPP_OK) return rc;
+		if ((rc = to_device((SegInst**)&B.seg_segs, SP.segs, st)) != LPP_OK) return rc;
+		if ((rc = to_device((SegCross**)&B.seg_cross, SP.cross, st)) != LPP_OK) return rc;
+		if ((rc = to_device((SegHh**)&B.seg_hh, SP.hh, st)) != LPP_OK) return rc;
+		if ((rc = to_device((SegSlice**)&B.seg_slices, SP.slices, st)) != LPP_OK) return rc;
+		if ((rc = to_device(&B.seg_tw, SP.words, st)) != LPP_OK) return rc;
+		if ((rc = to_device(&B.seg_xw, SP.xwords, st)) != LPP_OK) return rc;
+		B.seg = true;
+		B.seg_nitems = (int)SP.items.size();
+		B.seg_nsegs = (int)SP.segs.size();
+		B.seg_ws = SP.ws;
+		B.seg_wmax = SP.wmax;
+		B.seg_nc = SP.nc_pad;
+		B.seg_nh = SP.nh_pad;
+		B.seg_pre0 = SP.pre0;
+		B.seg_bytes = (int64_t)(SP.words.size() * 4 + SP.xwords.size() * 4 + SP.slices.size() * 16 + SP.cross.size() * 32 + SP.hh.size() * 16 + SP.segs.size() * 32 + SP.items.size() * 32);
 	}
 	B.n_up = n_up;
 	B.n_blk = n_blk;
@@ -220,7 +265,7 @@ lpp_status pb_build(lpp_engine* e, int64_t n_up, int64_t n_blk, const int64_t* t
 	if ((rc = to_device(&B.tw_off, T.off, st)) != LPP_OK) return rc;
 	if ((rc = to_device(&B.tw_len, T.len, st)) != LPP_OK) return rc;
 	B.pre0 = kPbPre;
-	if (T.G == 2) {
+	if (T.G == 2 && !seg) {
 		// look-ahead split of the in-block kernels: the depth pair (3,5), (4,4) or (5,3) that leaves the fewest chunks beyond it
 		int64_t best = -1;
 		for (int p0 = 3; p0 <= 5; p0++) {
@@ -236,8 +281,8 @@ lpp_status pb_build(lpp_engine* e, int64_t n_up, int64_t n_blk, const int64_t* t
 	B.big = W > 0;
 	B.big2 = B.big && big2 && (T.G == 1 || T.G == 2) && pb_big2_lds_bytes((int)W) <= (size_t)160 * 1024 - 64 && (W + kPbZeroSlots) * 8 < 65536;
 	B.W = (int)W;
-	B.npieces = W > 0 ? (int)((n_up + W - 1) / W) : 1;
-	if (B.big) {
+	B.npieces = seg ? B.seg_nitems : W > 0 ? (int)((n_up + W - 1) / W) : 1;
+	if (B.big && !seg) {
 		B.f_words = (int64_t)T.fwords.size();
 		B.f_entries = T.far_entries;
 		if ((rc = to_device(&B.fw, T.fwords, st)) != LPP_OK) return rc;
@@ -461,7 +506,7 @@ template <bool DOT> static void launch_up(const PbState& B, const PbUpArgs& u, i
 static int big_grid(const lpp_engine* e, int64_t cnt)
 {
 	const PbState& B = e->pb;
-	if (B.big2) { // one 1024-thread workgroup per CU, items = (pair of blocks of one XCD, piece)
+	if (B.big2 || B.seg) { // one workgroup per CU, items = (pair of blocks of one XCD, piece)
 		int nb = (int)std::max<int64_t>(1, std::min<int64_t>(((cnt + 1) / 2) * B.npieces, (int64_t)e->num_cus));
 		if (nb >= 8) nb &= ~7;
 		return nb;
@@ -498,6 +543,55 @@ static int launch_up_big(lpp_engine* e, const double* y, double* u, const uint8_
 	a.partial = partial;
 	a.sc = sc;
 	const int nb = big_grid(e, cnt);
+	if (B.seg) {
+		PbSegArgs g;
+		g.items = (const SegItem*)B.seg_items;
+		g.nitems = B.seg_nitems;
+		g.cross = (const SegCross*)B.seg_cross;
+		g.hh = (const SegHh*)B.seg_hh;
+		g.slices = (const SegSlice*)B.seg_slices;
+		g.tw = B.seg_tw;
+		g.xw = B.seg_xw;
+		g.G = B.G;
+		g.gval[0] = B.gval[0];
+		g.gval[1] = B.G > 1 ? B.gval[1] : 0.0;
+		g.dict = B.dict;
+		g.dcode = dcode;
+		g.n_up = B.n_up;
+		g.pitch = B.pitch;
+		g.n_blk = cnt;
+		g.ws = B.seg_ws;
+		g.wmax = B.seg_wmax;
+		g.y = y;
+		g.u = u;
+		g.partial = partial;
+		g.sc = sc;
+		const size_t lds = pb_seg_lds_bytes(B.seg_ws, B.seg_wmax);
+#define LPP_PB_SEG(DOT_, GT_, P0_, NC_, NH_)                                                                            \
+	do {                                                                                                              \
+		(void)hipFuncSetAttribute((const void*)k_pb_up_seg<DOT_, GT_, P0_, 4, NC_, NH_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+		k_pb_up_seg<DOT_, GT_, P0_, 4, NC_, NH_><<<nb, kSegThreads, lds, st>>>(g);                                      \
+	} while (0)
+#define LPP_PB_SEG_N(DOT_, GT_, P0_)                                                                                   \
+	do {                                                                                                              \
+		if (B.seg_nc == 2) LPP_PB_SEG(DOT_, GT_, P0_, 2, 2);                                                            \
+		else if (B.seg_nc == 5) LPP_PB_SEG(DOT_, GT_, P0_, 5, 4);                                                       \
+		else LPP_PB_SEG(DOT_, GT_, P0_, 6, 8);                                                                          \
+	} while (0)
+		// cross / high-high hops per segment: the instance the plan padded its lists for; chunks of value group 0 requested ahead: its choice
+		if (partial) {
+			if (B.G == 1) LPP_PB_SEG_N(true, 1, 4);
+			else if (B.seg_pre0 == 2) LPP_PB_SEG_N(true, 2, 2);
+			else LPP_PB_SEG_N(true, 2, 4);
+		} else {
+			if (B.G == 1) LPP_PB_SEG_N(false, 1, 4);
+			else if (B.seg_pre0 == 2) LPP_PB_SEG_N(false, 2, 2);
+			else LPP_PB_SEG_N(false, 2, 4);
+		}
+#undef LPP_PB_SEG_N
+#undef LPP_PB_SEG
+		return partial ? nb : 0;
+	}
 	if (B.big2) {
 		const size_t lds2 = pb_big2_lds_bytes(B.W);
 #define LPP_PB_BIG2(DOT_, GT_, PRE_)                                                                                   \

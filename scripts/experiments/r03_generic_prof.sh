@@ -1,7 +1,7 @@
 #!/bin/bash
 R=$GRAFT_REPO_ROOT; cd /tmp; export TMPDIR=/tmp
 O=$R/gpurun_out/prof_gen; rm -rf $O; mkdir -p $O
-CMD="python3 $R/scripts/experiments/r03_generic_leg.py"
+CMD="python3 $R/scripts/experiments/r03_generic_leg.py $NAME"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- $CMD > $O/trace.log 2>&1
 timeout -k 10 300 rocprofv3 --pmc TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum TCC_HIT_sum --output-format csv -d $O/ea -- $CMD > $O/ea.log 2>&1
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/wr -- $CMD > $O/wr.log 2>&1

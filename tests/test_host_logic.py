@@ -262,3 +262,63 @@ def test_bench_workloads_are_well_formed():
         assert name in bench.WORKLOADS
         g = json.load(open(os.path.join(root, "tests", "golden", fixture)))
         assert len(g["a"]) == len(g["b"]) >= 30 and "e0" in g, fixture
+
+
+def test_segmented_in_block_form_reproduces_the_hopping_matrix():
+    """lpp_pb_seg_plan_stats (host part of k_pb_up_seg, csrc/lpp_pbseg.h): the in-block matrix of one species -- the oracle's restatement of
+    HubbardHelper.h:191-243 in the basis of BasisOneSpin.h:53-61 -- is read as (L sites, n particles, hopping amplitudes), cut into
+    segments by the high sites of the basis word and packed as low-low lists per item type, cross tables per class and high-high pairs
+    per segment; the library expands that description again and compares it with the matrix entry by entry (out[0] == 1).  BASELINE
+    config 5's species (4x5 lattice, 7 and 6 particles) at full size; matrices that are not of that form are refused, not mangled."""
+    import ctypes as C
+    import oracle
+    from helpers import chain, square
+    from math import comb
+    L = _capi.lib()
+
+    def vp(a):
+        return a.ctypes.data_as(C.c_void_p)
+
+    def plan(A, wcap):
+        out = (C.c_int64 * 16)()
+        perm = np.full(A.nrows, -1, np.int32)
+        _capi.check(L.lpp_pb_seg_plan_stats(A.nrows, vp(A.rowptr), vp(A.colind), vp(A.values), wcap, out, vp(perm)))
+        return list(out), perm
+
+    def species(nsites, n, hop):
+        return oracle.hubbard_csr(nsites, n, 0, hop, np.zeros(nsites), np.linspace(-1, 1, nsites))  # T plus a diagonal that is skipped
+
+    # (sites, particles, hoppings, wcap) -> (high sites, segments, items)
+    cases = [((12, 6, chain(12, -1.0, True), 256), (2, 4, 4)), ((12, 5, square(3, 4, -1.0), 320), (2, 4, 4)), ((16, 8, square(4, 4, -1.0), 4096), (2, 4, 4)),
+             ((20, 7, square(4, 5, -1.0), 8128), (5, 32, 14)), ((20, 6, square(4, 5, -1.0), 8128), (4, 16, 7))]
+    for (nsites, n, hop, wcap), (s, nseg, nitems) in cases:
+        A = species(nsites, n, hop)
+        o, perm = plan(A, wcap)
+        assert o[0] == 1 and (o[1], o[2]) == (nsites, n), o
+        assert (o[3], o[4], o[5]) == (s, nseg, nitems) and o[7] <= wcap, o
+        assert sorted(perm.tolist()) == list(range(A.nrows))  # a permutation of the positions
+        # segments by length: the first one is the longest class, in the basis order inside
+        longest = max(comb(nsites - s, n - p) for p in range(min(s, n) + 1) if n - p <= nsites - s)
+        assert np.all(np.diff(perm[:longest]) == 1)
+        if nsites == 20:  # everything that is shared by class stays far below one XCD's 4 MiB L2; what is per segment is a few KB
+            assert o[8] < 2 << 20 and o[9] < 16 << 10, o
+    # not the hopping matrix of one species: refused
+    A = species(12, 6, chain(12, -1.0, True))
+    k = A.rowptr[400] + (0 if A.colind[A.rowptr[400]] != 400 else 1)
+    B = oracle.Csr(A.rowptr.copy(), A.colind.copy(), A.values.copy())
+    B.values[k] *= 1.5  # one entry of one row differs from its bond's amplitude
+    assert plan(B, 256)[0][0] == 0
+    B = oracle.Csr(A.rowptr.copy(), A.colind.copy(), A.values.copy())
+    B.colind[k] = (B.colind[k] + 7) % A.nrows if abs(int(B.colind[k]) - 400) > 8 else B.colind[k] + 9  # an entry that is not one hop
+    assert plan(B, 256)[0][0] == 0
+    # more than two hopping magnitudes among the low sites: the kernel's two value groups do not hold them
+    tt = chain(12, -1.0, False) + 0.5 * (np.diag(np.ones(10), 2) + np.diag(np.ones(10), -2))
+    assert plan(species(12, 5, tt), 256)[0][0] == 0
+    # Heisenberg.h:278-307 for S = 1/2: S+S- moves an up spin without a sign.  On an open chain nothing sits between neighbours, so the
+    # off-diagonal part IS a hopping matrix (hard-core bosons = fermions there) and is taken; on a ladder the leg bonds skip a site,
+    # the fermion sign the form implies is not in the matrix, and it is refused
+    H = oracle.heis_csr(12, 1, 6, chain(12, 1.0), chain(12, 1.0))
+    o, _ = plan(H, 256)
+    assert o[0] == 1 and (o[1], o[2]) == (12, 6)
+    H = oracle.heis_csr(12, 1, 6, square(2, 6, 1.0, False), square(2, 6, 1.0, False))
+    assert plan(H, 256)[0][0] == 0
