@@ -26,7 +26,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured float4 copy is ~6290 GB/s
 METRIC = "Lanczos iterations/sec + SpMV achieved HBM GB/s vs roofline, 1/2/4/8 GPU"
 # environment switches that change the kernel or the layout: a committed PMC traffic figure only applies without them
-LAYOUT_ENV = ("LPP_PB_CHAIN", "LPP_ONTHEFLY_KRON", "LPP_COMPRESS_VALUES", "LPP_SHARED_OFFSETS", "LPP_LOCAL16", "LPP_DIAG_CODES", "LPP_BLOCK_TEMPLATE", "LPP_SPMV_KERNEL",
+LAYOUT_ENV = ("LPP_PB_CHAIN", "LPP_PB_SEG", "LPP_SPLIT_PANEL", "LPP_ONTHEFLY_KRON", "LPP_COMPRESS_VALUES", "LPP_SHARED_OFFSETS", "LPP_LOCAL16", "LPP_DIAG_CODES", "LPP_BLOCK_TEMPLATE", "LPP_SPMV_KERNEL",
               "LPP_WINDOW_ROWS", "LPP_K2_VARIANT", "LPP_KRON_NO_WINDOW", "LPP_KRON_NO_PACK", "LPP_TEMPLATE_PACK", "LPP_PRODUCT_LAYOUT")
 
 
@@ -52,7 +52,11 @@ def committed_traffic(engine, name, world, spmv_kernel):
         return None, "no profiles/traffic.json"
     if tj.get("csrc_hash") != csrc_hash():
         return None, "stale: profiles/traffic.json was measured on other engine sources"
-    if world != 1 or spmv_kernel != 0 or any(os.environ.get(k) is not None for k in LAYOUT_ENV):
+    if engine == "onthefly" and os.environ.get("LPP_ONTHEFLY_KRON") not in (None, "0") and not any(os.environ.get(k) is not None for k in LAYOUT_ENV if k != "LPP_ONTHEFLY_KRON"):
+        engine = "onthefly_kron"  # the fused block-order kernel has a PMC pass of its own (profiles/*_c2otf_kron_*)
+    elif world != 1 or spmv_kernel != 0 or any(os.environ.get(k) is not None for k in LAYOUT_ENV):
+        return None, "not measured for this configuration"
+    if world != 1 or spmv_kernel != 0:
         return None, "not measured for this configuration"
     ent = tj.get(engine, {}).get(name)
     if not ent:

@@ -833,12 +833,15 @@ lpp_status finalize_csr(lpp_engine* e, DevCsr& A, bool allow_drop_plain, int for
 		{
 			int want_dia = A.no_dia ? 0 : 1;
 			if (const char* s2 = getenv("LPP_SHARED_OFFSETS")) want_dia = A.no_dia ? 0 : atoi(s2);
-			// Opt-in (LPP_SPLIT_PANEL=1; bench.py's plain-format leg takes it).  Measured at BASELINE config 2: the two launches take
-			// 8.1 + 9.9 = 17.9 ms against 18.7 ms for the one-kernel form -- the leaving entries' gathers still miss L2 half of the
-			// time (rows are not 128-byte aligned in the general layout: a panel of 16 positions is two lines per source block, and
-			// 42 MB of columns and values stream through the same L2 per panel), so the fabric reads only fall from 102 to 106 -> see
-			// DESIGN.md section 5; the product-basis layout (pitched rows, lists in LDS) is what removes them
-			const bool off = !(getenv("LPP_SPLIT_PANEL") && atoi(getenv("LPP_SPLIT_PANEL")) != 0);
+			// Taken by itself where a panel of 16 positions is ONE 128-byte line of every source block -- basis blocks of a multiple of 16
+			// rows (vectors are not pitched in the general layout) -- from 256 MB per vector on.  Measured on the 4x4 cluster with
+			// 7 + 7 electrons (N_up = 11440 = 16 x 715, 1.3e8 rows, 58.6 GB algorithmic): 6.2 + 7.0 = 13.2 ms and 72 GB of fabric reads in two
+			// launches against 13.9 ms / 85.6 GB in one kernel (4.45 against 4.2 TB/s algorithmic = 0.56 of 8 TB/s; both launches stream at
+			// 5.2-5.75 TB/s: the 12-byte format's ceiling on this matrix).  At BASELINE config 2 (N_up = 12870 = 6 mod 16: two lines per
+			// source block and panel, which no longer fit the L2 beside the entry streams) it loses, 8.1 + 9.9 ms against 18.3-18.7 ms in
+			// one kernel, and is not taken.  LPP_SPLIT_PANEL=0 / 1: never / wherever a basis block is known.
+			bool off = (A.hint_block & 15) != 0 || (size_t)A.nrows * e->esz < ((size_t)256 << 20);
+			if (const char* sp = getenv("LPP_SPLIT_PANEL")) off = atoi(sp) == 0;
 			if (win && !force_mode && !want_dia && !off && A.hint_block > 0 && B == A.hint_block && !A.out_part && A.src_elems == 0) {
 				bool did = false;
 				lpp_status st2 = e->is_complex ? split_panel_t<cplx>(e, A, B, &did) : split_panel_t<double>(e, A, B, &did);

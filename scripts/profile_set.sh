@@ -6,19 +6,21 @@
 #   call 2:  bash scripts/profile_set.sh <tag> lines      re-runs ONLY the bench lines (same sources, traffic.json now matches)
 #   here:    bash scripts/stamp_round.sh <tag> lines      copies the lines over the ones of call 1
 R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=$(pwd)
-T=${1:-r03}; MODE=${2:-counters}
+T=${1:-r04}; MODE=${2:-counters}
 cd $R; mkdir -p gpurun_out
 cfg() { # name, bench args, env
   case $1 in
     c2_stored) echo "" ;;
     c2otf) echo "--engine onthefly" ;;
+    c2otf_kron) echo "--engine onthefly --no-generic-csr" ;; # with LPP_ONTHEFLY_KRON=1: the fused block-order kernel
     c3) echo "--workload heisenberg_chain_L28_sz0_obc" ;;
     c4) echo "--workload tj_4x5_9up9down_complex" ;;
     c1) echo "--workload hubbard_chain_L12_half_filling_U4" ;;
     c5_76) echo "--engine onthefly --workload hubbard_4x5_7up6down_pbc_U4 --no-generic-csr" ;;
   esac
 }
-for c in c2_stored c2otf c3 c4 c1 c5_76; do
+for c in c2_stored c2otf c2otf_kron c3 c4 c1 c5_76; do
+  if [ $c = c2otf_kron ]; then export LPP_ONTHEFLY_KRON=1; else unset LPP_ONTHEFLY_KRON; fi
   if [ $MODE = counters ]; then
     SQ_PASS=$([ $c = c2_stored ] && echo 1) BENCH_ARGS="$(cfg $c)" bash scripts/profile_round.sh ${T}_$c > gpurun_out/ps_$c.out 2>&1 || { tail -5 gpurun_out/ps_$c.out; exit 1; }
   else

@@ -190,3 +190,63 @@ def test_complex_hoppings_take_the_product_basis_layout_free_fermions():
     finally:
         del os.environ["LPP_PB_COMPLEX"]
     assert np.linalg.norm(xp - xg) <= 1e-13 * np.linalg.norm(xg)
+
+
+def test_config2_handed_over_as_a_host_csr_full_size():
+    """The reference's hand-over at BASELINE config 2's size: DefaultSymmetry.h:54-57 -> InternalProductStored.h:116 delivers a HOST CSR.
+    165,636,900 rows / 5,819,376,420 non-zeros = 71 GB of int64 row pointers + int32 columns + f64 values go through lpp_engine_set_csr
+    without a hint: PCIe upload, basis-block detection, T / C / D read off the matrix, every row verified against them bit by bit
+    (pb_from_csr), then the same layout, the same ground-state energy and the same stopping step as the device-assembled matrix, and
+    lpp_engine_get_csr hands the uploaded arrays back.  (The host arrays come from reading a device-assembled matrix back -- itself
+    checked bit for bit against the oracle at the sizes the oracle reaches -- because the oracle's host assembly takes minutes here.)"""
+    import json
+    import os
+    L = 16
+    hop, U = square(4, 4, -1.0, pbc=True), np.full(L, 4.0)
+    with LanczosEngine(max_steps=200) as d:
+        d.assemble_hubbard(L, 8, 8, hop, U)
+        lay_d = d.layout()
+        rp, ci, va = d.get_csr()
+        e_d, _, st_d = d.lanczos(1, want_vectors=False)
+    assert len(rp) - 1 == 165636900 and len(ci) == 5819376420 and rp[-1] == len(ci)
+    assert rp.nbytes + ci.nbytes + va.nbytes > 71e9
+    with LanczosEngine(max_steps=200) as e:
+        e.set_csr(rp, ci, va)
+        lay = e.layout()
+        assert lay["kernel"] == 4 and lay == lay_d, (lay, lay_d)
+        eg, _, st = e.lanczos(1, want_vectors=False)
+        assert st["steps"] == st_d["steps"] and abs(eg[0] - e_d[0]) <= 1e-12 * abs(e_d[0])
+        fix = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "c2_hubbard4x4_U4.json")))
+        assert abs(eg[0] - fix["e0"]) <= 1e-10 * abs(fix["e0"])  # the CPU-oracle run of this configuration
+        # lpp_engine_get_csr from the layout the upload ended in: the bits that went in (row pointers whole, three windows of 2e7 entries)
+        r2, c2, v2 = e.get_csr()
+        assert np.array_equal(r2, rp) and len(c2) == len(ci) and len(v2) == len(va)
+        for lo in (0, len(ci) // 2 - 10 ** 7, len(ci) - 2 * 10 ** 7):
+            w = slice(lo, lo + 2 * 10 ** 7)
+            assert np.array_equal(c2[w], ci[w]) and np.array_equal(v2[w].view(np.uint64), va[w].view(np.uint64))
+
+
+def test_plain_format_matrix_with_line_aligned_blocks_takes_the_split_panel_order(monkeypatch):
+    """Plain 12-byte format (no value dictionary, no shared offsets, no product-basis layout) of the 4x4 cluster with 7 + 7 electrons:
+    N_up = 11440 = 16 x 715, so a panel of 16 positions is one 128-byte line of every source block and the entries that leave the row
+    blocks are taken panel-major by themselves (round 4; 13.2 against 13.9 ms per product).  130,873,600 rows: exact free-fermion
+    energy, the same through the one-kernel form."""
+    for k in ("LPP_PRODUCT_LAYOUT", "LPP_COMPRESS_VALUES", "LPP_SHARED_OFFSETS"):
+        monkeypatch.setenv(k, "0")
+    L = 16
+    hop = square(4, 4, -1.0, pbc=True)
+    lev = np.sort(np.linalg.eigvalsh(hop))
+    exact = 2 * lev[:7].sum()
+    es = []
+    for sp in (None, "0"):
+        if sp is not None:
+            monkeypatch.setenv("LPP_SPLIT_PANEL", sp)
+        with LanczosEngine(max_steps=300, eps=1e-11, save_vectors=0, compress_values=0) as e:
+            e.assemble_hubbard(L, 7, 7, hop, np.zeros(L))
+            lay = e.layout()
+            assert lay["kernel"] == 3 and lay["coded"] == 0 and (lay["split_panel"] >= 1) == (sp is None), lay
+            assert e.stats()["nrows"] == 11440 * 11440
+            eg, _, st = e.lanczos(1, want_vectors=False)
+        assert abs(eg[0] - exact) <= 1e-10 * abs(exact), (eg[0], exact, st["steps"])
+        es.append(eg[0])
+    assert abs(es[0] - es[1]) <= 1e-12 * abs(exact)
