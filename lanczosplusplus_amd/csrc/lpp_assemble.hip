@@ -76,7 +76,7 @@ struct DevBuf {
 };
 
 template <int MODEL, typename T>
-lpp_status run_assembly(lpp_engine* e, AsmParams P, DevCsr& A, int force_mode = 0, int64_t force_block = 0)
+lpp_status run_assembly(lpp_engine* e, AsmParams P, DevCsr& A, int force_mode = 0, int64_t force_block = 0, bool raw = false)
 {
 	hipStream_t st = e->stream;
 	const auto t_asm0 = std::chrono::steady_clock::now();
@@ -112,12 +112,13 @@ lpp_status run_assembly(lpp_engine* e, AsmParams P, DevCsr& A, int force_mode = 
 	HIP_TRY(hipStreamSynchronize(st));
 	if (getenv("LPP_VERBOSE"))
 		fprintf(stderr, "lpp: %-28s %8.1f ms\n", "assembly (count, scan, fill)", 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t_asm0).count());
+	if (raw) return LPP_OK; // the caller decides the layout (lpp_engine_assemble_heisenberg: pb_chain, else finalize_csr)
 	return finalize_csr(e, A, true, force_mode, force_block);
 }
 
-template <int MODEL> lpp_status dispatch(lpp_engine* e, const AsmParams& P, DevCsr& A, int force_mode = 0, int64_t force_block = 0)
+template <int MODEL> lpp_status dispatch(lpp_engine* e, const AsmParams& P, DevCsr& A, int force_mode = 0, int64_t force_block = 0, bool raw = false)
 {
-	return e->is_complex ? run_assembly<MODEL, cplx>(e, P, A, force_mode, force_block) : run_assembly<MODEL, double>(e, P, A, force_mode, force_block);
+	return e->is_complex ? run_assembly<MODEL, cplx>(e, P, A, force_mode, force_block, raw) : run_assembly<MODEL, double>(e, P, A, force_mode, force_block, raw);
 }
 
 lpp_status upload(hipStream_t st, DevBuf& b, const void* src, size_t bytes)
@@ -636,8 +637,31 @@ lpp_status lpp_engine_assemble_heisenberg(lpp_engine* e, int32_t L, int32_t szPl
 	e->bind_scalars(e->scal_own);
 	free_csr(e->A_rem);
 	drop_product(e);
-	st = dispatch<ASM_HEISENBERG>(e, P, e->A_loc);
+	st = dispatch<ASM_HEISENBERG>(e, P, e->A_loc, 0, 0, true);
 	if (st != LPP_OK) return st;
+	// A chain (couplings between neighbours, and between the two ends): S+S- moves an up spin and nothing sits between the two sites, so
+	// the off-diagonal part is the hopping matrix of the up spins -- one block of the product-basis form, the in-block kernel decomposed by
+	// the high sites of the basis word (pb_chain, lpp_pbseg.h).  Amplitudes in the planner's convention: value x (-1)^(up spins between),
+	// which for the bond between the two ends is the constant (-1)^(n - 1).
+	bool chain = L >= 2 && !e->is_complex;
+	std::vector<double> hv((size_t)L * L, 0.0);
+	for (int i = 0; i < L && chain; i++)
+		for (int j = 0; j < L && chain; j++) {
+			if (i == j || jpm[i * L + j] == 0) continue;
+			const int d = i > j ? i - j : j - i;
+			if ((d != 1 && d != L - 1) || std::memcmp(&jpm[i * L + j], &jpm[j * L + i], sizeof(double)) != 0) chain = false;
+			const double v = 0.5 * 1.0 * jpm[i * L + j];
+			hv[(size_t)i * L + j] = (d == L - 1 && d != 1 && ((szPlusConst - 1) & 1)) ? -v : v;
+		}
+	bool as_chain = false;
+	if (chain && szPlusConst >= 1 && szPlusConst < L) {
+		st = pb_chain(e, e->A_loc, L, szPlusConst, hv, &as_chain);
+		if (st != LPP_OK) return st;
+	}
+	if (!as_chain) {
+		st = finalize_csr(e, e->A_loc, true, 0, 0);
+		if (st != LPP_OK) return st;
+	}
 	e->n_local = e->n_global = nrows;
 	e->row_start = 0;
 	e->active = false;

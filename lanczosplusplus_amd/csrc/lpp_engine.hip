@@ -1229,7 +1229,7 @@ lpp_status lpp_engine_get_csr(lpp_engine* e, int32_t which, int64_t* nrows, int6
 {
 	if (!e) return fail(LPP_ERR_INVALID, "lpp_engine_get_csr: null engine");
 	DevCsr& A = which == 0 ? e->A_loc : e->A_rem;
-	if (e->pb.active) { // product-basis layout: the CSR is regenerated from T, C and the diagonal codes
+	if (e->pb.active && !e->pb.csr_kept) { // product-basis layout: the CSR is regenerated from T, C and the diagonal codes (a chain keeps its CSR: below)
 		if (e->pb.tx) return fail(LPP_ERR_STATE, "lpp_engine_get_csr: not available for the product-basis layout on several GPUs");
 		if (nrows) *nrows = which == 0 ? e->n_local : 0;
 		if (nnz) *nnz = which == 0 ? e->pb.nnz : 0;

@@ -163,6 +163,8 @@ struct PbState {
 	// rows beyond one LDS window, segmented form (lpp_pbseg.h, k_pb_up_seg): T decomposed by the high sites of the species' basis word;
 	// the stored order of the positions (perm / inv) is then the segments by length
 	bool seg = false;
+	bool seg_one = false; // one block per workgroup (pb_chain)
+	bool csr_kept = false; // the plain CSR of A_loc stays resident and is what lpp_engine_get_csr hands out (pb_chain)
 	int seg_nitems = 0, seg_nsegs = 0, seg_ws = 0, seg_wmax = 0, seg_nc = 0, seg_nh = 0, seg_pre0 = 4;
 	int64_t seg_bytes = 0; // description of T held on the device
 	void* seg_items = nullptr;
@@ -297,7 +299,13 @@ void pb_realify(int64_t n, const int64_t* rp, const int32_t* ci, const double* v
 // value; the caller fills pb.dcode (n_blk*pitch codes) afterwards
 lpp_status pb_build(lpp_engine* e, int64_t n_up, int64_t n_blk, const int64_t* t_rp, const int32_t* t_ci, const double* t_va,
                     const int64_t* c_rp, const int32_t* c_ci, const double* c_va, const double* dict256, int ndict,
-                    int64_t blk0 = 0, int64_t nblk_loc = -1, int64_t pitch_dn = 0, int64_t nblk_padded = 0, const struct PbCplxInput* cx = nullptr);
+                    int64_t blk0 = 0, int64_t nblk_loc = -1, int64_t pitch_dn = 0, int64_t nblk_padded = 0, const struct PbCplxInput* cx = nullptr,
+                    struct SegPlan* pre = nullptr, int64_t pre_nnz = 0);
+// A matrix whose off-diagonal part is the hopping matrix of ONE species on a chain -- the S = 1/2 Heisenberg chain in the S_z basis
+// (Heisenberg.h:278-307: S+S- moves an up spin, nothing sits between neighbours) -- as ONE block of the product-basis form: the in-block
+// kernel k_pb_up_seg and the streaming pass, no couplings.  A keeps its plain CSR (lpp_engine_get_csr hands it out); hv[to * L + from] != 0
+// are the amplitudes in the planner's convention.  The layout is checked against the CSR by one product before it is used.
+lpp_status pb_chain(lpp_engine* e, DevCsr& A, int L, int n, const std::vector<double>& hv, bool* done);
 int pb_launch(lpp_engine* e, const void* y, void* x, double* partial, const EpiScale& sc = EpiScale { nullptr, nullptr, 0 }, bool defer_combine = false);
 // the streaming pass of the scale-free Lanczos step on a product-basis matrix: x = beta x + u + z - (a/b2_prev) y, |x|^2 partials
 bool pb_chain_ok(const lpp_engine* e);

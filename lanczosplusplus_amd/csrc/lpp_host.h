@@ -102,5 +102,8 @@ struct SegPlan {
 // T: n_up x n_up CSR (diagonal entries skipped).  *ok = false: T is not the hopping matrix of one species in the ascending-word basis,
 // or something exceeds the kernel's limits -- the caller keeps the per-position template.  wcap: longest segment / item (<= 8128).
 lpp_status pb_seg_plan(int64_t n_up, const int64_t* rp, const int32_t* ci, const double* va, int wcap, SegPlan& out, bool* ok);
+// the same from the species itself: L sites, n particles, amplitudes hv[to * L + from] (entry = hv x (-1)^(particles strictly between the two
+// sites)), cnt[to * L + from] != 0 where a hop exists.  Nothing to verify against: the caller checks the layout it builds (pb_chain).
+lpp_status pb_seg_plan_model(int L, int n, const std::vector<double>& hv, const std::vector<int64_t>& cnt, int wcap, SegPlan& out, bool* ok);
 
 } // namespace lpp

@@ -85,7 +85,7 @@ void pb_realify(int64_t n, const int64_t* rp, const int32_t* ci, const double* v
 
 lpp_status pb_build(lpp_engine* e, int64_t n_up, int64_t n_blk, const int64_t* t_rp, const int32_t* t_ci, const double* t_va,
                     const int64_t* c_rp, const int32_t* c_ci, const double* c_va, const double* dict256, int ndict,
-                    int64_t blk0, int64_t nblk_loc, int64_t pitch_dn, int64_t nblk_padded, const PbCplxInput* cx)
+                    int64_t blk0, int64_t nblk_loc, int64_t pitch_dn, int64_t nblk_padded, const PbCplxInput* cx, SegPlan* pre, int64_t pre_nnz)
 {
 	free_pb(e);
 	PbState& B = e->pb;
@@ -113,7 +113,7 @@ lpp_status pb_build(lpp_engine* e, int64_t n_up, int64_t n_blk, const int64_t* t
 	if (wmax > 0) {
 		const int64_t np = (n_up + wmax - 1) / wmax;
 		W = (((n_up + np - 1) / np) + 63) & ~(int64_t)63;
-		if (n_up >= ((int64_t)1 << 24)) return fail(LPP_ERR_INVALID, "pb_build: more than 2^24 positions per block");
+		if (n_up >= ((int64_t)1 << 24) && !pre) return fail(LPP_ERR_INVALID, "pb_build: more than 2^24 positions per block"); // (24-bit positions of the per-position template)
 	}
 	// Couplings: the panel of 16 positions of all blocks has to stay in one XCD's L2 (4 MiB) while it is gathered from.  Beyond
 	// ~1.6 MB the source blocks are walked in parts (k_pb_down_parts, which also forms 64-bit addresses: vectors beyond 4 GiB).
@@ -193,7 +193,12 @@ lpp_status pb_build(lpp_engine* e, int64_t n_up, int64_t n_blk, const int64_t* t
 	// per-position template of lpp_pbig_kernels.h.  One GPU or the transposition exchange alike: every kernel of a step is position-blind.
 	SegPlan SP;
 	bool seg = false;
-	if (W > 0 && !cx && big2 && !(getenv("LPP_PB_SEG") && atoi(getenv("LPP_PB_SEG")) == 0)) {
+	if (pre) { // the caller made the plan from the model's parameters (pb_chain): there is no host copy of T
+		if (W == 0 || cx || tx || n_blk != 1 || c_rp[1] != 0) return fail(LPP_ERR_INVALID, "pb_build: a ready-made plan is for one block beyond the LDS window");
+		SP = std::move(*pre);
+		seg = pb_seg_lds_bytes(SP.ws, SP.wmax) <= (size_t)160 * 1024 - 64;
+		if (!seg) return fail(LPP_ERR_INVALID, "pb_build: the plan exceeds LDS");
+	} else if (W > 0 && !cx && big2 && !(getenv("LPP_PB_SEG") && atoi(getenv("LPP_PB_SEG")) == 0)) {
 		const int wcap = (int)std::min<int64_t>(wmax, 8128);
 		lpp_status rs = pb_seg_plan(n_up, t_rp, t_ci, t_va, wcap, SP, &seg);
 		if (rs != LPP_OK) return rs;
@@ -246,6 +251,7 @@ lpp_status pb_build(lpp_engine* e, int64_t n_up, int64_t n_blk, const int64_t* t
 		B.seg_nc = SP.nc_pad;
 		B.seg_nh = SP.nh_pad;
 		B.seg_pre0 = SP.pre0;
+		B.seg_one = pre != nullptr; // one block per workgroup, work dealt over all workgroups
 		B.seg_bytes = (int64_t)(SP.words.size() * 4 + SP.xwords.size() * 4 + SP.slices.size() * 16 + SP.cross.size() * 32 + SP.hh.size() * 16 + SP.segs.size() * 32 + SP.items.size() * 32);
 	}
 	B.n_up = n_up;
@@ -301,7 +307,7 @@ lpp_status pb_build(lpp_engine* e, int64_t n_up, int64_t n_blk, const int64_t* t
 		const int64_t* rp = cx ? cx->t_rp : t_rp;
 		const int32_t* ci = cx ? cx->t_ci : t_ci;
 		const double* va = cx ? cx->t_va : t_va;
-		for (int64_t r = 0; r < n_rows_t; r++) {
+		for (int64_t r = 0; r < n_rows_t && rp; r++) { // (no host T with a ready-made plan: lpp_engine_get_csr then hands out the CSR that was kept)
 			for (int64_t p = rp[r]; p < rp[r + 1]; p++) {
 				if (ci[p] == r) continue;
 				if (!tc.empty() && (int64_t)tc.size() > tp[(size_t)r] && tc.back() >= ci[p]) return fail(LPP_ERR_INVALID, "pb_build: in-block rows must be sorted by column");
@@ -367,6 +373,7 @@ lpp_status pb_build(lpp_engine* e, int64_t n_up, int64_t n_blk, const int64_t* t
 	for (int64_t b = 0; b < n_blk; b++) base[(size_t)b + 1] = base[(size_t)b] + zt + n_rows_t * (1 + cp[(size_t)b + 1] - cp[(size_t)b]);
 	B.nnz = base[(size_t)n_blk];
 	B.nnz_loc = base[(size_t)(blk0 + nblk_loc)] - base[(size_t)blk0];
+	if (pre) B.nnz = B.nnz_loc = pre_nnz;
 	if ((rc = to_device(&B.blockbase, base, st)) != LPP_OK) return rc;
 	// k_pb_down geometry: one workgroup per CU, 8 groups; the couplings of a workgroup's blocks must fit LDS
 	int grid = e->num_cus & ~7;
@@ -507,7 +514,7 @@ static int big_grid(const lpp_engine* e, int64_t cnt)
 {
 	const PbState& B = e->pb;
 	if (B.big2 || B.seg) { // one workgroup per CU, items = (pair of blocks of one XCD, piece)
-		int nb = (int)std::max<int64_t>(1, std::min<int64_t>(((cnt + 1) / 2) * B.npieces, (int64_t)e->num_cus));
+		int nb = (int)std::max<int64_t>(1, std::min<int64_t>((B.seg_one ? cnt : (cnt + 1) / 2) * B.npieces, (int64_t)e->num_cus));
 		if (nb >= 8) nb &= ~7;
 		return nb;
 	}
@@ -566,15 +573,23 @@ static int launch_up_big(lpp_engine* e, const double* y, double* u, const uint8_
 		g.u = u;
 		g.partial = partial;
 		g.sc = sc;
+		g.flat = B.seg_one ? 1 : 0;
 		const size_t lds = pb_seg_lds_bytes(B.seg_ws, B.seg_wmax);
 #define LPP_PB_SEG(DOT_, GT_, P0_, NC_, NH_)                                                                            \
 	do {                                                                                                              \
 		(void)hipFuncSetAttribute((const void*)k_pb_up_seg<DOT_, GT_, P0_, 4, NC_, NH_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
 		k_pb_up_seg<DOT_, GT_, P0_, 4, NC_, NH_><<<nb, kSegThreads, lds, st>>>(g);                                      \
 	} while (0)
+#define LPP_PB_SEG1(DOT_, GT_, P0_, NC_, NH_)                                                                           \
+	do {                                                                                                              \
+		(void)hipFuncSetAttribute((const void*)k_pb_up_seg<DOT_, GT_, P0_, 4, NC_, NH_, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+		k_pb_up_seg<DOT_, GT_, P0_, 4, NC_, NH_, 1><<<nb, kSegThreads, lds, st>>>(g);                                   \
+	} while (0)
 #define LPP_PB_SEG_N(DOT_, GT_, P0_)                                                                                   \
 	do {                                                                                                              \
-		if (B.seg_nc == 2) LPP_PB_SEG(DOT_, GT_, P0_, 2, 2);                                                            \
+		if (B.seg_one && B.seg_nh == 12) LPP_PB_SEG1(DOT_, GT_, P0_, 2, 12);                                            \
+		else if (B.seg_one) LPP_PB_SEG1(DOT_, GT_, P0_, 2, 2);                                                          \
+		else if (B.seg_nc == 2) LPP_PB_SEG(DOT_, GT_, P0_, 2, 2);                                                            \
 		else if (B.seg_nc == 5) LPP_PB_SEG(DOT_, GT_, P0_, 5, 4);                                                       \
 		else LPP_PB_SEG(DOT_, GT_, P0_, 6, 8);                                                                          \
 	} while (0)
@@ -589,6 +604,7 @@ static int launch_up_big(lpp_engine* e, const double* y, double* u, const uint8_
 			else LPP_PB_SEG_N(false, 2, 4);
 		}
 #undef LPP_PB_SEG_N
+#undef LPP_PB_SEG1
 #undef LPP_PB_SEG
 		return partial ? nb : 0;
 	}
@@ -755,7 +771,7 @@ int pb_launch(lpp_engine* e, const void* y, void* x, double* partial, const EpiS
 		c.x = (double2*)x;
 		c.y = (const double2*)y;
 		c.u = (const double2*)B.u;
-		c.z = (const double2*)B.z;
+		c.z = B.c_nnz > 0 ? (const double2*)B.z : nullptr;
 		c.sc = sc;
 		c.a_ptr = nullptr;
 		c.b2_prev = nullptr;
@@ -955,7 +971,7 @@ int pb_combine_axpy(lpp_engine* e, void* x, const void* y, const EpiScale& sc, c
 	c.x = (double2*)x;
 	c.y = (const double2*)y;
 	c.u = (const double2*)B.u;
-	c.z = (const double2*)B.z;
+	c.z = B.c_nnz > 0 ? (const double2*)B.z : nullptr;
 	c.sc = sc;
 	c.a_ptr = a_ptr;
 	c.b2_prev = b2_prev;
@@ -1153,6 +1169,160 @@ lpp_status pb_from_csr(lpp_engine* e, const DevCsr& A, int64_t n_up, bool* done)
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipStreamSynchronize(st));
 	if (bad[1] || B.nnz != A.nnz) return LPP_OK; // some row is not what (T, C, D) say: not a product-basis matrix (the guard drops the layout)
+	*done = true;
+	return LPP_OK;
+}
+
+// ---- one block: the S = 1/2 Heisenberg chain ------------------------------------------------------------------------------
+namespace {
+// reference product for the check of pb_chain: x = A y, one thread per row (a few ms once per matrix)
+__global__ void k_csr_rows_ref(int64_t n, const int64_t* __restrict__ rp, const int32_t* __restrict__ ci, const double* __restrict__ va, const double* __restrict__ y,
+                               double* __restrict__ x)
+{
+	for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (int64_t)gridDim.x * blockDim.x) {
+		double s = 0.0;
+		for (int64_t p = rp[r]; p < rp[r + 1]; p++) s = fma(va[p], y[ci[p]], s);
+		x[r] = s;
+	}
+}
+// largest |a - b| and largest |b| as the bit patterns of non-negative doubles (ordered like unsigned integers)
+__global__ void k_max_diff(int64_t n, const double* __restrict__ a, const double* __restrict__ b, unsigned long long* __restrict__ out)
+{
+	double d = 0.0, m = 0.0;
+	for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+		d = fmax(d, fabs(a[i] - b[i]));
+		m = fmax(m, fabs(b[i]));
+		if (a[i] != a[i]) d = 1e300;
+	}
+	atomicMax(out, (unsigned long long)__double_as_longlong(d));
+	atomicMax(out + 1, (unsigned long long)__double_as_longlong(m));
+}
+} // namespace
+
+lpp_status pb_chain(lpp_engine* e, DevCsr& A, int L, int n, const std::vector<double>& hv, bool* done)
+{
+	*done = false;
+	if (e->is_complex || A.nrows <= 0 || !A.rowptr || !A.col || !A.val) return LPP_OK;
+	bool forced = false;
+	if (const char* s = getenv("LPP_PRODUCT_LAYOUT")) {
+		if (atoi(s) == 0) return LPP_OK;
+		forced = true;
+	}
+	if (!forced && (size_t)A.nrows * sizeof(double) < ((size_t)32 << 20)) return LPP_OK; // as for the Hubbard matrices (assemble_hubbard_pb)
+	if (e->cfg.spmv_kernel != LPP_SPMV_AUTO || getenv("LPP_SPMV_KERNEL")) return LPP_OK;
+	int want = e->cfg.compress_values;
+	if (const char* s = getenv("LPP_COMPRESS_VALUES")) want = atoi(s);
+	if (want == 0) return LPP_OK;
+	for (const char* k : { "LPP_SHARED_OFFSETS", "LPP_LOCAL16", "LPP_DIAG_CODES", "LPP_BLOCK_TEMPLATE", "LPP_WINDOW_ROWS" })
+		if (getenv(k)) return LPP_OK; // switches of the general layout: measure that one
+	if (getenv("LPP_PB_SEG") && atoi(getenv("LPP_PB_SEG")) == 0) return LPP_OK;
+	const int64_t n_up = A.nrows, pitch = pb_pitch_for(n_up);
+	if ((size_t)(pitch + kPbZeroSlots) * sizeof(double) <= (size_t)156 * 1024 && !getenv("LPP_PB_PIECE_ROWS")) return LPP_OK; // a row that fits one LDS window: the general layout's window kernel
+	int wcap = 8128;
+	if (const char* s = getenv("LPP_PB_PIECE_ROWS")) wcap = (int)std::max<int64_t>(64, std::min<int64_t>(atoll(s), 8128));
+	std::vector<int64_t> cnt((size_t)L * L, 0);
+	for (size_t k = 0; k < cnt.size(); k++) cnt[k] = hv[k] != 0.0 ? 1 : 0;
+	SegPlan SP;
+	bool ok = false;
+	lpp_status rc = pb_seg_plan_model(L, n, hv, cnt, wcap, SP, &ok);
+	if (rc != LPP_OK) return rc;
+	if (getenv("LPP_VERBOSE"))
+		fprintf(stderr, "lpp: chain as one block of the segmented form %s (L = %d, n = %d, %d high sites, %zu segments, %zu items of <= %d positions, <= %d + %d hops per segment)\n",
+		        ok ? "planned" : "does not apply", SP.L, SP.n, SP.s, SP.segs.size(), SP.items.size(), SP.wmax, SP.max_cross, SP.max_hh);
+	if (!ok || SP.n_up != n_up || SP.nc_pad != 2) return LPP_OK; // (one block per workgroup: the instances with <= 2 pairs of cross hops)
+	hipStream_t st = e->stream;
+	struct Buf {
+		void* p = nullptr;
+		~Buf()
+		{
+			if (p) (void)hipFree(p);
+		}
+	} d_bad, d_dval, d_table, d_ov, d_y, d_x, d_ys, d_xs, d_cmp;
+	// D: the stored diagonal of every row (pb_from_csr's route)
+	const size_t loc = (size_t)pitch;
+	HIP_TRY_MEM(hipMalloc(&d_bad.p, sizeof(int) * 2));
+	HIP_TRY(hipMemsetAsync(d_bad.p, 0, sizeof(int) * 2, st));
+	HIP_TRY_MEM(hipMalloc(&d_dval.p, sizeof(double) * loc));
+	HIP_TRY(hipMemsetAsync(d_dval.p, 0, sizeof(double) * loc, st));
+	const int nbr = (int)std::max<int64_t>(1, std::min<int64_t>((n_up + 255) / 256, 1 << 16));
+	k_pb_csr_diagonal<<<nbr, 256, 0, st>>>(n_up, 1, pitch, A.rowptr, A.col, (const double*)A.val, (double*)d_dval.p, (int*)d_bad.p);
+	HIP_TRY_MEM(hipMalloc(&d_table.p, sizeof(unsigned long long) * kDictTable));
+	HIP_TRY_MEM(hipMalloc(&d_ov.p, sizeof(int)));
+	HIP_TRY(hipMemsetAsync(d_table.p, 0xff, sizeof(unsigned long long) * kDictTable, st));
+	HIP_TRY(hipMemsetAsync(d_ov.p, 0, sizeof(int), st));
+	k_dict_collect<<<2048, kBlock, 0, st>>>((const double*)d_dval.p, (int64_t)loc, (unsigned long long*)d_table.p, (int*)d_ov.p);
+	std::vector<unsigned long long> host(kDictTable);
+	int ov = 0, bad[2] = { 0, 0 };
+	HIP_TRY(hipMemcpyAsync(host.data(), d_table.p, sizeof(unsigned long long) * kDictTable, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipMemcpyAsync(&ov, d_ov.p, sizeof(int), hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipMemcpyAsync(bad, d_bad.p, sizeof(int) * 2, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipStreamSynchronize(st));
+	if (bad[0]) return LPP_OK; // a row without a stored diagonal
+	std::vector<unsigned long long> keys;
+	keys.push_back(0ull);
+	size_t ndiag = 0;
+	for (unsigned long long k : host)
+		if (k != kDictEmpty) ndiag++;
+	const bool plain_diag = ov != 0 || ndiag > 250;
+	if (!plain_diag)
+		for (unsigned long long k : host)
+			if (k != kDictEmpty && std::find(keys.begin(), keys.end(), k) == keys.end()) keys.push_back(k);
+	std::sort(keys.begin(), keys.end());
+	std::vector<double> dict(256);
+	for (size_t i = 0; i < 256; i++) std::memcpy(&dict[i], &keys[std::min(i, keys.size() - 1)], 8);
+	const int64_t c_rp[2] = { 0, 0 };
+	rc = pb_build(e, n_up, 1, nullptr, nullptr, nullptr, c_rp, nullptr, nullptr, dict.data(), (int)keys.size(), 0, -1, 0, 0, nullptr, &SP, A.nnz);
+	if (rc == LPP_ERR_INVALID || rc == LPP_ERR_NOMEM) {
+		if (getenv("LPP_VERBOSE")) fprintf(stderr, "lpp: the chain keeps the general layout: %s\n", lpp_last_error());
+		free_pb(e);
+		return LPP_OK;
+	}
+	if (rc != LPP_OK) return rc;
+	PbState& B = e->pb;
+	struct Undo { // until the check below has passed the engine must not describe a product-basis matrix
+		lpp_engine* e;
+		bool* done;
+		~Undo()
+		{
+			if (!*done) free_pb(e);
+		}
+	} undo { e, done };
+	// the diagonal into the stored order of the positions (pb.u is free until the first product)
+	k_pb_permute<true><<<nbr, 256, 0, st>>>(B.u, (const double*)d_dval.p, B.perm, 1, n_up, pitch);
+	HIP_TRY(hipMemcpyAsync(d_dval.p, B.u, sizeof(double) * loc, hipMemcpyDeviceToDevice, st));
+	if (plain_diag) {
+		B.dval = (double*)d_dval.p; // the codes stay 0 (+0.0)
+		d_dval.p = nullptr;
+	} else
+		k_pb_codes_from_values<<<nbr, 256, 0, st>>>((int64_t)loc, (const double*)d_dval.p, B.dict, B.ndict, B.dcode);
+	// the layout against the CSR: one product of a random vector through both, element by element
+	HIP_TRY_MEM(hipMalloc(&d_y.p, sizeof(double) * loc));
+	HIP_TRY_MEM(hipMalloc(&d_x.p, sizeof(double) * loc));
+	HIP_TRY_MEM(hipMalloc(&d_ys.p, sizeof(double) * loc));
+	HIP_TRY_MEM(hipMalloc(&d_xs.p, sizeof(double) * loc));
+	HIP_TRY_MEM(hipMalloc(&d_cmp.p, sizeof(unsigned long long) * 2));
+	HIP_TRY(hipMemsetAsync(d_y.p, 0, sizeof(double) * loc, st));
+	HIP_TRY(hipMemsetAsync(d_xs.p, 0, sizeof(double) * loc, st));
+	HIP_TRY(hipMemsetAsync(d_cmp.p, 0, sizeof(unsigned long long) * 2, st));
+	k_fill_random<<<1024, 256, 0, st>>>((double*)d_y.p, n_up, 0, 4711);
+	k_csr_rows_ref<<<4096, 256, 0, st>>>(n_up, A.rowptr, A.col, (const double*)A.val, (const double*)d_y.p, (double*)d_x.p);
+	k_pb_permute<true><<<nbr, 256, 0, st>>>((double*)d_ys.p, (const double*)d_y.p, B.perm, 1, n_up, pitch);
+	B.active = true; // (pb_launch reads the state; the guard above drops it again if the check fails)
+	e->pitch = pitch;
+	pb_launch(e, d_ys.p, d_xs.p, nullptr); // x += H y on a zeroed x
+	k_pb_permute<false><<<nbr, 256, 0, st>>>((double*)d_y.p, (const double*)d_xs.p, B.perm, 1, n_up, pitch); // back into the basis order (d_y is free now)
+	k_max_diff<<<1024, 256, 0, st>>>(n_up, (const double*)d_y.p, (const double*)d_x.p, (unsigned long long*)d_cmp.p);
+	unsigned long long cmp[2] = { 0, 0 };
+	HIP_TRY(hipMemcpyAsync(cmp, d_cmp.p, sizeof(cmp), hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipStreamSynchronize(st));
+	double dmax, xmax;
+	std::memcpy(&dmax, &cmp[0], 8);
+	std::memcpy(&xmax, &cmp[1], 8);
+	if (getenv("LPP_VERBOSE")) fprintf(stderr, "lpp: chain layout against its CSR: largest difference %.3g of %.3g\n", dmax, xmax);
+	if (!(dmax <= 1e-12 * std::max(xmax, 1e-300))) return LPP_OK; // not the same matrix: the general layout (the guard drops this one)
+	B.csr_kept = true;
 	*done = true;
 	return LPP_OK;
 }

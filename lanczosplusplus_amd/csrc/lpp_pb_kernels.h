@@ -583,6 +583,7 @@ static __global__ __launch_bounds__(kBlock) void k_pb_combine(PbCombineArgs a)
 	double alpha, beta;
 	epi_coeffs(a.sc, alpha, beta);
 	const bool hasd = a.d != nullptr;
+	const bool hasz = a.z != nullptr; // null: a matrix without block couplings (one block: pb_chain)
 	double g = 0.0;
 	if (a.a_ptr) {
 		g = *a.a_ptr;
@@ -604,7 +605,7 @@ static __global__ __launch_bounds__(kBlock) void k_pb_combine(PbCombineArgs a)
 #pragma unroll
 		for (int k = 0; k < U; k++) uv[k] = nt_load2(&a.u[i + k * stride]);
 #pragma unroll
-		for (int k = 0; k < U; k++) zv[k] = nt_load2(&a.z[i + k * stride]);
+		for (int k = 0; k < U; k++) zv[k] = hasz ? nt_load2(&a.z[i + k * stride]) : double2 { 0.0, 0.0 };
 		double2 dv[U];
 		if (hasd) {
 #pragma unroll
@@ -626,7 +627,7 @@ static __global__ __launch_bounds__(kBlock) void k_pb_combine(PbCombineArgs a)
 		}
 	}
 	for (; i < a.n2; i += stride) {
-		const double2 xv = a.x[i], yv = a.y[i], uv = a.u[i], zv = a.z[i];
+		const double2 xv = a.x[i], yv = a.y[i], uv = a.u[i], zv = hasz ? a.z[i] : double2 { 0.0, 0.0 };
 		double2 r;
 		r.x = beta * xv.x + uv.x + zv.x - g * yv.x;
 		r.y = beta * xv.y + uv.y + zv.y - g * yv.y;

@@ -26,7 +26,7 @@
 namespace lpp {
 
 constexpr int kSegMaxCross = 6; // PAIRS of cross hops per segment the kernel carries (every segment's list is padded to the instance's NC with value 0.0)
-constexpr int kSegMaxHh = 8; // high-high entries per segment
+constexpr int kSegMaxHh = 12; // high-high entries per segment
 constexpr int kSegMaxSegs = 16; // segments per item (LDS tables)
 constexpr int kSegWinPad = 2; // window index of an item's first position (the staged run starts at an even element)
 

@@ -64,24 +64,25 @@ inline bool same_bits(double a, double b) { return std::memcmp(&a, &b, 8) == 0; 
 
 } // namespace
 
-lpp_status pb_seg_plan(int64_t n_up, const int64_t* rp, const int32_t* ci, const double* va, int wcap, SegPlan& P, bool* ok)
+namespace {
+
+// steps 1-2 of the plan: the basis (L sites, n particles: the candidate whose ascending words explain every entry of T as one hop) and the
+// hopping amplitudes hv[to][from] -- every entry (r, c) is hv * (-1)^(particles strictly between the two sites) -- with the number of
+// entries that carry each.  false: T is not the hopping matrix of one species in that basis.
+bool seg_decode(int64_t n_up, const int64_t* rp, const int32_t* ci, const double* va, int& L, int& n, std::vector<double>& hv, std::vector<int64_t>& cnt)
 {
-	*ok = false;
-	P = SegPlan();
-	if (n_up < 128 || n_up >= ((int64_t)1 << 24) || wcap < 64 || wcap > 8128) return LPP_OK;
-	// ---- 1. the basis: L sites, n particles with C(L, n) = n_up, the candidate whose words explain every entry as one hop -------
 	std::vector<uint32_t> W;
-	int L = 0, n = 0;
+	L = n = 0;
 	for (int l = 2; l <= 30 && L == 0; l++)
 		for (int k = 1; k < l && L == 0; k++) {
 			if ((int64_t)kBinom.c[l][k] != n_up) continue;
 			words_of(l, k, W);
 			bool good = true;
-			const int64_t step = std::max<int64_t>(1, n_up / 257); // a sample decides between C(L, n) and C(L, L - n); step 2 checks every entry
+			const int64_t step = std::max<int64_t>(1, n_up / 257); // a sample decides between C(L, n) and C(L, L - n); every entry is checked below
 			for (int64_t r = 0; r < n_up && good; r += step)
 				for (int64_t p = rp[r]; p < rp[r + 1] && good; p++) {
 					if (ci[p] == r) continue;
-					if (ci[p] < 0 || ci[p] >= n_up) return LPP_OK;
+					if (ci[p] < 0 || ci[p] >= n_up) return false;
 					const uint32_t x = W[(size_t)r] ^ W[(size_t)ci[p]];
 					good = __builtin_popcount(x) == 2 && __builtin_popcount(x & W[(size_t)r]) == 1;
 				}
@@ -90,31 +91,42 @@ lpp_status pb_seg_plan(int64_t n_up, const int64_t* rp, const int32_t* ci, const
 				n = k;
 			}
 		}
-	if (L == 0) return LPP_OK;
-	// ---- 2. hopping amplitudes hv[to][from]: every entry (r, c) is  hv * (-1)^(particles strictly between the two sites) ----------
-	std::vector<double> hv((size_t)L * L, 0.0);
-	std::vector<int64_t> cnt((size_t)L * L, 0);
+	if (L == 0) return false;
+	hv.assign((size_t)L * L, 0.0);
+	cnt.assign((size_t)L * L, 0);
 	for (int64_t r = 0; r < n_up; r++)
 		for (int64_t p = rp[r]; p < rp[r + 1]; p++) {
 			const int64_t c = ci[p];
 			if (c == r) continue; // the diagonal lives in D
-			if (c < 0 || c >= n_up) return LPP_OK;
+			if (c < 0 || c >= n_up) return false;
 			const uint32_t wr = W[(size_t)r], wc = W[(size_t)c], x = wr ^ wc;
-			if (__builtin_popcount(x) != 2 || __builtin_popcount(x & wr) != 1) return LPP_OK;
+			if (__builtin_popcount(x) != 2 || __builtin_popcount(x & wr) != 1) return false;
 			const int to = __builtin_ctz(x & wr), from = __builtin_ctz(x & wc);
 			const double v = parity(wc & between(to, from)) ? -va[p] : va[p];
-			if (v == 0.0 || v != v) return LPP_OK;
+			if (v == 0.0 || v != v) return false;
 			const size_t k = (size_t)to * L + from;
 			if (cnt[k] == 0)
 				hv[k] = v;
 			else if (!same_bits(hv[k], v))
-				return LPP_OK;
+				return false;
 			cnt[k]++;
 		}
 	const int64_t per_bond = n >= 1 && L >= 2 ? (int64_t)kBinom.c[L - 2][n - 1] : 0;
 	for (size_t k = 0; k < cnt.size(); k++)
-		if (cnt[k] != 0 && cnt[k] != per_bond) return LPP_OK; // a hop that is allowed must be there (CSR rows hold a column once)
-	// in-window value groups: +-hv of the low-low hops (decided below, after s is known); negation must be exact
+		if (cnt[k] != 0 && cnt[k] != per_bond) return false; // a hop that is allowed must be there (CSR rows hold a column once)
+	return true;
+}
+
+} // namespace
+
+// steps 3-7: the plan from (L, n, amplitudes); cnt[to * L + from] != 0 marks the hops that exist
+lpp_status pb_seg_plan_model(int L, int n, const std::vector<double>& hv, const std::vector<int64_t>& cnt, int wcap, SegPlan& P, bool* ok)
+{
+	*ok = false;
+	P = SegPlan();
+	if (L < 2 || L > 30 || n < 1 || n >= L || wcap < 64 || wcap > 8128) return LPP_OK;
+	const int64_t n_up = (int64_t)kBinom.c[L][n];
+	if (n_up < 128 || n_up > (int64_t)400000000) return LPP_OK; // 32-bit byte offsets into a row
 	// ---- 3. the cut: smallest s whose longest segment fits the window --------------------------------------------------------
 	int s = 0;
 	int64_t maxseg = 0;
@@ -428,8 +440,12 @@ lpp_status pb_seg_plan(int64_t n_up, const int64_t* rp, const int32_t* ci, const
 	// every segment's lists padded to the kernel instance's width with entries of value 0.0 that read valid addresses: the slice
 	// loop then carries no condition at all (padded cross entries: a table of the segment's own class -- or table 0, the longest --
 	// and the row's first elements; padded high-high entries: the segment itself)
-	P.nc_pad = P.max_cross <= 2 && P.max_hh <= 2 ? 2 : P.max_cross <= 5 && P.max_hh <= 4 ? 5 : 6;
-	P.nh_pad = P.nc_pad == 2 ? 2 : P.nc_pad == 5 ? 4 : 8;
+	// kernel instances (NC, NH): (2, 2), (5, 4), (6, 8) and -- one block per workgroup only: chains -- (2, 12)
+	if (P.max_cross <= 2 && P.max_hh <= 2) P.nc_pad = 2, P.nh_pad = 2;
+	else if (P.max_cross <= 5 && P.max_hh <= 4) P.nc_pad = 5, P.nh_pad = 4;
+	else if (P.max_cross <= 6 && P.max_hh <= 8) P.nc_pad = 6, P.nh_pad = 8;
+	else if (P.max_cross <= 2) P.nc_pad = 2, P.nh_pad = 12;
+	else return LPP_OK;
 	{
 		std::vector<SegCross> cp(P.segs.size() * (size_t)P.nc_pad);
 		std::vector<SegHh> hp(P.segs.size() * (size_t)P.nh_pad);
@@ -444,7 +460,16 @@ lpp_status pb_seg_plan(int64_t n_up, const int64_t* rp, const int32_t* ci, const
 		P.cross.swap(cp);
 		P.hh.swap(hp);
 	}
-	// ---- 8. expand the packed description again and compare it with T, entry by entry and bit by bit -------------------------
+	*ok = true;
+	return LPP_OK;
+}
+
+namespace {
+// step 8: expand the packed description again and compare it with T, entry by entry and bit by bit
+bool seg_verify(SegPlan& P, const int64_t* rp, const int32_t* ci, const double* va)
+{
+	const int G = P.G;
+	const int64_t n_up = P.n_up;
 	{
 		std::vector<std::pair<int32_t, double>> row;
 		for (const SegItem& I : P.items)
@@ -460,7 +485,7 @@ lpp_status pb_seg_plan(int64_t n_up, const int64_t* rp, const int32_t* ci, const
 								const int idx = (int)((q & 1) ? (w >> 16) : (w & 0xffffu));
 								if (idx >= I.zero_at) continue; // filling
 								const int64_t sp = (int64_t)I.c0 + idx - kSegWinPad;
-								if (sp < I.c0 || sp >= (int64_t)I.c0 + I.wlen) return LPP_OK;
+								if (sp < I.c0 || sp >= (int64_t)I.c0 + I.wlen) return false;
 								row.emplace_back(P.perm[(size_t)sp], P.gval[g]);
 							}
 					}
@@ -483,16 +508,32 @@ lpp_status pb_seg_plan(int64_t n_up, const int64_t* rp, const int32_t* ci, const
 					size_t k = 0;
 					for (int64_t p = rp[r]; p < rp[r + 1]; p++) {
 						if (ci[p] == r) continue;
-						if (k >= row.size() || row[k].first != ci[p] || !same_bits(row[k].second, va[p])) return LPP_OK;
+						if (k >= row.size() || row[k].first != ci[p] || !same_bits(row[k].second, va[p])) return false;
 						k++;
 					}
-					if (k != row.size()) return LPP_OK;
+					if (k != row.size()) return false;
 					P.entries++;
 				}
 			}
-		if (P.entries != n_up) return LPP_OK; // every row was visited once
+		if (P.entries != n_up) return false; // every row was visited once
 	}
-	*ok = true;
+	return true;
+}
+} // namespace
+
+lpp_status pb_seg_plan(int64_t n_up, const int64_t* rp, const int32_t* ci, const double* va, int wcap, SegPlan& P, bool* ok)
+{
+	*ok = false;
+	P = SegPlan();
+	if (n_up < 128 || n_up >= ((int64_t)1 << 24)) return LPP_OK; // (T is walked on the host: one-species spaces of a Hubbard model)
+	int L = 0, n = 0;
+	std::vector<double> hv;
+	std::vector<int64_t> cnt;
+	if (!seg_decode(n_up, rp, ci, va, L, n, hv, cnt)) return LPP_OK;
+	bool built = false;
+	const lpp_status st = pb_seg_plan_model(L, n, hv, cnt, wcap, P, &built);
+	if (st != LPP_OK || !built) return st;
+	*ok = seg_verify(P, rp, ci, va);
 	return LPP_OK;
 }
 

@@ -34,6 +34,7 @@ struct PbSegArgs {
 	double* u;
 	double* partial; // per-workgroup Re<y|u> (null: not wanted)
 	EpiScale sc; // only alpha is used
+	int flat; // 1: work items are dealt over ALL workgroups (few blocks: a Heisenberg chain is one block), 0: blocks by XCD
 };
 
 constexpr int kSegThreads = 512; // 8 waves of up to 256 registers: two slices' loads from the rows in flight per wave
@@ -59,8 +60,8 @@ template <int GG> struct SegWinWords {
 template <int NC> struct SegCrossWords {
 	uint32_t x[NC]; // two 16-bit words each
 };
-template <int NC, int NH> struct SegData { // what a slice reads from the rows in memory, both blocks
-	double xa[2 * NC], xb[2 * NC], ha[NH], hb[NH];
+template <int NC, int NH, int ROWS> struct SegData { // what a slice reads from the rows in memory, both blocks
+	double xa[2 * NC], xb[ROWS == 2 ? 2 * NC : 1], ha[NH], hb[ROWS == 2 ? NH : 1];
 	uint32_t sg; // bits 14..15 of the cross words, two bits per hop
 };
 
@@ -72,9 +73,12 @@ template <int NC, int NH> struct SegData { // what a slice reads from the rows i
 // and the segments' scalars are LDS copies made while the windows are staged, and that staging is ONE round trip -- all of a thread's
 // pieces of both windows, the codes and the tables are requested before the first is stored (the first version's 6 + 6 round trips per
 // item were a third of its time).
-template <bool DOT, int GT, int P0, int P1, int NC, int NH> __global__ __launch_bounds__(kSegThreads) void k_pb_up_seg(PbSegArgs a)
+// ROWS: blocks per workgroup (2: every word loaded serves two blocks; 1: a matrix of one block -- a Heisenberg chain, whose S+S- part
+// is the hopping matrix of its up spins (pb_chain) -- where the second window stays unused).
+template <bool DOT, int GT, int P0, int P1, int NC, int NH, int ROWS = 2> __global__ __launch_bounds__(kSegThreads) void k_pb_up_seg(PbSegArgs a)
 {
 	static_assert(GT == 1 || GT == 2, "one or two value groups");
+	static_assert(ROWS == 1 || ROWS == 2, "one or two blocks per workgroup");
 	static_assert(P0 <= kSegPre && P1 <= kSegPre && !(P0 & 1) && !(P1 & 1) && NC <= kSegMaxCross && NH <= kSegMaxHh && NC <= 8, "limits");
 	extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
 	double* win = (double*)lds_raw; // block 0's window at LDS address 0 (a list entry * 8 IS the byte address), block 1's at ws * 8
@@ -103,27 +107,27 @@ template <bool DOT, int GT, int P0, int P1, int NC, int NH> __global__ __launch_
 	double dot = 0.0;
 	// blocks xcd, xcd + 8, ... belong to this workgroup's XCD (round-robin dispatch: speed only); its workgroups walk
 	// seq = (pair of blocks, item) together, so the rows that are read from memory are the ones being staged right now
-	const int nx = (gridDim.x & 7) == 0 ? 8 : 1;
+	const int nx = (gridDim.x & 7) == 0 && !a.flat ? 8 : 1;
 	const int xcd = nx == 8 ? (int)(blockIdx.x & 7) : 0;
 	const int64_t slot = nx == 8 ? (int64_t)(blockIdx.x >> 3) : (int64_t)blockIdx.x, nslots = gridDim.x / nx;
 	const int64_t nbx = (a.n_blk - xcd + nx - 1) / nx;
-	const int64_t npairs = (nbx + 1) >> 1;
+	const int64_t npairs = ROWS == 2 ? (nbx + 1) >> 1 : nbx;
 	auto gather4x2 = [=](const uint2& w, double& a0, double& a1, double& b0, double& b1) __attribute__((always_inline)) {
 		const uint32_t p0 = pb_lo8(w.x), p1 = pb_hi8(w.x), p2 = pb_lo8(w.y), p3 = pb_hi8(w.y);
 		a0 += pb_lds_abs(p0);
-		b0 += pb_lds_abs(p0 + wbytes);
+		if (ROWS == 2) b0 += pb_lds_abs(p0 + wbytes);
 		a1 += pb_lds_abs(p1);
-		b1 += pb_lds_abs(p1 + wbytes);
+		if (ROWS == 2) b1 += pb_lds_abs(p1 + wbytes);
 		a0 += pb_lds_abs(p2);
-		b0 += pb_lds_abs(p2 + wbytes);
+		if (ROWS == 2) b0 += pb_lds_abs(p2 + wbytes);
 		a1 += pb_lds_abs(p3);
-		b1 += pb_lds_abs(p3 + wbytes);
+		if (ROWS == 2) b1 += pb_lds_abs(p3 + wbytes);
 	};
 	for (int64_t seq = slot; seq < npairs * nitems; seq += nslots) {
 		const int64_t pr = seq / nitems;
 		const int it = (int)(seq - pr * nitems);
-		const int64_t blk0 = (2 * pr) * nx + xcd;
-		const bool two = 2 * pr + 1 < nbx; // the last pair of an odd count holds one block: its twin re-reads it and stores nothing
+		const int64_t blk0 = (ROWS * pr) * nx + xcd;
+		const bool two = ROWS == 2 && 2 * pr + 1 < nbx; // the last pair of an odd count holds one block: its twin re-reads it and stores nothing
 		const int64_t blk1 = two ? (2 * pr + 1) * nx + xcd : blk0;
 		const SegItem I = a.items[it];
 		const int c0 = I.c0, wlen = I.wlen, nsl = I.nslices;
@@ -136,18 +140,19 @@ template <bool DOT, int GT, int P0, int P1, int NC, int NH> __global__ __launch_
 			// Everything this thread stages is requested here, in front of the barrier that waits for the previous item's slices
 			const int e0 = c0 & ~1, e1 = (c0 + wlen + 1) & ~1;
 			const int p2 = (e1 - e0) >> 1, lbase = e0 - c0 + kSegWinPad;
-			double2 t[kSegStage];
+			constexpr int NST = kSegStage * ROWS / 2;
+			double2 t[NST];
 #pragma unroll
-			for (int k = 0; k < kSegStage; k++) { // [0, p2): block 0, [p2, 2 p2): block 1; clamped lanes re-load the last pair
-				const int idx = min((int)threadIdx.x + k * kSegThreads, 2 * p2 - 1);
+			for (int k = 0; k < NST; k++) { // [0, p2): block 0, [p2, 2 p2): block 1; clamped lanes re-load the last pair
+				const int idx = min((int)threadIdx.x + k * kSegThreads, ROWS * p2 - 1);
 				const bool second = idx >= p2;
 				t[k] = ((const double2*)((second ? yrow1 : yrow0) + e0))[second ? idx - p2 : idx];
 			}
 			const int d0 = c0 & ~15, p16 = (((c0 + wlen + 15) & ~15) - d0) >> 4; // 16 codes per piece: at most 2 x 510 pieces
-			uint4 dc[2];
+			uint4 dc[ROWS];
 #pragma unroll
-			for (int k = 0; k < 2; k++) {
-				const int i0 = min((int)threadIdx.x + k * kSegThreads, 2 * p16 - 1);
+			for (int k = 0; k < ROWS; k++) {
+				const int i0 = min((int)threadIdx.x + k * kSegThreads, ROWS * p16 - 1);
 				const bool second = i0 >= p16;
 				dc[k] = ((const uint4*)(a.dcode + (second ? rowbase1 : rowbase0) + d0))[second ? i0 - p16 : i0];
 			}
@@ -157,23 +162,23 @@ template <bool DOT, int GT, int P0, int P1, int NC, int NH> __global__ __launch_
 			const uint4 hq = ((const uint4*)(a.hh + (size_t)I.seg_first * NH))[min((int)threadIdx.x, nhh - 1)];
 			__syncthreads(); // everyone is done with the previous windows and tables
 #pragma unroll
-			for (int k = 0; k < kSegStage; k++) {
-				const int idx = min((int)threadIdx.x + k * kSegThreads, 2 * p2 - 1);
+			for (int k = 0; k < NST; k++) {
+				const int idx = min((int)threadIdx.x + k * kSegThreads, ROWS * p2 - 1);
 				const bool second = idx >= p2;
 				double* const d = win + (second ? WS : 0) + lbase + 2 * (second ? idx - p2 : idx);
 				d[0] = t[k].x;
 				d[1] = t[k].y;
 			}
 #pragma unroll
-			for (int k = 0; k < 2; k++) {
-				const int i0 = min((int)threadIdx.x + k * kSegThreads, 2 * p16 - 1);
+			for (int k = 0; k < ROWS; k++) {
+				const int i0 = min((int)threadIdx.x + k * kSegThreads, ROWS * p16 - 1);
 				const bool second = i0 >= p16;
 				((uint4*)(dcode_s + (second ? dstride : 0)))[second ? i0 - p16 : i0] = dc[k];
 			}
 			if ((int)threadIdx.x < nhd) ((uint4*)heads_s)[threadIdx.x] = hd;
 			if ((int)threadIdx.x < ncr) ((uint4*)cross_s)[threadIdx.x] = cr;
 			if ((int)threadIdx.x < nhh) ((uint4*)hh_s)[threadIdx.x] = hq;
-			if (threadIdx.x < 2 * kPbZeroSlots) win[(threadIdx.x >> 5) * WS + I.zero_at + (threadIdx.x & 31)] = 0.0;
+			if (threadIdx.x < ROWS * kPbZeroSlots) win[(threadIdx.x >> 5) * WS + I.zero_at + (threadIdx.x & 31)] = 0.0;
 		}
 		__syncthreads();
 		const int doff = (c0 & 15); // dcode_s index of the item's first position
@@ -203,16 +208,16 @@ template <bool DOT, int GT, int P0, int P1, int NC, int NH> __global__ __launch_
 #pragma unroll
 			for (int b = 0; b < NC; b++) s.x[b] = xw[(size_t)(cross_s[h.seg * NC + b].wordoff + h.segoff) + lane];
 		};
-		auto issue_data = [=](const SegHeads<GG>& h, const SegCrossWords<NC>& s, SegData<NC, NH>& d) __attribute__((always_inline)) {
+		auto issue_data = [=](const SegHeads<GG>& h, const SegCrossWords<NC>& s, SegData<NC, NH, ROWS>& d) __attribute__((always_inline)) {
 			uint32_t sg = 0;
 #pragma unroll
 			for (int b = 0; b < NC; b++) {
 				const uint32_t sb = (uint32_t)cross_s[h.seg * NC + b].srcbase;
 				const uint32_t at0 = (sb + (s.x[b] & 0x1fffu)) * 8u, at1 = (sb + ((s.x[b] >> 16) & 0x1fffu)) * 8u;
 				d.xa[2 * b] = *(const double*)((const char*)yrow0 + at0);
-				d.xb[2 * b] = *(const double*)((const char*)yrow1 + at0);
+				if (ROWS == 2) d.xb[2 * b] = *(const double*)((const char*)yrow1 + at0);
 				d.xa[2 * b + 1] = *(const double*)((const char*)yrow0 + at1);
-				d.xb[2 * b + 1] = *(const double*)((const char*)yrow1 + at1);
+				if (ROWS == 2) d.xb[2 * b + 1] = *(const double*)((const char*)yrow1 + at1);
 				sg |= (((s.x[b] >> 14) & 3u) | ((s.x[b] >> 28) & 0xcu)) << (4 * b);
 			}
 			d.sg = sg;
@@ -221,10 +226,10 @@ template <bool DOT, int GT, int P0, int P1, int NC, int NH> __global__ __launch_
 			for (int b = 0; b < NH; b++) {
 				const uint32_t at = (uint32_t)(hh_s[h.seg * NH + b].srcbase + (h.segoff + lc) * hh_s[h.seg * NH + b].pad) * 8u;
 				d.ha[b] = *(const double*)((const char*)yrow0 + at);
-				d.hb[b] = *(const double*)((const char*)yrow1 + at);
+				if (ROWS == 2) d.hb[b] = *(const double*)((const char*)yrow1 + at);
 			}
 		};
-		auto compute = [=, &dot](int jj, const SegHeads<GG>& h, const SegWinWords<GG>& s, const SegData<NC, NH>& d) __attribute__((always_inline)) {
+		auto compute = [=, &dot](int jj, const SegHeads<GG>& h, const SegWinWords<GG>& s, const SegData<NC, NH, ROWS>& d) __attribute__((always_inline)) {
 			if (jj >= nsl) return; // wave-uniform
 			double acc0 = 0.0, acc1 = 0.0;
 #pragma unroll
@@ -254,26 +259,26 @@ template <bool DOT, int GT, int P0, int P1, int NC, int NH> __global__ __launch_
 					}
 				}
 				acc0 = fma(gv[g], a0 + a1, acc0);
-				acc1 = fma(gv[g], b0 + b1, acc1);
+				if (ROWS == 2) acc1 = fma(gv[g], b0 + b1, acc1);
 			}
 #pragma unroll
 			for (int b = 0; b < 2 * NC; b++) {
 				// two bits per hop as a signed field: +1, -1 or 0 (no entry: the element read was the source segment's first)
 				const double v = cross_s[h.seg * NC + (b >> 1)].val[b & 1] * (double)((int32_t)(d.sg << (30 - 2 * b)) >> 30);
 				acc0 = fma(v, d.xa[b], acc0);
-				acc1 = fma(v, d.xb[b], acc1);
+				if (ROWS == 2) acc1 = fma(v, d.xb[b], acc1);
 			}
 #pragma unroll
 			for (int b = 0; b < NH; b++) {
 				const double v = hh_s[h.seg * NH + b].val;
 				acc0 = fma(v, d.ha[b], acc0);
-				acc1 = fma(v, d.hb[b], acc1);
+				if (ROWS == 2) acc1 = fma(v, d.hb[b], acc1);
 			}
 			const int lc = min(lane, h.count - 1);
 			const int il = h.first + lc; // position in the item
-			const double y0 = win[il + kSegWinPad], y1 = win[WS + il + kSegWinPad];
+			const double y0 = win[il + kSegWinPad], y1 = ROWS == 2 ? win[WS + il + kSegWinPad] : 0.0;
 			acc0 = fma(dict_s[dcode_s[il + doff]], y0, acc0);
-			acc1 = fma(dict_s[dcode_s[dstride + il + doff]], y1, acc1);
+			if (ROWS == 2) acc1 = fma(dict_s[dcode_s[dstride + il + doff]], y1, acc1);
 			if (lane < h.count) {
 				const double u0 = alpha * acc0, u1 = alpha * acc1;
 				__builtin_nontemporal_store(u0, &uout[rowbase0 + c0 + il]);
@@ -289,7 +294,7 @@ template <bool DOT, int GT, int P0, int P1, int NC, int NH> __global__ __launch_
 		SegHeads<GG> h0, h1, h2, h3, h4;
 		SegWinWords<GG> WA, WB;
 		SegCrossWords<NC> XA, XB;
-		SegData<NC, NH> DA, DB;
+		SegData<NC, NH, ROWS> DA, DB;
 		load_heads(wave, h0);
 		load_heads(wave + NW, h1);
 		load_heads(wave + 2 * NW, h2);

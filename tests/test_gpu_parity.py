@@ -1100,3 +1100,59 @@ def test_recurrence_started_from_an_eigenvector(monkeypatch):
             assert abs(a[0] - eg[0]) <= 1e-10 * abs(eg[0]) and b[0] < 1e-5
             runs[(layout, sv)] = len(a)
     assert len(set(runs.values())) == 1, runs
+
+
+@pytest.mark.parametrize("periodic,field", [(False, False), (True, True)])
+def test_heisenberg_chain_as_one_block_of_the_segmented_form(periodic, field, monkeypatch):
+    """S = 1/2 Heisenberg chain (Heisenberg.h:80-114, 278-307): S+S- moves an up spin and nothing sits between neighbours, so the
+    off-diagonal part is the hopping matrix of the up spins in the basis of BasisHeisenberg.h:38-46 -- ONE block of the product-basis
+    form.  Round 4: such a matrix takes the in-block kernel decomposed by the high sites of the basis word (pb_chain, k_pb_up_seg with
+    one block per workgroup) + the streaming pass; its CSR stays resident and is what lpp_engine_get_csr hands out.  Forced here onto
+    16 sites (12870 states, segments of <= 252 positions); BASELINE config 3 (L = 28) takes it by itself.  Checks: CSR bits, x += H y,
+    energies, coefficients, Ritz vector, reorthogonalised run; periodic chain = the bond between the two ends (constant sign
+    (-1)^(n-1) in the hopping picture), site-dependent field = more diagonal values."""
+    monkeypatch.setenv("LPP_PRODUCT_LAYOUT", "1")
+    monkeypatch.setenv("LPP_PB_PIECE_ROWS", "256")
+    L, m = 16, 8
+    jpm, jzz = chain(L, 1.0, periodic), chain(L, 0.7, periodic)
+    h = np.linspace(-0.3, 0.4, L) if field else None
+    A = oracle.heis_csr(L, 1, m, jpm, jzz, h) if field else oracle.heis_csr(L, 1, m, jpm, jzz)
+    x0, y = oracle.fill_random(A.nrows, 7), oracle.fill_random(A.nrows, 8)
+    xo = oracle.spmv_acc(A, x0.copy(), y)
+    init = oracle.fill_random(A.nrows, 4321)
+    eo, zo, so = oracle.lanczos_solve(A, oracle.fill_random(A.nrows, 1234), nstates=1)
+    steps_o, ao, bo, _, _ = oracle.lanczos_decomposition(A, init)
+    with LanczosEngine() as e:
+        e.assemble_heisenberg(L, m, jpm, jzz, h)
+        lay = e.layout()
+        assert lay["kernel"] == 4 and lay["segments"] == 64 and lay["nnz"] == A.nnz and lay["chained_step"] == 0, lay  # 6 high sites
+        rp, ci, va = e.get_csr()
+        assert np.array_equal(rp, A.rowptr) and np.array_equal(ci, A.colind) and np.array_equal(_bits(va), _bits(A.values))
+        xg = e.matrixVectorProduct(x0.copy(), y)
+        assert rel(xg, xo) < SPMV_TOL
+        eg, zg, st = e.lanczos(1, want_vectors=True)
+        assert abs(eg[0] - eo[0]) <= E_TOL * abs(eo[0]) and st["steps"] == so
+        r = oracle.spmv_acc(A, np.zeros_like(zg[0]), zg[0]) - eg[0] * zg[0]
+        assert np.linalg.norm(r) < 1e-5 and abs(np.linalg.norm(zg[0]) - 1) < 1e-8
+        ag, bg, _ = e.decomposition(init)
+        assert len(ag) == steps_o and rel(ag, ao) < 1e-8 and rel(bg, bo) < 1e-8
+    with LanczosEngine(save_vectors=0) as e:  # scale-free recurrence + two-pass Ritz vector
+        e.assemble_heisenberg(L, m, jpm, jzz, h)
+        eg2, zg2, st2 = e.lanczos(1, want_vectors=True)
+        assert st2["vectors_saved"] == 0 and abs(eg2[0] - eo[0]) <= E_TOL * abs(eo[0])
+    e3o, _, s3o = oracle.lanczos_solve(A, oracle.fill_random(A.nrows, 1234), nstates=3, max_steps=150, eps=1e-11, reortho=True)
+    with LanczosEngine(reortho=True, max_steps=150, eps=1e-11) as e:
+        e.assemble_heisenberg(L, m, jpm, jzz, h)
+        e3, z3, st3 = e.lanczos(3, want_vectors=True)
+        assert st3["steps"] == s3o and rel(e3, e3o) < 1e-8
+    monkeypatch.setenv("LPP_PRODUCT_LAYOUT", "0")  # the general layout: the same numbers
+    with LanczosEngine() as e:
+        e.assemble_heisenberg(L, m, jpm, jzz, h)
+        assert e.layout()["kernel"] != 4
+        assert rel(e.matrixVectorProduct(x0.copy(), y), xg) < SPMV_TOL
+    # couplings beyond neighbours are not a chain: the general layout
+    monkeypatch.setenv("LPP_PRODUCT_LAYOUT", "1")
+    j2 = chain(L, 1.0, False) + 0.5 * (np.diag(np.ones(L - 2), 2) + np.diag(np.ones(L - 2), -2))
+    with LanczosEngine() as e:
+        e.assemble_heisenberg(L, m, j2, jzz)
+        assert e.layout()["kernel"] != 4
