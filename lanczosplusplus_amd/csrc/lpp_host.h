@@ -104,6 +104,6 @@ struct SegPlan {
 lpp_status pb_seg_plan(int64_t n_up, const int64_t* rp, const int32_t* ci, const double* va, int wcap, SegPlan& out, bool* ok);
 // the same from the species itself: L sites, n particles, amplitudes hv[to * L + from] (entry = hv x (-1)^(particles strictly between the two
 // sites)), cnt[to * L + from] != 0 where a hop exists.  Nothing to verify against: the caller checks the layout it builds (pb_chain).
-lpp_status pb_seg_plan_model(int L, int n, const std::vector<double>& hv, const std::vector<int64_t>& cnt, int wcap, SegPlan& out, bool* ok);
+lpp_status pb_seg_plan_model(int L, int n, const std::vector<double>& hv, const std::vector<int64_t>& cnt, int wcap, SegPlan& out, bool* ok, bool one_block = false);
 
 } // namespace lpp

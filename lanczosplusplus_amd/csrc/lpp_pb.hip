@@ -251,7 +251,8 @@ lpp_status pb_build(lpp_engine* e, int64_t n_up, int64_t n_blk, const int64_t* t
 		B.seg_nc = SP.nc_pad;
 		B.seg_nh = SP.nh_pad;
 		B.seg_pre0 = SP.pre0;
-		B.seg_one = pre != nullptr; // one block per workgroup, work dealt over all workgroups
+		B.seg_one = pre != nullptr; // one block per workgroup
+
 		B.seg_bytes = (int64_t)(SP.words.size() * 4 + SP.xwords.size() * 4 + SP.slices.size() * 16 + SP.cross.size() * 32 + SP.hh.size() * 16 + SP.segs.size() * 32 + SP.items.size() * 32);
 	}
 	B.n_up = n_up;
@@ -1224,7 +1225,7 @@ lpp_status pb_chain(lpp_engine* e, DevCsr& A, int L, int n, const std::vector<do
 	for (size_t k = 0; k < cnt.size(); k++) cnt[k] = hv[k] != 0.0 ? 1 : 0;
 	SegPlan SP;
 	bool ok = false;
-	lpp_status rc = pb_seg_plan_model(L, n, hv, cnt, wcap, SP, &ok);
+	lpp_status rc = pb_seg_plan_model(L, n, hv, cnt, wcap, SP, &ok, true);
 	if (rc != LPP_OK) return rc;
 	if (getenv("LPP_VERBOSE"))
 		fprintf(stderr, "lpp: chain as one block of the segmented form %s (L = %d, n = %d, %d high sites, %zu segments, %zu items of <= %d positions, <= %d + %d hops per segment)\n",

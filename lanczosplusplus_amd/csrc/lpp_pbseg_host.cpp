@@ -120,7 +120,7 @@ bool seg_decode(int64_t n_up, const int64_t* rp, const int32_t* ci, const double
 } // namespace
 
 // steps 3-7: the plan from (L, n, amplitudes); cnt[to * L + from] != 0 marks the hops that exist
-lpp_status pb_seg_plan_model(int L, int n, const std::vector<double>& hv, const std::vector<int64_t>& cnt, int wcap, SegPlan& P, bool* ok)
+lpp_status pb_seg_plan_model(int L, int n, const std::vector<double>& hv, const std::vector<int64_t>& cnt, int wcap, SegPlan& P, bool* ok, bool one_block)
 {
 	*ok = false;
 	P = SegPlan();
@@ -429,22 +429,43 @@ lpp_status pb_seg_plan_model(int L, int n, const std::vector<double>& hv, const 
 		i0 = i1;
 	}
 	P.ntypes = (int)types.size();
-	if (G == 2) { // group 0 requested two chunks ahead when its lists rarely hold more (4x5 lattice: the + hops hold 2, the - hops 3-4 chunks)
+	if (G == 2) { // a value group no low-low entry uses (an open chain: nothing ever sits between neighbours, only +hv occurs) is dropped
+		int64_t used[2] = { 0, 0 };
+		for (const SegSlice& sl : P.slices) {
+			used[0] += sl.nc[0];
+			used[1] += sl.nc[1];
+		}
+		if (used[0] == 0 || used[1] == 0) {
+			const int keep = used[0] == 0 ? 1 : 0;
+			for (SegSlice& sl : P.slices) {
+				sl.nc[0] = sl.nc[keep];
+				sl.off[0] = sl.off[keep];
+				sl.nc[1] = 0;
+				sl.off[1] = 0;
+			}
+			P.gval[0] = P.gval[keep];
+			P.gval[1] = 0.0;
+			P.G = 1;
+		}
+	}
+	if (P.G == 2) { // group 0 requested two chunks ahead when its lists rarely hold more (4x5 lattice: the + hops hold 2, the - hops 3-4 chunks)
 		int64_t longer = 0;
 		for (size_t j = 0; j < P.slices.size(); j++) longer += P.slices[j].nc[0] > 2 ? 1 : 0;
 		if (longer * 8 <= (int64_t)P.slices.size()) P.pre0 = 2;
 	}
 	P.ws = P.zmax + kPbZeroSlotsHost; // window stride in elements (even)
 	P.words.resize(P.words.size() + 256 * 4, (uint32_t)P.zmax | ((uint32_t)P.zmax << 16)); // slack for the look-ahead loads
-	P.xwords.resize(P.xwords.size() + 8192 + 64, 0); // a slice of any segment may read any table at its own offset
+	const int32_t zero_table = (int32_t)P.xwords.size(); // 8192 + 64 zero words: the table of the filling entries (any offset of any segment stays inside)
+	P.xwords.resize(P.xwords.size() + 8192 + 64, 0);
 	// every segment's lists padded to the kernel instance's width with entries of value 0.0 that read valid addresses: the slice
 	// loop then carries no condition at all (padded cross entries: a table of the segment's own class -- or table 0, the longest --
 	// and the row's first elements; padded high-high entries: the segment itself)
 	// kernel instances (NC, NH): (2, 2), (5, 4), (6, 8) and -- one block per workgroup only: chains -- (2, 12)
 	if (P.max_cross <= 2 && P.max_hh <= 2) P.nc_pad = 2, P.nh_pad = 2;
+	else if (one_block && P.max_cross <= 2) P.nc_pad = 2, P.nh_pad = 12;
+	else if (one_block) return LPP_OK;
 	else if (P.max_cross <= 5 && P.max_hh <= 4) P.nc_pad = 5, P.nh_pad = 4;
 	else if (P.max_cross <= 6 && P.max_hh <= 8) P.nc_pad = 6, P.nh_pad = 8;
-	else if (P.max_cross <= 2) P.nc_pad = 2, P.nh_pad = 12;
 	else return LPP_OK;
 	{
 		std::vector<SegCross> cp(P.segs.size() * (size_t)P.nc_pad);
@@ -452,7 +473,7 @@ lpp_status pb_seg_plan_model(int L, int n, const std::vector<double>& hv, const 
 		for (size_t i = 0; i < P.segs.size(); i++) {
 			SegInst& S = P.segs[i];
 			for (int b = 0; b < P.nc_pad; b++)
-				cp[i * P.nc_pad + b] = b < S.ncross ? P.cross[(size_t)(S.cross_first + b)] : SegCross { S.ncross > 0 ? P.cross[(size_t)S.cross_first].wordoff : 0, 0, { 0.0, 0.0 }, 0 };
+				cp[i * P.nc_pad + b] = b < S.ncross ? P.cross[(size_t)(S.cross_first + b)] : SegCross { zero_table, 0, { 0.0, 0.0 }, 0 }; // all-zero words: every lane reads the row's first element (one line)
 			for (int b = 0; b < P.nh_pad; b++) hp[i * P.nh_pad + b] = b < S.nhh ? P.hh[(size_t)(S.hh_first + b)] : SegHh { S.sbase, 0, 0.0 }; // pad = 0: every lane reads the segment's first element (one line)
 			S.cross_first = (int32_t)(i * P.nc_pad);
 			S.hh_first = (int32_t)(i * P.nh_pad);

@@ -34,19 +34,22 @@ struct PbSegArgs {
 	double* u;
 	double* partial; // per-workgroup Re<y|u> (null: not wanted)
 	EpiScale sc; // only alpha is used
-	int flat; // 1: work items are dealt over ALL workgroups (few blocks: a Heisenberg chain is one block), 0: blocks by XCD
+	// 1: one block only (pb_chain) -- its items are dealt over ALL workgroups, item i to workgroup i mod gridDim.  (Contiguous ranges of the
+	// stored order per XCD, so that the segments a slice reads from memory were staged by the same XCD a moment ago, cut the fabric reads
+	// from 2.4 to 1.9 GB per product at L = 28 and ran 4 % SLOWER whatever the balance between the ranges: not kept.)  0: blocks by XCD
+	int flat;
 };
 
 constexpr int kSegThreads = 512; // 8 waves of up to 256 registers: two slices' loads from the rows in flight per wave
 constexpr int kSegPre = 4; // in-window chunks of every (slice, group) requested one slice ahead
 constexpr int kSegStage = 16; // 16-byte pieces per thread that stage the two windows: ALL in flight together (2 x 8128 elements at most)
 
-// LDS: [0, 2 ws) windows | dcode[2][wmax + 32] | slice heads[160] | cross[16 * 12] | hh[16 * 8] | dict[256] | smem[8]
+// LDS: [0, 2 ws) windows | dcode[2][wmax + 32] | 2 x slice heads[160] | 2 x cross[16 * 6] | 2 x hh[16 * 12] | dict[256] | smem[8]
 __host__ __device__ inline size_t pb_seg_dcode_stride(int wmax) { return ((size_t)wmax + 32 + 15) & ~(size_t)15; }
 __host__ __device__ inline size_t pb_seg_tab_offset(int ws, int wmax) { return (2 * sizeof(double) * (size_t)ws + 2 * pb_seg_dcode_stride(wmax) + 15) & ~(size_t)15; }
 __host__ __device__ inline size_t pb_seg_lds_bytes(int ws, int wmax)
 {
-	return pb_seg_tab_offset(ws, wmax) + sizeof(SegSlice) * kSegMaxSlices + sizeof(SegCross) * kSegMaxSegs * kSegMaxCross + sizeof(SegHh) * kSegMaxSegs * kSegMaxHh + sizeof(double) * (256 + kSegThreads / 64) + 16;
+	return pb_seg_tab_offset(ws, wmax) + 2 * (sizeof(SegSlice) * kSegMaxSlices + sizeof(SegCross) * kSegMaxSegs * kSegMaxCross + sizeof(SegHh) * kSegMaxSegs * kSegMaxHh) + sizeof(double) * (256 + kSegThreads / 64) + 16;
 }
 
 template <int GG> struct SegHeads { // wave-uniform
@@ -86,9 +89,9 @@ template <bool DOT, int GT, int P0, int P1, int NC, int NH, int ROWS = 2> __glob
 	const size_t dstride = pb_seg_dcode_stride(a.wmax);
 	uint8_t* dcode_s = (uint8_t*)(win + 2 * WS); // [2][dstride]
 	SegSlice* heads_s = (SegSlice*)(lds_raw + pb_seg_tab_offset(a.ws, a.wmax));
-	SegCross* cross_s = (SegCross*)(heads_s + kSegMaxSlices);
-	SegHh* hh_s = (SegHh*)(cross_s + kSegMaxSegs * kSegMaxCross);
-	double* dict_s = (double*)(hh_s + kSegMaxSegs * kSegMaxHh);
+	SegCross* cross_s = (SegCross*)(heads_s + 2 * kSegMaxSlices); // (two sets of tables: one block per workgroup alternates between them)
+	SegHh* hh_s = (SegHh*)(cross_s + 2 * kSegMaxSegs * kSegMaxCross);
+	double* dict_s = (double*)(hh_s + 2 * kSegMaxSegs * kSegMaxHh);
 	double* smem = dict_s + 256;
 	for (int i = threadIdx.x; i < 256; i += kSegThreads) dict_s[i] = a.dict[i];
 	double alpha, beta_unused;
@@ -112,78 +115,132 @@ template <bool DOT, int GT, int P0, int P1, int NC, int NH, int ROWS = 2> __glob
 	const int64_t slot = nx == 8 ? (int64_t)(blockIdx.x >> 3) : (int64_t)blockIdx.x, nslots = gridDim.x / nx;
 	const int64_t nbx = (a.n_blk - xcd + nx - 1) / nx;
 	const int64_t npairs = ROWS == 2 ? (nbx + 1) >> 1 : nbx;
-	auto gather4x2 = [=](const uint2& w, double& a0, double& a1, double& b0, double& b1) __attribute__((always_inline)) {
-		const uint32_t p0 = pb_lo8(w.x), p1 = pb_hi8(w.x), p2 = pb_lo8(w.y), p3 = pb_hi8(w.y);
-		a0 += pb_lds_abs(p0);
-		if (ROWS == 2) b0 += pb_lds_abs(p0 + wbytes);
-		a1 += pb_lds_abs(p1);
-		if (ROWS == 2) b1 += pb_lds_abs(p1 + wbytes);
-		a0 += pb_lds_abs(p2);
-		if (ROWS == 2) b0 += pb_lds_abs(p2 + wbytes);
-		a1 += pb_lds_abs(p3);
-		if (ROWS == 2) b1 += pb_lds_abs(p3 + wbytes);
+	// Staging of an item: the run [c0, c0 + wlen) starts at any element: the pairs [e0, e1) around it are loaded as aligned 16-byte pieces
+	// and land at window index e - c0 + kSegWinPad (>= 1), as two 8-byte LDS stores (the pair may straddle a 16-byte LDS boundary).  ALL
+	// of a thread's pieces -- rows, codes, slice heads, the segments' scalars -- are requested before the first is stored: one round trip.
+	constexpr int NST = kSegStage * ROWS / 2;
+	struct Stage {
+		double2 t[NST];
+		uint4 dc[ROWS];
+		uint4 hd, cr, hq;
 	};
-	for (int64_t seq = slot; seq < npairs * nitems; seq += nslots) {
-		const int64_t pr = seq / nitems;
-		const int it = (int)(seq - pr * nitems);
+	struct Work { // one (blocks, item) of the sequence
+		SegItem I;
+		int64_t rowbase0, rowbase1;
+		bool two;
+	};
+	auto decode = [=](int64_t sq, Work& w) __attribute__((always_inline)) {
+		const int64_t pr = sq / nitems;
+		const int it = (int)(sq - pr * nitems);
 		const int64_t blk0 = (ROWS * pr) * nx + xcd;
-		const bool two = ROWS == 2 && 2 * pr + 1 < nbx; // the last pair of an odd count holds one block: its twin re-reads it and stores nothing
-		const int64_t blk1 = two ? (2 * pr + 1) * nx + xcd : blk0;
-		const SegItem I = a.items[it];
-		const int c0 = I.c0, wlen = I.wlen, nsl = I.nslices;
-		const int64_t rowbase0 = blk0 * a.pitch, rowbase1 = blk1 * a.pitch;
-		const double* const yrow0 = a.y + rowbase0;
-		const double* const yrow1 = a.y + rowbase1;
-		{
-			// the run [c0, c0 + wlen) starts at any element: the pairs [e0, e1) around it are loaded as aligned 16-byte pieces and land at
-			// window index e - c0 + kSegWinPad (>= 1), as two 8-byte LDS stores (the pair may straddle a 16-byte LDS boundary).
-			// Everything this thread stages is requested here, in front of the barrier that waits for the previous item's slices
-			const int e0 = c0 & ~1, e1 = (c0 + wlen + 1) & ~1;
-			const int p2 = (e1 - e0) >> 1, lbase = e0 - c0 + kSegWinPad;
-			constexpr int NST = kSegStage * ROWS / 2;
-			double2 t[NST];
+		w.two = ROWS == 2 && 2 * pr + 1 < nbx; // the last pair of an odd count holds one block: its twin re-reads it and stores nothing
+		const int64_t blk1 = w.two ? (2 * pr + 1) * nx + xcd : blk0;
+		w.I = a.items[it];
+		w.rowbase0 = blk0 * a.pitch;
+		w.rowbase1 = blk1 * a.pitch;
+	};
+	auto stage_load = [=](const Work& w, Stage& S) __attribute__((always_inline)) {
+		const int c0 = w.I.c0, wlen = w.I.wlen;
+		const double* const yr0 = a.y + w.rowbase0;
+		const double* const yr1 = a.y + w.rowbase1;
+		const int e0 = c0 & ~1, e1 = (c0 + wlen + 1) & ~1;
+		const int p2 = (e1 - e0) >> 1;
 #pragma unroll
-			for (int k = 0; k < NST; k++) { // [0, p2): block 0, [p2, 2 p2): block 1; clamped lanes re-load the last pair
-				const int idx = min((int)threadIdx.x + k * kSegThreads, ROWS * p2 - 1);
-				const bool second = idx >= p2;
-				t[k] = ((const double2*)((second ? yrow1 : yrow0) + e0))[second ? idx - p2 : idx];
-			}
-			const int d0 = c0 & ~15, p16 = (((c0 + wlen + 15) & ~15) - d0) >> 4; // 16 codes per piece: at most 2 x 510 pieces
-			uint4 dc[ROWS];
+		for (int k = 0; k < NST; k++) { // [0, p2): block 0, [p2, 2 p2): block 1; clamped lanes re-load the last pair
+			const int idx = min((int)threadIdx.x + k * kSegThreads, ROWS * p2 - 1);
+			const bool second = idx >= p2;
+			S.t[k] = ((const double2*)((second ? yr1 : yr0) + e0))[second ? idx - p2 : idx];
+		}
+		const int d0 = c0 & ~15, p16 = (((c0 + wlen + 15) & ~15) - d0) >> 4; // 16 codes per piece: at most 510 pieces per row
 #pragma unroll
-			for (int k = 0; k < ROWS; k++) {
-				const int i0 = min((int)threadIdx.x + k * kSegThreads, ROWS * p16 - 1);
-				const bool second = i0 >= p16;
-				dc[k] = ((const uint4*)(a.dcode + (second ? rowbase1 : rowbase0) + d0))[second ? i0 - p16 : i0];
-			}
-			const int nhd = nsl, ncr = I.nseg * NC * 2, nhh = I.nseg * NH; // <= 160, 192, 128: one 16-byte piece per thread each
-			const uint4 hd = ((const uint4*)(a.slices + I.slice_first))[min((int)threadIdx.x, nhd - 1)];
-			const uint4 cr = ((const uint4*)(a.cross + (size_t)I.seg_first * NC))[min((int)threadIdx.x, ncr - 1)]; // (an entry is two pieces)
-			const uint4 hq = ((const uint4*)(a.hh + (size_t)I.seg_first * NH))[min((int)threadIdx.x, nhh - 1)];
-			__syncthreads(); // everyone is done with the previous windows and tables
+		for (int k = 0; k < ROWS; k++) {
+			const int i0 = min((int)threadIdx.x + k * kSegThreads, ROWS * p16 - 1);
+			const bool second = i0 >= p16;
+			S.dc[k] = ((const uint4*)(a.dcode + (second ? w.rowbase1 : w.rowbase0) + d0))[second ? i0 - p16 : i0];
+		}
+		// <= 160 slice heads, 16 x 6 x 2 cross pieces, 16 x 12 high-high entries: one 16-byte piece per thread each
+		S.hd = ((const uint4*)(a.slices + w.I.slice_first))[min((int)threadIdx.x, w.I.nslices - 1)];
+		S.cr = ((const uint4*)(a.cross + (size_t)w.I.seg_first * NC))[min((int)threadIdx.x, w.I.nseg * NC * 2 - 1)]; // (an entry is two pieces)
+		S.hq = ((const uint4*)(a.hh + (size_t)w.I.seg_first * NH))[min((int)threadIdx.x, w.I.nseg * NH - 1)];
+	};
+	// ROWS == 2: the two blocks' windows are windows 0 and 1; ROWS == 1: the block's window is window `buf` (with its own codes and tables)
+	auto stage_store = [=](const Work& w, int buf, const Stage& S) __attribute__((always_inline)) {
+		const int c0 = w.I.c0, wlen = w.I.wlen;
+		const int e0 = c0 & ~1, e1 = (c0 + wlen + 1) & ~1;
+		const int p2 = (e1 - e0) >> 1, lbase = e0 - c0 + kSegWinPad;
 #pragma unroll
-			for (int k = 0; k < NST; k++) {
-				const int idx = min((int)threadIdx.x + k * kSegThreads, ROWS * p2 - 1);
-				const bool second = idx >= p2;
-				double* const d = win + (second ? WS : 0) + lbase + 2 * (second ? idx - p2 : idx);
-				d[0] = t[k].x;
-				d[1] = t[k].y;
-			}
+		for (int k = 0; k < NST; k++) {
+			const int idx = min((int)threadIdx.x + k * kSegThreads, ROWS * p2 - 1);
+			const bool second = idx >= p2;
+			double* const d = win + (ROWS == 2 ? (second ? WS : 0) : buf * WS) + lbase + 2 * (second ? idx - p2 : idx);
+			d[0] = S.t[k].x;
+			d[1] = S.t[k].y;
+		}
+		const int d0 = c0 & ~15, p16 = (((c0 + wlen + 15) & ~15) - d0) >> 4;
 #pragma unroll
-			for (int k = 0; k < ROWS; k++) {
-				const int i0 = min((int)threadIdx.x + k * kSegThreads, ROWS * p16 - 1);
-				const bool second = i0 >= p16;
-				((uint4*)(dcode_s + (second ? dstride : 0)))[second ? i0 - p16 : i0] = dc[k];
-			}
-			if ((int)threadIdx.x < nhd) ((uint4*)heads_s)[threadIdx.x] = hd;
-			if ((int)threadIdx.x < ncr) ((uint4*)cross_s)[threadIdx.x] = cr;
-			if ((int)threadIdx.x < nhh) ((uint4*)hh_s)[threadIdx.x] = hq;
-			if (threadIdx.x < ROWS * kPbZeroSlots) win[(threadIdx.x >> 5) * WS + I.zero_at + (threadIdx.x & 31)] = 0.0;
+		for (int k = 0; k < ROWS; k++) {
+			const int i0 = min((int)threadIdx.x + k * kSegThreads, ROWS * p16 - 1);
+			const bool second = i0 >= p16;
+			((uint4*)(dcode_s + (ROWS == 2 ? (second ? dstride : 0) : buf * dstride)))[second ? i0 - p16 : i0] = S.dc[k];
+		}
+		if ((int)threadIdx.x < w.I.nslices) ((uint4*)(heads_s + buf * kSegMaxSlices))[threadIdx.x] = S.hd;
+		if ((int)threadIdx.x < w.I.nseg * NC * 2) ((uint4*)(cross_s + buf * kSegMaxSegs * kSegMaxCross))[threadIdx.x] = S.cr;
+		if ((int)threadIdx.x < w.I.nseg * NH) ((uint4*)(hh_s + buf * kSegMaxSegs * kSegMaxHh))[threadIdx.x] = S.hq;
+		if (threadIdx.x < ROWS * kPbZeroSlots) win[(ROWS == 2 ? (threadIdx.x >> 5) : buf) * WS + w.I.zero_at + (threadIdx.x & 31)] = 0.0;
+	};
+	const int64_t total = npairs * nitems;
+	Stage S;
+	Work wk, wn;
+	int cur = 0;
+	if (ROWS == 1) { // one block per workgroup: the second window takes the NEXT item while this one's slices run (one barrier per item)
+		if (slot < total) {
+			decode(slot, wk);
+			stage_load(wk, S);
+			stage_store(wk, 0, S);
 		}
 		__syncthreads();
+	}
+	for (int64_t seq = slot; seq < total; seq += nslots) {
+		bool has_next = false;
+		if (ROWS == 2) {
+			decode(seq, wk);
+			stage_load(wk, S); // requested in front of the barrier that waits for the previous item's slices
+			__syncthreads(); // everyone is done with the previous windows and tables
+			stage_store(wk, 0, S);
+			__syncthreads();
+		} else {
+			has_next = seq + nslots < total;
+			if (has_next) {
+				decode(seq + nslots, wn);
+				stage_load(wn, S); // in flight while this item's slices run
+			}
+		}
+		const int c0 = wk.I.c0, nsl = wk.I.nslices;
+		const bool two = wk.two;
+		const int64_t rowbase0 = wk.rowbase0, rowbase1 = wk.rowbase1;
+		const double* const yrow0 = a.y + rowbase0;
+		const double* const yrow1 = a.y + rowbase1;
+		// this item's window, codes and tables
+		const uint32_t woff = ROWS == 1 ? (uint32_t)cur * wbytes : 0u;
+		const double* const win_c = win + (ROWS == 1 ? cur * WS : 0);
+		const uint8_t* const dcode_c = dcode_s + (ROWS == 1 ? cur * dstride : 0);
+		const SegSlice* const heads_c = heads_s + (ROWS == 1 ? cur * kSegMaxSlices : 0);
+		const SegCross* const cross_c = cross_s + (ROWS == 1 ? cur * kSegMaxSegs * kSegMaxCross : 0);
+		const SegHh* const hh_c = hh_s + (ROWS == 1 ? cur * kSegMaxSegs * kSegMaxHh : 0);
+		auto gather4x2 = [=](const uint2& w, double& a0, double& a1, double& b0, double& b1) __attribute__((always_inline)) {
+			const uint32_t p0 = pb_lo8(w.x) + woff, p1 = pb_hi8(w.x) + woff, p2 = pb_lo8(w.y) + woff, p3 = pb_hi8(w.y) + woff;
+			a0 += pb_lds_abs(p0);
+			if (ROWS == 2) b0 += pb_lds_abs(p0 + wbytes);
+			a1 += pb_lds_abs(p1);
+			if (ROWS == 2) b1 += pb_lds_abs(p1 + wbytes);
+			a0 += pb_lds_abs(p2);
+			if (ROWS == 2) b0 += pb_lds_abs(p2 + wbytes);
+			a1 += pb_lds_abs(p3);
+			if (ROWS == 2) b1 += pb_lds_abs(p3 + wbytes);
+		};
 		const int doff = (c0 & 15); // dcode_s index of the item's first position
 		auto load_heads = [=](int jj, SegHeads<GG>& h) __attribute__((always_inline)) {
-			const uint4 q = ((const uint4*)heads_s)[min(jj, nsl - 1)]; // one LDS read, the same address in every lane; beyond the item: a valid slice, never used
+			const uint4 q = ((const uint4*)heads_c)[min(jj, nsl - 1)]; // one LDS read, the same address in every lane; beyond the item: a valid slice, never used
 			h.first = __builtin_amdgcn_readfirstlane((int)(q.x & 0xffffu));
 			h.count = __builtin_amdgcn_readfirstlane((int)((q.x >> 16) & 0xffu));
 			h.seg = __builtin_amdgcn_readfirstlane((int)(q.x >> 24));
@@ -206,13 +263,13 @@ template <bool DOT, int GT, int P0, int P1, int NC, int NH, int ROWS = 2> __glob
 		};
 		auto load_cross_words = [=](const SegHeads<GG>& h, SegCrossWords<NC>& s) __attribute__((always_inline)) {
 #pragma unroll
-			for (int b = 0; b < NC; b++) s.x[b] = xw[(size_t)(cross_s[h.seg * NC + b].wordoff + h.segoff) + lane];
+			for (int b = 0; b < NC; b++) s.x[b] = xw[(size_t)(cross_c[h.seg * NC + b].wordoff + h.segoff) + lane];
 		};
 		auto issue_data = [=](const SegHeads<GG>& h, const SegCrossWords<NC>& s, SegData<NC, NH, ROWS>& d) __attribute__((always_inline)) {
 			uint32_t sg = 0;
 #pragma unroll
 			for (int b = 0; b < NC; b++) {
-				const uint32_t sb = (uint32_t)cross_s[h.seg * NC + b].srcbase;
+				const uint32_t sb = (uint32_t)cross_c[h.seg * NC + b].srcbase;
 				const uint32_t at0 = (sb + (s.x[b] & 0x1fffu)) * 8u, at1 = (sb + ((s.x[b] >> 16) & 0x1fffu)) * 8u;
 				d.xa[2 * b] = *(const double*)((const char*)yrow0 + at0);
 				if (ROWS == 2) d.xb[2 * b] = *(const double*)((const char*)yrow1 + at0);
@@ -224,7 +281,7 @@ template <bool DOT, int GT, int P0, int P1, int NC, int NH, int ROWS = 2> __glob
 			const int lc = min(lane, h.count - 1);
 #pragma unroll
 			for (int b = 0; b < NH; b++) {
-				const uint32_t at = (uint32_t)(hh_s[h.seg * NH + b].srcbase + (h.segoff + lc) * hh_s[h.seg * NH + b].pad) * 8u;
+				const uint32_t at = (uint32_t)(hh_c[h.seg * NH + b].srcbase + (h.segoff + lc) * hh_c[h.seg * NH + b].pad) * 8u;
 				d.ha[b] = *(const double*)((const char*)yrow0 + at);
 				if (ROWS == 2) d.hb[b] = *(const double*)((const char*)yrow1 + at);
 			}
@@ -264,21 +321,21 @@ template <bool DOT, int GT, int P0, int P1, int NC, int NH, int ROWS = 2> __glob
 #pragma unroll
 			for (int b = 0; b < 2 * NC; b++) {
 				// two bits per hop as a signed field: +1, -1 or 0 (no entry: the element read was the source segment's first)
-				const double v = cross_s[h.seg * NC + (b >> 1)].val[b & 1] * (double)((int32_t)(d.sg << (30 - 2 * b)) >> 30);
+				const double v = cross_c[h.seg * NC + (b >> 1)].val[b & 1] * (double)((int32_t)(d.sg << (30 - 2 * b)) >> 30);
 				acc0 = fma(v, d.xa[b], acc0);
 				if (ROWS == 2) acc1 = fma(v, d.xb[b], acc1);
 			}
 #pragma unroll
 			for (int b = 0; b < NH; b++) {
-				const double v = hh_s[h.seg * NH + b].val;
+				const double v = hh_c[h.seg * NH + b].val;
 				acc0 = fma(v, d.ha[b], acc0);
 				if (ROWS == 2) acc1 = fma(v, d.hb[b], acc1);
 			}
 			const int lc = min(lane, h.count - 1);
 			const int il = h.first + lc; // position in the item
-			const double y0 = win[il + kSegWinPad], y1 = ROWS == 2 ? win[WS + il + kSegWinPad] : 0.0;
-			acc0 = fma(dict_s[dcode_s[il + doff]], y0, acc0);
-			if (ROWS == 2) acc1 = fma(dict_s[dcode_s[dstride + il + doff]], y1, acc1);
+			const double y0 = win_c[il + kSegWinPad], y1 = ROWS == 2 ? win_c[WS + il + kSegWinPad] : 0.0;
+			acc0 = fma(dict_s[dcode_c[il + doff]], y0, acc0);
+			if (ROWS == 2) acc1 = fma(dict_s[dcode_c[dstride + il + doff]], y1, acc1);
 			if (lane < h.count) {
 				const double u0 = alpha * acc0, u1 = alpha * acc1;
 				__builtin_nontemporal_store(u0, &uout[rowbase0 + c0 + il]);
@@ -317,6 +374,12 @@ template <bool DOT, int GT, int P0, int P1, int NC, int NH, int ROWS = 2> __glob
 			h0 = h2;
 			h1 = h3;
 			h2 = h4;
+		}
+		if (ROWS == 1) {
+			if (has_next) stage_store(wn, cur ^ 1, S);
+			__syncthreads(); // this item's slices are done with window `cur`; the next item's window is complete
+			cur ^= 1;
+			wk = wn;
 		}
 	}
 	if (DOT) {
