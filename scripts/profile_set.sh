@@ -19,7 +19,7 @@ cfg() { # name, bench args, env
     c5_76) echo "--engine onthefly --workload hubbard_4x5_7up6down_pbc_U4 --no-generic-csr" ;;
   esac
 }
-for c in c2_stored c2otf c2otf_kron c3 c4 c1 c5_76; do
+for c in ${CONFIGS:-c2_stored c2otf c2otf_kron c3 c4 c1 c5_76}; do
   if [ $c = c2otf_kron ]; then export LPP_ONTHEFLY_KRON=1; else unset LPP_ONTHEFLY_KRON; fi
   if [ $MODE = counters ]; then
     SQ_PASS=$([ $c = c2_stored ] && echo 1) BENCH_ARGS="$(cfg $c)" bash scripts/profile_round.sh ${T}_$c > gpurun_out/ps_$c.out 2>&1 || { tail -5 gpurun_out/ps_$c.out; exit 1; }
@@ -29,7 +29,7 @@ for c in c2_stored c2otf c2otf_kron c3 c4 c1 c5_76; do
   fi
   echo "$c done: $(python3 -c "import json;d=json.loads(open('gpurun_out/profile_${T}_$c/bench.json').read().strip().splitlines()[-1]);print(round(d['value'],1),'it/s; traffic',d['roofline'].get('traffic'),d['roofline'].get('traffic_note',''))")"
 done
-if [ $MODE = counters ]; then
+if [ $MODE = counters ] && [ -z "$NO_REORTHO" ]; then
   export TMPDIR=/tmp; O=$R/gpurun_out/profile_${T}_reortho; mkdir -p $O; cd /tmp
   CMDR="python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-generic-csr --no-e0-check"
   timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- $CMDR > $O/bench.json 2> $O/trace.log
