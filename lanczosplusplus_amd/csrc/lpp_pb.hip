@@ -196,13 +196,29 @@ lpp_status pb_build(lpp_engine* e, int64_t n_up, int64_t n_blk, const int64_t* t
 	if (pre) { // the caller made the plan from the model's parameters (pb_chain): there is no host copy of T
 		if (W == 0 || cx || tx || n_blk != 1 || c_rp[1] != 0) return fail(LPP_ERR_INVALID, "pb_build: a ready-made plan is for one block beyond the LDS window");
 		SP = std::move(*pre);
-		seg = pb_seg_lds_bytes(SP.ws, SP.wmax) <= (size_t)160 * 1024 - 64;
+		seg = pb_seg_lds_bytes(SP.ws, SP.wmax, 1) <= (size_t)160 * 1024 - 64;
 		if (!seg) return fail(LPP_ERR_INVALID, "pb_build: the plan exceeds LDS");
-	} else if (W > 0 && !cx && big2 && !(getenv("LPP_PB_SEG") && atoi(getenv("LPP_PB_SEG")) == 0)) {
-		const int wcap = (int)std::min<int64_t>(wmax, 8128);
+	// Taken by itself from 65536 positions per row on: below that the per-position template (80 bytes per position: 3.1 MB at the 38760
+	// positions of the 4x5 lattice's 6-electron species) still shares an XCD's L2 with the rows, and k_pb_up_big2 -- compact far lists, fewer
+	// lines through L1 -- is faster (the (6,6) sector: 36.8 against 42.7 ms per step; the (7,6) sector, 77520 positions: 91.9 against 90.0).
+	// LPP_PB_SEG=0 / 1: never / wherever it applies.
+	} else if (W > 0 && !cx && big2 && (getenv("LPP_PB_SEG") ? atoi(getenv("LPP_PB_SEG")) != 0 : n_up >= 65536)) {
+		int wcap = (int)std::min<int64_t>(wmax, 8128);
 		lpp_status rs = pb_seg_plan(n_up, t_rp, t_ci, t_va, wcap, SP, &seg);
 		if (rs != LPP_OK) return rs;
-		if (seg && pb_seg_lds_bytes(SP.ws, SP.wmax) > (size_t)160 * 1024 - 64) seg = false;
+		// One more high site when the two windows of the longest item do not fit beside the tables, or when the cut runs through a ring of
+		// the lattice and a segment has more hops than the (5 pairs, 4) kernel instance carries -- the (6, 8) one spills: the (6,6) sector of the
+		// 4x5 lattice cut at 4 high sites ran 71 ms per step against 37 with the per-position template
+		for (int more = 0; more < 2 && seg && (pb_seg_lds_bytes(SP.ws, SP.wmax, 2) > (size_t)160 * 1024 - 64 || SP.nc_pad > 5); more++) {
+			SegPlan SP2;
+			bool seg2 = false;
+			wcap = std::max(64, SP.wmax - 1);
+			rs = pb_seg_plan(n_up, t_rp, t_ci, t_va, wcap, SP2, &seg2);
+			if (rs != LPP_OK) return rs;
+			if (!seg2 || SP2.s <= SP.s) break;
+			SP = std::move(SP2);
+		}
+		if (seg && pb_seg_lds_bytes(SP.ws, SP.wmax, 2) > (size_t)160 * 1024 - 64) seg = false;
 		if (getenv("LPP_VERBOSE"))
 			fprintf(stderr, "lpp: segmented in-block form %s (L = %d, n = %d, %d high sites, %zu segments, %zu items of <= %d positions, %d types, %.2f MB)\n", seg ? "taken" : "does not apply",
 			        SP.L, SP.n, SP.s, SP.segs.size(), SP.items.size(), SP.wmax, SP.ntypes, (SP.words.size() * 4 + SP.xwords.size() * 4) / 1048576.0);
@@ -575,7 +591,7 @@ static int launch_up_big(lpp_engine* e, const double* y, double* u, const uint8_
 		g.partial = partial;
 		g.sc = sc;
 		g.flat = B.seg_one ? 1 : 0;
-		const size_t lds = pb_seg_lds_bytes(B.seg_ws, B.seg_wmax);
+		const size_t lds = pb_seg_lds_bytes(B.seg_ws, B.seg_wmax, B.seg_one ? 1 : 2);
 #define LPP_PB_SEG(DOT_, GT_, P0_, NC_, NH_)                                                                            \
 	do {                                                                                                              \
 		(void)hipFuncSetAttribute((const void*)k_pb_up_seg<DOT_, GT_, P0_, 4, NC_, NH_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \

@@ -47,9 +47,10 @@ constexpr int kSegStage = 16; // 16-byte pieces per thread that stage the two wi
 // LDS: [0, 2 ws) windows | dcode[2][wmax + 32] | 2 x slice heads[160] | 2 x cross[16 * 6] | 2 x hh[16 * 12] | dict[256] | smem[8]
 __host__ __device__ inline size_t pb_seg_dcode_stride(int wmax) { return ((size_t)wmax + 32 + 15) & ~(size_t)15; }
 __host__ __device__ inline size_t pb_seg_tab_offset(int ws, int wmax) { return (2 * sizeof(double) * (size_t)ws + 2 * pb_seg_dcode_stride(wmax) + 15) & ~(size_t)15; }
-__host__ __device__ inline size_t pb_seg_lds_bytes(int ws, int wmax)
+// (rows: blocks per workgroup; one block per workgroup alternates between TWO sets of tables)
+__host__ __device__ inline size_t pb_seg_lds_bytes(int ws, int wmax, int rows)
 {
-	return pb_seg_tab_offset(ws, wmax) + 2 * (sizeof(SegSlice) * kSegMaxSlices + sizeof(SegCross) * kSegMaxSegs * kSegMaxCross + sizeof(SegHh) * kSegMaxSegs * kSegMaxHh) + sizeof(double) * (256 + kSegThreads / 64) + 16;
+	return pb_seg_tab_offset(ws, wmax) + (rows == 1 ? 2 : 1) * (sizeof(SegSlice) * kSegMaxSlices + sizeof(SegCross) * kSegMaxSegs * kSegMaxCross + sizeof(SegHh) * kSegMaxSegs * kSegMaxHh) + sizeof(double) * (256 + kSegThreads / 64) + 16;
 }
 
 template <int GG> struct SegHeads { // wave-uniform
@@ -89,9 +90,10 @@ template <bool DOT, int GT, int P0, int P1, int NC, int NH, int ROWS = 2> __glob
 	const size_t dstride = pb_seg_dcode_stride(a.wmax);
 	uint8_t* dcode_s = (uint8_t*)(win + 2 * WS); // [2][dstride]
 	SegSlice* heads_s = (SegSlice*)(lds_raw + pb_seg_tab_offset(a.ws, a.wmax));
-	SegCross* cross_s = (SegCross*)(heads_s + 2 * kSegMaxSlices); // (two sets of tables: one block per workgroup alternates between them)
-	SegHh* hh_s = (SegHh*)(cross_s + 2 * kSegMaxSegs * kSegMaxCross);
-	double* dict_s = (double*)(hh_s + 2 * kSegMaxSegs * kSegMaxHh);
+	constexpr int NT = ROWS == 1 ? 2 : 1; // sets of tables: one block per workgroup alternates between two
+	SegCross* cross_s = (SegCross*)(heads_s + NT * kSegMaxSlices);
+	SegHh* hh_s = (SegHh*)(cross_s + NT * kSegMaxSegs * kSegMaxCross);
+	double* dict_s = (double*)(hh_s + NT * kSegMaxSegs * kSegMaxHh);
 	double* smem = dict_s + 256;
 	for (int i = threadIdx.x; i < 256; i += kSegThreads) dict_s[i] = a.dict[i];
 	double alpha, beta_unused;

@@ -109,6 +109,8 @@ def test_config5_7up6down_sector_matrix_free_free_fermions():
     with LanczosEngine(max_steps=300, eps=1e-11, save_vectors=0) as e:
         e.setup_hubbard_onthefly(L, 7, 6, hop, np.zeros(L))
         assert e.rows() == 77520 * 38760 == 3004675200
+        lay = e.layout()  # rows of 77520 positions: the in-block matrix decomposed by the 5 high sites (one slab of the lattice), 32 segments in 14 items
+        assert lay["kernel"] == 4 and (lay["segments"], lay["pieces"]) == (32, 14), lay
         eg, _, st = e.lanczos(1, want_vectors=False)
     assert abs(eg[0] - exact) <= E_TOL * abs(exact), (eg[0], exact, st["steps"])
 

@@ -146,11 +146,18 @@ def test_config5_lattice_products_agree_beyond_the_lds_window(monkeypatch):
     with LanczosEngine(save_vectors=0) as e:
         e.setup_hubbard_onthefly(L, 6, 5, hop, U)
         lay = e.layout()
-        assert lay["kernel"] == 4 and lay["pieces"] > 1
+        assert lay["kernel"] == 4 and lay["pieces"] > 1 and lay["segments"] == 0  # below 65536 positions: the per-position template (k_pb_up_big2)
         hv = e.matrixVectorProduct(np.zeros(n), v)
         hu = e.matrixVectorProduct(np.zeros(n), u)
         acc = e.matrixVectorProduct(u.copy(), v)
         lin = e.matrixVectorProduct(np.zeros(n), 2.0 * u - 0.5 * v)
+    monkeypatch.setenv("LPP_PB_SEG", "1")  # the same rows decomposed by the high sites of the basis word (k_pb_up_seg; what longer rows take by themselves)
+    with LanczosEngine(save_vectors=0) as e:
+        e.setup_hubbard_onthefly(L, 6, 5, hop, U)
+        assert e.layout()["segments"] == 32
+        hv3 = e.matrixVectorProduct(np.zeros(n), v)
+    monkeypatch.delenv("LPP_PB_SEG")
+    assert np.max(np.abs(hv3 - hv)) <= 1e-13 * np.max(np.abs(hv))
     assert np.max(np.abs(acc - (u + hv))) <= 1e-12 * np.max(np.abs(hv))
     assert np.max(np.abs(lin - (2.0 * hu - 0.5 * hv))) <= 1e-12 * np.max(np.abs(hv))
     assert abs(np.dot(u, hv) - np.dot(hu, v)) <= 1e-11 * abs(np.dot(u, hv))

@@ -312,7 +312,8 @@ def _worker_beyond_lds(rank, world, port, q):
         q.put((rank, {"error": traceback.format_exc()}))
 
 
-def test_two_ranks_matrix_free_beyond_lds():
+def test_two_ranks_matrix_free_beyond_lds(monkeypatch):
+    monkeypatch.setenv("LPP_PB_SEG", "1")  # the in-block matrix decomposed by the high sites (taken by itself from 65536 positions on) on the exchange too
     world = 2
     res = _run_ranks(_worker_beyond_lds, world, timeout=400)
     for r in range(world):
