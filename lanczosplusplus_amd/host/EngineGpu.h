@@ -348,11 +348,43 @@ public:
 	bool usedFullDiag() const { return usedFullDiag_; }
 
 private:
+	// What one symmetry sector yields: its lowest levels and their vectors (sector-local), from the device solver or -- when that
+	// throws -- from the dense fallback of the reference (Engine.h:627-639).
+	struct SectorStates {
+		VectorRealType levels;
+		VectorVectorType states;
+	};
+
+	SectorStates solveSector(InternalProductType& h, LanczosSolverType& solver, SizeType nstates)
+	{
+		const SizeType dim = h.rows();
+		SectorStates out { VectorRealType(nstates), VectorVectorType(nstates, VectorType(dim)) };
+		VectorType start(dim);
+		fillRandom(start); // Engine.h:621
+		try {
+			solver.computeAllStatesBelow(out.levels, out.states, start, nstates); // Engine.h:626
+			steps_ = solver.steps();
+			return out;
+		} catch (std::exception& ex) {
+			std::cerr << "Engine: Lanczos Solver failed (" << ex.what() << ") trying exact diagonalization...\n";
+		}
+		if (nstates > dim) throw std::runtime_error("Engine: more states requested than the sector holds\n");
+		typename InternalProductType::VectorRealType all(dim);
+		typename InternalProductType::MatrixType vecs;
+		h.fullDiag(all, vecs);
+		for (SizeType k = 0; k < nstates; ++k) {
+			out.levels[k] = all[k];
+			for (SizeType r = 0; r < dim; ++r) out.states[k][r] = vecs(r, k);
+		}
+		usedFullDiag_ = true;
+		return out;
+	}
+
+	// Engine::computeAllStatesBelow (Engine.h:601-657): every sector of the symmetry is solved for `excited` + 1 states; the sector whose
+	// lowest level is the lowest overall supplies energies_ and vectors_, which the symmetry then maps back to the full basis.
 	void computeAllStatesBelow(SizeType excited)
-	{ // Engine.h:601-657
-		const SizeType excitedPlusOne = excited + 1;
-		energies_.assign(excitedPlusOne, 0);
-		vectors_.assign(excitedPlusOne, VectorType());
+	{
+		const SizeType nstates = excited + 1;
 		ParametersForSolverType params(io_, "Lanczos");
 		lpp_config cfg;
 		lpp_config_default(&cfg);
@@ -361,48 +393,29 @@ private:
 		SpecialSymmetryType rs(model_.basis(), model_.geometry(), "");
 		InternalProductType hamiltonian(model_, rs, cfg);
 		LanczosSolverType lanczosSolver(hamiltonian, params); // pushes params into the engine
-		SizeType offset = model_.size();
-		SizeType currentOffset = 0;
-		bool firstNonZeroSectorSeen = false;
-		for (SizeType i = 0; i < rs.sectors(); ++i) { // :616-652
-			hamiltonian.specialSymmetrySector(i);
-			const SizeType n = hamiltonian.rows();
-			if (n == 0) continue;
-			VectorType initial(n);
-			fillRandom(initial);
-			VectorVectorType zs(excitedPlusOne, VectorType(n));
-			VectorRealType eigs(excitedPlusOne);
-			try {
-				lanczosSolver.computeAllStatesBelow(eigs, zs, initial, excitedPlusOne);
-				steps_ = lanczosSolver.steps();
-			} catch (std::exception& ex) { // :627-639
-				std::cerr << "Engine: Lanczos Solver failed (" << ex.what() << ") trying exact diagonalization...\n";
-				typename InternalProductType::VectorRealType eigs2(n);
-				typename InternalProductType::MatrixType fm;
-				hamiltonian.fullDiag(eigs2, fm);
-				if (excitedPlusOne > n) throw std::runtime_error("Engine: more states requested than the sector holds\n");
-				for (SizeType k = 0; k < excitedPlusOne; ++k) {
-					for (SizeType j = 0; j < n; ++j) zs[k][j] = fm(j, k);
-					eigs[k] = eigs2[k];
-				}
-				usedFullDiag_ = true;
+		energies_.assign(nstates, 0);
+		vectors_.assign(nstates, VectorType());
+		bool have = false;
+		SizeType rowsBefore = 0, bestOffset = model_.size();
+		for (SizeType sec = 0; sec < rs.sectors(); ++sec) {
+			hamiltonian.specialSymmetrySector(sec);
+			if (hamiltonian.rows() == 0) continue; // an empty sector takes no rows either (Engine.h:619)
+			SectorStates found = solveSector(hamiltonian, lanczosSolver, nstates);
+			const SizeType dim = found.states[0].size();
+			if (!have || found.levels[0] < energies_[0]) { // Engine.h:641-649
+				energies_.swap(found.levels);
+				vectors_.swap(found.states);
+				bestOffset = rowsBefore;
+				sector_ = sec;
+				have = true;
 			}
-			if (eigs[0] < energies_[0] || !firstNonZeroSectorSeen) { // :641-649
-				for (SizeType j = 0; j < excitedPlusOne; ++j) {
-					vectors_[j] = zs[j];
-					energies_[j] = eigs[j];
-				}
-				offset = currentOffset;
-				firstNonZeroSectorSeen = true;
-				sector_ = i;
-			}
-			currentOffset += zs[0].size();
+			rowsBefore += dim;
 		}
-		rs.transform(vectors_, offset); // :654
-		for (SizeType i = 0; i < excitedPlusOne; i++) { // printEnergiesAndNorms, Engine.h:666-674
+		rs.transform(vectors_, bestOffset); // Engine.h:654
+		for (SizeType k = 0; k < nstates; k++) { // printEnergiesAndNorms, Engine.h:666-674
 			RealType nrm = 0;
-			for (const ComplexOrRealType& z : vectors_[i]) nrm += LppHost::real(z * LppHost::conj(z));
-			std::cout << "E[" << i << "]=" << energies_[i] << " norm=" << nrm << "\n";
+			for (const ComplexOrRealType& z : vectors_[k]) nrm += LppHost::real(z * LppHost::conj(z));
+			std::cout << "E[" << k << "]=" << energies_[k] << " norm=" << nrm << "\n";
 		}
 	}
 	const ModelType& model_;
