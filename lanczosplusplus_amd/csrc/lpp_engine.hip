@@ -1412,7 +1412,9 @@ lpp_status lpp_engine_get_layout(lpp_engine* e, int32_t which, lpp_layout* out)
 		    + (size_t)B.seg_bytes + (size_t)B.t_entries * 12 + sizeof(int64_t) * (size_t)(B.n_up + 1) + (size_t)B.c_nnz * 5 + sizeof(int64_t) * 2 * (size_t)(B.n_blk + 1) + 256 * sizeof(double);
 		// one diagonal code per row this rank holds, or one plain double when the diagonal has more than 256 distinct values
 		const size_t codes = (size_t)(B.tx ? B.nblk_loc : B.n_blk) * (size_t)B.pitch * (B.dval ? 9 : 1);
-		L.resident_bytes = (int64_t)(small + codes);
+		// (a chain keeps its plain CSR for lpp_engine_get_csr: resident, never read by a product)
+		const size_t kept = B.csr_kept ? (size_t)e->A_loc.nnz * (sizeof(int32_t) + s) + sizeof(int64_t) * (size_t)(e->A_loc.nrows + 1) : 0;
+		L.resident_bytes = (int64_t)(small + codes + kept);
 		// per product: one diagonal code per row; the template words and the couplings are re-read from L2 / LDS
 		L.stream_bytes = (int64_t)(codes + sizeof(uint32_t) * (size_t)(B.tw_words + B.f_words) + (size_t)B.seg_bytes + (size_t)B.c_nnz * 5);
 		*out = L;

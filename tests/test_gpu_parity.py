@@ -1156,3 +1156,28 @@ def test_heisenberg_chain_as_one_block_of_the_segmented_form(periodic, field, mo
     with LanczosEngine() as e:
         e.assemble_heisenberg(L, m, j2, jzz)
         assert e.layout()["kernel"] != 4
+
+
+def test_heisenberg_periodic_chain_L24_chain_layout_against_the_general_layout(monkeypatch):
+    """The chain layout at the window size BASELINE config 3 uses (segments of <= 6435 positions, 9 high sites here), periodic: the bond
+    between the two ends carries the constant sign (-1)^(n-1) in the hopping picture.  2,704,156 states: x += H y and the solve against the
+    general layout of the same device-assembled matrix, and the CSR handed back bit for bit."""
+    L, m = 24, 12
+    jpm, jzz = chain(L, 1.0, True), chain(L, 1.0, True)
+    res = {}
+    for lay_env in ("1", "0"):
+        monkeypatch.setenv("LPP_PRODUCT_LAYOUT", lay_env)
+        with LanczosEngine(max_steps=300, save_vectors=0) as e:
+            e.assemble_heisenberg(L, m, jpm, jzz)
+            lay = e.layout()
+            assert (lay["kernel"] == 4) == (lay_env == "1"), lay
+            if lay_env == "1":
+                assert lay["segments"] == 512 and lay["pieces"] > 100
+            n = e.rows()
+            y = oracle.fill_random(n, 8)
+            res[lay_env] = (e.matrixVectorProduct(np.zeros(n), y), e.lanczos(1, want_vectors=False), e.get_csr())
+    (x1, (e1, _, s1), c1), (x0, (e0, _, s0), c0) = res["1"], res["0"]
+    assert rel(x1, x0) < SPMV_TOL
+    assert abs(e1[0] - e0[0]) <= E_TOL * abs(e0[0]) and abs(s1["steps"] - s0["steps"]) <= 1
+    assert all(np.array_equal(_bits(a) if a.dtype == np.float64 else a, _bits(b) if b.dtype == np.float64 else b) for a, b in zip(c1, c0))
+    assert -0.4450 < e1[0] / L < -0.4440  # Bethe ansatz: E0 / L = 1/4 - ln 2 - pi^2 / (12 L^2) + ... = -0.44315 - 0.00143 at L = 24
