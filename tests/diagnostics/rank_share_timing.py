@@ -36,22 +36,28 @@ class NullComm:
 
 
 def main():
-    name = "hubbard_4x4_half_filling_pbc_U4"
+    # python tests/diagnostics/rank_share_timing.py [--onthefly] [--workload NAME] [P ...]
+    onthefly = "--onthefly" in sys.argv
+    name = sys.argv[sys.argv.index("--workload") + 1] if "--workload" in sys.argv else "hubbard_4x4_half_filling_pbc_U4"
+    sys.argv = [a for i, a in enumerate(sys.argv) if a != "--onthefly" and a != "--workload" and (i == 0 or sys.argv[i - 1] != "--workload")]
     model, p = WORKLOADS[name]
     n_up, n_dn = comb(p["L"], p["nup"]), comb(p["L"], p["ndown"])
     hop, U = p["hop"](), np.full(p["L"], p["U"])
     steps, warm = 30, 5
     for P in [int(a) for a in sys.argv[1:]] or [2, 4, 8]:
-        for exchange in ("transpose", "allgather"):
+        for exchange in (("transpose",) if onthefly else ("transpose", "allgather")):
             per = -(-n_dn // P)
             chunk = lib().lpp_xchg_chunk(n_up, n_dn, P) if exchange == "transpose" else 0
             c = NullComm(0, P, per * n_up, steps + warm + 2, chunk, "cuda")
             with LanczosEngine(max_steps=steps + warm + 2, eps=0.0, save_vectors=0, time_kernels=True) as e:
                 t0 = time.time()
-                e.assemble_hubbard(p["L"], p["nup"], p["ndown"], hop, U, comm=c)
+                if onthefly:
+                    e.setup_hubbard_onthefly(p["L"], p["nup"], p["ndown"], hop, U, comm=c)
+                else:
+                    e.assemble_hubbard(p["L"], p["nup"], p["ndown"], hop, U, comm=c)
                 e.sync()
                 t_asm = time.time() - t0
-                lay = e.layout(0)["kernel"]
+                lay = e.layout(0)["kernel"] if not onthefly or True else 0
                 e.begin(None)
                 e.step(warm)
                 e.sync()
