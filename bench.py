@@ -113,6 +113,8 @@ WORKLOADS = {
     # 6.4e7 states, complex: the largest 4x4 sector whose one-species space (8008 complex positions = 125 KB) fits the LDS window of the
     # product-basis layout for complex hoppings
     "hubbard_4x4_6up6down_complex_U4": ("hubbard", dict(L=16, nup=6, ndown=6, hop=lambda: square_lattice(4, 4, -1.0) * np.where(np.triu(np.ones((16, 16)), 1) > 0, np.exp(0.2j), np.exp(-0.2j)), U=4.0)),
+    # 1.47e8 complex states (2.36 GB per vector): 12870 complex positions per row do not fit one LDS window -- the pieces form with four value groups
+    "hubbard_4x4_8up7down_complex_U4": ("hubbard", dict(L=16, nup=8, ndown=7, hop=lambda: square_lattice(4, 4, -1.0) * np.where(np.triu(np.ones((16, 16)), 1) > 0, np.exp(0.2j), np.exp(-0.2j)), U=4.0)),
     "heisenberg_chain_L28_sz0_obc": ("heisenberg", dict(L=28, sz=14, j=1.0, pbc=False)),
     "heisenberg_chain_L24_sz0_obc": ("heisenberg", dict(L=24, sz=12, j=1.0, pbc=False)),
     "tj_4x5_9up9down_complex": ("tj", dict(L=20, nup=9, ndown=9, lx=5, ly=4, t=-1.0, j=0.4)),
@@ -226,6 +228,12 @@ def kernel_name(engine, layout):
     if engine == "onthefly" and (layout or {}).get("kernel") != "product":
         return "k_spmv_kron_packed / k_spmv_kron_chunked (matrix-free x += H y, fused a_j partial)"
     k = (layout or {}).get("kernel")
+    if k == "product" and layout.get("segments", 0) > 0:
+        # in-block matrix decomposed by the high sites of the basis word (lpp_pbseg.h); a one-block matrix (the spin chain) has no couplings
+        return ("%sk_pb_up_seg + k_pb_combine (product-basis form H = 1(x)T + C(x)1 + D; T by %d high-site segments per row in %d LDS-window items: "
+                "class-shared 16-bit low-low lists and cross-hop word tables, high-high hops as runs of the row in L2; the streaming pass forms x and applies "
+                "the recurrence update: the launches are the WHOLE scale-free Lanczos step)"
+                % ("" if layout.get("one_block") else "k_pb_down + ", layout["segments"], layout.get("pieces", 1)))
     if k == "product" and (layout.get("pieces", 1) > 1 or not layout.get("chained_step")):
         return ("k_pb_down%s + k_pb_up%s + k_pb_combine (product-basis form H = 1(x)T + C(x)1 + D; rows of %d LDS-window pieces, entries that leave a piece read "
                 "from the row in L2; the streaming pass forms x and applies the recurrence update: the three launches are the WHOLE scale-free Lanczos step)"
@@ -605,7 +613,7 @@ def main():
             lay = None
         if lay is not None and (args.engine == "stored" or lay["kernel"] == 4):
             layout = {"kernel": {1: "rowgroup", 2: "sliced", 3: "window", 4: "product"}.get(lay["kernel"]), "value_codes": bool(lay["coded"]),
-                      "pieces": lay["pieces"], "coupling_parts": lay["coupling_parts"], "chained_step": bool(lay["chained_step"]), "rows_by_list_length": bool(lay.get("rows_by_list_length", 0)),
+                      "pieces": lay["pieces"], "segments": lay.get("segments", 0), "one_block": bool(lay["kernel"] == 4 and lay["rows_per_block"] >= st0["nrows"]), "coupling_parts": lay["coupling_parts"], "chained_step": bool(lay["chained_step"]), "rows_by_list_length": bool(lay.get("rows_by_list_length", 0)),
                       "local16_columns": bool(lay["local16"]), "block_template": lay["block_template"], "diagonal_codes": bool(lay["diagonal_codes"]), "per_row_entries": lay["per_row_entries"],
                       "shared_offset_entries": lay["shared_entries"], "resident_GB": round(lay["resident_bytes"] / 1e9, 2)}
             min_bytes = float(lay["stream_bytes"]) + 3.0 * st0["nrows"] * esz

@@ -139,7 +139,9 @@ lpp_status pb_build(lpp_engine* e, int64_t n_up, int64_t n_blk, const int64_t* t
 	std::vector<int64_t> p_rp;
 	std::vector<int32_t> p_ci;
 	std::vector<double> p_va;
-	if (cx && (W > 0 || tx || parts || wide)) return fail(LPP_ERR_INVALID, "pb_build: complex hoppings are held in the one-window single-GPU form only");
+	// complex hoppings: the realified in-block matrix is an ordinary real template (4-8 value groups: k_pb_up / k_pb_up_big with any number
+	// of groups), in one window or in pieces; the couplings' kernel multiplies complex values (k_pb_down<CPLX>, with 64-bit addresses too)
+	if (cx && (tx || parts)) return fail(LPP_ERR_INVALID, "pb_build: complex hoppings are held in the single-GPU forms with whole-panel couplings only");
 	const bool want_perm = !cx && W == 0 && !tx && nblk_loc == n_blk && n_up >= 128 && !(getenv("LPP_PB_PERM") && atoi(getenv("LPP_PB_PERM")) == 0);
 	if (want_perm) {
 		std::vector<unsigned long long> vals; // distinct values, ascending bit pattern (the order pb_pack_template numbers its groups in does not matter here)
@@ -284,6 +286,26 @@ lpp_status pb_build(lpp_engine* e, int64_t n_up, int64_t n_blk, const int64_t* t
 	B.tw_words = (int64_t)T.words.size();
 	B.t_entries = T.entries;
 	B.t_slots = T.slots;
+	const bool pairs = kPbPairs && W == 0; // one-window form: chunk pairs, even look-ahead depths (2,6), (4,4) or (6,4)
+	if (pairs && !seg) {
+		// chunk pairs: lane l's two words of chunk 2q and of chunk 2q+1 side by side (one 16-byte load); a list of an odd number of chunks ends
+		// with half a pair of zero-slot indices; offsets count pairs (k_pb_up)
+		std::vector<uint32_t> pw;
+		pw.reserve(T.words.size() + T.words.size() / 4);
+		const uint32_t zw = T.words.empty() ? 0u : T.words.back(); // the slack behind the lists: (zero slot, zero slot)
+		for (size_t i = 0; i < T.off.size(); i++) {
+			const size_t src = (size_t)T.off[i] * 128;
+			const int nc = T.len[i];
+			T.off[i] = (int32_t)(pw.size() / 256);
+			for (int q = 0; q < (nc + 1) / 2; q++)
+				for (int l = 0; l < 64; l++)
+					for (int h = 0; h < 2; h++)
+						for (int k = 0; k < 2; k++) pw.push_back(2 * q + h < nc ? T.words[src + (size_t)(2 * q + h) * 128 + (size_t)l * 2 + k] : zw);
+		}
+		pw.resize(pw.size() + 256 * 4, zw); // slack for the look-ahead loads
+		T.words.swap(pw);
+		B.tw_words = (int64_t)T.words.size();
+	}
 	if ((rc = to_device(&B.tw, T.words, st)) != LPP_OK) return rc;
 	if ((rc = to_device(&B.tw_off, T.off, st)) != LPP_OK) return rc;
 	if ((rc = to_device(&B.tw_len, T.len, st)) != LPP_OK) return rc;
@@ -291,15 +313,16 @@ lpp_status pb_build(lpp_engine* e, int64_t n_up, int64_t n_blk, const int64_t* t
 	if (T.G == 2 && !seg) {
 		// look-ahead split of the in-block kernels: the depth pair (3,5), (4,4) or (5,3) that leaves the fewest chunks beyond it
 		int64_t best = -1;
-		for (int p0 = 3; p0 <= 5; p0++) {
+		for (int p0 = pairs ? 2 : 3; p0 <= (pairs ? 6 : 5); p0 += pairs ? 2 : 1) {
 			int64_t beyond = 0;
-			for (int j = 0; j < T.spb; j++) beyond += std::max(0, (int)T.len[(size_t)j * 2] - p0) + std::max(0, (int)T.len[(size_t)j * 2 + 1] - (2 * kPbPre - p0));
+			const int p1 = pairs ? pb_depth(2, 1, p0) : 2 * kPbPre - p0;
+			for (int j = 0; j < T.spb; j++) beyond += std::max(0, (int)T.len[(size_t)j * 2] - p0) + std::max(0, (int)T.len[(size_t)j * 2 + 1] - p1);
 			if (best < 0 || beyond < best || (beyond == best && p0 == kPbPre)) {
 				best = beyond;
 				B.pre0 = p0;
 			}
 		}
-		if (const char* s = getenv("LPP_PB_PRE0")) B.pre0 = std::max(3, std::min(atoi(s), 5));
+		if (const char* s = getenv("LPP_PB_PRE0")) B.pre0 = pairs ? std::max(2, std::min(atoi(s), 6)) & ~1 : std::max(3, std::min(atoi(s), 5));
 	}
 	B.big = W > 0;
 	B.big2 = B.big && big2 && (T.G == 1 || T.G == 2) && pb_big2_lds_bytes((int)W) <= (size_t)160 * 1024 - 64 && (W + kPbZeroSlots) * 8 < 65536;
@@ -503,6 +526,7 @@ lpp_status pb_build(lpp_engine* e, int64_t n_up, int64_t n_blk, const int64_t* t
 // and a streaming pass x = beta x + u + z (k_pb_combine).  defer_combine: the caller runs that pass itself, folded into its own
 // pass over x (pb_combine_axpy of the scale-free recurrence).  Returns the number of partials written; their sum is
 // Re<y | u + z>, to which the caller adds beta Re<y | x_old> (pb.xy, left by the previous combine pass).
+constexpr int kPreLo = kPbPairs ? 2 : 3, kPreHi = kPbPairs ? 6 : 5; // the unequal look-ahead splits k_pb_up is instantiated for
 template <bool DOT> static void launch_up(const PbState& B, const PbUpArgs& u, int nb, size_t lds, hipStream_t st)
 {
 	const int gt = B.G <= 2 ? B.G : 0;
@@ -517,8 +541,8 @@ template <bool DOT> static void launch_up(const PbState& B, const PbUpArgs& u, i
 		k_pb_up<DOT, 2, false, PRE_><<<nb, kPbUpThreads, lds, st>>>(u);                                                 \
 	} while (0)
 	if (gt == 1) LPP_PB_UP(1);
-	else if (gt == 2 && B.pre0 == 3) LPP_PB_UP2(3); // look-ahead split of the two value groups (pb_build)
-	else if (gt == 2 && B.pre0 == 5) LPP_PB_UP2(5);
+	else if (gt == 2 && B.pre0 == kPreLo) LPP_PB_UP2(kPreLo); // look-ahead split of the two value groups (pb_build)
+	else if (gt == 2 && B.pre0 == kPreHi) LPP_PB_UP2(kPreHi);
 	else if (gt == 2) LPP_PB_UP(2);
 	else LPP_PB_UP(0);
 #undef LPP_PB_UP2
@@ -647,20 +671,22 @@ static int launch_up_big(lpp_engine* e, const double* y, double* u, const uint8_
 		return partial ? nb : 0;
 	}
 	const size_t lds = pb_big_lds_bytes(B.W);
-	const int gt = B.G <= 2 ? B.G : 0;
-#define LPP_PB_BIG(DOT_, GT_)                                                                                          \
+	const int gt = B.G <= 2 || B.G == 4 ? B.G : 0;
+#define LPP_PB_BIG(DOT_, GT_, PRE_)                                                                                    \
 	do {                                                                                                              \
-		(void)hipFuncSetAttribute((const void*)k_pb_up_big<DOT_, GT_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-		k_pb_up_big<DOT_, GT_><<<nb, kPbBigThreads, lds, st>>>(a);                                                      \
+		(void)hipFuncSetAttribute((const void*)k_pb_up_big<DOT_, GT_, PRE_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+		k_pb_up_big<DOT_, GT_, PRE_><<<nb, kPbBigThreads, lds, st>>>(a);                                                \
 	} while (0)
 	if (partial) {
-		if (gt == 1) LPP_PB_BIG(true, 1);
-		else if (gt == 2) LPP_PB_BIG(true, 2);
-		else LPP_PB_BIG(true, 0);
+		if (gt == 1) LPP_PB_BIG(true, 1, kBigPre);
+		else if (gt == 2) LPP_PB_BIG(true, 2, kBigPre);
+		else if (gt == 4) LPP_PB_BIG(true, 4, 3);
+		else LPP_PB_BIG(true, 0, kBigPre);
 	} else {
-		if (gt == 1) LPP_PB_BIG(false, 1);
-		else if (gt == 2) LPP_PB_BIG(false, 2);
-		else LPP_PB_BIG(false, 0);
+		if (gt == 1) LPP_PB_BIG(false, 1, kBigPre);
+		else if (gt == 2) LPP_PB_BIG(false, 2, kBigPre);
+		else if (gt == 4) LPP_PB_BIG(false, 4, 3);
+		else LPP_PB_BIG(false, 0, kBigPre);
 	}
 #undef LPP_PB_BIG
 	return partial ? nb : 0;
@@ -745,7 +771,10 @@ int pb_launch(lpp_engine* e, const void* y, void* x, double* partial, const EpiS
 		d.u_has_beta = 0;
 		if (d.pace) (void)hipMemsetAsync(d.pace, 0, sizeof(int) * 8 * (size_t)d.npanels, sd);
 		d.cdict = (const double2*)B.cdict;
-		if (B.cplx) {
+		if (B.cplx && B.wide) {
+			(void)hipFuncSetAttribute((const void*)k_pb_down<1024, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B.down_lds);
+			k_pb_down<1024, false, true, true><<<B.down_grid, 1024, B.down_lds, sd>>>(d);
+		} else if (B.cplx) {
 			(void)hipFuncSetAttribute((const void*)k_pb_down<1024, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B.down_lds);
 			k_pb_down<1024, false, false, true><<<B.down_grid, 1024, B.down_lds, sd>>>(d);
 		} else if (B.wide) {
@@ -935,8 +964,8 @@ int pb_launch_chain(lpp_engine* e, void* w, void* y, double* partial, const EpiS
 		const size_t lds = pb_up_lds_bytes(B.pitch, B.spb, B.G);
 		if (B.G == 1) launch_up_chain<1>(u, nb, lds, st);
 		else if (B.G > 2) launch_up_chain<0>(u, nb, lds, st);
-		else if (B.pre0 == 3) launch_up_chain<2, 3>(u, nb, lds, st);
-		else if (B.pre0 == 5) launch_up_chain<2, 5>(u, nb, lds, st);
+		else if (B.pre0 == kPreLo) launch_up_chain<2, kPreLo>(u, nb, lds, st);
+		else if (B.pre0 == kPreHi) launch_up_chain<2, kPreHi>(u, nb, lds, st);
 		else launch_up_chain<2>(u, nb, lds, st);
 	}
 	PbDownArgs d = {};

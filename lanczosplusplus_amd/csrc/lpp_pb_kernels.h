@@ -62,7 +62,17 @@ constexpr int kPbPre = 4; // chunks (of 4 slots) of every (slice, group) request
 // address, the window sits at LDS address 0), one ds_read_b64, one v_add_f64.  Both ends of that were measured: with a
 // plain and/shift/add unpacking the kernel was VALU-bound (10 vector instructions per pair of entries); with ready-made
 // 32-bit addresses the template words (19 GB per product through a ~57 GB/s-per-CU L2->L1 path) bound it instead.
+// One-window form: the chunks of a list are stored in PAIRS (lane l's words of chunks 2q and 2q+1 side by side, pb_build) and requested with
+// one 16-byte load per pair.  A wave-level load of 8 or of 16 bytes per lane occupies a CU's vector-memory pipeline for the same ~17 cycles
+// (scripts/experiments/r04_tcp_rate.hip: 70 against 130-140 GB/s per CU), and the number of template loads was what the gather phase of
+// this kernel waited for.  Look-ahead depths are then even.
+#ifndef LPP_PB_PAIRS
+#define LPP_PB_PAIRS 1
+#endif
+constexpr bool kPbPairs = LPP_PB_PAIRS != 0;
 constexpr int kPbPreMax = 6; // deepest look-ahead of one value group (k_pb_up's PRE0)
+// look-ahead depth of value group g (two groups share 8 chunks as PRE0 + (8 - PRE0); with pairs PRE0 = 6 leaves group 1 four)
+__host__ __device__ constexpr int pb_depth(int GG, int g, int PRE0) { return GG == 2 ? (g == 0 ? PRE0 : (kPbPairs && PRE0 >= 6 ? 4 : 2 * kPbPre - PRE0)) : kPbPre; }
 constexpr int kPbPreMin = 1; // chunks of a group requested whatever its list length (no branch)
 template <int GT> struct PbWords {
 	uint2 w[GT][kPbPreMax]; // only the first `depth(g)` chunks of group g are ever touched (the others take no register)
@@ -140,6 +150,7 @@ template <bool DOT, int GT, bool CHAIN = false, int PRE0 = kPbPre> __global__ __
 	// plain locals for everything the stage functions touch: a reference to the kernel-argument struct inside a lambda made
 	// hipcc keep a private copy of it in scratch memory
 	const uint2* const tw2 = (const uint2*)a.tw;
+	const uint4* const tw4 = (const uint4*)a.tw;
 	double* const uout = a.u;
 	const int spb = a.spb, n_up = (int)a.n_up, G = a.G;
 	double gv[GG];
@@ -234,11 +245,23 @@ template <bool DOT, int GT, bool CHAIN = false, int PRE0 = kPbPre> __global__ __
 #pragma unroll
 				for (int g = 0; g < GG; g++) {
 					s.nc[g] = __builtin_amdgcn_readfirstlane((int)len_s[j * GG + g]); // uniform: scalar branches below
-					const uint2* wp = tw2 + (size_t)off_s[j * GG + g] * 64 + lane;
-					const int depth = GG == 2 ? (g == 0 ? PRE0 : 2 * kPbPre - PRE0) : kPbPre;
+					constexpr int PRE0_ = PRE0;
+					const int depth = pb_depth(GG, g, PRE0_);
+					if (kPbPairs) {
+						const uint4* wp4 = tw4 + (size_t)off_s[j * GG + g] * 64 + lane; // offsets count pairs
 #pragma unroll
-					for (int c = 0; c < kPbPreMax; c++)
-						if (c < depth && (c < kPbPreMin || c < s.nc[g])) s.w[g][c] = wp[c * 64]; // beyond the first chunks only what the list holds (scalar branch)
+						for (int c = 0; c < kPbPreMax; c += 2)
+							if (c < depth && (c < kPbPreMin || c < s.nc[g])) {
+								const uint4 t = wp4[(c >> 1) * 64];
+								s.w[g][c] = uint2 { t.x, t.y };
+								s.w[g][c + 1] = uint2 { t.z, t.w };
+							}
+					} else {
+						const uint2* wp = tw2 + (size_t)off_s[j * GG + g] * 64 + lane;
+#pragma unroll
+						for (int c = 0; c < kPbPreMax; c++)
+							if (c < depth && (c < kPbPreMin || c < s.nc[g])) s.w[g][c] = wp[c * 64]; // beyond the first chunks only what the list holds (scalar branch)
+					}
 				}
 				// chained form: r_{j-1} at this row, re-read one slice ahead with the words.  By the counters the re-read does NOT hit L2
 				// (the XCD streams ~10 MB between staging and here): 1.33 GB more fabric reads per step at config 2, served one slice
@@ -265,10 +288,19 @@ template <bool DOT, int GT, bool CHAIN = false, int PRE0 = kPbPre> __global__ __
 					}
 				}
 				if (nc > depth) {
-					const uint2* wp = tw2 + (size_t)off_s[j * GG + g] * 64 + lane;
-					for (int c = depth; c < nc; c++) {
-						const uint2 wr = wp[c * 64];
-						gather4(wr, s0, s1);
+					if (kPbPairs) {
+						const uint4* wp4 = tw4 + (size_t)off_s[j * GG + g] * 64 + lane;
+						for (int c = depth; c < nc; c += 2) { // depth is even
+							const uint4 t = wp4[(c >> 1) * 64];
+							gather4(uint2 { t.x, t.y }, s0, s1);
+							if (c + 1 < nc) gather4(uint2 { t.z, t.w }, s0, s1);
+						}
+					} else {
+						const uint2* wp = tw2 + (size_t)off_s[j * GG + g] * 64 + lane;
+						for (int c = depth; c < nc; c++) {
+							const uint2 wr = wp[c * 64];
+							gather4(wr, s0, s1);
+						}
 					}
 				}
 				return s0 + s1;
@@ -279,7 +311,7 @@ template <bool DOT, int GT, bool CHAIN = false, int PRE0 = kPbPre> __global__ __
 				own(j, yc, dv);
 				double acc = 0.0;
 #pragma unroll
-				for (int g = 0; g < GG; g++) acc = fma(gv[g], group_sum(j, g, s.nc[g], s.w[g], GG == 2 ? (g == 0 ? PRE0 : 2 * kPbPre - PRE0) : kPbPre), acc);
+				for (int g = 0; g < GG; g++) acc = fma(gv[g], group_sum(j, g, s.nc[g], s.w[g], pb_depth(GG, g, PRE0)), acc);
 				finish(j, acc, yc, dv, CHAIN ? s.yo : 0.0);
 			};
 			PbWords<GG> wa, wb;
@@ -299,22 +331,36 @@ template <bool DOT, int GT, bool CHAIN = false, int PRE0 = kPbPre> __global__ __
 				const double yo_g = CHAIN ? yold[min(j * 64 + lane, n_up - 1)] : 0.0; // chained form: beta r_{j-1} rides in u (as in the unrolled paths)
 				uint2 wn[4];
 				int ncn = __builtin_amdgcn_readfirstlane((int)len_s[j * G]);
-				const uint2* wpn = tw2 + (size_t)off_s[j * G] * 64 + lane;
+				// four chunks of a list from chunk c0 on: four 8-byte loads, or two 16-byte loads of the pair layout
+				auto load4 = [=](size_t off, int c0, int nc, uint2* w) __attribute__((always_inline)) {
+					if (kPbPairs) {
+						const uint4* wp4 = tw4 + off * 64 + lane;
 #pragma unroll
-				for (int q = 0; q < 4; q++)
-					if (q < ncn) wn[q] = wpn[q * 64];
+						for (int q = 0; q < 4; q += 2)
+							if (c0 + q < nc) {
+								const uint4 t = wp4[((c0 + q) >> 1) * 64];
+								w[q] = uint2 { t.x, t.y };
+								w[q + 1] = uint2 { t.z, t.w };
+							}
+					} else {
+						const uint2* wp = tw2 + off * 64 + lane;
+#pragma unroll
+						for (int q = 0; q < 4; q++)
+							if (c0 + q < nc) w[q] = wp[(c0 + q) * 64];
+					}
+				};
+				size_t offn = (size_t)off_s[j * G];
+				load4(offn, 0, ncn, wn);
 				for (int g = 0; g < G; g++) { // wave-uniform trip counts
 					const int nc = ncn;
-					const uint2* wp = wpn;
+					const size_t off = offn;
 					uint2 w[4];
 #pragma unroll
 					for (int q = 0; q < 4; q++) w[q] = wn[q];
 					if (g + 1 < G) {
 						ncn = __builtin_amdgcn_readfirstlane((int)len_s[j * G + g + 1]);
-						wpn = tw2 + (size_t)off_s[j * G + g + 1] * 64 + lane;
-#pragma unroll
-						for (int q = 0; q < 4; q++)
-							if (q < ncn) wn[q] = wpn[q * 64];
+						offn = (size_t)off_s[j * G + g + 1];
+						load4(offn, 0, ncn, wn);
 					}
 					double s0 = 0.0, s1 = 0.0;
 #pragma unroll
@@ -322,9 +368,7 @@ template <bool DOT, int GT, bool CHAIN = false, int PRE0 = kPbPre> __global__ __
 						if (q < nc) gather4(w[q], s0, s1);
 					for (int c0 = 4; c0 < nc; c0 += 4) { // longer lists: four more chunks in flight at a time
 						uint2 wr[4];
-#pragma unroll
-						for (int q = 0; q < 4; q++)
-							if (c0 + q < nc) wr[q] = wp[(c0 + q) * 64];
+						load4(off, c0, nc, wr);
 #pragma unroll
 						for (int q = 0; q < 4; q++)
 							if (c0 + q < nc) gather4(wr[q], s0, s1);

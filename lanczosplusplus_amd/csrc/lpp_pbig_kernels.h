@@ -73,13 +73,15 @@ constexpr int kBigFarPre = 8; // far slots requested one slice ahead
 template <int GG> struct BigHeads { // wave-uniform
 	int nc[GG], off[GG], nf, foff;
 };
-template <int GG> struct BigWords {
-	uint2 w[GG][kBigPre];
+template <int GG, int PRE = kBigPre> struct BigWords {
+	uint2 w[GG][PRE];
 	uint32_t f[kBigFarPre];
 };
 
-// GT = number of value groups (1 or 2: unrolled with look-ahead; 0: any G <= 8, plain loop)
-template <bool DOT, int GT> __global__ __launch_bounds__(kPbBigThreads, 4) void k_pb_up_big(PbUpBigArgs a)
+// GT = number of value groups (1, 2 or 4: unrolled with look-ahead; 0: any G <= 8, plain loop).  Four groups is what complex hoppings
+// realified over (re, im) pairs come to (+-cos, +-sin of a Peierls phase; +-t and +-lambda of a Kane-Mele model): their lists are half as
+// long as a real matrix's two, so three chunks per group are requested ahead (PRE; 118 registers).
+template <bool DOT, int GT, int PRE = kBigPre> __global__ __launch_bounds__(kPbBigThreads, 4) void k_pb_up_big(PbUpBigArgs a)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
 	double* win = (double*)lds_raw; // at LDS address 0: a 16-bit template entry * 8 IS the byte address (pb_lds_abs)
@@ -171,18 +173,18 @@ template <bool DOT, int GT> __global__ __launch_bounds__(kPbBigThreads, 4) void 
 				h.nf = f_len[j];
 				h.foff = f_off[j];
 			};
-			auto load_words = [=](const BigHeads<GG>& h, BigWords<GG>& s) __attribute__((always_inline)) {
+			auto load_words = [=](const BigHeads<GG>& h, BigWords<GG, PRE>& s) __attribute__((always_inline)) {
 #pragma unroll
 				for (int g = 0; g < GG; g++) {
 					const uint2* wp = tw2 + (size_t)h.off[g] * 64 + lane;
 #pragma unroll
-					for (int c = 0; c < kBigPre; c++) s.w[g][c] = wp[c * 64]; // chunks beyond the list belong to the next list (or the slack): never used
+					for (int c = 0; c < PRE; c++) s.w[g][c] = wp[c * 64]; // chunks beyond the list belong to the next list (or the slack): never used
 				}
 				const uint32_t* fp = fw + (size_t)h.foff * 64 + lane;
 #pragma unroll
 				for (int k = 0; k < kBigFarPre; k++) s.f[k] = fp[k * 64];
 			};
-			auto compute = [=](int jj, const BigHeads<GG>& h, const BigWords<GG>& s) __attribute__((always_inline)) {
+			auto compute = [=](int jj, const BigHeads<GG>& h, const BigWords<GG, PRE>& s) __attribute__((always_inline)) {
 				if (jj >= nsl) return; // wave-uniform
 				// far elements first (requested here, used at the end); slots beyond the list are not requested
 				double fv[kBigFarPre];
@@ -204,15 +206,19 @@ template <bool DOT, int GT> __global__ __launch_bounds__(kPbBigThreads, 4) void 
 					} else if (nc == 1) {
 						gather4(s.w[g][0], s0, s1);
 					}
-					if (nc >= 4) {
-						gather4(s.w[g][2], s0, s1);
-						gather4(s.w[g][3], s0, s1);
-					} else if (nc == 3) {
-						gather4(s.w[g][2], s0, s1);
+					if constexpr (PRE >= 4) {
+						if (nc >= 4) {
+							gather4(s.w[g][2], s0, s1);
+							gather4(s.w[g][3], s0, s1);
+						} else if (nc == 3) {
+							gather4(s.w[g][2], s0, s1);
+						}
+					} else if constexpr (PRE == 3) {
+						if (nc >= 3) gather4(s.w[g][2], s0, s1);
 					}
-					if (nc > kBigPre) {
+					if (nc > PRE) {
 						const uint2* wp = tw2 + (size_t)h.off[g] * 64 + lane;
-						for (int c = kBigPre; c < nc; c++) {
+						for (int c = PRE; c < nc; c++) {
 							const uint2 wr = wp[c * 64];
 							gather4(wr, s0, s1);
 						}
@@ -241,7 +247,7 @@ template <bool DOT, int GT> __global__ __launch_bounds__(kPbBigThreads, 4) void 
 				epilogue(jj, acc);
 			};
 			BigHeads<GG> h0, h1, h2, h3;
-			BigWords<GG> wa, wb;
+			BigWords<GG, PRE> wa, wb;
 			load_heads(wave, h0);
 			load_heads(wave + NW, h1);
 			load_words(h0, wa);

@@ -904,6 +904,62 @@ def test_product_basis_layout_with_complex_hoppings(case, monkeypatch):
         assert rel(e.matrixVectorProduct(x0.copy(), y), xo) < SPMV_TOL
 
 
+@pytest.mark.parametrize("form", ["pieces", "pieces_wide"])
+@pytest.mark.parametrize("case", ["peierls_ring", "kane_mele_like", "disorder"])
+def test_complex_hoppings_beyond_one_lds_window(case, form, monkeypatch):
+    """Complex hoppings with rows that do not fit one LDS window (4x4 lattice at 7/8 up electrons: 12870 complex positions): the realified
+    in-block matrix is cut into pieces like any real one (k_pb_up_big, 4-8 value groups), the couplings stay complex (k_pb_down<CPLX>, with
+    64-bit addresses for vectors beyond 4 GiB).  Small case, pieces of 256 positions forced; same checks as the one-window test."""
+    monkeypatch.setenv("LPP_PRODUCT_LAYOUT", "1")
+    monkeypatch.setenv("LPP_PB_PIECE_ROWS", "256")
+    if form == "pieces_wide":
+        monkeypatch.setenv("LPP_PB_WIDE", "1")
+    L, nup, ndown = 12, 6, 5
+    ring = chain(L, -1.0, True).astype(complex)
+    up = np.triu(np.ones((L, L)), 1) > 0
+    if case == "kane_mele_like":
+        nnn = (np.diag(np.ones(L - 2), 2) + np.diag(np.ones(L - 2), -2)).astype(complex)
+        hop = ring + 0.3j * np.where(up, nnn, -nnn)
+    else:
+        hop = ring * np.where(up, np.exp(0.37j), np.exp(-0.37j))
+    U = np.full(L, 4.0) if case != "disorder" else np.random.default_rng(5).uniform(1, 5, L)
+    V = np.zeros(2 * L) if case != "disorder" else np.random.default_rng(6).uniform(-0.5, 0.5, 2 * L)
+    A = oracle.hubbard_csr(L, nup, ndown, hop, U, V)
+    x0, y = oracle.fill_random(A.nrows, 7, True), oracle.fill_random(A.nrows, 8, True)
+    xo = oracle.spmv_acc(A, x0.copy(), y)
+    init = oracle.fill_random(A.nrows, 4321, True)
+    eo, zo, so = oracle.lanczos_solve(A, oracle.fill_random(A.nrows, 1234, True), nstates=1)
+    steps_o, ao, bo, _, _ = oracle.lanczos_decomposition(A, init)
+    with LanczosEngine(dtype="c128") as e:
+        e.assemble_hubbard(L, nup, ndown, hop, U, V)
+        lay = e.layout()
+        assert lay["kernel"] == 4 and lay["nnz"] == A.nnz and lay["pieces"] == 8 and lay["chained_step"] == 0 and lay["segments"] == 0
+        rp, ci, va = e.get_csr()
+        assert np.array_equal(rp, A.rowptr) and np.array_equal(ci, A.colind)
+        assert np.array_equal(np.ascontiguousarray(va).view(np.uint64), np.ascontiguousarray(A.values).view(np.uint64))
+        xg = e.matrixVectorProduct(x0.copy(), y)
+        assert rel(xg, xo) < SPMV_TOL
+        eg, zg, st = e.lanczos(1, want_vectors=True)
+        assert abs(eg[0] - eo[0]) <= E_TOL * abs(eo[0]) and st["steps"] == so
+        r = oracle.spmv_acc(A, np.zeros_like(zg[0]), zg[0]) - eg[0] * zg[0]
+        assert np.linalg.norm(r) < 1e-5 and abs(np.linalg.norm(zg[0]) - 1) < 1e-8
+        ag, bg, _ = e.decomposition(init)
+        assert len(ag) == steps_o and rel(ag, ao) < 1e-8 and rel(bg, bo) < 1e-8
+    with LanczosEngine(dtype="c128", save_vectors=0) as e:  # scale-free recurrence + two-pass Ritz vector
+        e.assemble_hubbard(L, nup, ndown, hop, U, V)
+        eg2, zg2, st2 = e.lanczos(1, want_vectors=True)
+        assert st2["vectors_saved"] == 0 and abs(eg2[0] - eo[0]) <= E_TOL * abs(eo[0])
+        r = oracle.spmv_acc(A, np.zeros_like(zg2[0]), zg2[0]) - eg2[0] * zg2[0]
+        assert np.linalg.norm(r) < 1e-5
+    with LanczosEngine(dtype="c128") as e:  # the same matrix handed over as a CSR
+        e.set_csr(A.rowptr, A.colind, A.values)
+        assert e.layout()["kernel"] == 4 and e.layout()["pieces"] == 8
+        rp, ci, va = e.get_csr()
+        assert np.array_equal(rp, A.rowptr) and np.array_equal(ci, A.colind)
+        assert np.array_equal(np.ascontiguousarray(va).view(np.uint64), np.ascontiguousarray(A.values).view(np.uint64))
+        assert rel(e.matrixVectorProduct(x0.copy(), y), xo) < SPMV_TOL
+
+
 def test_product_basis_layout_falls_back_when_it_does_not_apply(monkeypatch):
     """more than 8 distinct in-block values, or a many-valued diagonal with the plain stream switched off (LPP_PB_PLAIN_DIAG=0): the
     general layout takes over, results unchanged"""
