@@ -628,7 +628,8 @@ static int launch_up_big(lpp_engine* e, const double* y, double* u, const uint8_
 	} while (0)
 #define LPP_PB_SEG_N(DOT_, GT_, P0_)                                                                                   \
 	do {                                                                                                              \
-		if (B.seg_one && B.seg_nh == 12) LPP_PB_SEG1(DOT_, GT_, P0_, 2, 12);                                            \
+		if (B.seg_one && B.seg_nh == 12 && B.seg_nc == 1) LPP_PB_SEG1(DOT_, GT_, P0_, 1, 12);                           \
+		else if (B.seg_one && B.seg_nh == 12) LPP_PB_SEG1(DOT_, GT_, P0_, 2, 12);                                       \
 		else if (B.seg_one) LPP_PB_SEG1(DOT_, GT_, P0_, 2, 2);                                                          \
 		else if (B.seg_nc == 2) LPP_PB_SEG(DOT_, GT_, P0_, 2, 2);                                                            \
 		else if (B.seg_nc == 5) LPP_PB_SEG(DOT_, GT_, P0_, 5, 4);                                                       \
@@ -1275,7 +1276,7 @@ lpp_status pb_chain(lpp_engine* e, DevCsr& A, int L, int n, const std::vector<do
 	if (getenv("LPP_VERBOSE"))
 		fprintf(stderr, "lpp: chain as one block of the segmented form %s (L = %d, n = %d, %d high sites, %zu segments, %zu items of <= %d positions, <= %d + %d hops per segment)\n",
 		        ok ? "planned" : "does not apply", SP.L, SP.n, SP.s, SP.segs.size(), SP.items.size(), SP.wmax, SP.max_cross, SP.max_hh);
-	if (!ok || SP.n_up != n_up || SP.nc_pad != 2) return LPP_OK; // (one block per workgroup: the instances with <= 2 pairs of cross hops)
+	if (!ok || SP.n_up != n_up || SP.nc_pad > 2) return LPP_OK; // (one block per workgroup: the instances with <= 2 pairs of cross hops)
 	hipStream_t st = e->stream;
 	struct Buf {
 		void* p = nullptr;

@@ -460,9 +460,14 @@ lpp_status pb_seg_plan_model(int L, int n, const std::vector<double>& hv, const 
 	// every segment's lists padded to the kernel instance's width with entries of value 0.0 that read valid addresses: the slice
 	// loop then carries no condition at all (padded cross entries: a table of the segment's own class -- or table 0, the longest --
 	// and the row's first elements; padded high-high entries: the segment itself)
-	// kernel instances (NC, NH): (2, 2), (5, 4), (6, 8) and -- one block per workgroup only: chains -- (2, 12)
+	// kernel instances (NC, NH): (2, 2), (5, 4), (6, 8) and -- one block per workgroup only: chains -- (1, 12), (2, 12)
+	if (one_block) { // k_pb_up_seg<..., ROWS = 1> reads the first hop of a pair only: a chain's high sites have one low neighbour each
+		for (const SegCross& c : P.cross)
+			if (c.val[1] != 0.0) return LPP_OK;
+	}
 	if (P.max_cross <= 2 && P.max_hh <= 2) P.nc_pad = 2, P.nh_pad = 2;
-	else if (one_block && P.max_cross <= 2) P.nc_pad = 2, P.nh_pad = 12;
+	else if (one_block && P.max_cross <= 1) P.nc_pad = 1, P.nh_pad = 12; // an open chain: the one bond between the low and the high sites
+	else if (one_block && P.max_cross <= 2) P.nc_pad = 2, P.nh_pad = 12; // ... and the bond between the two ends
 	else if (one_block) return LPP_OK;
 	else if (P.max_cross <= 5 && P.max_hh <= 4) P.nc_pad = 5, P.nh_pad = 4;
 	else if (P.max_cross <= 6 && P.max_hh <= 8) P.nc_pad = 6, P.nh_pad = 8;
@@ -474,12 +479,19 @@ lpp_status pb_seg_plan_model(int L, int n, const std::vector<double>& hv, const 
 			SegInst& S = P.segs[i];
 			for (int b = 0; b < P.nc_pad; b++)
 				cp[i * P.nc_pad + b] = b < S.ncross ? P.cross[(size_t)(S.cross_first + b)] : SegCross { zero_table, 0, { 0.0, 0.0 }, 0 }; // all-zero words: every lane reads the row's first element (one line)
-			for (int b = 0; b < P.nh_pad; b++) hp[i * P.nh_pad + b] = b < S.nhh ? P.hh[(size_t)(S.hh_first + b)] : SegHh { S.sbase, 0, 0.0 }; // pad = 0: every lane reads the segment's first element (one line)
+			for (int b = 0; b < P.nh_pad; b++) hp[i * P.nh_pad + b] = b < S.nhh ? P.hh[(size_t)(S.hh_first + b)] : SegHh { std::max(S.sbase - 1, 0), 0, 0.0 }; // pad = 0: every lane reads the same pair of elements, the segment's first and the one in front of it (one line, inside the row)
 			S.cross_first = (int32_t)(i * P.nc_pad);
 			S.hh_first = (int32_t)(i * P.nh_pad);
 		}
 		P.cross.swap(cp);
 		P.hh.swap(hp);
+		// the high-high hops an item's slices carry: the longest list of its segments in whole fours (bits 16.. of the item's type; the
+		// one-block kernel runs the instance's loop for 4, 8 or 12 of them -- on a chain of 28 sites 3.9 instead of 6 loads per slice)
+		for (SegItem& I : P.items) {
+			int m = 0;
+			for (int k = 0; k < I.nseg; k++) m = std::max(m, (int)P.segs[(size_t)(I.seg_first + k)].nhh);
+			I.type |= std::min(P.nh_pad, std::max(4, (m + 3) & ~3)) << 16;
+		}
 	}
 	*ok = true;
 	return LPP_OK;

@@ -44,13 +44,13 @@ constexpr int kSegThreads = 512; // 8 waves of up to 256 registers: two slices' 
 constexpr int kSegPre = 4; // in-window chunks of every (slice, group) requested one slice ahead
 constexpr int kSegStage = 16; // 16-byte pieces per thread that stage the two windows: ALL in flight together (2 x 8128 elements at most)
 
-// LDS: [0, 2 ws) windows | dcode[2][wmax + 32] | 2 x slice heads[160] | 2 x cross[16 * 6] | 2 x hh[16 * 12] | dict[256] | smem[8]
+// LDS: [0, 2 ws) windows | dcode[2][wmax + 32] | 2 x slice heads[160] | 2 x cross[16 * 6] | 2 x hh[16 * 12] | dict[256] | smem[8] | per wave 64 x 2 doubles (high-high sums)
 __host__ __device__ inline size_t pb_seg_dcode_stride(int wmax) { return ((size_t)wmax + 32 + 15) & ~(size_t)15; }
 __host__ __device__ inline size_t pb_seg_tab_offset(int ws, int wmax) { return (2 * sizeof(double) * (size_t)ws + 2 * pb_seg_dcode_stride(wmax) + 15) & ~(size_t)15; }
 // (rows: blocks per workgroup; one block per workgroup alternates between TWO sets of tables)
 __host__ __device__ inline size_t pb_seg_lds_bytes(int ws, int wmax, int rows)
 {
-	return pb_seg_tab_offset(ws, wmax) + (rows == 1 ? 2 : 1) * (sizeof(SegSlice) * kSegMaxSlices + sizeof(SegCross) * kSegMaxSegs * kSegMaxCross + sizeof(SegHh) * kSegMaxSegs * kSegMaxHh) + sizeof(double) * (256 + kSegThreads / 64) + 16;
+	return pb_seg_tab_offset(ws, wmax) + (rows == 1 ? 2 : 1) * (sizeof(SegSlice) * kSegMaxSlices + sizeof(SegCross) * kSegMaxSegs * kSegMaxCross + sizeof(SegHh) * kSegMaxSegs * kSegMaxHh) + sizeof(double) * (256 + kSegThreads / 64 + 2 * kSegThreads) + 16;
 }
 
 template <int GG> struct SegHeads { // wave-uniform
@@ -63,6 +63,12 @@ template <int GG> struct SegWinWords {
 };
 template <int NC> struct SegCrossWords {
 	uint32_t x[NC]; // two 16-bit words each
+};
+template <int N> struct SegInt {
+	static constexpr int value = N;
+};
+struct __attribute__((aligned(8))) SegPair8 { // two consecutive elements of a row at any (8-byte aligned) position: one 16-byte load
+	double x, y;
 };
 template <int NC, int NH, int ROWS> struct SegData { // what a slice reads from the rows in memory, both blocks
 	double xa[2 * NC], xb[ROWS == 2 ? 2 * NC : 1], ha[NH], hb[ROWS == 2 ? NH : 1];
@@ -83,7 +89,7 @@ template <bool DOT, int GT, int P0, int P1, int NC, int NH, int ROWS = 2> __glob
 {
 	static_assert(GT == 1 || GT == 2, "one or two value groups");
 	static_assert(ROWS == 1 || ROWS == 2, "one or two blocks per workgroup");
-	static_assert(P0 <= kSegPre && P1 <= kSegPre && !(P0 & 1) && !(P1 & 1) && NC <= kSegMaxCross && NH <= kSegMaxHh && NC <= 8, "limits");
+	static_assert(P0 <= kSegPre && P1 <= kSegPre && !(P0 & 1) && !(P1 & 1) && NC >= 1 && NC <= kSegMaxCross && NH <= kSegMaxHh && NC <= 8 && !(NH & 1), "limits");
 	extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
 	double* win = (double*)lds_raw; // block 0's window at LDS address 0 (a list entry * 8 IS the byte address), block 1's at ws * 8
 	const int WS = a.ws;
@@ -95,11 +101,15 @@ template <bool DOT, int GT, int P0, int P1, int NC, int NH, int ROWS = 2> __glob
 	SegHh* hh_s = (SegHh*)(cross_s + NT * kSegMaxSegs * kSegMaxCross);
 	double* dict_s = (double*)(hh_s + NT * kSegMaxSegs * kSegMaxHh);
 	double* smem = dict_s + 256;
+	double* const tr_s = smem + kSegThreads / 64 + (threadIdx.x >> 6) * 128; // this wave's 64 pairs (compute: the high-high sums change lanes)
 	for (int i = threadIdx.x; i < 256; i += kSegThreads) dict_s[i] = a.dict[i];
 	double alpha, beta_unused;
 	epi_coeffs(a.sc, alpha, beta_unused);
 	constexpr int NW = kSegThreads / 64;
 	constexpr int GG = GT;
+	// one block per workgroup = a chain (pb_chain): a high site has ONE low neighbour, so a "pair" of cross hops holds one hop and the second
+	// read of every pair is left out (the planner refuses a one-block plan with a true pair)
+	constexpr bool X1 = ROWS == 1;
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	const uint4* const tw4 = (const uint4*)a.tw;
 	const uint32_t* const xw = a.xw;
@@ -267,7 +277,9 @@ template <bool DOT, int GT, int P0, int P1, int NC, int NH, int ROWS = 2> __glob
 #pragma unroll
 			for (int b = 0; b < NC; b++) s.x[b] = xw[(size_t)(cross_c[h.seg * NC + b].wordoff + h.segoff) + lane];
 		};
-		auto issue_data = [=](const SegHeads<GG>& h, const SegCrossWords<NC>& s, SegData<NC, NH, ROWS>& d) __attribute__((always_inline)) {
+		// NHI (a type that carries the number): the high-high hops this ITEM's slices carry (<= NH; SegItem::type)
+		auto issue_data = [=](auto nhi, const SegHeads<GG>& h, const SegCrossWords<NC>& s, SegData<NC, decltype(nhi)::value, ROWS>& d) __attribute__((always_inline)) {
+			constexpr int NHI = decltype(nhi)::value;
 			uint32_t sg = 0;
 #pragma unroll
 			for (int b = 0; b < NC; b++) {
@@ -275,20 +287,33 @@ template <bool DOT, int GT, int P0, int P1, int NC, int NH, int ROWS = 2> __glob
 				const uint32_t at0 = (sb + (s.x[b] & 0x1fffu)) * 8u, at1 = (sb + ((s.x[b] >> 16) & 0x1fffu)) * 8u;
 				d.xa[2 * b] = *(const double*)((const char*)yrow0 + at0);
 				if (ROWS == 2) d.xb[2 * b] = *(const double*)((const char*)yrow1 + at0);
-				d.xa[2 * b + 1] = *(const double*)((const char*)yrow0 + at1);
+				if (!X1) d.xa[2 * b + 1] = *(const double*)((const char*)yrow0 + at1);
 				if (ROWS == 2) d.xb[2 * b + 1] = *(const double*)((const char*)yrow1 + at1);
 				sg |= (((s.x[b] >> 14) & 3u) | ((s.x[b] >> 28) & 0xcu)) << (4 * b);
 			}
 			d.sg = sg;
-			const int lc = min(lane, h.count - 1);
+			// High-high hops: position-preserving runs of the source segments.  A wave-level load costs a CU's vector-memory pipeline the same
+			// ~17 cycles for 8 as for 16 bytes per lane (scripts/experiments/r04_tcp_rate.hip), so one load serves TWO hops: lanes 0..31 read
+			// the positions (2l, 2l + 1) of hop 2b's run, lanes 32..63 those of hop 2b + 1 -- 16 bytes at an 8-byte aligned address.  The sums
+			// change lanes once per slice (compute).  The last pair of a slice of `count` positions starts at count - 2 (-1 for a single
+			// position: never in front of the row, a lone position is not the row's first).
+			const int hst = min(2 * (lane & 31), h.count - 2);
 #pragma unroll
-			for (int b = 0; b < NH; b++) {
-				const uint32_t at = (uint32_t)(hh_c[h.seg * NH + b].srcbase + (h.segoff + lc) * hh_c[h.seg * NH + b].pad) * 8u;
-				d.ha[b] = *(const double*)((const char*)yrow0 + at);
-				if (ROWS == 2) d.hb[b] = *(const double*)((const char*)yrow1 + at);
+			for (int b = 0; b < NHI; b += 2) {
+				const SegHh* const en = hh_c + h.seg * NH + b + (lane >> 5);
+				const int el = max(en->srcbase + (h.segoff + hst) * en->pad, 0);
+				const SegPair8 t0 = *(const SegPair8*)(yrow0 + el);
+				d.ha[b] = t0.x;
+				d.ha[b + 1] = t0.y;
+				if (ROWS == 2) {
+					const SegPair8 t1 = *(const SegPair8*)(yrow1 + el);
+					d.hb[b] = t1.x;
+					d.hb[b + 1] = t1.y;
+				}
 			}
 		};
-		auto compute = [=, &dot](int jj, const SegHeads<GG>& h, const SegWinWords<GG>& s, const SegData<NC, NH, ROWS>& d) __attribute__((always_inline)) {
+		auto compute = [=, &dot](auto nhi, int jj, const SegHeads<GG>& h, const SegWinWords<GG>& s, const SegData<NC, decltype(nhi)::value, ROWS>& d) __attribute__((always_inline)) {
+			constexpr int NHI = decltype(nhi)::value;
 			if (jj >= nsl) return; // wave-uniform
 			double acc0 = 0.0, acc1 = 0.0;
 #pragma unroll
@@ -321,17 +346,33 @@ template <bool DOT, int GT, int P0, int P1, int NC, int NH, int ROWS = 2> __glob
 				if (ROWS == 2) acc1 = fma(gv[g], b0 + b1, acc1);
 			}
 #pragma unroll
-			for (int b = 0; b < 2 * NC; b++) {
+			for (int b = 0; b < 2 * NC; b += X1 ? 2 : 1) {
 				// two bits per hop as a signed field: +1, -1 or 0 (no entry: the element read was the source segment's first)
 				const double v = cross_c[h.seg * NC + (b >> 1)].val[b & 1] * (double)((int32_t)(d.sg << (30 - 2 * b)) >> 30);
 				acc0 = fma(v, d.xa[b], acc0);
 				if (ROWS == 2) acc1 = fma(v, d.xb[b], acc1);
 			}
+			{
+				// this lane's half of the hops at the positions (hst, hst + 1); then position `lane` collects both halves' sums of its pair
+				double p0x = 0.0, p0y = 0.0, p1x = 0.0, p1y = 0.0;
 #pragma unroll
-			for (int b = 0; b < NH; b++) {
-				const double v = hh_c[h.seg * NH + b].val;
-				acc0 = fma(v, d.ha[b], acc0);
-				if (ROWS == 2) acc1 = fma(v, d.hb[b], acc1);
+				for (int b = 0; b < NHI; b += 2) {
+					const double v = hh_c[h.seg * NH + b + (lane >> 5)].val;
+					p0x = fma(v, d.ha[b], p0x);
+					p0y = fma(v, d.ha[b + 1], p0y);
+					if (ROWS == 2) {
+						p1x = fma(v, d.hb[b], p1x);
+						p1y = fma(v, d.hb[b + 1], p1y);
+					}
+				}
+				const int comp = (lane - min(lane & ~1, h.count - 2)) & 1; // where this position sits in its pair (the last pair starts at count - 2)
+				const int src = 2 * (lane >> 1) + comp;
+				((double2*)tr_s)[lane] = double2 { p0x, p0y }; // LDS instructions of a wave run in order: no barrier
+				acc0 += tr_s[src] + tr_s[64 + src];
+				if (ROWS == 2) {
+					((double2*)tr_s)[lane] = double2 { p1x, p1y };
+					acc1 += tr_s[src] + tr_s[64 + src];
+				}
 			}
 			const int lc = min(lane, h.count - 1);
 			const int il = h.first + lc; // position in the item
@@ -350,33 +391,43 @@ template <bool DOT, int GT, int P0, int P1, int NC, int NH, int ROWS = 2> __glob
 		};
 		// slices m = 0, 1, ... of this wave are jj = wave + m NW.  At the top of an iteration: WA = lists of m, DA = data of m (in flight),
 		// XB = cross words of m + 1 (loaded), XA = cross words of m + 2 (in flight); fixed register sets, the loop is unrolled by two
-		SegHeads<GG> h0, h1, h2, h3, h4;
-		SegWinWords<GG> WA, WB;
-		SegCrossWords<NC> XA, XB;
-		SegData<NC, NH, ROWS> DA, DB;
-		load_heads(wave, h0);
-		load_heads(wave + NW, h1);
-		load_heads(wave + 2 * NW, h2);
-		load_cross_words(h0, XA);
-		load_win_words(h0, WA);
-		load_cross_words(h1, XB);
-		issue_data(h0, XA, DA);
-		load_cross_words(h2, XA);
-		for (int jj = wave; jj < nsl; jj += 2 * NW) {
-			issue_data(h1, XB, DB);
-			load_win_words(h1, WB);
-			load_heads(jj + 3 * NW, h3);
-			load_cross_words(h3, XB);
-			compute(jj, h0, WA, DA);
-			issue_data(h2, XA, DA);
-			load_win_words(h2, WA);
-			load_heads(jj + 4 * NW, h4);
-			load_cross_words(h4, XA);
-			compute(jj + NW, h1, WB, DB);
-			h0 = h2;
-			h1 = h3;
-			h2 = h4;
-		}
+		auto run_slices = [&](auto nhi) __attribute__((always_inline)) {
+			SegHeads<GG> h0, h1, h2, h3, h4;
+			SegWinWords<GG> WA, WB;
+			SegCrossWords<NC> XA, XB;
+			SegData<NC, decltype(nhi)::value, ROWS> DA, DB;
+			load_heads(wave, h0);
+			load_heads(wave + NW, h1);
+			load_heads(wave + 2 * NW, h2);
+			load_cross_words(h0, XA);
+			load_win_words(h0, WA);
+			load_cross_words(h1, XB);
+			issue_data(nhi, h0, XA, DA);
+			load_cross_words(h2, XA);
+			for (int jj = wave; jj < nsl; jj += 2 * NW) {
+				issue_data(nhi, h1, XB, DB);
+				load_win_words(h1, WB);
+				load_heads(jj + 3 * NW, h3);
+				load_cross_words(h3, XB);
+				compute(nhi, jj, h0, WA, DA);
+				issue_data(nhi, h2, XA, DA);
+				load_win_words(h2, WA);
+				load_heads(jj + 4 * NW, h4);
+				load_cross_words(h4, XA);
+				compute(nhi, jj + NW, h1, WB, DB);
+				h0 = h2;
+				h1 = h3;
+				h2 = h4;
+			}
+		};
+		// one block per workgroup (a chain: up to 12 high-high hops per segment, 6.0 on average): the loop for the 4, 8 or 12 this item holds
+		if constexpr (ROWS == 1 && NH == 12) {
+			const int nhc = __builtin_amdgcn_readfirstlane(wk.I.type >> 16);
+			if (nhc <= 4) run_slices(SegInt<4> {});
+			else if (nhc <= 8) run_slices(SegInt<8> {});
+			else run_slices(SegInt<NH> {});
+		} else
+			run_slices(SegInt<NH> {});
 		if (ROWS == 1) {
 			if (has_next) stage_store(wn, cur ^ 1, S);
 			__syncthreads(); // this item's slices are done with window `cur`; the next item's window is complete
