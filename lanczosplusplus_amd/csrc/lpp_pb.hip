@@ -990,13 +990,20 @@ int pb_launch_chain(lpp_engine* e, void* w, void* y, double* partial, const EpiS
 	d.u_has_beta = 1; // the in-block kernel has put beta r_{j-1} into u
 	if (d.pace) (void)hipMemsetAsync(d.pace, 0, sizeof(int) * 8 * (size_t)d.npanels, st);
 	d.cdict = (const double2*)B.cdict;
-	if (B.cplx) {
-		(void)hipFuncSetAttribute((const void*)k_pb_down<1024, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B.down_lds);
-		k_pb_down<1024, true, false, true><<<B.down_grid, 1024, B.down_lds, st>>>(d);
-		return B.down_grid;
-	}
-	(void)hipFuncSetAttribute((const void*)k_pb_down<1024, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B.down_lds);
-	k_pb_down<1024, true><<<B.down_grid, 1024, B.down_lds, st>>>(d);
+	// the last wave touches the u lines ahead of the tasks and the tasks are handed out by a counter (k_pb_down<..., PF>): config 2 3.03 -> 2.88 ms
+	// per step; LPP_PB_DOWN_PF=0: every wave its fixed share of the tasks, no touching
+	static const bool pf = !(getenv("LPP_PB_DOWN_PF") && atoi(getenv("LPP_PB_DOWN_PF")) == 0);
+	d.pf_lead = 2;
+#define LPP_PB_DOWN_RMW(CPLX_, PF_)                                                                                    \
+	do {                                                                                                              \
+		(void)hipFuncSetAttribute((const void*)k_pb_down<1024, true, false, CPLX_, PF_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B.down_lds); \
+		k_pb_down<1024, true, false, CPLX_, PF_><<<B.down_grid, 1024, B.down_lds, st>>>(d);                             \
+	} while (0)
+	if (B.cplx && pf) LPP_PB_DOWN_RMW(true, true);
+	else if (B.cplx) LPP_PB_DOWN_RMW(true, false);
+	else if (pf) LPP_PB_DOWN_RMW(false, true);
+	else LPP_PB_DOWN_RMW(false, false);
+#undef LPP_PB_DOWN_RMW
 	return B.down_grid;
 }
 

@@ -424,6 +424,7 @@ struct PbDownArgs {
 	int* pace; // [8][npanels] finished-workgroup counters (zeroed before the launch); null: free-running
 	int u_has_beta; // RMW: u_in already holds beta * (old z) (k_pb_up<CHAIN> adds it): z is written only, one stream less
 	const double2* cdict; // CPLX: 256 complex coupling values (the codes of c_code index it; `dict` then only serves the diagonal)
+	int pf_lead; // PF: batches of 64 blocks whose u lines are touched for the NEXT panel
 };
 
 // RMW (chained Lanczos step, see k_pb_up): z holds the previous Lanczos vector r' and receives the finished
@@ -436,7 +437,7 @@ struct PbDownArgs {
 // CPLX: complex hoppings.  The vector is complex, one element per 16-byte lane (a line = 8 positions; pitch and npanels still count
 // doubles), the coupling values are complex (cdict) and a gather is multiplied as a complex number; everything else -- lines, panels,
 // pacing, the partial sums (Re<y|z> is the real dot product of the doubles) -- is the real kernel.
-template <int THREADS, bool RMW = false, bool WIDE = false, bool CPLX = false> __global__ __launch_bounds__(THREADS) void k_pb_down(PbDownArgs a)
+template <int THREADS, bool RMW = false, bool WIDE = false, bool CPLX = false, bool PF = false> __global__ __launch_bounds__(THREADS) void k_pb_down(PbDownArgs a)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
 	__shared__ double dict_s[CPLX ? 512 : 256]; // CPLX: (re, im) pairs
@@ -447,6 +448,8 @@ template <int THREADS, bool RMW = false, bool WIDE = false, bool CPLX = false> _
 	int32_t* len_s = (int32_t*)(row_s + a.ids_per_wg); // [ids_per_wg] list length
 	uint32_t* place_s = (uint32_t*)(lds_raw + (((size_t)a.ids_per_wg * 8 + 15) & ~(size_t)15)); // [ids_per_wg][stride] source block (n_blk < 65536: the lists must fit LDS anyway) | code << 16
 	__shared__ double smem_d[THREADS / 64];
+	__shared__ int task_s[3]; // PF: next task of the panels k, k + 1, k + 2 (mod 3)
+	if (PF && threadIdx.x < 3) task_s[threadIdx.x] = 0;
 	for (int i = threadIdx.x; i < (CPLX ? 512 : 256); i += THREADS) dict_s[i] = CPLX ? ((const double*)a.cdict)[i] : a.dict[i];
 	double alpha, beta;
 	epi_coeffs(a.sc, alpha, beta);
@@ -496,7 +499,35 @@ template <int THREADS, bool RMW = false, bool WIDE = false, bool CPLX = false> _
 		const uint32_t colb = WIDE ? (uint32_t)(c * 16) : (uint32_t)((p << LSH) + c * 16); // byte offset of this lane's two positions inside a row (WIDE: inside the panel line)
 		// byte offset of (row `r` as stored in the LDS image, this lane's two positions of panel p)
 		auto at = [=](uint32_t r) __attribute__((always_inline)) -> size_t { return WIDE ? (((size_t)(r + (uint32_t)p) << LSH) + colb) : (size_t)(r + colb); };
-		for (int g = wave; g < ngroups; g += THREADS / 64) {
+		// PF: the tasks of a panel are handed out by an LDS counter (three counters in rotation: the one of panel k + 2 is zeroed during
+		// panel k, between the barriers that end panels k - 1 and k), and the LAST wave first touches this workgroup's lines of u -- from
+		// the third batch of 64 blocks on for this panel, the first two batches for the group's next panel (a batch = 8 tasks; the first
+		// tasks of a panel start before anything asked for now has arrived).  The tasks' own u loads are then L2 hits.  A wave's results
+		// return in order, so an HBM round trip in front of a task's gathers is waited for by all of them: 0.33 ms of this kernel's 1.67
+		// at config 2 were that.  Here ONE wave waits once per panel, and takes fewer tasks for it.  (Touching the next panel's y lines
+		// the same way: slower, 3.32 against 3.02 ms per step -- 1.6 MB more in the 4 MB L2 that holds the panel.)
+		const int pk = (p - grp) / nx; // the group's k-th panel
+		constexpr int NP = 8;
+		uint32_t pft[PF ? NP : 1];
+		if (PF) {
+			if (threadIdx.x == 0) task_s[(pk + 2) % 3] = 0;
+			if (wave == THREADS / 64 - 1) {
+				const bool nextp = p + nx < a.npanels;
+#pragma unroll
+				for (int k = 0; k < NP; k++) {
+					const uint32_t r = row_s[min(lane + 64 * k, nown - 1)];
+					const uint32_t pp = (uint32_t)(k < a.pf_lead && nextp ? p + nx : p);
+					pft[k] = *(const uint32_t*)((const char*)a.u_in + (WIDE ? (((size_t)(r + pp)) << LSH) : (size_t)(r + (pp << LSH))));
+				}
+			}
+		}
+		auto next_task = [&](int prev) __attribute__((always_inline)) -> int {
+			if (!PF) return prev < 0 ? wave : prev + THREADS / 64;
+			int g = 0;
+			if (lane == 0) g = atomicAdd(&task_s[pk % 3], 1);
+			return __builtin_amdgcn_readfirstlane(g);
+		};
+		for (int g = next_task(-1); g < ngroups; g = next_task(g)) {
 			const int il = min(g * BPT + sub, nown - 1);
 			const bool valid = g * BPT + sub < nown;
 			// trip count of the task: the longest list is the first one (decreasing order), in chunks of 4
@@ -563,9 +594,15 @@ template <int THREADS, bool RMW = false, bool WIDE = false, bool CPLX = false> _
 				}
 			}
 		}
-		if (a.pace) {
+		if (PF && wave == THREADS / 64 - 1) { // (the touched lines are used by nobody here: this only keeps the loads)
+			uint32_t x = 0;
+#pragma unroll
+			for (int k = 0; k < NP; k++) x ^= pft[k];
+			asm volatile("" ::"v"(x));
+		}
+		if (a.pace || PF) {
 			__syncthreads();
-			if (threadIdx.x == 0) __hip_atomic_fetch_add(a.pace + (int64_t)grp * a.npanels + p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			if (a.pace && threadIdx.x == 0) __hip_atomic_fetch_add(a.pace + (int64_t)grp * a.npanels + p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		}
 	}
 	if (a.partial) {

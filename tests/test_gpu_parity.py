@@ -904,8 +904,7 @@ def test_product_basis_layout_with_complex_hoppings(case, monkeypatch):
         assert rel(e.matrixVectorProduct(x0.copy(), y), xo) < SPMV_TOL
 
 
-@pytest.mark.parametrize("form", ["pieces", "pieces_wide"])
-@pytest.mark.parametrize("case", ["peierls_ring", "kane_mele_like", "disorder"])
+@pytest.mark.parametrize("case,form", [("peierls_ring", "pieces"), ("kane_mele_like", "pieces"), ("disorder", "pieces"), ("peierls_ring", "pieces_wide")])
 def test_complex_hoppings_beyond_one_lds_window(case, form, monkeypatch):
     """Complex hoppings with rows that do not fit one LDS window (4x4 lattice at 7/8 up electrons: 12870 complex positions): the realified
     in-block matrix is cut into pieces like any real one (k_pb_up_big, 4-8 value groups), the couplings stay complex (k_pb_down<CPLX>, with
