@@ -17,6 +17,7 @@ cfg() { # name, bench args, env
     c4) echo "--workload tj_4x5_9up9down_complex" ;;
     c1) echo "--workload hubbard_chain_L12_half_filling_U4" ;;
     c5_76) echo "--engine onthefly --workload hubbard_4x5_7up6down_pbc_U4 --no-generic-csr" ;;
+    cx87) echo "--workload hubbard_4x4_8up7down_complex_U4 --no-generic-csr" ;; # complex hoppings beyond one LDS window (pieces form, four value groups)
   esac
 }
 for c in ${CONFIGS:-c2_stored c2otf c2otf_kron c3 c4 c1 c5_76}; do
