@@ -749,6 +749,25 @@ PB_CASES = {
 }
 
 
+_PB_ORACLE = {}
+
+
+def _pb_oracle(case):
+    """the oracle's side of test_product_basis_layout, once per case (its five forms compare against the same numbers)"""
+    if case not in _PB_ORACLE:
+        L, nup, ndown, hop, U, V = PB_CASES[case]()
+        A = oracle.hubbard_csr(L, nup, ndown, hop, U, V)
+        x0, y = oracle.fill_random(A.nrows, 7), oracle.fill_random(A.nrows, 8)
+        xo = oracle.spmv_acc(A, x0.copy(), y)
+        init = oracle.fill_random(A.nrows, 4321)
+        eo, zo, so = oracle.lanczos_solve(A, oracle.fill_random(A.nrows, 1234), nstates=1)
+        steps_o, ao, bo, _, _ = oracle.lanczos_decomposition(A, init)
+        e3o, _, s3o = oracle.lanczos_solve(A, oracle.fill_random(A.nrows, 1234), nstates=3, max_steps=150, eps=1e-11, reortho=True)
+        _PB_ORACLE.clear()  # one case at a time (the parametrisation runs a case's forms back to back)
+        _PB_ORACLE[case] = (A, x0, y, xo, init, eo, so, steps_o, ao, bo, e3o, s3o)
+    return _PB_ORACLE[case]
+
+
 @pytest.mark.parametrize("form", ["window", "natural", "segments", "pieces", "wide"])
 @pytest.mark.parametrize("case", sorted(PB_CASES))
 def test_product_basis_layout(case, form, monkeypatch):
@@ -774,12 +793,7 @@ def test_product_basis_layout(case, form, monkeypatch):
         monkeypatch.setenv("LPP_PB_PIECE_ROWS", "320")
         monkeypatch.setenv("LPP_PB_WIDE", "1")
         monkeypatch.setenv("LPP_PB_BIG2", "0")  # one block per workgroup (k_pb_up_big); "pieces" runs two per workgroup (k_pb_up_big2)
-    A = oracle.hubbard_csr(L, nup, ndown, hop, U, V)
-    x0, y = oracle.fill_random(A.nrows, 7), oracle.fill_random(A.nrows, 8)
-    xo = oracle.spmv_acc(A, x0.copy(), y)
-    init = oracle.fill_random(A.nrows, 4321)
-    eo, zo, so = oracle.lanczos_solve(A, oracle.fill_random(A.nrows, 1234), nstates=1)
-    steps_o, ao, bo, _, _ = oracle.lanczos_decomposition(A, init)
+    A, x0, y, xo, init, eo, so, steps_o, ao, bo, e3o, s3o = _pb_oracle(case)
     with LanczosEngine() as e:
         e.assemble_hubbard(L, nup, ndown, hop, U, V)
         lay = e.layout()
@@ -820,7 +834,6 @@ def test_product_basis_layout(case, form, monkeypatch):
         assert st2["vectors_saved"] == 0 and abs(eg2[0] - eo[0]) <= E_TOL * abs(eo[0])
         r = oracle.spmv_acc(A, np.zeros_like(zg2[0]), zg2[0]) - eg2[0] * zg2[0]
         assert np.linalg.norm(r) < 1e-5
-    e3o, _, s3o = oracle.lanczos_solve(A, oracle.fill_random(A.nrows, 1234), nstates=3, max_steps=150, eps=1e-11, reortho=True)
     with LanczosEngine(reortho=True, max_steps=150, eps=1e-11) as e:  # blocked CGS2 on pitched Krylov columns
         e.assemble_hubbard(L, nup, ndown, hop, U, V)
         e3, z3, st3 = e.lanczos(3, want_vectors=True)
