@@ -847,6 +847,39 @@ def test_product_basis_layout(case, form, monkeypatch):
         assert rel(xw, xg) < SPMV_TOL
 
 
+def test_chained_step_with_fixed_task_shares():
+    """LPP_PB_DOWN_PF=0: the coupling kernel of the chained step without the task counter and without the wave that touches the u lines
+    ahead (round 3's form, kept as a switch) gives the same energy, stopping step and coefficients.  The switch is read once per process,
+    so the run is a child process."""
+    import json
+    import os
+    import subprocess
+    import sys
+    case = "ladder_2x6"
+    A, x0, y, xo, init, eo, so, steps_o, ao, bo, e3o, s3o = _pb_oracle(case)
+    code = (
+        "import sys, json, numpy as np\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import oracle\n"
+        "from test_gpu_parity import PB_CASES\n"
+        "from lanczosplusplus_amd import LanczosEngine\n"
+        "L, nup, ndown, hop, U, V = PB_CASES[%r]()\n"
+        "with LanczosEngine(save_vectors=0) as e:\n"
+        "    e.assemble_hubbard(L, nup, ndown, hop, U, V)\n"
+        "    lay = e.layout()\n"
+        "    eg, _, st = e.lanczos(1, want_vectors=False)\n"
+        "    ag, bg, _ = e.decomposition(oracle.fill_random(e.stats()['nrows'], 4321))\n"
+        "print('RESULT ' + json.dumps({'chained': lay['chained_step'], 'e0': float(eg[0]), 'steps': st['steps'], 'a': list(map(float, ag)), 'b': list(map(float, bg))}))\n"
+    ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)), case)
+    env = dict(os.environ, LPP_PRODUCT_LAYOUT="1", LPP_PB_DOWN_PF="0")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    r = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("RESULT ")][-1][7:])
+    assert r["chained"] == 1
+    assert abs(r["e0"] - eo[0]) <= E_TOL * abs(eo[0]) and r["steps"] == so
+    assert len(r["a"]) == steps_o and rel(np.array(r["a"]), ao) < 1e-8 and rel(np.array(r["b"]), bo) < 1e-8
+
+
 @pytest.mark.parametrize("case", ["peierls_ring", "kane_mele_like", "disorder"])
 def test_product_basis_layout_with_complex_hoppings(case, monkeypatch):
     """Complex hoppings (SolverOptions=useComplex, HubbardHelper.h:63-66; Peierls phases, KaneMele's imaginary second-neighbour hops) in the
