@@ -840,7 +840,8 @@ lpp_status finalize_csr(lpp_engine* e, DevCsr& A, bool allow_drop_plain, int for
 			// 5.2-5.75 TB/s: the 12-byte format's ceiling on this matrix).  At BASELINE config 2 (N_up = 12870 = 6 mod 16: two lines per
 			// source block and panel, which no longer fit the L2 beside the entry streams) it loses, 8.1 + 9.9 ms against 18.3-18.7 ms in
 			// one kernel, and is not taken.  LPP_SPLIT_PANEL=0 / 1: never / wherever a basis block is known.
-			bool off = (A.hint_block & 15) != 0 || (size_t)A.nrows * e->esz < ((size_t)256 << 20);
+			// (real matrices only: 16 complex positions are two lines, and no complex shape has been measured)
+			bool off = e->is_complex || (A.hint_block & 15) != 0 || (size_t)A.nrows * e->esz < ((size_t)256 << 20);
 			if (const char* sp = getenv("LPP_SPLIT_PANEL")) off = atoi(sp) == 0;
 			if (win && !force_mode && !want_dia && !off && A.hint_block > 0 && B == A.hint_block && !A.out_part && A.src_elems == 0) {
 				bool did = false;

@@ -511,7 +511,7 @@ template <int THREADS, bool RMW = false, bool WIDE = false, bool CPLX = false, b
 		uint32_t pft[PF ? NP : 1];
 		if (PF) {
 			if (threadIdx.x == 0) task_s[(pk + 2) % 3] = 0;
-			if (wave == THREADS / 64 - 1) {
+			if (wave == THREADS / 64 - 1 && nown > 0) { // (a workgroup without blocks -- more slots than ranges -- has no line to touch: row_s[-1] is not its word)
 				const bool nextp = p + nx < a.npanels;
 #pragma unroll
 				for (int k = 0; k < NP; k++) {
@@ -594,7 +594,7 @@ template <int THREADS, bool RMW = false, bool WIDE = false, bool CPLX = false, b
 				}
 			}
 		}
-		if (PF && wave == THREADS / 64 - 1) { // (the touched lines are used by nobody here: this only keeps the loads)
+		if (PF && wave == THREADS / 64 - 1 && nown > 0) { // (the touched lines are used by nobody here: this only keeps the loads)
 			uint32_t x = 0;
 #pragma unroll
 			for (int k = 0; k < NP; k++) x ^= pft[k];

@@ -288,6 +288,9 @@ lpp_status pb_seg_plan_model(int L, int n, const std::vector<double>& hv, const 
 				SegHh h;
 				h.srcbase = (int32_t)sbase[(size_t)seg_of_t[(size_t)t2]];
 				h.pad = 1; // lane l reads element srcbase + offset in the segment
+				// the kernel reads a lone position as the SECOND element of the pair in front of it (k_pb_up_seg, issue_data): a one-position source
+				// segment at the very start of the row has no element in front of it -- such a space keeps the per-position template
+				if (h.srcbase == 0 && segs[i].len == 1) return LPP_OK;
 				h.val = parity((uint32_t)t & (between(a, b))) ? -hv[kk] : hv[kk];
 				P.hh.push_back(h);
 			}

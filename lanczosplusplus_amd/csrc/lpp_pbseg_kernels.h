@@ -367,10 +367,15 @@ template <bool DOT, int GT, int P0, int P1, int NC, int NH, int ROWS = 2> __glob
 				}
 				const int comp = (lane - min(lane & ~1, h.count - 2)) & 1; // where this position sits in its pair (the last pair starts at count - 2)
 				const int src = 2 * (lane >> 1) + comp;
-				((double2*)tr_s)[lane] = double2 { p0x, p0y }; // LDS instructions of a wave run in order: no barrier
+				// LDS instructions of a wave run in order, so the hardware needs no barrier; the wave barriers (no instruction) only keep the
+				// compiler from moving the reads of other lanes' slots across this lane's store
+				((double2*)tr_s)[lane] = double2 { p0x, p0y };
+				__builtin_amdgcn_wave_barrier();
 				acc0 += tr_s[src] + tr_s[64 + src];
 				if (ROWS == 2) {
+					__builtin_amdgcn_wave_barrier();
 					((double2*)tr_s)[lane] = double2 { p1x, p1y };
+					__builtin_amdgcn_wave_barrier();
 					acc1 += tr_s[src] + tr_s[64 + src];
 				}
 			}

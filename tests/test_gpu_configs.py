@@ -41,6 +41,8 @@ def test_config2_hubbard4x4_U4_against_the_cpu_oracle(engine, monkeypatch):
     with LanczosEngine(max_steps=g["max_steps"], min_steps=g["min_steps"], eps=g["eps"], save_vectors=0, seed=g["seed"]) as e:
         if engine == "stored":
             e.assemble_hubbard(L, g["nup"], g["ndown"], hop, U)
+            lay = e.layout()  # a silent fall-back to the general layout would leave every check below green: say which layout ran
+            assert lay["kernel"] == 4 and lay["chained_step"] == 1 and lay["pieces"] == 1 and lay["segments"] == 0, lay
         else:
             e.setup_hubbard_onthefly(L, g["nup"], g["ndown"], hop, U)
             if engine == "onthefly":
@@ -69,6 +71,8 @@ def test_config3_heisenberg_L28_full_size():
     assert (A.nrows, A.nnz) == (40116600, 601749000)  # C(28,14) states, OBC
     with LanczosEngine(max_steps=300, save_vectors=0) as e:
         e.assemble_heisenberg(L, 14, jpm, jzz)
+        lay = e.layout()  # the chain as ONE block of the segmented form (13 high sites), not the general layout
+        assert lay["kernel"] == 4 and lay["segments"] == 8192, lay
         rp, ci, va = e.get_csr()
         assert np.array_equal(rp, A.rowptr) and np.array_equal(ci, A.colind) and np.array_equal(_bits(va), _bits(A.values))
         del rp, ci, va

@@ -11,7 +11,7 @@ import pytest
 
 import oracle
 from helpers import chain, rel, square
-from lanczosplusplus_amd import LanczosEngine, LppError
+from lanczosplusplus_amd import LanczosEngine, LppError, tridiag_lowest
 
 pytestmark = pytest.mark.gpu
 
@@ -878,6 +878,27 @@ def test_chained_step_with_fixed_task_shares():
     assert r["chained"] == 1
     assert abs(r["e0"] - eo[0]) <= E_TOL * abs(eo[0]) and r["steps"] == so
     assert len(r["a"]) == steps_o and rel(np.array(r["a"]), ao) < 1e-8 and rel(np.array(r["b"]), bo) < 1e-8
+
+
+def test_chained_step_when_some_coupling_workgroups_own_no_block(monkeypatch):
+    """364 blocks (14 sites, 3 particles of the block species) on the coupling kernel's 32 ranges of 12: the last workgroup of every
+    group owns NO block (ceil(364 / 32) * 31 >= 364).  The wave of the chained step that touches the u lines ahead indexed its row table
+    at -1 there (advisor finding, round 4); energy, stopping step and coefficients against the oracle."""
+    L, nup, ndown = 14, 7, 3
+    hop, U = chain(L, -1.0, True), np.full(L, 4.0)
+    monkeypatch.setenv("LPP_PRODUCT_LAYOUT", "1")
+    A = oracle.hubbard_csr(L, nup, ndown, hop, U)
+    assert A.nrows == 3432 * 364
+    init = oracle.fill_random(A.nrows, 4321)
+    steps_o, ao, bo, _, hist = oracle.lanczos_decomposition(A, init, nthreads=0)
+    with LanczosEngine(save_vectors=0) as e:
+        e.assemble_hubbard(L, nup, ndown, hop, U)
+        lay = e.layout()
+        assert lay["kernel"] == 4 and lay["chained_step"] == 1, lay
+        ag, bg, _ = e.decomposition(init)
+    assert len(ag) == steps_o and rel(ag, ao) < 1e-8 and rel(bg, bo) < 1e-8
+    eg = tridiag_lowest(ag, bg[:-1], 1)[0]
+    assert abs(eg - hist[-1]) <= E_TOL * abs(hist[-1])
 
 
 @pytest.mark.parametrize("case", ["peierls_ring", "kane_mele_like", "disorder"])
