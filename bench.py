@@ -241,6 +241,8 @@ def kernel_name(engine, layout):
     return {"window": "k_spmv_window (stored matrix, LDS source window; x += H y, fused a_j partial)",
             "sliced": "k_spmv_sliced (stored matrix, wave-interleaved slices; x += H y, fused a_j partial)",
             "rowgroup": "k_spmv_rowgroup (plain CSR; x += H y, fused a_j partial)",
+            "hole_major": ("k_tj_apply (t-J without a stored matrix: states ordered (hole configuration, spin pattern of the occupied sites); every row re-derives its "
+                           "entries from its block's bonds and hole moves, patterns ranked through two LDS tables; x += H y, fused a_j partial)"),
             "product": ("k_pb_up<CHAIN> + k_pb_down<RMW> (product-basis form H = 1(x)T + C(x)1 + D: in-block part from the LDS window, block couplings "
                         "panel-wise from L2; the two launches are the WHOLE scale-free Lanczos step -- the previous step's axpy rides in k_pb_up)"
                         if (layout or {}).get("chained_step") else
@@ -612,7 +614,7 @@ def main():
         except Exception:
             lay = None
         if lay is not None and (args.engine == "stored" or lay["kernel"] == 4):
-            layout = {"kernel": {1: "rowgroup", 2: "sliced", 3: "window", 4: "product"}.get(lay["kernel"]), "value_codes": bool(lay["coded"]),
+            layout = {"kernel": {1: "rowgroup", 2: "sliced", 3: "window", 4: "product", 5: "hole_major"}.get(lay["kernel"]), "value_codes": bool(lay["coded"]),
                       "pieces": lay["pieces"], "segments": lay.get("segments", 0), "one_block": bool(lay["kernel"] == 4 and lay["rows_per_block"] >= st0["nrows"]), "coupling_parts": lay["coupling_parts"], "chained_step": bool(lay["chained_step"]), "rows_by_list_length": bool(lay.get("rows_by_list_length", 0)),
                       "local16_columns": bool(lay["local16"]), "block_template": lay["block_template"], "diagonal_codes": bool(lay["diagonal_codes"]), "per_row_entries": lay["per_row_entries"],
                       "shared_offset_entries": lay["shared_entries"], "resident_GB": round(lay["resident_bytes"] / 1e9, 2)}

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define LPP_ABI_VERSION 4 /* 4: lpp_layout.segments, lpp_pb_seg_plan_stats; 2: lpp_layout.stream_bytes, lpp_pb_pack_template(bank_ways), set_solver / stream / _ext / _spin entry points; 3: lpp_layout.pieces / coupling_parts / diagonal_plain / chained_step / split_panel, lpp_stats.reortho_* */
+#define LPP_ABI_VERSION 5 /* 5: LPP_SPMV_HOLE_MAJOR (lpp_layout.kernel of the t-J model); 4: lpp_layout.segments, lpp_pb_seg_plan_stats; 2: lpp_layout.stream_bytes, lpp_pb_pack_template(bank_ways), set_solver / stream / _ext / _spin entry points; 3: lpp_layout.pieces / coupling_parts / diagonal_plain / chained_step / split_panel, lpp_stats.reortho_* */
 
 typedef int32_t lpp_status;
 enum {
@@ -44,7 +44,10 @@ enum { LPP_F64 = 0, LPP_C128 = 1 };
 
 /* SpMV kernel selection (0 = automatic) */
 enum { LPP_SPMV_AUTO = 0, LPP_SPMV_ROWGROUP = 1, LPP_SPMV_SLICED = 2, LPP_SPMV_WINDOW = 3,
-       LPP_SPMV_PRODUCT = 4 /* reported by lpp_engine_get_layout only: product-basis layout (device-assembled Hubbard) */ };
+       LPP_SPMV_PRODUCT = 4, /* reported by lpp_engine_get_layout only: product-basis layout (device-assembled Hubbard) */
+       LPP_SPMV_HOLE_MAJOR = 5 /* reported by lpp_engine_get_layout only (ABI 5): the one-orbital t-J model without a stored matrix -- states
+                                  ordered (hole configuration, spin pattern of the occupied sites), every entry re-derived per product from
+                                  the block's bonds and hole moves (csrc/lpp_tj_kernels.h); rows_per_block = spin patterns per hole configuration */ };
 
 typedef struct lpp_engine lpp_engine;
 

@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # LPP_ENGINE_LIB: another build of the same library (scripts/experiments build their variants into a scratch directory, never over this one)
 LIB_PATH = os.environ.get("LPP_ENGINE_LIB") or os.path.join(_HERE, "csrc", "liblpp_engine.so")
 
-LPP_ABI_VERSION = 4
+LPP_ABI_VERSION = 5
 LPP_OK, LPP_ERR_INVALID, LPP_ERR_HIP, LPP_ERR_NOMEM, LPP_ERR_NOCONV, LPP_ERR_STATE, LPP_ERR_COMM = range(7)
 LPP_F64, LPP_C128 = 0, 1
 LPP_SPMV_AUTO, LPP_SPMV_ROWGROUP, LPP_SPMV_SLICED, LPP_SPMV_WINDOW = 0, 1, 2, 3

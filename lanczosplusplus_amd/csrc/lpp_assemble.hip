@@ -389,6 +389,93 @@ lpp_status assemble_hubbard_pb(lpp_engine* e, AsmParams P, int nup, int ndown, i
 
 } // namespace
 
+namespace {
+// the term list and couplings of the one-orbital t-J model on the device (lpp_engine_assemble_tj, assemble_tj_raw, tj_build)
+struct TjDev {
+	DevBuf procs, comb, pv, z, w;
+};
+lpp_status tj_asm_params(lpp_engine* e, const TjModel& M, TjDev& D, AsmParams& P)
+{
+	const int L = M.L, nup = M.nup, ndown = M.ndown;
+	const std::vector<uint64_t> comb = comb_table();
+	const int64_t cfree = (int64_t)binom(comb, L - ndown, nup);
+	const int64_t nrows = (int64_t)binom(comb, L, ndown) * cfree;
+	const double* hop_re = M.hop_re.data();
+	const double* hop_im = M.hop_im.empty() ? nullptr : M.hop_im.data();
+	const double* jpm = M.jpm.data();
+	std::vector<HostProc> hp;
+	for (int i = 0; i < L; i++) {
+		for (int j = i + 1; j < L; j++) { // the reference only visits j >= i (TjMultiOrb.h:666,725); i == j never applies
+			const double hr = hop_re[i * L + j], hi = hop_im ? hop_im[i * L + j] : 0.0;
+			if (hr != 0 || hi != 0) {
+				// hopping, TjMultiOrb.h:673-692: value h*extraSign*doSign(ket_s,i,j), doSign = parity of bits [i,j)
+				for (int spin = 0; spin < 2; spin++) {
+					const int sh = spin * L, oh = (1 - spin) * L; // own / other species shift
+					// s_i=1, s_j=0: needs the other species absent at j; extraSign = -1
+					push(hp, bit(i + sh), bit(j + sh) | bit(j + oh), bit(i + sh) | bit(j + sh), range_mask(i, j) << sh, 0, 1, hr, hi);
+					// s_i=0, s_j=1: needs the other species absent at i; extraSign = +1
+					push(hp, bit(j + sh), bit(i + sh) | bit(i + oh), bit(i + sh) | bit(j + sh), range_mask(i, j) << sh, 0, 0, hr, hi);
+				}
+			}
+			const double h = jpm[i * L + j] * 0.5; // TjMultiOrb.h:736
+			if (h != 0) {
+				const uint64_t x4 = bit(i) | bit(j) | bit(i + L) | bit(j + L);
+				const uint64_t sm = range_mask(i, j) | (range_mask(i, j) << L); // signSplusSminus on bra1,bra2 (:772-783)
+				// up at i, down at j  ->  up at j, down at i   (:743-754)
+				push(hp, bit(i) | bit(j + L), bit(j) | bit(i + L), x4, 0, sm, 0, h, 0.0, true);
+				// up at j, down at i  ->  up at i, down at j   (:756-767)
+				push(hp, bit(j) | bit(i + L), bit(i) | bit(j + L), x4, 0, sm, 0, h, 0.0, true);
+			}
+		}
+	}
+	std::vector<Proc> procs;
+	int nneg = 0;
+	lpp_status st = finish_procs(hp, procs, &nneg);
+	if (st != LPP_OK) return st;
+	std::vector<double> pv(2 * (size_t)L, 0.0);
+	const int npv = std::min<int>(std::max(M.npot, 0), L);
+	if (M.has_pv)
+		for (int i = 0; i < 2 * L; i++) pv[i] = M.pv[(size_t)i];
+	if ((st = upload(e->stream, D.procs, procs.data(), sizeof(Proc) * procs.size())) != LPP_OK) return st;
+	if ((st = upload(e->stream, D.comb, comb.data(), sizeof(uint64_t) * comb.size())) != LPP_OK) return st;
+	if ((st = upload(e->stream, D.pv, pv.data(), sizeof(double) * pv.size())) != LPP_OK) return st;
+	if ((st = upload(e->stream, D.z, M.jzz.data(), sizeof(double) * L * L)) != LPP_OK) return st;
+	if ((st = upload(e->stream, D.w, M.w.data(), sizeof(double) * L * L)) != LPP_OK) return st;
+	HIP_TRY(hipStreamSynchronize(e->stream)); // the host copies above are locals
+	P = AsmParams {};
+	P.model = ASM_TJ;
+	P.L = L;
+	P.nup = nup;
+	P.ndown = ndown;
+	P.nproc = (int)procs.size();
+	P.nneg = nneg;
+	P.n_up = cfree;
+	P.nrows_global = nrows;
+	P.procs = (const Proc*)D.procs.p;
+	P.comb = (const uint64_t*)D.comb.p;
+	P.d0 = (const double*)D.pv.p;
+	P.nd0 = M.has_pv ? npv : 0;
+	P.d1 = (const double*)D.z.p;
+	P.d2 = (const double*)D.w.p;
+	P.row0 = 0;
+	P.nloc = nrows;
+	P.part = 0;
+	return LPP_OK;
+}
+} // namespace
+
+namespace lpp {
+// the plain CSR of the model in the reference's order, nothing else (lpp_engine_get_csr of the hole-major form)
+lpp_status assemble_tj_raw(lpp_engine* e, const TjModel& M, DevCsr& A)
+{
+	TjDev D;
+	AsmParams P {};
+	lpp_status st = tj_asm_params(e, M, D, P);
+	if (st != LPP_OK) return st;
+	return dispatch<ASM_TJ>(e, P, A, 0, 0, true);
+}
+} // namespace lpp
+
 extern "C" {
 
 lpp_status lpp_engine_assemble_hubbard(lpp_engine* e, const lpp_comm* comm, int32_t L, int32_t nup, int32_t ndown,
@@ -784,78 +871,42 @@ lpp_status lpp_engine_assemble_tj(lpp_engine* e, int32_t L, int32_t nup, int32_t
 {
 	if (!e || !hop_re || !jpm || !jzz || !w || L < 1 || L > 31 || nup < 0 || ndown < 0 || nup + ndown > L)
 		return fail(LPP_ERR_INVALID, "lpp_engine_assemble_tj: bad argument (1 <= L <= 31, nup+ndown <= L)");
-	const std::vector<uint64_t> comb = comb_table();
-	const int64_t cfree = (int64_t)binom(comb, L - ndown, nup);
-	const int64_t nrows = (int64_t)binom(comb, L, ndown) * cfree;
-	bool cplx_in = false;
-	if (hop_im)
-		for (int k = 0; k < L * L; k++) cplx_in |= (hop_im[k] != 0);
-	lpp_status st = common_setup(e, nrows, cplx_in);
-	if (st != LPP_OK) return st;
-	std::vector<HostProc> hp;
-	for (int i = 0; i < L; i++) {
-		for (int j = i + 1; j < L; j++) { // the reference only visits j >= i (TjMultiOrb.h:666,725); i == j never applies
-			const double hr = hop_re[i * L + j], hi = hop_im ? hop_im[i * L + j] : 0.0;
-			if (hr != 0 || hi != 0) {
-				// hopping, TjMultiOrb.h:673-692: value h*extraSign*doSign(ket_s,i,j), doSign = parity of bits [i,j)
-				for (int spin = 0; spin < 2; spin++) {
-					const int sh = spin * L, oh = (1 - spin) * L; // own / other species shift
-					// s_i=1, s_j=0: needs the other species absent at j; extraSign = -1
-					push(hp, bit(i + sh), bit(j + sh) | bit(j + oh), bit(i + sh) | bit(j + sh), range_mask(i, j) << sh, 0, 1, hr, hi);
-					// s_i=0, s_j=1: needs the other species absent at i; extraSign = +1
-					push(hp, bit(j + sh), bit(i + sh) | bit(i + oh), bit(i + sh) | bit(j + sh), range_mask(i, j) << sh, 0, 0, hr, hi);
-				}
-			}
-			const double h = jpm[i * L + j] * 0.5; // TjMultiOrb.h:736
-			if (h != 0) {
-				const uint64_t x4 = bit(i) | bit(j) | bit(i + L) | bit(j + L);
-				const uint64_t sm = range_mask(i, j) | (range_mask(i, j) << L); // signSplusSminus on bra1,bra2 (:772-783)
-				// up at i, down at j  ->  up at j, down at i   (:743-754)
-				push(hp, bit(i) | bit(j + L), bit(j) | bit(i + L), x4, 0, sm, 0, h, 0.0, true);
-				// up at j, down at i  ->  up at i, down at j   (:756-767)
-				push(hp, bit(j) | bit(i + L), bit(i) | bit(j + L), x4, 0, sm, 0, h, 0.0, true);
-			}
-		}
-	}
-	std::vector<Proc> procs;
-	int nneg = 0;
-	st = finish_procs(hp, procs, &nneg);
-	if (st != LPP_OK) return st;
 	if (potentialV && npot > 0 && npot < 2 * L) return fail(LPP_ERR_INVALID, "lpp_engine_assemble_tj: potentialV needs 2*L entries (up then down)");
-	std::vector<double> pv(2 * (size_t)L, 0.0);
-	const int npv = std::min<int>(std::max(npot, 0), L);
-	if (potentialV && npot > 0)
-		for (int i = 0; i < 2 * L; i++) pv[i] = potentialV[i];
-	DevBuf d_procs, d_comb, d_pv, d_z, d_w;
-	if ((st = upload(e->stream, d_procs, procs.data(), sizeof(Proc) * procs.size())) != LPP_OK) return st;
-	if ((st = upload(e->stream, d_comb, comb.data(), sizeof(uint64_t) * comb.size())) != LPP_OK) return st;
-	if ((st = upload(e->stream, d_pv, pv.data(), sizeof(double) * pv.size())) != LPP_OK) return st;
-	if ((st = upload(e->stream, d_z, jzz, sizeof(double) * L * L)) != LPP_OK) return st;
-	if ((st = upload(e->stream, d_w, w, sizeof(double) * L * L)) != LPP_OK) return st;
+	TjModel M;
+	M.L = L;
+	M.nup = nup;
+	M.ndown = ndown;
+	M.npot = npot;
+	const size_t LL = (size_t)L * L;
+	M.hop_re.assign(hop_re, hop_re + LL);
+	if (hop_im) M.hop_im.assign(hop_im, hop_im + LL);
+	M.jpm.assign(jpm, jpm + LL);
+	M.jzz.assign(jzz, jzz + LL);
+	M.w.assign(w, w + LL);
+	M.has_pv = potentialV && npot > 0;
+	if (M.has_pv) M.pv.assign(potentialV, potentialV + 2 * (size_t)L);
+	if (hop_im)
+		for (size_t k = 0; k < LL; k++) M.has_im |= (hop_im[k] != 0);
+	const std::vector<uint64_t> comb = comb_table();
+	const int64_t nrows = (int64_t)binom(comb, L, ndown) * (int64_t)binom(comb, L - ndown, nup);
+	lpp_status st = common_setup(e, nrows, M.has_im);
+	if (st != LPP_OK) return st;
+	TjDev D;
 	AsmParams P {};
-	P.model = ASM_TJ;
-	P.L = L;
-	P.nup = nup;
-	P.ndown = ndown;
-	P.nproc = (int)procs.size();
-	P.nneg = nneg;
-	P.n_up = cfree;
-	P.nrows_global = nrows;
-	P.procs = (const Proc*)d_procs.p;
-	P.comb = (const uint64_t*)d_comb.p;
-	P.d0 = (const double*)d_pv.p;
-	P.nd0 = (potentialV && npot > 0) ? npv : 0;
-	P.d1 = (const double*)d_z.p;
-	P.d2 = (const double*)d_w.p;
-	P.row0 = 0;
-	P.nloc = nrows;
-	P.part = 0;
+	if ((st = tj_asm_params(e, M, D, P)) != LPP_OK) return st;
 	e->has_comm = false;
 	e->bind_scalars(e->scal_own);
 	free_csr(e->A_rem);
 	drop_product(e);
-	st = dispatch<ASM_TJ>(e, P, e->A_loc);
-	if (st != LPP_OK) return st;
+	// the hole-major form without a stored matrix (lpp_tj_kernels.h) where it applies; otherwise the CSR in the general layout
+	bool as_tj = false;
+	if ((st = tj_build(e, M, P, &as_tj)) != LPP_OK) return st;
+	if (as_tj)
+		free_csr(e->A_loc);
+	else {
+		st = dispatch<ASM_TJ>(e, P, e->A_loc);
+		if (st != LPP_OK) return st;
+	}
 	e->n_local = e->n_global = nrows;
 	e->row_start = 0;
 	e->active = false;
@@ -1277,6 +1328,7 @@ namespace lpp {
 void drop_product(lpp_engine* e)
 {
 	free_kron(e);
+	free_tj(e);
 	free_pb(e);
 	e->tx = false;
 }

@@ -213,6 +213,7 @@ template <typename T> static int spmv_launch_out_t(lpp_engine* e, const DevCsr& 
 
 int spmv_launch(lpp_engine* e, const DevCsr& A, const void* src, void* x, const void* ydot, double* partial, const EpiScale& sc)
 {
+	if (e->tj.active && &A == &e->A_loc) return tj_launch(e, src, x, ydot, partial, sc); // t-J without a stored matrix (lpp_tj_kernels.h)
 	if (A.out_part) { // split-panel layout: the in-block entries first (x = beta x + alpha A_in src), then the leaving ones on top
 		if (e->is_complex) spmv_launch_t<cplx>(e, A, src, x, nullptr, nullptr, sc);
 		else spmv_launch_t<double>(e, A, src, x, nullptr, nullptr, sc);
@@ -874,6 +875,10 @@ void set_spmv_bytes(lpp_engine* e)
 		e->spmv_bytes = (double)e->pb.nnz_loc * (s + 4.0) + (N + 1.0) * 8.0 + 3.0 * N * s;
 		return;
 	}
+	if (e->tj.active) { // the CSR the hole-major t-J form stands for
+		e->spmv_bytes = (double)e->tj.nnz * (s + 4.0) + (N + 1.0) * 8.0 + 3.0 * N * s;
+		return;
+	}
 	if (e->kron.active) {
 		// matrix-free product: no matrix stream.  Vector-streaming model: x in/out and y once (3 N s) plus one
 		// coalesced pass over the source block of every connected down-configuration (H_down off-diagonals).
@@ -1239,6 +1244,24 @@ lpp_status lpp_engine_get_csr(lpp_engine* e, int32_t which, int64_t* nrows, int6
 		HIP_TRY(hipSetDevice(e->cfg.device));
 		return pb_get_csr(e, rowptr, colind, values);
 	}
+	if (e->tj.active) { // t-J without a stored matrix: the device assembler runs again, in the reference's order
+		if (nrows) *nrows = which == 0 ? e->n_local : 0;
+		if (nnz) *nnz = which == 0 ? e->tj.nnz : 0;
+		if (!rowptr && !colind && !values) return LPP_OK;
+		if (which != 0) return fail(LPP_ERR_STATE, "lpp_engine_get_csr: no remote part");
+		HIP_TRY(hipSetDevice(e->cfg.device));
+		DevCsr T;
+		lpp_status st = assemble_tj_raw(e, e->tj.model, T);
+		if (st == LPP_OK && T.nnz != e->tj.nnz) st = fail(LPP_ERR_HIP, "lpp_engine_get_csr: the regenerated t-J matrix has a different number of entries");
+		hipError_t he = hipSuccess;
+		if (st == LPP_OK && rowptr) he = hipMemcpy(rowptr, T.rowptr, sizeof(int64_t) * (size_t)(T.nrows + 1), hipMemcpyDeviceToHost);
+		if (st == LPP_OK && he == hipSuccess && colind) he = hipMemcpy(colind, T.col, sizeof(int32_t) * (size_t)T.nnz, hipMemcpyDeviceToHost);
+		if (st == LPP_OK && he == hipSuccess && values) he = hipMemcpy(values, T.val, e->esz * (size_t)T.nnz, hipMemcpyDeviceToHost);
+		free_csr(T);
+		if (st != LPP_OK) return st;
+		if (he != hipSuccess) return fail(LPP_ERR_HIP, std::string("lpp_engine_get_csr: ") + hipGetErrorString(he));
+		return LPP_OK;
+	}
 	const int64_t nnz_all = A.nnz + A.out_nnz();
 	if (nrows) *nrows = A.nrows;
 	if (nnz) *nnz = nnz_all;
@@ -1391,6 +1414,19 @@ lpp_status lpp_engine_get_layout(lpp_engine* e, int32_t which, lpp_layout* out)
 	const DevCsr& A = which == 0 ? e->A_loc : e->A_rem;
 	const size_t s = e->esz;
 	lpp_layout L {};
+	if (e->tj.active && which == 0) {
+		const TjState& S = e->tj;
+		L.kernel = LPP_SPMV_HOLE_MAJOR;
+		L.nnz = S.nnz;
+		L.rows_per_block = S.ns;
+		L.pieces = 1;
+		L.diagonal_plain = 1;
+		// the tables (L2 / LDS resident during a product), one f64 of diagonal per stored position, the boundary's permutation
+		L.resident_bytes = S.table_bytes + (int64_t)sizeof(double) * S.nblk * S.pitch + (int64_t)sizeof(int32_t) * S.nblk * S.ns;
+		L.stream_bytes = (int64_t)sizeof(double) * S.nblk * S.pitch;
+		*out = L;
+		return LPP_OK;
+	}
 	if (e->pb.active && which == 0) {
 		const PbState& B = e->pb;
 		L.kernel = LPP_SPMV_PRODUCT;
@@ -1487,7 +1523,7 @@ lpp_status lpp_engine_get_stats(lpp_engine* e, lpp_stats* s)
 	e->collect_spmv_times();
 	*s = e->stats;
 	s->nrows = e->n_local;
-	s->nnz = e->pb.active ? e->pb.nnz_loc : (e->kron.active ? (int64_t)e->kron.equiv_nnz : e->A_loc.nnz + e->A_loc.out_nnz() + e->A_rem.nnz);
+	s->nnz = e->tj.active ? e->tj.nnz : e->pb.active ? e->pb.nnz_loc : (e->kron.active ? (int64_t)e->kron.equiv_nnz : e->A_loc.nnz + e->A_loc.out_nnz() + e->A_rem.nnz);
 	s->spmv_bytes = e->spmv_bytes;
 	return LPP_OK;
 }

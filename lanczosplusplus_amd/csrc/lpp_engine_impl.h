@@ -195,6 +195,29 @@ struct PbState {
 	int64_t* blockbase = nullptr; // first CSR entry of every block (n_blk + 1), for get_csr
 };
 
+// one-orbital t-J Hamiltonian without a stored matrix, hole-major order (lpp_tj_kernels.h)
+struct TjModel { // host copy of what lpp_engine_assemble_tj was given: lpp_engine_get_csr re-runs the device assembler from it
+	int L = 0, nup = 0, ndown = 0, npot = 0;
+	bool has_im = false, has_pv = false;
+	std::vector<double> hop_re, hop_im, jpm, jzz, w, pv;
+};
+struct TjState {
+	bool active = false;
+	TjModel model;
+	int Lo = 0, lb = 0, nhi = 0, nlo = 0, ns = 0, nblk = 0, chunks = 0, grid = 0;
+	int64_t pitch = 0; // elements between blocks
+	int64_t nnz = 0; // entries of the CSR this stands for
+	int64_t table_bytes = 0;
+	bool cplx_hops = false;
+	uint32_t* pat = nullptr;
+	int32_t* hi_base = nullptr;
+	uint16_t* lo_rank = nullptr;
+	void *blocks = nullptr, *pairs = nullptr, *hops = nullptr;
+	int32_t* order = nullptr;
+	double* diag = nullptr; // nblk * pitch
+	int32_t* perm = nullptr; // nblk * ns: stored (block, pattern) -> index in the reference's basis
+};
+
 } // namespace lpp
 
 struct lpp_engine {
@@ -212,6 +235,7 @@ struct lpp_engine {
 	lpp::DevCsr A_loc, A_rem;
 	lpp::KronState kron;
 	lpp::PbState pb;
+	lpp::TjState tj;
 	// pitched vector layout (product-basis matrices): block b of `pitch_rows` valid elements starts at element b*pitch; 0 = contiguous
 	int64_t pitch = 0, pitch_rows = 0, pitch_blocks = 0;
 	// transposition exchange (multi-GPU Hubbard): A_loc = diagonal + up-hops on the rank's slice, A_rem = down-hops
@@ -219,7 +243,7 @@ struct lpp_engine {
 	bool tx = false;
 	int64_t tx_per = 0, tx_peru = 0;
 	int64_t kron_n_up_tx = 1; // N_up of the transposition layout
-	bool has_matrix() const { return A_loc.rowptr != nullptr || kron.active || pb.active; }
+	bool has_matrix() const { return A_loc.rowptr != nullptr || kron.active || pb.active || tj.active; }
 	int64_t n_local = 0, n_global = 0, row_start = 0;
 	double spmv_bytes = 0;
 
@@ -319,6 +343,16 @@ lpp_status pb_get_csr(lpp_engine* e, int64_t* rowptr, int32_t* colind, void* val
 // a handed-over CSR of product-basis form -> the product-basis layout (verified row by row); *done == false: keep the general layout
 lpp_status pb_from_csr(lpp_engine* e, const DevCsr& A, int64_t n_up, bool* done);
 int64_t pb_pitch_for(int64_t n_up);
+// t-J without a stored matrix (lpp_tj.hip).  tj_build: P = the assembler's parameters of the same model (device pointers valid during the
+// call); *done == false: the layout does not apply, the caller assembles the CSR
+struct AsmParams;
+void free_tj(lpp_engine* e);
+lpp_status tj_build(lpp_engine* e, const TjModel& M, const AsmParams& P, bool* done);
+int tj_launch(lpp_engine* e, const void* src, void* x, const void* ydot, double* partial, const EpiScale& sc);
+lpp_status tj_vec_from_host(lpp_engine* e, double* dev, const void* host);
+lpp_status tj_vec_to_host(lpp_engine* e, void* host, const double* dev);
+void tj_fill_random(lpp_engine* e, double* dev, uint64_t seed);
+lpp_status assemble_tj_raw(lpp_engine* e, const TjModel& M, DevCsr& A); // the plain CSR in the reference's order (lpp_assemble.hip)
 // host <-> device vector copies that know the pitched layout
 lpp_status vec_from_host(lpp_engine* e, double* dev, const void* host);
 lpp_status vec_to_host(lpp_engine* e, void* host, const double* dev);

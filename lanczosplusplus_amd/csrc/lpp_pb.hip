@@ -1415,6 +1415,7 @@ lpp_status pb_get_csr(lpp_engine* e, int64_t* rowptr, int32_t* colind, void* val
 // ---- vector copies that know the pitched layout ------------------------------------------------
 lpp_status vec_from_host(lpp_engine* e, double* dev, const void* host)
 {
+	if (e->tj.active) return tj_vec_from_host(e, dev, host);
 	if (e->pitch > 0) {
 		const PbState& B = e->pb;
 		// stored order of the positions (PbState::perm): the copy lands in pb.u in the basis order and is gathered from there
@@ -1434,6 +1435,7 @@ lpp_status vec_from_host(lpp_engine* e, double* dev, const void* host)
 
 lpp_status vec_to_host(lpp_engine* e, void* host, const double* dev)
 {
+	if (e->tj.active) return tj_vec_to_host(e, host, dev);
 	if (e->pitch > 0) {
 		const PbState& B = e->pb;
 		const double* from = dev;
@@ -1452,6 +1454,10 @@ lpp_status vec_to_host(lpp_engine* e, void* host, const double* dev)
 
 void vec_fill_random(lpp_engine* e, double* dev, uint64_t seed)
 {
+	if (e->tj.active) {
+		tj_fill_random(e, dev, seed);
+		return;
+	}
 	if (e->pitch > 0) {
 		if (e->pb.cplx) // complex elements: the stream is indexed by doubles (2 per element), rows and pitch counted in doubles
 			k_fill_random_pitched<<<1024, 256, 0, e->stream>>>(dev, e->pitch_blocks, e->pb.n_up, e->pb.pitch, e->row_start * 2, seed, nullptr);

@@ -93,6 +93,8 @@ def test_config4_tj_4x5_complex_full_size():
     assert A.nrows == 9237800 and A.is_complex  # C(20,9)*C(11,9)
     with LanczosEngine(dtype="c128", max_steps=300, save_vectors=0) as e:
         e.assemble_tj(L, nup, ndown, lat(t), lat(J), lat(J), lat(-J / 4))
+        lay = e.layout()  # round 5: no stored matrix -- 190 hole configurations x 48620 spin patterns, the CSR below is REGENERATED by the assembler
+        assert lay["kernel"] == 5 and lay["rows_per_block"] == 48620 and lay["nnz"] == A.nnz and lay["resident_bytes"] < 0.2e9, lay
         rp, ci, va = e.get_csr()
         assert np.array_equal(rp, A.rowptr) and np.array_equal(ci, A.colind) and np.array_equal(_bits(va), _bits(A.values))
         del rp, ci, va

@@ -1303,3 +1303,76 @@ def test_heisenberg_periodic_chain_L24_chain_layout_against_the_general_layout(m
     assert abs(e1[0] - e0[0]) <= E_TOL * abs(e0[0]) and abs(s1["steps"] - s0["steps"]) <= 1
     assert all(np.array_equal(_bits(a) if a.dtype == np.float64 else a, _bits(b) if b.dtype == np.float64 else b) for a, b in zip(c1, c0))
     assert -0.4450 < e1[0] / L < -0.4440  # Bethe ansatz: E0 / L = 1/4 - ln 2 - pi^2 / (12 L^2) + ... = -0.44315 - 0.00143 at L = 24
+
+
+TJ_CASES = {
+    # name: (L, nup, ndown, hop, jpm, jzz, w, potentialV, engine dtype)
+    # open chain, two holes, real model in a complex engine (BASELINE config 4's shape: SolverOptions=useComplex with real couplings)
+    "chain_c128": lambda: (12, 5, 5, chain(12, -1.0), chain(12, 0.4), chain(12, 0.4), chain(12, -0.1), None, "c128"),
+    # 3 x 4 torus, three holes, f64 engine: wrap-around bonds rotate long bit ranges, bonds with different J, potentials (up != down)
+    "torus_f64": lambda: (12, 5, 4, square(3, 4, -1.0, pbc=True), square(3, 4, 0.4, pbc=True) * (1 + 0.25 * np.triu(np.ones((12, 12)), 3) + 0.25 * np.tril(np.ones((12, 12)), -3)),
+                          square(3, 4, 0.3, pbc=True), square(3, 4, -0.1, pbc=True), np.linspace(-0.2, 0.3, 24), "f64"),
+    # complex hopping amplitudes (a Peierls phase on every bond of a ring; the reference does NOT conjugate the reverse direction,
+    # TjMultiOrb.h:674-692 -- reproduced): one hole, odd number of occupied sites
+    "ring_peierls": lambda: (10, 5, 4, chain(10, -1.0, True) * np.exp(0.3j), chain(10, 0.5, True), chain(10, 0.5, True), chain(10, -0.125, True), None, "c128"),
+    # no hole at all: the t-J model is the Heisenberg model of the occupied sites (one block, no moves)
+    "no_holes": lambda: (12, 6, 6, chain(12, -1.0, True), chain(12, 0.4, True), chain(12, 0.4, True), chain(12, -0.1, True), None, "f64"),
+}
+
+
+@pytest.mark.parametrize("case", sorted(TJ_CASES))
+def test_tj_hole_major_form(case, monkeypatch):
+    """The one-orbital t-J model without a stored matrix (round 5, lpp_tj_kernels.h): states ordered (hole configuration, spin pattern of
+    the occupied sites), every entry re-derived per product from the block's bonds and hole moves.  Forced onto small lattices here
+    (BASELINE config 4 takes it by itself).  Against the oracle's restatement of TjMultiOrb::setupHamiltonian in the reference's
+    basis order: the CSR lpp_engine_get_csr regenerates (bit for bit), x += H y, the solve (energy, stopping step, Ritz vector in the
+    reference's order), the coefficients from a host start vector, the reorthogonalised run; and the general layout gives the same."""
+    L, nup, ndown, hop, jpm, jzz, w, pv, dtype = TJ_CASES[case]()
+    cplx = dtype == "c128"
+    monkeypatch.setenv("LPP_TJ_LAYOUT", "1")
+    A = oracle.tj_csr(L, nup, ndown, hop, jpm, jzz, w, pv, force_complex=cplx)
+    x0, y = oracle.fill_random(A.nrows, 7, cplx), oracle.fill_random(A.nrows, 8, cplx)
+    xo = oracle.spmv_acc(A, x0.copy(), y)
+    init = oracle.fill_random(A.nrows, 4321, cplx)
+    eo, zo, so = oracle.lanczos_solve(A, oracle.fill_random(A.nrows, 1234, cplx), nstates=1)
+    steps_o, ao, bo, _, _ = oracle.lanczos_decomposition(A, init)
+    with LanczosEngine(dtype=dtype) as e:
+        e.assemble_tj(L, nup, ndown, hop, jpm, jzz, w, pv)
+        lay = e.layout()
+        assert lay["kernel"] == 5 and lay["nnz"] == A.nnz and lay["rows_per_block"] == comb(nup + ndown, nup), lay
+        assert lay["resident_bytes"] < 0.2 * 12 * A.nnz
+        st = e.stats()
+        assert (st["nrows"], st["nnz"]) == (A.nrows, A.nnz)
+        rp, ci, va = e.get_csr()
+        assert np.array_equal(rp, A.rowptr) and np.array_equal(ci, A.colind) and np.array_equal(_bits(va), _bits(A.values))
+        xg = e.matrixVectorProduct(x0.copy(), y)
+        assert rel(xg, xo) < SPMV_TOL
+        assert rel(e.matrixVectorProduct(xg.copy(), y) - xg, xo - x0) < 1e-12  # accumulate semantics
+        # ring_peierls is NOT Hermitian (the reference keeps h unconjugated for the reverse hop): the recurrence is the oracle's all the
+        # same, but its Ritz vector is no eigenvector -- compared with the oracle's vector instead of through a residual
+        hermitian = case != "ring_peierls"
+        eg, zg, st = e.lanczos(1, want_vectors=True)  # built-in start vector == the oracle's stream in the reference's order
+        assert abs(eg[0] - eo[0]) <= E_TOL * abs(eo[0]) and st["steps"] == so
+        if hermitian:
+            r = oracle.spmv_acc(A, np.zeros_like(zg[0]), zg[0]) - eg[0] * zg[0]
+            assert np.linalg.norm(r) < 1e-5
+        assert abs(np.linalg.norm(zg[0]) - 1) < 1e-8 and abs(abs(np.vdot(zo[0], zg[0])) - 1) < 1e-8  # the oracle's vector up to its sign
+        ag, bg, _ = e.decomposition(init)
+        assert len(ag) == steps_o and rel(ag, ao) < 1e-8 and rel(bg, bo) < 1e-8
+        assert e.bench_spmv(1, 2) > 0
+    with LanczosEngine(dtype=dtype, save_vectors=0) as e:  # scale-free recurrence + two-pass Ritz vector
+        e.assemble_tj(L, nup, ndown, hop, jpm, jzz, w, pv)
+        eg2, zg2, st2 = e.lanczos(1, want_vectors=True)
+        assert st2["vectors_saved"] == 0 and abs(eg2[0] - eo[0]) <= E_TOL * abs(eo[0])
+        assert abs(abs(np.vdot(zo[0], zg2[0])) - 1) < 1e-8
+    if hermitian:  # (a symmetric recurrence has no excited-state bar on a non-Hermitian matrix)  # (not Hermitian: the reference keeps h unconjugated for the reverse hop; a symmetric recurrence has no excited-state bar there)
+        e3o, _, s3o = oracle.lanczos_solve(A, oracle.fill_random(A.nrows, 1234, cplx), nstates=3, max_steps=150, eps=1e-11, reortho=True)
+        with LanczosEngine(dtype=dtype, reortho=True, max_steps=150, eps=1e-11) as e:
+            e.assemble_tj(L, nup, ndown, hop, jpm, jzz, w, pv)
+            e3, z3, st3 = e.lanczos(3, want_vectors=True)
+            assert st3["steps"] == s3o and rel(e3, e3o) < 1e-8
+    monkeypatch.setenv("LPP_TJ_LAYOUT", "0")  # the general layout: the same numbers
+    with LanczosEngine(dtype=dtype) as e:
+        e.assemble_tj(L, nup, ndown, hop, jpm, jzz, w, pv)
+        assert e.layout()["kernel"] in (1, 2, 3)
+        assert rel(e.matrixVectorProduct(x0.copy(), y), xg) < SPMV_TOL
