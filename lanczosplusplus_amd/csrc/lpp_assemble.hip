@@ -390,6 +390,66 @@ lpp_status assemble_hubbard_pb(lpp_engine* e, AsmParams P, int nup, int ndown, i
 } // namespace
 
 namespace {
+// the term list and couplings of the S = 1/2 Heisenberg model on the device (lpp_engine_assemble_heisenberg, assemble_heisenberg_raw, pb_chain)
+struct HeisDev {
+	DevBuf procs, comb, f, z;
+};
+lpp_status heis_asm_params(lpp_engine* e, int L, int szPlusConst, const double* jpm, const double* jzz, const double* field, int nfield, HeisDev& D, AsmParams& P)
+{
+	const std::vector<uint64_t> comb = comb_table();
+	const int64_t nrows = (int64_t)binom(comb, L, szPlusConst);
+	// terms: raise site i (0->1), lower site j (1->0) for every ordered pair with jpm_(i,j) != 0,
+	// value 0.5*sqrt(..)*sqrt(..)*jpm = 0.5*jpm for S=1/2   (Heisenberg.h:278-307)
+	std::vector<HostProc> hp;
+	for (int i = 0; i < L; i++)
+		for (int j = 0; j < L; j++) {
+			if (i == j || jpm[i * L + j] == 0) continue;
+			push(hp, bit(j), bit(i), bit(i) | bit(j), 0, 0, 0, 0.5 * 1.0 * jpm[i * L + j], 0.0, true);
+		}
+	std::vector<Proc> procs;
+	int nneg = 0;
+	lpp_status st = finish_procs(hp, procs, &nneg);
+	if (st != LPP_OK) return st;
+	if ((st = upload(e->stream, D.procs, procs.data(), sizeof(Proc) * procs.size())) != LPP_OK) return st;
+	if ((st = upload(e->stream, D.comb, comb.data(), sizeof(uint64_t) * comb.size())) != LPP_OK) return st;
+	if ((st = upload(e->stream, D.f, field, sizeof(double) * (size_t)std::max(nfield, 0))) != LPP_OK) return st;
+	if ((st = upload(e->stream, D.z, jzz, sizeof(double) * L * L)) != LPP_OK) return st;
+	HIP_TRY(hipStreamSynchronize(e->stream)); // the host copies above are locals
+	P = AsmParams {};
+	P.model = ASM_HEISENBERG;
+	P.L = L;
+	P.nup = szPlusConst;
+	P.ndown = 0;
+	P.nproc = (int)procs.size();
+	P.nneg = nneg;
+	P.n_up = nrows;
+	P.nrows_global = nrows;
+	P.procs = (const Proc*)D.procs.p;
+	P.comb = (const uint64_t*)D.comb.p;
+	P.d0 = (const double*)D.f.p;
+	P.nd0 = std::min<int>(std::max(nfield, 0), L);
+	P.d1 = nullptr;
+	P.nd1 = 0;
+	P.d2 = (const double*)D.z.p;
+	P.row0 = 0;
+	P.nloc = nrows;
+	P.part = 0;
+	return LPP_OK;
+}
+} // namespace
+
+namespace lpp {
+lpp_status assemble_heisenberg_raw(lpp_engine* e, int L, int m, const double* jpm, const double* jzz, const double* field, int nfield, DevCsr& A)
+{
+	HeisDev D;
+	AsmParams P {};
+	lpp_status st = heis_asm_params(e, L, m, jpm, jzz, field, nfield, D, P);
+	if (st != LPP_OK) return st;
+	return dispatch<ASM_HEISENBERG>(e, P, A, 0, 0, true);
+}
+} // namespace lpp
+
+namespace {
 // the term list and couplings of the one-orbital t-J model on the device (lpp_engine_assemble_tj, assemble_tj_raw, tj_build)
 struct TjDev {
 	DevBuf procs, comb, pv, z, w;
@@ -684,52 +744,18 @@ lpp_status lpp_engine_assemble_heisenberg(lpp_engine* e, int32_t L, int32_t szPl
 	const int64_t nrows = (int64_t)binom(comb, L, szPlusConst);
 	lpp_status st = common_setup(e, nrows, 0);
 	if (st != LPP_OK) return st;
-	// terms: raise site i (0->1), lower site j (1->0) for every ordered pair with jpm_(i,j) != 0,
-	// value 0.5*sqrt(..)*sqrt(..)*jpm = 0.5*jpm for S=1/2   (Heisenberg.h:278-307)
-	std::vector<HostProc> hp;
-	for (int i = 0; i < L; i++)
-		for (int j = 0; j < L; j++) {
-			if (i == j || jpm[i * L + j] == 0) continue;
-			push(hp, bit(j), bit(i), bit(i) | bit(j), 0, 0, 0, 0.5 * 1.0 * jpm[i * L + j], 0.0, true);
-		}
-	std::vector<Proc> procs;
-	int nneg = 0;
-	st = finish_procs(hp, procs, &nneg);
-	if (st != LPP_OK) return st;
-	DevBuf d_procs, d_comb, d_f, d_a, d_z;
-	if ((st = upload(e->stream, d_procs, procs.data(), sizeof(Proc) * procs.size())) != LPP_OK) return st;
-	if ((st = upload(e->stream, d_comb, comb.data(), sizeof(uint64_t) * comb.size())) != LPP_OK) return st;
-	if ((st = upload(e->stream, d_f, field, sizeof(double) * (size_t)std::max(nfield, 0))) != LPP_OK) return st;
-	if ((st = upload(e->stream, d_z, jzz, sizeof(double) * L * L)) != LPP_OK) return st;
+	HeisDev D;
 	AsmParams P {};
-	P.model = ASM_HEISENBERG;
-	P.L = L;
-	P.nup = szPlusConst;
-	P.ndown = 0;
-	P.nproc = (int)procs.size();
-	P.nneg = nneg;
-	P.n_up = nrows;
-	P.nrows_global = nrows;
-	P.procs = (const Proc*)d_procs.p;
-	P.comb = (const uint64_t*)d_comb.p;
-	P.d0 = (const double*)d_f.p;
-	P.nd0 = std::min<int>(std::max(nfield, 0), L);
-	P.d1 = nullptr;
-	P.nd1 = 0;
-	P.d2 = (const double*)d_z.p;
-	P.row0 = 0;
-	P.nloc = nrows;
-	P.part = 0;
+	if ((st = heis_asm_params(e, L, szPlusConst, jpm, jzz, field, nfield, D, P)) != LPP_OK) return st;
 	e->has_comm = false;
 	e->bind_scalars(e->scal_own);
 	free_csr(e->A_rem);
 	drop_product(e);
-	st = dispatch<ASM_HEISENBERG>(e, P, e->A_loc, 0, 0, true);
-	if (st != LPP_OK) return st;
 	// A chain (couplings between neighbours, and between the two ends): S+S- moves an up spin and nothing sits between the two sites, so
 	// the off-diagonal part is the hopping matrix of the up spins -- one block of the product-basis form, the in-block kernel decomposed by
 	// the high sites of the basis word (pb_chain, lpp_pbseg.h).  Amplitudes in the planner's convention: value x (-1)^(up spins between),
-	// which for the bond between the two ends is the constant (-1)^(n - 1).
+	// which for the bond between the two ends is the constant (-1)^(n - 1).  Planned from the couplings alone: no CSR is assembled
+	// (lpp_engine_get_csr re-runs the assembler), so the largest chain is bounded by its vectors, not by 12 bytes per entry.
 	bool chain = L >= 2 && !e->is_complex;
 	std::vector<double> hv((size_t)L * L, 0.0);
 	for (int i = 0; i < L && chain; i++)
@@ -742,11 +768,20 @@ lpp_status lpp_engine_assemble_heisenberg(lpp_engine* e, int32_t L, int32_t szPl
 		}
 	bool as_chain = false;
 	if (chain && szPlusConst >= 1 && szPlusConst < L) {
-		st = pb_chain(e, e->A_loc, L, szPlusConst, hv, &as_chain);
+		st = pb_chain(e, P, L, szPlusConst, hv, &as_chain);
 		if (st != LPP_OK) return st;
 	}
-	if (!as_chain) {
-		st = finalize_csr(e, e->A_loc, true, 0, 0);
+	if (as_chain) {
+		free_csr(e->A_loc);
+		PbState& B = e->pb;
+		B.chain_L = L;
+		B.chain_m = szPlusConst;
+		B.chain_nfield = std::max(nfield, 0);
+		B.chain_jpm.assign(jpm, jpm + (size_t)L * L);
+		B.chain_jzz.assign(jzz, jzz + (size_t)L * L);
+		if (field && nfield > 0) B.chain_field.assign(field, field + nfield);
+	} else {
+		st = dispatch<ASM_HEISENBERG>(e, P, e->A_loc);
 		if (st != LPP_OK) return st;
 	}
 	e->n_local = e->n_global = nrows;

@@ -1235,24 +1235,20 @@ lpp_status lpp_engine_get_csr(lpp_engine* e, int32_t which, int64_t* nrows, int6
 {
 	if (!e) return fail(LPP_ERR_INVALID, "lpp_engine_get_csr: null engine");
 	DevCsr& A = which == 0 ? e->A_loc : e->A_rem;
-	if (e->pb.active && !e->pb.csr_kept) { // product-basis layout: the CSR is regenerated from T, C and the diagonal codes (a chain keeps its CSR: below)
-		if (e->pb.tx) return fail(LPP_ERR_STATE, "lpp_engine_get_csr: not available for the product-basis layout on several GPUs");
+	if (e->tj.active || (e->pb.active && e->pb.chain_model)) {
+		// t-J without a stored matrix / a spin chain planned from its couplings: the device assembler runs again, in the reference's order
+		const int64_t have = e->tj.active ? e->tj.nnz : e->pb.nnz;
 		if (nrows) *nrows = which == 0 ? e->n_local : 0;
-		if (nnz) *nnz = which == 0 ? e->pb.nnz : 0;
-		if (!rowptr && !colind && !values) return LPP_OK;
-		if (which != 0) return fail(LPP_ERR_STATE, "lpp_engine_get_csr: no remote part");
-		HIP_TRY(hipSetDevice(e->cfg.device));
-		return pb_get_csr(e, rowptr, colind, values);
-	}
-	if (e->tj.active) { // t-J without a stored matrix: the device assembler runs again, in the reference's order
-		if (nrows) *nrows = which == 0 ? e->n_local : 0;
-		if (nnz) *nnz = which == 0 ? e->tj.nnz : 0;
+		if (nnz) *nnz = which == 0 ? have : 0;
 		if (!rowptr && !colind && !values) return LPP_OK;
 		if (which != 0) return fail(LPP_ERR_STATE, "lpp_engine_get_csr: no remote part");
 		HIP_TRY(hipSetDevice(e->cfg.device));
 		DevCsr T;
-		lpp_status st = assemble_tj_raw(e, e->tj.model, T);
-		if (st == LPP_OK && T.nnz != e->tj.nnz) st = fail(LPP_ERR_HIP, "lpp_engine_get_csr: the regenerated t-J matrix has a different number of entries");
+		const PbState& B = e->pb;
+		lpp_status st = e->tj.active ? assemble_tj_raw(e, e->tj.model, T)
+		                             : assemble_heisenberg_raw(e, B.chain_L, B.chain_m, B.chain_jpm.data(), B.chain_jzz.data(),
+		                                                       B.chain_field.empty() ? nullptr : B.chain_field.data(), B.chain_nfield, T);
+		if (st == LPP_OK && T.nnz != have) st = fail(LPP_ERR_HIP, "lpp_engine_get_csr: the regenerated matrix has a different number of entries");
 		hipError_t he = hipSuccess;
 		if (st == LPP_OK && rowptr) he = hipMemcpy(rowptr, T.rowptr, sizeof(int64_t) * (size_t)(T.nrows + 1), hipMemcpyDeviceToHost);
 		if (st == LPP_OK && he == hipSuccess && colind) he = hipMemcpy(colind, T.col, sizeof(int32_t) * (size_t)T.nnz, hipMemcpyDeviceToHost);
@@ -1261,6 +1257,15 @@ lpp_status lpp_engine_get_csr(lpp_engine* e, int32_t which, int64_t* nrows, int6
 		if (st != LPP_OK) return st;
 		if (he != hipSuccess) return fail(LPP_ERR_HIP, std::string("lpp_engine_get_csr: ") + hipGetErrorString(he));
 		return LPP_OK;
+	}
+	if (e->pb.active) { // product-basis layout: the CSR is regenerated from T, C and the diagonal codes
+		if (e->pb.tx) return fail(LPP_ERR_STATE, "lpp_engine_get_csr: not available for the product-basis layout on several GPUs");
+		if (nrows) *nrows = which == 0 ? e->n_local : 0;
+		if (nnz) *nnz = which == 0 ? e->pb.nnz : 0;
+		if (!rowptr && !colind && !values) return LPP_OK;
+		if (which != 0) return fail(LPP_ERR_STATE, "lpp_engine_get_csr: no remote part");
+		HIP_TRY(hipSetDevice(e->cfg.device));
+		return pb_get_csr(e, rowptr, colind, values);
 	}
 	const int64_t nnz_all = A.nnz + A.out_nnz();
 	if (nrows) *nrows = A.nrows;
@@ -1446,12 +1451,10 @@ lpp_status lpp_engine_get_layout(lpp_engine* e, int32_t which, lpp_layout* out)
 		L.segments = B.seg ? B.seg_nsegs : 0;
 		L.diagonal_plain = B.dval ? 1 : 0;
 		const size_t small = sizeof(uint32_t) * (size_t)B.f_words + sizeof(uint32_t) * (size_t)B.tw_words + (sizeof(int32_t) + sizeof(uint16_t)) * (size_t)B.spb * (size_t)B.G
-		    + (size_t)B.seg_bytes + (size_t)B.t_entries * 12 + sizeof(int64_t) * (size_t)(B.n_up + 1) + (size_t)B.c_nnz * 5 + sizeof(int64_t) * 2 * (size_t)(B.n_blk + 1) + 256 * sizeof(double);
+		    + (size_t)B.seg_bytes + (size_t)B.t_entries * 12 + (B.chain_model ? 0 : sizeof(int64_t) * (size_t)(B.n_up + 1)) + (size_t)B.c_nnz * 5 + sizeof(int64_t) * 2 * (size_t)(B.n_blk + 1) + 256 * sizeof(double);
 		// one diagonal code per row this rank holds, or one plain double when the diagonal has more than 256 distinct values
 		const size_t codes = (size_t)(B.tx ? B.nblk_loc : B.n_blk) * (size_t)B.pitch * (B.dval ? 9 : 1);
-		// (a chain keeps its plain CSR for lpp_engine_get_csr: resident, never read by a product)
-		const size_t kept = B.csr_kept ? (size_t)e->A_loc.nnz * (sizeof(int32_t) + s) + sizeof(int64_t) * (size_t)(e->A_loc.nrows + 1) : 0;
-		L.resident_bytes = (int64_t)(small + codes + kept);
+		L.resident_bytes = (int64_t)(small + codes);
 		// per product: one diagonal code per row; the template words and the couplings are re-read from L2 / LDS
 		L.stream_bytes = (int64_t)(codes + sizeof(uint32_t) * (size_t)(B.tw_words + B.f_words) + (size_t)B.seg_bytes + (size_t)B.c_nnz * 5);
 		*out = L;

@@ -164,7 +164,11 @@ struct PbState {
 	// the stored order of the positions (perm / inv) is then the segments by length
 	bool seg = false;
 	bool seg_one = false; // one block per workgroup (pb_chain)
-	bool csr_kept = false; // the plain CSR of A_loc stays resident and is what lpp_engine_get_csr hands out (pb_chain)
+	// a chain (pb_chain) is planned from the model's parameters alone: no CSR is ever held, lpp_engine_get_csr re-runs the device assembler
+	// from this host copy of what lpp_engine_assemble_heisenberg was given
+	bool chain_model = false;
+	int chain_L = 0, chain_m = 0, chain_nfield = 0;
+	std::vector<double> chain_jpm, chain_jzz, chain_field;
 	int seg_nitems = 0, seg_nsegs = 0, seg_ws = 0, seg_wmax = 0, seg_nc = 0, seg_nh = 0, seg_pre0 = 4;
 	int64_t seg_bytes = 0; // description of T held on the device
 	void* seg_items = nullptr;
@@ -297,6 +301,7 @@ struct lpp_engine {
 };
 
 namespace lpp {
+struct AsmParams; // lpp_assemble_kernels.h
 void free_csr(DevCsr& A);
 lpp_status finalize_csr(lpp_engine* e, DevCsr& A, bool allow_drop_plain, int force_mode = 0, int64_t force_block = 0);
 void free_kron(lpp_engine* e);
@@ -327,9 +332,12 @@ lpp_status pb_build(lpp_engine* e, int64_t n_up, int64_t n_blk, const int64_t* t
                     struct SegPlan* pre = nullptr, int64_t pre_nnz = 0);
 // A matrix whose off-diagonal part is the hopping matrix of ONE species on a chain -- the S = 1/2 Heisenberg chain in the S_z basis
 // (Heisenberg.h:278-307: S+S- moves an up spin, nothing sits between neighbours) -- as ONE block of the product-basis form: the in-block
-// kernel k_pb_up_seg and the streaming pass, no couplings.  A keeps its plain CSR (lpp_engine_get_csr hands it out); hv[to * L + from] != 0
-// are the amplitudes in the planner's convention.  The layout is checked against the CSR by one product before it is used.
-lpp_status pb_chain(lpp_engine* e, DevCsr& A, int L, int n, const std::vector<double>& hv, bool* done);
+// kernel k_pb_up_seg and the streaming pass, no couplings.  Planned from the model alone (P: the assembler's parameters of the same model,
+// device pointers valid during the call; hv[to * L + from] != 0: the amplitudes in the planner's convention): no CSR is built.  The layout
+// is checked by one product against the assembler's row walk (k_asm_apply) before it is used.
+lpp_status pb_chain(lpp_engine* e, const AsmParams& P, int L, int n, const std::vector<double>& hv, bool* done);
+// the plain CSR of the S = 1/2 Heisenberg model in the reference's order, nothing else (lpp_assemble.hip; lpp_engine_get_csr of a chain)
+lpp_status assemble_heisenberg_raw(lpp_engine* e, int L, int m, const double* jpm, const double* jzz, const double* field, int nfield, DevCsr& A);
 int pb_launch(lpp_engine* e, const void* y, void* x, double* partial, const EpiScale& sc = EpiScale { nullptr, nullptr, 0 }, bool defer_combine = false);
 // the streaming pass of the scale-free Lanczos step on a product-basis matrix: x = beta x + u + z - (a/b2_prev) y, |x|^2 partials
 bool pb_chain_ok(const lpp_engine* e);
@@ -345,7 +353,6 @@ lpp_status pb_from_csr(lpp_engine* e, const DevCsr& A, int64_t n_up, bool* done)
 int64_t pb_pitch_for(int64_t n_up);
 // t-J without a stored matrix (lpp_tj.hip).  tj_build: P = the assembler's parameters of the same model (device pointers valid during the
 // call); *done == false: the layout does not apply, the caller assembles the CSR
-struct AsmParams;
 void free_tj(lpp_engine* e);
 lpp_status tj_build(lpp_engine* e, const TjModel& M, const AsmParams& P, bool* done);
 int tj_launch(lpp_engine* e, const void* src, void* x, const void* ydot, double* partial, const EpiScale& sc);

@@ -7,6 +7,7 @@
 #include <cstring>
 #include <vector>
 
+#include "lpp_assemble_kernels.h"
 #include "lpp_engine_impl.h"
 #include "lpp_pbig_kernels.h"
 #include "lpp_pbseg_kernels.h"
@@ -343,11 +344,12 @@ lpp_status pb_build(lpp_engine* e, int64_t n_up, int64_t n_blk, const int64_t* t
 	std::vector<uint8_t> ccode;
 	const int64_t n_rows_t = cx ? cx->n_c : n_up; // rows of the matrix lpp_engine_get_csr walks
 	if (cx) tp.assign((size_t)n_rows_t + 1, 0);
+	if (!cx && !t_rp) tp.assign(1, 0); // a ready-made plan (pb_chain): no host T, and lpp_engine_get_csr re-runs the assembler -- nothing to keep
 	{
 		const int64_t* rp = cx ? cx->t_rp : t_rp;
 		const int32_t* ci = cx ? cx->t_ci : t_ci;
 		const double* va = cx ? cx->t_va : t_va;
-		for (int64_t r = 0; r < n_rows_t && rp; r++) { // (no host T with a ready-made plan: lpp_engine_get_csr then hands out the CSR that was kept)
+		for (int64_t r = 0; r < n_rows_t && rp; r++) {
 			for (int64_t p = rp[r]; p < rp[r + 1]; p++) {
 				if (ci[p] == r) continue;
 				if (!tc.empty() && (int64_t)tc.size() > tp[(size_t)r] && tc.back() >= ci[p]) return fail(LPP_ERR_INVALID, "pb_build: in-block rows must be sorted by column");
@@ -630,6 +632,8 @@ static int launch_up_big(lpp_engine* e, const double* y, double* u, const uint8_
 	do {                                                                                                              \
 		if (B.seg_one && B.seg_nh == 12 && B.seg_nc == 1) LPP_PB_SEG1(DOT_, GT_, P0_, 1, 12);                           \
 		else if (B.seg_one && B.seg_nh == 12) LPP_PB_SEG1(DOT_, GT_, P0_, 2, 12);                                       \
+		else if (B.seg_one && B.seg_nh == 16 && B.seg_nc == 1) LPP_PB_SEG1(DOT_, GT_, P0_, 1, 16);                      \
+		else if (B.seg_one && B.seg_nh == 16) LPP_PB_SEG1(DOT_, GT_, P0_, 2, 16);                                       \
 		else if (B.seg_one) LPP_PB_SEG1(DOT_, GT_, P0_, 2, 2);                                                          \
 		else if (B.seg_nc == 2) LPP_PB_SEG(DOT_, GT_, P0_, 2, 2);                                                            \
 		else if (B.seg_nc == 5) LPP_PB_SEG(DOT_, GT_, P0_, 5, 4);                                                       \
@@ -1229,16 +1233,6 @@ lpp_status pb_from_csr(lpp_engine* e, const DevCsr& A, int64_t n_up, bool* done)
 
 // ---- one block: the S = 1/2 Heisenberg chain ------------------------------------------------------------------------------
 namespace {
-// reference product for the check of pb_chain: x = A y, one thread per row (a few ms once per matrix)
-__global__ void k_csr_rows_ref(int64_t n, const int64_t* __restrict__ rp, const int32_t* __restrict__ ci, const double* __restrict__ va, const double* __restrict__ y,
-                               double* __restrict__ x)
-{
-	for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (int64_t)gridDim.x * blockDim.x) {
-		double s = 0.0;
-		for (int64_t p = rp[r]; p < rp[r + 1]; p++) s = fma(va[p], y[ci[p]], s);
-		x[r] = s;
-	}
-}
 // largest |a - b| and largest |b| as the bit patterns of non-negative doubles (ordered like unsigned integers)
 __global__ void k_max_diff(int64_t n, const double* __restrict__ a, const double* __restrict__ b, unsigned long long* __restrict__ out)
 {
@@ -1251,26 +1245,33 @@ __global__ void k_max_diff(int64_t n, const double* __restrict__ a, const double
 	atomicMax(out, (unsigned long long)__double_as_longlong(d));
 	atomicMax(out + 1, (unsigned long long)__double_as_longlong(m));
 }
+__global__ void k_sum_i64(const int64_t* __restrict__ v, int64_t n, unsigned long long* __restrict__ out)
+{
+	unsigned long long s = 0;
+	for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x) s += (unsigned long long)v[k];
+	for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+	if ((threadIdx.x & 63) == 0) atomicAdd(out, s);
+}
 } // namespace
 
-lpp_status pb_chain(lpp_engine* e, DevCsr& A, int L, int n, const std::vector<double>& hv, bool* done)
+lpp_status pb_chain(lpp_engine* e, const AsmParams& P, int L, int n, const std::vector<double>& hv, bool* done)
 {
 	*done = false;
-	if (e->is_complex || A.nrows <= 0 || !A.rowptr || !A.col || !A.val) return LPP_OK;
+	if (e->is_complex || P.nloc <= 0 || P.model != ASM_HEISENBERG) return LPP_OK;
 	bool forced = false;
 	if (const char* s = getenv("LPP_PRODUCT_LAYOUT")) {
 		if (atoi(s) == 0) return LPP_OK;
 		forced = true;
 	}
-	if (!forced && (size_t)A.nrows * sizeof(double) < ((size_t)32 << 20)) return LPP_OK; // as for the Hubbard matrices (assemble_hubbard_pb)
+	const int64_t n_up = P.nloc, pitch = pb_pitch_for(n_up);
+	if (!forced && (size_t)n_up * sizeof(double) < ((size_t)32 << 20)) return LPP_OK; // as for the Hubbard matrices (assemble_hubbard_pb)
 	if (e->cfg.spmv_kernel != LPP_SPMV_AUTO || getenv("LPP_SPMV_KERNEL")) return LPP_OK;
 	int want = e->cfg.compress_values;
 	if (const char* s = getenv("LPP_COMPRESS_VALUES")) want = atoi(s);
 	if (want == 0) return LPP_OK;
-	for (const char* k : { "LPP_SHARED_OFFSETS", "LPP_LOCAL16", "LPP_DIAG_CODES", "LPP_BLOCK_TEMPLATE", "LPP_WINDOW_ROWS" })
+	for (const char* k : { "LPP_SHARED_OFFSETS", "LPP_LOCAL16", "LPP_DIAG_CODES", "LPP_BLOCK_TEMPLATE", "LPP_WINDOW_ROWS", "LPP_KEEP_PLAIN_CSR" })
 		if (getenv(k)) return LPP_OK; // switches of the general layout: measure that one
 	if (getenv("LPP_PB_SEG") && atoi(getenv("LPP_PB_SEG")) == 0) return LPP_OK;
-	const int64_t n_up = A.nrows, pitch = pb_pitch_for(n_up);
 	if ((size_t)(pitch + kPbZeroSlots) * sizeof(double) <= (size_t)156 * 1024 && !getenv("LPP_PB_PIECE_ROWS")) return LPP_OK; // a row that fits one LDS window: the general layout's window kernel
 	int wcap = 8128;
 	if (const char* s = getenv("LPP_PB_PIECE_ROWS")) wcap = (int)std::max<int64_t>(64, std::min<int64_t>(atoll(s), 8128));
@@ -1291,28 +1292,34 @@ lpp_status pb_chain(lpp_engine* e, DevCsr& A, int L, int n, const std::vector<do
 		{
 			if (p) (void)hipFree(p);
 		}
-	} d_bad, d_dval, d_table, d_ov, d_y, d_x, d_ys, d_xs, d_cmp;
-	// D: the stored diagonal of every row (pb_from_csr's route)
+	} d_dval, d_table, d_ov, d_len, d_sum, d_y, d_x, d_ys, d_xs, d_cmp;
+	// D: the diagonal of every row straight from the state (the assembler's diag_of: Heisenberg.h:251-275 in the reference's loop order),
+	// in the basis order; and the number of entries of the CSR this stands for (the assembler's counting pass)
 	const size_t loc = (size_t)pitch;
-	HIP_TRY_MEM(hipMalloc(&d_bad.p, sizeof(int) * 2));
-	HIP_TRY(hipMemsetAsync(d_bad.p, 0, sizeof(int) * 2, st));
 	HIP_TRY_MEM(hipMalloc(&d_dval.p, sizeof(double) * loc));
 	HIP_TRY(hipMemsetAsync(d_dval.p, 0, sizeof(double) * loc, st));
 	const int nbr = (int)std::max<int64_t>(1, std::min<int64_t>((n_up + 255) / 256, 1 << 16));
-	k_pb_csr_diagonal<<<nbr, 256, 0, st>>>(n_up, 1, pitch, A.rowptr, A.col, (const double*)A.val, (double*)d_dval.p, (int*)d_bad.p);
+	k_pb_diag_values<ASM_HEISENBERG><<<nbr, kBlock, 0, st>>>(P, pitch, (double*)d_dval.p);
+	HIP_TRY_MEM(hipMalloc(&d_len.p, sizeof(int64_t) * (size_t)n_up));
+	HIP_TRY_MEM(hipMalloc(&d_sum.p, sizeof(unsigned long long)));
+	HIP_TRY(hipMemsetAsync(d_sum.p, 0, sizeof(unsigned long long), st));
+	k_asm_count<ASM_HEISENBERG><<<nbr, kBlock, 0, st>>>(P, (int64_t*)d_len.p);
+	k_sum_i64<<<1024, 256, 0, st>>>((const int64_t*)d_len.p, n_up, (unsigned long long*)d_sum.p);
 	HIP_TRY_MEM(hipMalloc(&d_table.p, sizeof(unsigned long long) * kDictTable));
 	HIP_TRY_MEM(hipMalloc(&d_ov.p, sizeof(int)));
 	HIP_TRY(hipMemsetAsync(d_table.p, 0xff, sizeof(unsigned long long) * kDictTable, st));
 	HIP_TRY(hipMemsetAsync(d_ov.p, 0, sizeof(int), st));
 	k_dict_collect<<<2048, kBlock, 0, st>>>((const double*)d_dval.p, (int64_t)loc, (unsigned long long*)d_table.p, (int*)d_ov.p);
 	std::vector<unsigned long long> host(kDictTable);
-	int ov = 0, bad[2] = { 0, 0 };
+	int ov = 0;
+	unsigned long long nnz = 0;
 	HIP_TRY(hipMemcpyAsync(host.data(), d_table.p, sizeof(unsigned long long) * kDictTable, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipMemcpyAsync(&ov, d_ov.p, sizeof(int), hipMemcpyDeviceToHost, st));
-	HIP_TRY(hipMemcpyAsync(bad, d_bad.p, sizeof(int) * 2, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipMemcpyAsync(&nnz, d_sum.p, sizeof(nnz), hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipStreamSynchronize(st));
-	if (bad[0]) return LPP_OK; // a row without a stored diagonal
+	(void)hipFree(d_len.p);
+	d_len.p = nullptr;
 	std::vector<unsigned long long> keys;
 	keys.push_back(0ull);
 	size_t ndiag = 0;
@@ -1326,7 +1333,7 @@ lpp_status pb_chain(lpp_engine* e, DevCsr& A, int L, int n, const std::vector<do
 	std::vector<double> dict(256);
 	for (size_t i = 0; i < 256; i++) std::memcpy(&dict[i], &keys[std::min(i, keys.size() - 1)], 8);
 	const int64_t c_rp[2] = { 0, 0 };
-	rc = pb_build(e, n_up, 1, nullptr, nullptr, nullptr, c_rp, nullptr, nullptr, dict.data(), (int)keys.size(), 0, -1, 0, 0, nullptr, &SP, A.nnz);
+	rc = pb_build(e, n_up, 1, nullptr, nullptr, nullptr, c_rp, nullptr, nullptr, dict.data(), (int)keys.size(), 0, -1, 0, 0, nullptr, &SP, (int64_t)nnz);
 	if (rc == LPP_ERR_INVALID || rc == LPP_ERR_NOMEM) {
 		if (getenv("LPP_VERBOSE")) fprintf(stderr, "lpp: the chain keeps the general layout: %s\n", lpp_last_error());
 		free_pb(e);
@@ -1350,17 +1357,19 @@ lpp_status pb_chain(lpp_engine* e, DevCsr& A, int L, int n, const std::vector<do
 		d_dval.p = nullptr;
 	} else
 		k_pb_codes_from_values<<<nbr, 256, 0, st>>>((int64_t)loc, (const double*)d_dval.p, B.dict, B.ndict, B.dcode);
-	// the layout against the CSR: one product of a random vector through both, element by element
+	// the layout against the model: one product of a random vector through it and through the assembler's row walk (every entry re-derived
+	// per row from the term list, in the reference's order), element by element
 	HIP_TRY_MEM(hipMalloc(&d_y.p, sizeof(double) * loc));
 	HIP_TRY_MEM(hipMalloc(&d_x.p, sizeof(double) * loc));
 	HIP_TRY_MEM(hipMalloc(&d_ys.p, sizeof(double) * loc));
 	HIP_TRY_MEM(hipMalloc(&d_xs.p, sizeof(double) * loc));
 	HIP_TRY_MEM(hipMalloc(&d_cmp.p, sizeof(unsigned long long) * 2));
 	HIP_TRY(hipMemsetAsync(d_y.p, 0, sizeof(double) * loc, st));
+	HIP_TRY(hipMemsetAsync(d_x.p, 0, sizeof(double) * loc, st));
 	HIP_TRY(hipMemsetAsync(d_xs.p, 0, sizeof(double) * loc, st));
 	HIP_TRY(hipMemsetAsync(d_cmp.p, 0, sizeof(unsigned long long) * 2, st));
 	k_fill_random<<<1024, 256, 0, st>>>((double*)d_y.p, n_up, 0, 4711);
-	k_csr_rows_ref<<<4096, 256, 0, st>>>(n_up, A.rowptr, A.col, (const double*)A.val, (const double*)d_y.p, (double*)d_x.p);
+	k_asm_apply<ASM_HEISENBERG, double, false><<<nbr, kBlock, 0, st>>>(P, (const double*)d_y.p, (double*)d_x.p, nullptr, EpiScale { nullptr, nullptr, 0 });
 	k_pb_permute<true><<<nbr, 256, 0, st>>>((double*)d_ys.p, (const double*)d_y.p, B.perm, 1, n_up, pitch);
 	B.active = true; // (pb_launch reads the state; the guard above drops it again if the check fails)
 	e->pitch = pitch;
@@ -1374,9 +1383,9 @@ lpp_status pb_chain(lpp_engine* e, DevCsr& A, int L, int n, const std::vector<do
 	double dmax, xmax;
 	std::memcpy(&dmax, &cmp[0], 8);
 	std::memcpy(&xmax, &cmp[1], 8);
-	if (getenv("LPP_VERBOSE")) fprintf(stderr, "lpp: chain layout against its CSR: largest difference %.3g of %.3g\n", dmax, xmax);
+	if (getenv("LPP_VERBOSE")) fprintf(stderr, "lpp: chain layout against the assembler's row walk: largest difference %.3g of %.3g\n", dmax, xmax);
 	if (!(dmax <= 1e-12 * std::max(xmax, 1e-300))) return LPP_OK; // not the same matrix: the general layout (the guard drops this one)
-	B.csr_kept = true;
+	B.chain_model = true; // (the caller records the model: lpp_engine_get_csr re-runs the assembler from it)
 	*done = true;
 	return LPP_OK;
 }

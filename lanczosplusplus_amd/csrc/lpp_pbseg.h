@@ -26,7 +26,8 @@
 namespace lpp {
 
 constexpr int kSegMaxCross = 6; // PAIRS of cross hops per segment the kernel carries (every segment's list is padded to the instance's NC with value 0.0)
-constexpr int kSegMaxHh = 12; // high-high entries per segment
+constexpr int kSegMaxHh = 16; // high-high entries per segment (one block per workgroup -- chains up to 17 high sites; two blocks per workgroup: 12)
+__host__ __device__ constexpr int pb_seg_hh_cap(int rows) { return rows == 1 ? kSegMaxHh : 12; } // entries per segment in the LDS copy
 constexpr int kSegMaxSegs = 16; // segments per item (LDS tables)
 constexpr int kSegWinPad = 2; // window index of an item's first position (the staged run starts at an even element)
 

@@ -124,9 +124,10 @@ lpp_status pb_seg_plan_model(int L, int n, const std::vector<double>& hv, const 
 {
 	*ok = false;
 	P = SegPlan();
-	if (L < 2 || L > 30 || n < 1 || n >= L || wcap < 64 || wcap > 8128) return LPP_OK;
+	// (one block per workgroup -- chains -- forms 64-bit addresses: rows up to 2^31 positions, 32 sites, 17 high sites)
+	if (L < 2 || L > (one_block ? 32 : 30) || n < 1 || n >= L || wcap < 64 || wcap > 8128) return LPP_OK;
 	const int64_t n_up = (int64_t)kBinom.c[L][n];
-	if (n_up < 128 || n_up > (int64_t)400000000) return LPP_OK; // 32-bit byte offsets into a row
+	if (n_up < 128 || n_up > (one_block ? (int64_t)2000000000 : (int64_t)400000000)) return LPP_OK; // 32-bit byte offsets into a row
 	// ---- 3. the cut: smallest s whose longest segment fits the window --------------------------------------------------------
 	int s = 0;
 	int64_t maxseg = 0;
@@ -139,7 +140,7 @@ lpp_status pb_seg_plan_model(int L, int n, const std::vector<double>& hv, const 
 			maxseg = m;
 		}
 	}
-	if (s == 0 || s > 16 || L - s < 1) return LPP_OK;
+	if (s == 0 || s > (one_block ? 17 : 16) || L - s < 1) return LPP_OK;
 	const int Ll = L - s; // low sites 0..Ll-1, high sites Ll..L-1
 	P.L = L;
 	P.n = n;
@@ -295,7 +296,7 @@ lpp_status pb_seg_plan_model(int L, int n, const std::vector<double>& hv, const 
 				P.hh.push_back(h);
 			}
 		S.nhh = (int32_t)P.hh.size() - S.hh_first;
-		if (S.ncross > kSegMaxCross || S.nhh > kSegMaxHh) return LPP_OK;
+		if (S.ncross > kSegMaxCross || S.nhh > (one_block ? kSegMaxHh : 12)) return LPP_OK;
 		P.max_cross = std::max(P.max_cross, (int)S.ncross);
 		P.max_hh = std::max(P.max_hh, (int)S.nhh);
 	}
@@ -469,8 +470,8 @@ lpp_status pb_seg_plan_model(int L, int n, const std::vector<double>& hv, const 
 			if (c.val[1] != 0.0) return LPP_OK;
 	}
 	if (P.max_cross <= 2 && P.max_hh <= 2) P.nc_pad = 2, P.nh_pad = 2;
-	else if (one_block && P.max_cross <= 1) P.nc_pad = 1, P.nh_pad = 12; // an open chain: the one bond between the low and the high sites
-	else if (one_block && P.max_cross <= 2) P.nc_pad = 2, P.nh_pad = 12; // ... and the bond between the two ends
+	else if (one_block && P.max_cross <= 1) P.nc_pad = 1, P.nh_pad = P.max_hh <= 12 ? 12 : 16; // an open chain: the one bond between the low and the high sites
+	else if (one_block && P.max_cross <= 2) P.nc_pad = 2, P.nh_pad = P.max_hh <= 12 ? 12 : 16; // ... and the bond between the two ends
 	else if (one_block) return LPP_OK;
 	else if (P.max_cross <= 5 && P.max_hh <= 4) P.nc_pad = 5, P.nh_pad = 4;
 	else if (P.max_cross <= 6 && P.max_hh <= 8) P.nc_pad = 6, P.nh_pad = 8;

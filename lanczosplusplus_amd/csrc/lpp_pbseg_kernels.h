@@ -50,7 +50,7 @@ __host__ __device__ inline size_t pb_seg_tab_offset(int ws, int wmax) { return (
 // (rows: blocks per workgroup; one block per workgroup alternates between TWO sets of tables)
 __host__ __device__ inline size_t pb_seg_lds_bytes(int ws, int wmax, int rows)
 {
-	return pb_seg_tab_offset(ws, wmax) + (rows == 1 ? 2 : 1) * (sizeof(SegSlice) * kSegMaxSlices + sizeof(SegCross) * kSegMaxSegs * kSegMaxCross + sizeof(SegHh) * kSegMaxSegs * kSegMaxHh) + sizeof(double) * (256 + kSegThreads / 64 + 2 * kSegThreads) + 16;
+	return pb_seg_tab_offset(ws, wmax) + (rows == 1 ? 2 : 1) * (sizeof(SegSlice) * kSegMaxSlices + sizeof(SegCross) * kSegMaxSegs * kSegMaxCross + sizeof(SegHh) * kSegMaxSegs * pb_seg_hh_cap(rows)) + sizeof(double) * (256 + kSegThreads / 64 + 2 * kSegThreads) + 16;
 }
 
 template <int GG> struct SegHeads { // wave-uniform
@@ -89,7 +89,7 @@ template <bool DOT, int GT, int P0, int P1, int NC, int NH, int ROWS = 2> __glob
 {
 	static_assert(GT == 1 || GT == 2, "one or two value groups");
 	static_assert(ROWS == 1 || ROWS == 2, "one or two blocks per workgroup");
-	static_assert(P0 <= kSegPre && P1 <= kSegPre && !(P0 & 1) && !(P1 & 1) && NC >= 1 && NC <= kSegMaxCross && NH <= kSegMaxHh && NC <= 8 && !(NH & 1), "limits");
+	static_assert(P0 <= kSegPre && P1 <= kSegPre && !(P0 & 1) && !(P1 & 1) && NC >= 1 && NC <= kSegMaxCross && NH <= pb_seg_hh_cap(ROWS) && NC <= 8 && !(NH & 1), "limits");
 	extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
 	double* win = (double*)lds_raw; // block 0's window at LDS address 0 (a list entry * 8 IS the byte address), block 1's at ws * 8
 	const int WS = a.ws;
@@ -99,7 +99,7 @@ template <bool DOT, int GT, int P0, int P1, int NC, int NH, int ROWS = 2> __glob
 	constexpr int NT = ROWS == 1 ? 2 : 1; // sets of tables: one block per workgroup alternates between two
 	SegCross* cross_s = (SegCross*)(heads_s + NT * kSegMaxSlices);
 	SegHh* hh_s = (SegHh*)(cross_s + NT * kSegMaxSegs * kSegMaxCross);
-	double* dict_s = (double*)(hh_s + NT * kSegMaxSegs * kSegMaxHh);
+	double* dict_s = (double*)(hh_s + NT * kSegMaxSegs * pb_seg_hh_cap(ROWS));
 	double* smem = dict_s + 256;
 	double* const tr_s = smem + kSegThreads / 64 + (threadIdx.x >> 6) * 128; // this wave's 64 pairs (compute: the high-high sums change lanes)
 	for (int i = threadIdx.x; i < 256; i += kSegThreads) dict_s[i] = a.dict[i];
@@ -197,7 +197,7 @@ template <bool DOT, int GT, int P0, int P1, int NC, int NH, int ROWS = 2> __glob
 		}
 		if ((int)threadIdx.x < w.I.nslices) ((uint4*)(heads_s + buf * kSegMaxSlices))[threadIdx.x] = S.hd;
 		if ((int)threadIdx.x < w.I.nseg * NC * 2) ((uint4*)(cross_s + buf * kSegMaxSegs * kSegMaxCross))[threadIdx.x] = S.cr;
-		if ((int)threadIdx.x < w.I.nseg * NH) ((uint4*)(hh_s + buf * kSegMaxSegs * kSegMaxHh))[threadIdx.x] = S.hq;
+		if ((int)threadIdx.x < w.I.nseg * NH) ((uint4*)(hh_s + buf * kSegMaxSegs * pb_seg_hh_cap(ROWS)))[threadIdx.x] = S.hq;
 		if (threadIdx.x < ROWS * kPbZeroSlots) win[(ROWS == 2 ? (threadIdx.x >> 5) : buf) * WS + w.I.zero_at + (threadIdx.x & 31)] = 0.0;
 	};
 	const int64_t total = npairs * nitems;
@@ -238,7 +238,7 @@ template <bool DOT, int GT, int P0, int P1, int NC, int NH, int ROWS = 2> __glob
 		const uint8_t* const dcode_c = dcode_s + (ROWS == 1 ? cur * dstride : 0);
 		const SegSlice* const heads_c = heads_s + (ROWS == 1 ? cur * kSegMaxSlices : 0);
 		const SegCross* const cross_c = cross_s + (ROWS == 1 ? cur * kSegMaxSegs * kSegMaxCross : 0);
-		const SegHh* const hh_c = hh_s + (ROWS == 1 ? cur * kSegMaxSegs * kSegMaxHh : 0);
+		const SegHh* const hh_c = hh_s + (ROWS == 1 ? cur * kSegMaxSegs * pb_seg_hh_cap(ROWS) : 0);
 		auto gather4x2 = [=](const uint2& w, double& a0, double& a1, double& b0, double& b1) __attribute__((always_inline)) {
 			const uint32_t p0 = pb_lo8(w.x) + woff, p1 = pb_hi8(w.x) + woff, p2 = pb_lo8(w.y) + woff, p3 = pb_hi8(w.y) + woff;
 			a0 += pb_lds_abs(p0);
@@ -284,11 +284,16 @@ template <bool DOT, int GT, int P0, int P1, int NC, int NH, int ROWS = 2> __glob
 #pragma unroll
 			for (int b = 0; b < NC; b++) {
 				const uint32_t sb = (uint32_t)cross_c[h.seg * NC + b].srcbase;
-				const uint32_t at0 = (sb + (s.x[b] & 0x1fffu)) * 8u, at1 = (sb + ((s.x[b] >> 16) & 0x1fffu)) * 8u;
-				d.xa[2 * b] = *(const double*)((const char*)yrow0 + at0);
-				if (ROWS == 2) d.xb[2 * b] = *(const double*)((const char*)yrow1 + at0);
-				if (!X1) d.xa[2 * b + 1] = *(const double*)((const char*)yrow0 + at1);
-				if (ROWS == 2) d.xb[2 * b + 1] = *(const double*)((const char*)yrow1 + at1);
+				if constexpr (ROWS == 1) { // a chain's row may exceed 4 GiB (L = 32: 6.0e8 positions): element index, 64-bit address
+					d.xa[2 * b] = yrow0[sb + (s.x[b] & 0x1fffu)];
+					if (!X1) d.xa[2 * b + 1] = yrow0[sb + ((s.x[b] >> 16) & 0x1fffu)];
+				} else {
+					const uint32_t at0 = (sb + (s.x[b] & 0x1fffu)) * 8u, at1 = (sb + ((s.x[b] >> 16) & 0x1fffu)) * 8u;
+					d.xa[2 * b] = *(const double*)((const char*)yrow0 + at0);
+					d.xb[2 * b] = *(const double*)((const char*)yrow1 + at0);
+					d.xa[2 * b + 1] = *(const double*)((const char*)yrow0 + at1);
+					d.xb[2 * b + 1] = *(const double*)((const char*)yrow1 + at1);
+				}
 				sg |= (((s.x[b] >> 14) & 3u) | ((s.x[b] >> 28) & 0xcu)) << (4 * b);
 			}
 			d.sg = sg;
@@ -426,11 +431,12 @@ template <bool DOT, int GT, int P0, int P1, int NC, int NH, int ROWS = 2> __glob
 			}
 		};
 		// one block per workgroup (a chain: up to 12 high-high hops per segment, 6.0 on average): the loop for the 4, 8 or 12 this item holds
-		if constexpr (ROWS == 1 && NH == 12) {
+		if constexpr (ROWS == 1 && NH >= 12) {
 			const int nhc = __builtin_amdgcn_readfirstlane(wk.I.type >> 16);
 			if (nhc <= 4) run_slices(SegInt<4> {});
 			else if (nhc <= 8) run_slices(SegInt<8> {});
-			else run_slices(SegInt<NH> {});
+			else if (NH == 12 || nhc <= 12) run_slices(SegInt<12> {});
+			else run_slices(SegInt<NH> {}); // chains beyond 13 high sites (L = 32: 17 of them, up to 16 domain walls)
 		} else
 			run_slices(SegInt<NH> {});
 		if (ROWS == 1) {

@@ -283,3 +283,24 @@ def test_plain_format_matrix_with_line_aligned_blocks_takes_the_split_panel_orde
         assert abs(eg[0] - exact) <= 1e-10 * abs(exact), (eg[0], exact, st["steps"])
         es.append(eg[0])
     assert abs(es[0] - es[1]) <= 1e-12 * abs(exact)
+
+
+def test_xx_chain_L32_without_a_csr_free_fermions():
+    """A spin chain beyond what a CSR allows (round 5): L = 32, Sz = 0 -- 601,080,390 states, 9.6e9 entries, 115 GB as a plain CSR.  The chain
+    layout is planned from the couplings alone (pb_chain: no matrix is assembled, the diagonal comes straight from the states, the layout
+    is checked against the assembler's row walk by one product), so the engine holds its vectors and a few tables.  With J_zz = 0 the model
+    is the XX chain in a staggered field: by Jordan-Wigner free fermions with hopping J/2 and on-site energies h_i (Heisenberg.h:251-307:
+    S+S- moves an up spin between neighbours, the field term is h_i (n_i - 1/2)) -- an exact energy at full size."""
+    from helpers import chain
+    L, m, J, h = 32, 16, 1.0, 0.3
+    field = h * (-1.0) ** np.arange(L)
+    single = chain(L, 0.5 * J) + np.diag(field)
+    exact = np.sort(np.linalg.eigvalsh(single))[:m].sum() - 0.5 * field.sum()
+    with LanczosEngine(max_steps=400, eps=1e-11, save_vectors=0) as e:
+        e.assemble_heisenberg(L, m, chain(L, J), np.zeros((L, L)), field)
+        assert e.rows() == 601080390
+        lay = e.layout()  # 17 high sites: 2^17 - 2 segments of <= C(15, 7) positions; up to 16 high-high hops per segment
+        assert lay["kernel"] == 4 and lay["segments"] == 131070 and lay["nnz"] == 601080390 + 2 * 31 * 155117520, lay  # the diagonal + two antiparallel settings of every bond
+        assert lay["resident_bytes"] < 1.0e9, lay  # one diagonal code per row + tables (the boundary's permutation is not part of the matrix)
+        eg, _, st = e.lanczos(1, want_vectors=False)
+    assert abs(eg[0] - exact) <= 1e-10 * abs(exact), (eg[0], exact, st["steps"])

@@ -1229,7 +1229,9 @@ def test_heisenberg_chain_as_one_block_of_the_segmented_form(periodic, field, mo
     """S = 1/2 Heisenberg chain (Heisenberg.h:80-114, 278-307): S+S- moves an up spin and nothing sits between neighbours, so the
     off-diagonal part is the hopping matrix of the up spins in the basis of BasisHeisenberg.h:38-46 -- ONE block of the product-basis
     form.  Round 4: such a matrix takes the in-block kernel decomposed by the high sites of the basis word (pb_chain, k_pb_up_seg with
-    one block per workgroup) + the streaming pass; its CSR stays resident and is what lpp_engine_get_csr hands out.  Forced here onto
+    one block per workgroup) + the streaming pass.  Round 5: planned from the couplings alone -- no CSR is assembled; the one
+    lpp_engine_get_csr hands out is made by re-running the device assembler, so its bits check the assembler, and the layout itself is
+    checked by x += H y, the energies and the coefficients below.  Forced here onto
     16 sites (12870 states, segments of <= 252 positions); BASELINE config 3 (L = 28) takes it by itself.  Checks: CSR bits, x += H y,
     energies, coefficients, Ritz vector, reorthogonalised run; periodic chain = the bond between the two ends (constant sign
     (-1)^(n-1) in the hopping picture), site-dependent field = more diagonal values."""
@@ -1355,8 +1357,8 @@ def test_tj_hole_major_form(case, monkeypatch):
         assert abs(eg[0] - eo[0]) <= E_TOL * abs(eo[0]) and st["steps"] == so
         if hermitian:
             r = oracle.spmv_acc(A, np.zeros_like(zg[0]), zg[0]) - eg[0] * zg[0]
-            assert np.linalg.norm(r) < 1e-5
-        assert abs(np.linalg.norm(zg[0]) - 1) < 1e-8 and abs(abs(np.vdot(zo[0], zg[0])) - 1) < 1e-8  # the oracle's vector up to its sign
+            assert np.linalg.norm(r) < 1e-5 and abs(np.linalg.norm(zg[0]) - 1) < 1e-8
+        assert min(rel(zg[0], zo[0]), rel(zg[0], -zo[0])) < 1e-6  # the oracle's vector up to its sign
         ag, bg, _ = e.decomposition(init)
         assert len(ag) == steps_o and rel(ag, ao) < 1e-8 and rel(bg, bo) < 1e-8
         assert e.bench_spmv(1, 2) > 0
@@ -1364,7 +1366,7 @@ def test_tj_hole_major_form(case, monkeypatch):
         e.assemble_tj(L, nup, ndown, hop, jpm, jzz, w, pv)
         eg2, zg2, st2 = e.lanczos(1, want_vectors=True)
         assert st2["vectors_saved"] == 0 and abs(eg2[0] - eo[0]) <= E_TOL * abs(eo[0])
-        assert abs(abs(np.vdot(zo[0], zg2[0])) - 1) < 1e-8
+        assert min(rel(zg2[0], zo[0]), rel(zg2[0], -zo[0])) < 1e-6
     if hermitian:  # (a symmetric recurrence has no excited-state bar on a non-Hermitian matrix)  # (not Hermitian: the reference keeps h unconjugated for the reverse hop; a symmetric recurrence has no excited-state bar there)
         e3o, _, s3o = oracle.lanczos_solve(A, oracle.fill_random(A.nrows, 1234, cplx), nstates=3, max_steps=150, eps=1e-11, reortho=True)
         with LanczosEngine(dtype=dtype, reortho=True, max_steps=150, eps=1e-11) as e:
