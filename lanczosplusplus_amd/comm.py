@@ -297,3 +297,118 @@ class RcclComm:
         if self._h:
             self.lib().lpp_rccl_comm_destroy(self._h)
             self._h = C.c_void_p()
+
+
+class ThreadGroup:
+    """N ranks as THREADS of one process that share one GPU (a rehearsal of a rank count a one-GPU box cannot host as processes: at most
+    6 processes may use its card).  Every rank runs its own engine on its own stream; the collectives are device-to-device copies and host
+    sums between the ranks' buffers, ordered by a barrier.  Same callbacks, buffers and wire format as the other communicators -- the
+    engine cannot tell the difference -- so the kernels run with the geometry of the real rank count (shards, chunks, up ranges)."""
+
+    def __init__(self, nranks, device):
+        import threading
+        self.nranks = int(nranks)
+        self.device = torch.device(device)
+        self.barrier = threading.Barrier(self.nranks)
+        self.comms = [None] * self.nranks
+        self.parts = [None] * self.nranks
+
+    def wait(self):
+        self.barrier.wait(timeout=600)
+
+
+class ThreadComm:
+    def __init__(self, group, rank, shard_stride, max_steps, is_complex=False, xchg_chunk=0):
+        self.group, self.rank, self.nranks = group, int(rank), group.nranks
+        self.device = group.device
+        ncomp = 2 if is_complex else 1
+        self.shard_stride, self.xchg_chunk = int(shard_stride), int(xchg_chunk)
+        z = lambda n: torch.zeros(n, dtype=torch.float64, device=self.device)
+        if self.xchg_chunk > 0:
+            n = self.nranks * self.xchg_chunk * ncomp
+            self.send, self.gath, self.send2, self.recv2 = z(n), z(n), z(n), z(n)
+        else:
+            self.send, self.gath = z(self.shard_stride * ncomp), z(self.nranks * self.shard_stride * ncomp)
+            self.send2 = self.recv2 = None
+        self.red = z(6 * (max_steps + 2) + 8)
+        self.stream = torch.cuda.Stream(device=self.device)
+        self.calls = {"allgather": 0, "allreduce": 0, "exchange": 0}
+        self.sums = []  # every all-reduce as (offset, this rank's partial, the sum it got back)
+        group.comms[self.rank] = self
+
+        def guard(fn):
+            def wrapped(*a):
+                try:
+                    return fn(*a)
+                except Exception:
+                    traceback.print_exc(file=sys.stderr)
+                    try:
+                        self.group.barrier.abort()  # never leave the other ranks inside a collective
+                    except Exception:
+                        pass
+                    return 1
+            return wrapped
+
+        def _begin(_ctx):
+            self.calls["allgather"] += 1
+            self.stream.synchronize()  # this rank's slice is complete
+            self.group.wait()
+            with torch.cuda.stream(self.stream):
+                for q, t in enumerate(self.gath.chunk(self.nranks)):
+                    t.copy_(self.group.comms[q].send)
+            return 0
+
+        def _end(_ctx):
+            self.stream.synchronize()
+            self.group.wait()  # nobody overwrites a slice a peer is still copying
+            return 0
+
+        def _reduce(_ctx, offset, count):
+            self.calls["allreduce"] += 1
+            view = self.red[offset:offset + count]
+            with torch.cuda.stream(self.stream):
+                mine = view.cpu()  # waits for this rank's stream
+            self.group.parts[self.rank] = mine
+            self.group.wait()
+            total = self.group.parts[0].clone()
+            for q in range(1, self.nranks):  # the same order on every rank: bitwise identical sums, identical decisions
+                total += self.group.parts[q]
+            self.group.wait()  # everyone has read every partial
+            with torch.cuda.stream(self.stream):
+                view.copy_(total)
+            self.sums.append((int(offset), mine.clone(), total))
+            return 0
+
+        def _xbegin(_ctx, which):
+            self.calls["exchange"] += 1
+            self.stream.synchronize()  # this rank's chunks are packed
+            self.group.wait()
+            with torch.cuda.stream(self.stream):
+                dst = self.gath if which == 0 else self.recv2
+                for q, t in enumerate(dst.chunk(self.nranks)):
+                    peer = self.group.comms[q]
+                    t.copy_((peer.send if which == 0 else peer.send2).chunk(self.nranks)[self.rank])
+            return 0
+
+        def _xend(_ctx, which):
+            self.stream.synchronize()
+            self.group.wait()
+            return 0
+
+        self._cb = (CB_VOID(guard(_begin)), CB_VOID(guard(_end)), CB_REDUCE(guard(_reduce)), CB_XCHG(guard(_xbegin)), CB_XCHG(guard(_xend)))
+        s = Comm()
+        s.rank, s.nranks, s.ctx = self.rank, self.nranks, None
+        s.send_buf, s.gath_buf, s.red_buf = self.send.data_ptr(), self.gath.data_ptr(), self.red.data_ptr()
+        s.shard_stride, s.red_len = self.shard_stride, self.red.numel()
+        s.allgather_begin, s.allgather_end, s.allreduce_sum = self._cb[:3]
+        if self.xchg_chunk > 0:
+            s.send2_buf, s.recv2_buf, s.xchg_chunk = self.send2.data_ptr(), self.recv2.data_ptr(), self.xchg_chunk
+            s.exchange_begin, s.exchange_end = self._cb[3], self._cb[4]
+        self.struct = s
+
+    @property
+    def stream_handle(self):
+        return C.c_void_p(self.stream.cuda_stream)
+
+    def stream_context(self):
+        return torch.cuda.stream(self.stream)

@@ -675,3 +675,68 @@ def test_bench_launches_its_own_ranks():
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["steps"] == 4 and j["value"] > 0 and j["config"]["rows"] == 853776
     assert j["config"]["exchange"] == "transpose" and j["config"]["attempts"][-1]["ok"]
+
+
+def test_eight_ranks_as_threads_config2_uneven_shards():
+    """The driver's scaling run is P = 8; a one-GPU box may host 6 processes at most.  Here 8 ranks run as THREADS of one process (ThreadComm:
+    same callbacks, buffers and wire format; collectives = device copies and host sums between the ranks' buffers), each with its own engine
+    and stream, on BASELINE config 2 at full size: 12870 down configurations in shards of 1609 x 7 + 1607 (uneven), up ranges of 1616
+    (12870 = 7 x 1616 + 1558: the last rank's range is short), product-basis kernels on the transposition exchange with the fused
+    all-reduce.  Energy, stopping step and coefficients against the CPU-oracle fixture; every rank's all-reduces bitwise identical."""
+    import json
+    import threading
+    import torch
+    from helpers import rel, square
+    from lanczosplusplus_amd import LanczosEngine, tridiag_lowest
+    from lanczosplusplus_amd._capi import lib
+    from lanczosplusplus_amd.comm import ThreadComm, ThreadGroup
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "c2_hubbard4x4_U4.json")))
+    world, L = 8, g["L"]
+    n_up = n_dn = 12870
+    hop, U = square(4, 4, -1.0, pbc=True), np.full(L, g["U"])
+    per = -(-n_dn // world)
+    chunk = lib().lpp_xchg_chunk(n_up, n_dn, world)
+    assert per == 1609 and chunk == per * 1616
+    dev = torch.device("cuda", 0)
+    group = ThreadGroup(world, dev)
+    out = [None] * world
+
+    def run(rank):
+        try:
+            torch.cuda.set_device(dev)
+            comm = ThreadComm(group, rank, per * n_up, g["max_steps"], False, xchg_chunk=chunk)
+            with comm.stream_context():
+                e = LanczosEngine(max_steps=g["max_steps"], min_steps=g["min_steps"], eps=g["eps"], save_vectors=0, seed=g["seed"], stream=comm.stream_handle)
+                e.assemble_hubbard(L, g["nup"], g["ndown"], hop, U, comm=comm)
+                lay = e.layout(0)
+                a, b, st = e.decomposition()
+                rows = e.rows()
+                e.close()
+            out[rank] = {"kernel": lay["kernel"], "rows": rows, "a": a, "b": b, "ar": comm.calls["allreduce"], "xc": comm.calls["exchange"],
+                         "sums": [(o, t.numpy().tobytes()) for o, _, t in comm.sums]}
+        except Exception:
+            import traceback
+            out[rank] = {"error": traceback.format_exc()}
+            try:
+                group.barrier.abort()
+            except Exception:
+                pass
+
+    threads = [threading.Thread(target=run, args=(r,), daemon=True) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=600)
+    assert not any(t.is_alive() for t in threads), "a rank is stuck inside a collective"
+    for r in range(world):
+        assert "error" not in out[r], out[r]["error"]
+    assert [o["rows"] for o in out] == [1609 * n_up] * 7 + [1607 * n_up] and sum(o["rows"] for o in out) == g["rows"]
+    for o in out:
+        assert o["kernel"] == 4, "the product-basis layout was not taken"
+        assert o["sums"] == out[0]["sums"]  # every all-reduce gave every rank the same bits
+        a, b = o["a"], o["b"]
+        assert np.array_equal(a, out[0]["a"]) and np.array_equal(b, out[0]["b"])
+        e0 = tridiag_lowest(a, b[:-1], 1)[0]
+        assert abs(e0 - g["e0"]) <= 1e-10 * abs(g["e0"]) and abs(len(a) - g["steps"]) <= 1
+        assert rel(a[:40], np.array(g["a"][:40])) < 1e-8 and rel(b[:40], np.array(g["b"][:40])) < 1e-8
+        assert len(a) <= o["ar"] <= len(a) + 8 and o["xc"] >= 2 * len(a)  # ONE all-reduce and two all-to-alls per step
