@@ -208,7 +208,7 @@ struct TjModel { // host copy of what lpp_engine_assemble_tj was given: lpp_engi
 struct TjState {
 	bool active = false;
 	TjModel model;
-	int Lo = 0, lb = 0, nhi = 0, nlo = 0, ns = 0, nblk = 0, chunks = 0, grid = 0;
+	int Lo = 0, lb = 0, nhi = 0, nlo = 0, ns = 0, nblk = 0, chunks = 0, grid = 0, kbits = 0;
 	int64_t pitch = 0; // elements between blocks
 	int64_t nnz = 0; // entries of the CSR this stands for
 	int64_t table_bytes = 0;
@@ -216,7 +216,7 @@ struct TjState {
 	uint32_t* pat = nullptr;
 	int32_t* hi_base = nullptr;
 	uint16_t* lo_rank = nullptr;
-	void *blocks = nullptr, *pairs = nullptr, *hops = nullptr;
+	void *blocks = nullptr, *pairs = nullptr, *hops = nullptr, *items = nullptr;
 	int32_t* order = nullptr;
 	double* diag = nullptr; // nblk * pitch
 	int32_t* perm = nullptr; // nblk * ns: stored (block, pattern) -> index in the reference's basis

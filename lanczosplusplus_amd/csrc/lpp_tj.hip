@@ -139,7 +139,7 @@ void free_tj(lpp_engine* e)
 {
 	TjState& S = e->tj;
 	const bool was = S.active;
-	for (void* p : { (void*)S.pat, (void*)S.hi_base, (void*)S.lo_rank, S.blocks, S.pairs, S.hops, (void*)S.order, (void*)S.diag, (void*)S.perm })
+	for (void* p : { (void*)S.pat, (void*)S.hi_base, (void*)S.lo_rank, S.blocks, S.pairs, S.hops, S.items, (void*)S.order, (void*)S.diag, (void*)S.perm })
 		if (p) (void)hipFree(p);
 	S = TjState();
 	if (was) e->pitch = e->pitch_rows = e->pitch_blocks = 0;
@@ -159,6 +159,7 @@ int tj_launch(lpp_engine* e, const void* src, void* x, const void* ydot, double*
 	a.pitch = S.pitch;
 	a.nblk = S.nblk;
 	a.chunks = S.chunks;
+	a.items = (const TjItem*)S.items;
 	a.blocks = (const TjBlock*)S.blocks;
 	a.pairs = (const TjPair*)S.pairs;
 	a.hops = (const TjHop*)S.hops;
@@ -171,21 +172,22 @@ int tj_launch(lpp_engine* e, const void* src, void* x, const void* ydot, double*
 	a.sc = sc;
 	const bool dot = ydot != nullptr && partial != nullptr;
 	hipStream_t st = e->stream;
+	const size_t lds = tj_lds_bytes(e->esz, S.nhi, S.nlo);
 	if (!e->is_complex) {
 		if (dot)
-			k_tj_apply<double, false, true><<<S.grid, kTjThreads, 0, st>>>(a);
+			k_tj_apply<double, false, true><<<S.grid, kTjThreads, lds, st>>>(a);
 		else
-			k_tj_apply<double, false, false><<<S.grid, kTjThreads, 0, st>>>(a);
+			k_tj_apply<double, false, false><<<S.grid, kTjThreads, lds, st>>>(a);
 	} else if (S.cplx_hops) {
 		if (dot)
-			k_tj_apply<cplx, true, true><<<S.grid, kTjThreads, 0, st>>>(a);
+			k_tj_apply<cplx, true, true><<<S.grid, kTjThreads, lds, st>>>(a);
 		else
-			k_tj_apply<cplx, true, false><<<S.grid, kTjThreads, 0, st>>>(a);
+			k_tj_apply<cplx, true, false><<<S.grid, kTjThreads, lds, st>>>(a);
 	} else {
 		if (dot)
-			k_tj_apply<cplx, false, true><<<S.grid, kTjThreads, 0, st>>>(a);
+			k_tj_apply<cplx, false, true><<<S.grid, kTjThreads, lds, st>>>(a);
 		else
-			k_tj_apply<cplx, false, false><<<S.grid, kTjThreads, 0, st>>>(a);
+			k_tj_apply<cplx, false, false><<<S.grid, kTjThreads, lds, st>>>(a);
 	}
 	return dot ? S.grid : 0;
 }
@@ -272,6 +274,31 @@ lpp_status tj_build(lpp_engine* e, const TjModel& M, const AsmParams& P, bool* d
 		std::vector<int> seen((size_t)lb + 1, 0);
 		for (uint32_t l = 0; l < (1u << lb); l++) lo_rank[l] = (uint16_t)seen[(size_t)__builtin_popcount(l)]++;
 	}
+	// ---- work items: runs of whole segments (patterns sharing the bits above the low kbits), at most kTjWindow patterns ----------------
+	int kbits = 1;
+	for (int k = 1; k <= Lo; k++) {
+		uint64_t longest = 0;
+		for (int m = std::max(0, nup - (Lo - k)); m <= std::min(k, nup); m++) longest = std::max(longest, binom_h(k, m));
+		if (longest <= (uint64_t)kTjWindow) kbits = k;
+	}
+	std::vector<TjItem> items;
+	{
+		int64_t r0 = 0;
+		TjItem cur { 0, 0 };
+		for (uint32_t t = 0; t < (1u << (Lo - kbits)); t++) {
+			const int len = (int)binom_h(kbits, nup - __builtin_popcount(t));
+			if (len == 0) continue;
+			if (cur.len > 0 && cur.len + len > kTjWindow) {
+				items.push_back(cur);
+				cur = TjItem { (int32_t)r0, 0 };
+			}
+			if (cur.len == 0) cur.r0 = (int32_t)r0;
+			cur.len += len;
+			r0 += len;
+		}
+		if (cur.len > 0) items.push_back(cur);
+		if (r0 != ns) return fail(LPP_ERR_INVALID, "tj_build: segments do not add up");
+	}
 	// ---- hole configurations: bonds among the occupied sites, moves of an electron onto a neighbouring hole ------------------------
 	const std::vector<uint32_t> holes = words_of(L, nholes);
 	if ((int)holes.size() != nblk) return fail(LPP_ERR_INVALID, "tj_build: block count");
@@ -285,7 +312,7 @@ lpp_status tj_build(lpp_engine* e, const TjModel& M, const AsmParams& P, bool* d
 		int pos[32];
 		int np = 0;
 		for (int i = 0; i < L; i++) pos[i] = ((hm >> i) & 1u) ? -1 : np++;
-		TjBlock B;
+		TjBlock B {};
 		B.x_first = (int32_t)pairs.size();
 		B.h_first = (int32_t)hops.size();
 		for (int i = 0; i < L; i++)
@@ -321,12 +348,16 @@ lpp_status tj_build(lpp_engine* e, const TjModel& M, const AsmParams& P, bool* d
 				if (hi != 0) cplx_hops = true;
 				hops.push_back(hp);
 			}
-		B.nx = (int32_t)pairs.size() - B.x_first;
-		B.nh = (int32_t)hops.size() - B.h_first;
-		if (B.nx > kTjMaxPairs || B.nh > kTjMaxHops) {
-			if (verbose) fprintf(stderr, "lpp: t-J hole-major form does not apply: %d bonds / %d moves in one hole configuration\n", B.nx, B.nh);
+		const int nxb = (int)pairs.size() - B.x_first, nhb = (int)hops.size() - B.h_first;
+		if (nxb > kTjMaxPairs || nhb > kTjMaxHops) {
+			if (verbose) fprintf(stderr, "lpp: t-J hole-major form does not apply: %d bonds / %d moves in one hole configuration\n", nxb, nhb);
 			return LPP_OK;
 		}
+		// bonds among the low kbits positions first: their flips stay inside a segment (LDS reads of the item's window)
+		const auto low_end = std::stable_partition(pairs.begin() + B.x_first, pairs.end(), [&](const TjPair& q) { return q.mask < (1u << kbits); });
+		B.nx = (int16_t)nxb;
+		B.nxl = (int16_t)(low_end - (pairs.begin() + B.x_first));
+		B.nh = (int16_t)nhb;
 		blocks[(size_t)b] = B;
 	}
 	if (cplx_hops && !e->is_complex) return LPP_OK;
@@ -350,13 +381,14 @@ lpp_status tj_build(lpp_engine* e, const TjModel& M, const AsmParams& P, bool* d
 	S.nlo = 1 << lb;
 	S.ns = ns;
 	S.nblk = nblk;
-	S.chunks = (ns + kTjRows - 1) / kTjRows;
+	S.chunks = (int)items.size();
+	S.kbits = kbits;
 	const int64_t line = e->is_complex ? 8 : 16; // elements per 128-byte line
 	S.pitch = ((int64_t)ns + 1 + line - 1) / line * line; // > ns: element ns of every block stays zero (what a parallel pair reads)
 	S.cplx_hops = cplx_hops;
 	{
 		const int64_t per_xcd = ((int64_t)nblk + 7) / 8 * S.chunks;
-		const int nslots = (int)std::max<int64_t>(1, std::min<int64_t>(per_xcd, 5 * std::max(1, e->num_cus / 8)));
+		const int nslots = (int)std::max<int64_t>(1, std::min<int64_t>(per_xcd, 6 * std::max(1, e->num_cus / 8)));
 		S.grid = 8 * nslots;
 	}
 	lpp_status rc;
@@ -367,6 +399,7 @@ lpp_status tj_build(lpp_engine* e, const TjModel& M, const AsmParams& P, bool* d
 	if ((rc = to_dev((TjPair**)&S.pairs, pairs, st)) != LPP_OK) return rc;
 	if ((rc = to_dev((TjHop**)&S.hops, hops, st)) != LPP_OK) return rc;
 	if ((rc = to_dev(&S.order, order, st)) != LPP_OK) return rc;
+	if ((rc = to_dev((TjItem**)&S.items, items, st)) != LPP_OK) return rc;
 	uint32_t* d_holes = nullptr;
 	Buf holes_buf;
 	if ((rc = to_dev(&d_holes, holes, st)) != LPP_OK) return rc;
@@ -377,7 +410,7 @@ lpp_status tj_build(lpp_engine* e, const TjModel& M, const AsmParams& P, bool* d
 	HIP_TRY(hipMemsetAsync(S.diag, 0, sizeof(double) * (size_t)nstored, st));
 	k_tj_perm_diag<<<blocks_for(n), kBlock, 0, st>>>(P, d_holes, S.pat, nblk, ns, Lo, S.pitch, S.perm, S.diag);
 	S.table_bytes = (int64_t)(sizeof(uint32_t) * pat.size() + sizeof(int32_t) * hi_base.size() + sizeof(uint16_t) * lo_rank.size() + sizeof(TjBlock) * blocks.size()
-	                          + sizeof(TjPair) * pairs.size() + sizeof(TjHop) * hops.size() + sizeof(int32_t) * order.size());
+	                          + sizeof(TjPair) * pairs.size() + sizeof(TjHop) * hops.size() + sizeof(int32_t) * order.size() + sizeof(TjItem) * items.size());
 	// ---- entries of the CSR this stands for (the assembler's counting pass) -------------------------------------------------------
 	Buf d_len, d_sum;
 	HIP_TRY_MEM(hipMalloc(&d_len.p, sizeof(int64_t) * (size_t)n));
@@ -426,8 +459,8 @@ lpp_status tj_build(lpp_engine* e, const TjModel& M, const AsmParams& P, bool* d
 	std::memcpy(&dmax, &cmp[0], 8);
 	std::memcpy(&xmax, &cmp[1], 8);
 	if (verbose)
-		fprintf(stderr, "lpp: t-J hole-major form: %d hole configurations x %d spin patterns, %zu bonds, %zu moves, %.2f MB of tables; against the row walk: largest difference %.3g of %.3g\n",
-		        nblk, ns, pairs.size(), hops.size(), 1e-6 * (double)S.table_bytes, dmax, xmax);
+		fprintf(stderr, "lpp: t-J hole-major form: %d hole configurations x %d spin patterns in %zu items (segments of the low %d positions), %zu bonds, %zu moves, %.2f MB of tables; against the row walk: largest difference %.3g of %.3g\n",
+		        nblk, ns, items.size(), kbits, pairs.size(), hops.size(), 1e-6 * (double)S.table_bytes, dmax, xmax);
 	if (!(dmax <= 1e-12 * std::max(xmax, 1e-300))) return LPP_OK; // not the same matrix: the general layout (the guard drops this one)
 	S.nnz = (int64_t)nnz;
 	S.active = true;

@@ -29,9 +29,9 @@ namespace lpp {
 constexpr int kTjMaxPairs = 96; // bonds with both sites occupied, per hole configuration
 constexpr int kTjMaxHops = 64; // (electron, neighbouring hole) moves per hole configuration
 constexpr int kTjThreads = 256;
-constexpr int kTjRowsPerThread = 4;
-constexpr int kTjRows = kTjThreads * kTjRowsPerThread; // rows of one work item
-constexpr int kTjMaxHalf = 12; // bits of a half pattern (rank tables in LDS: 4096 x (4 + 2) bytes)
+constexpr int kTjRowsPerThread = 2; // rows of a thread per round (their gathers are in flight together)
+constexpr int kTjWindow = 1024; // patterns of one work item at most: its run of the vector is staged in LDS
+constexpr int kTjMaxHalf = 12; // bits of a half pattern (rank tables in LDS: 4096 x (4 + 2) bytes at most)
 
 struct TjPair { // 16 bytes
 	uint32_t mask; // bit p | bit q (compressed positions)
@@ -44,7 +44,12 @@ struct TjHop { // 24 bytes
 	double vr, vi;
 };
 struct TjBlock { // 16 bytes
-	int32_t x_first, nx, h_first, nh;
+	int32_t x_first, h_first;
+	int16_t nx, nxl; // bonds; of these the first nxl have both positions among the low kbits of the pattern
+	int16_t nh, pad;
+};
+struct TjItem { // a run of whole segments (patterns sharing the bits above the low kbits): a flip among the low bits stays inside
+	int32_t r0, len;
 };
 
 struct TjArgs {
@@ -56,6 +61,7 @@ struct TjArgs {
 	int64_t pitch; // elements between blocks (> ns: element ns of every block is zero)
 	int nblk;
 	int chunks; // work items per block
+	const TjItem* items; // [chunks], the same for every block
 	const TjBlock* blocks;
 	const TjPair* pairs;
 	const TjHop* hops;
@@ -68,6 +74,9 @@ struct TjArgs {
 	EpiScale sc;
 };
 
+// dynamic LDS of k_tj_apply: window (kTjWindow + 1 elements) | hi_base[nhi] | lo_rank[nlo]
+__host__ __device__ inline size_t tj_lds_bytes(size_t esz, int nhi, int nlo) { return esz * (size_t)(kTjWindow + 1) + sizeof(int32_t) * (size_t)nhi + ((sizeof(uint16_t) * (size_t)nlo + 15) & ~(size_t)15); }
+
 template <typename T> __device__ __forceinline__ void tj_mac_real(T& acc, double v, const T& y);
 template <> __device__ __forceinline__ void tj_mac_real<double>(double& acc, double v, const double& y) { acc = fma(v, y, acc); }
 template <> __device__ __forceinline__ void tj_mac_real<cplx>(cplx& acc, double v, const cplx& y)
@@ -76,15 +85,19 @@ template <> __device__ __forceinline__ void tj_mac_real<cplx>(cplx& acc, double 
 	acc.im = fma(v, y.im, acc.im);
 }
 
-// x = beta x + alpha H y  (+ partials of Re<ydot|x>).  One work item = kTjRows consecutive patterns of one block; a thread holds
-// kTjRowsPerThread of them (lanes = consecutive patterns: a flip or a rotation among the high positions moves all 64 by the same
-// amount -- coalesced --, one among the low positions keeps them inside a few lines).  The bond / hop loop is the outer loop: its
-// scalars are read from LDS once for all of a thread's rows, whose gathers are independent and in flight together.
+// x = beta x + alpha H y  (+ partials of Re<ydot|x>).  One work item = a run of <= kTjWindow consecutive patterns of one block made of
+// whole segments; its piece of y is staged in LDS.  A thread takes kTjRowsPerThread rows per round (lanes = consecutive patterns: a flip
+// or a rotation among the high positions moves all 64 by the same amount -- coalesced --, one among the low positions keeps them inside
+// a few lines).  The bond / hop loop is the outer loop: its scalars are read from LDS once for a thread's rows, whose gathers are in
+// flight together.  Flips among the low positions are LDS reads (54 % of the bonds of the 4x5 lattice with two holes): the first version
+// gathered everything from memory and had the CU's vector-memory pipeline busy 82 % of the time with 48 wave-level loads per 64 rows.
 // CH: complex hopping amplitudes (T = cplx only).
 template <typename T, bool CH, bool DOT> __global__ __launch_bounds__(kTjThreads) void k_tj_apply(TjArgs a)
 {
-	__shared__ int32_t hi_s[1 << kTjMaxHalf];
-	__shared__ uint16_t lo_s[1 << kTjMaxHalf];
+	extern __shared__ __attribute__((aligned(16))) unsigned char tj_lds[];
+	T* const win = (T*)tj_lds; // [kTjWindow + 1]: the item's run of y, then one zero element
+	int32_t* const hi_s = (int32_t*)(win + kTjWindow + 1);
+	uint16_t* const lo_s = (uint16_t*)(hi_s + a.nhi);
 	__shared__ TjPair pairs_s[kTjMaxPairs];
 	__shared__ TjHop hops_s[kTjMaxHops];
 	__shared__ double smem[kTjThreads / 64];
@@ -107,84 +120,103 @@ template <typename T, bool CH, bool DOT> __global__ __launch_bounds__(kTjThreads
 	const int64_t total = (int64_t)(k1 - k0) * a.chunks;
 	auto rank_of = [&](uint32_t s) __attribute__((always_inline)) -> int { return hi_s[s >> lb] + (int)lo_s[s & lbm]; };
 	for (int64_t seq = slot; seq < total; seq += nslots) {
+		// block-major: the XCD's workgroups hold ~3 consecutive blocks at a time, whose flips among the high positions hit this L2.  (Item-major
+		// inside the XCD's group of blocks -- the same few items of all its 24 blocks at a time, so that the pieces the blocks gather from each
+		// other would be in L2 -- was measured: 2.27 instead of 1.93 GB of fabric reads, 0.373 instead of 0.361 ms.)
 		const int blk = a.order[k0 + (int)(seq / a.chunks)];
-		const int chunk = (int)(seq % a.chunks);
+		const TjItem it = a.items[(int)(seq % a.chunks)];
 		const TjBlock B = a.blocks[blk];
-		__syncthreads(); // the previous item is done with the lists (and the rank tables are in place)
-		if ((int)threadIdx.x < B.nx) pairs_s[threadIdx.x] = a.pairs[B.x_first + threadIdx.x];
-		if ((int)threadIdx.x < B.nh) hops_s[threadIdx.x] = a.hops[B.h_first + threadIdx.x];
-		__syncthreads();
 		const int64_t rowbase = (int64_t)blk * a.pitch;
 		const T* const yb = yv + rowbase;
-		uint32_t sg[kTjRowsPerThread];
-		int r[kTjRowsPerThread];
-		T acc[kTjRowsPerThread];
-#pragma unroll
-		for (int k = 0; k < kTjRowsPerThread; k++) {
-			r[k] = chunk * kTjRows + k * kTjThreads + (int)threadIdx.x;
-			sg[k] = a.pat[min(r[k], ns - 1)];
-			acc[k] = VT<T>::zero();
-		}
-		// S+S-: an antiparallel pair flips; parallel pairs read the block's zero element (position ns) -- no select on the value
-		for (int e = 0; e < B.nx; e++) {
-			const uint32_t mask = pairs_s[e].mask;
-			const double v = pairs_s[e].v;
-			T g[kTjRowsPerThread];
+		__syncthreads(); // the previous item is done with the window and the lists (and the rank tables are in place)
+		if ((int)threadIdx.x < B.nx) pairs_s[threadIdx.x] = a.pairs[B.x_first + threadIdx.x];
+		if ((int)threadIdx.x < B.nh) hops_s[threadIdx.x] = a.hops[B.h_first + threadIdx.x];
+		for (int i = threadIdx.x; i < it.len; i += kTjThreads) win[i] = yb[it.r0 + i];
+		if (threadIdx.x == 0) win[it.len] = VT<T>::zero();
+		__syncthreads();
+		for (int base = 0; base < it.len; base += kTjThreads * kTjRowsPerThread) { // (uniform trip count)
+			uint32_t sg[kTjRowsPerThread];
+			int rl[kTjRowsPerThread]; // row inside the item
+			T acc[kTjRowsPerThread];
 #pragma unroll
 			for (int k = 0; k < kTjRowsPerThread; k++) {
-				const bool anti = __popc(sg[k] & mask) == 1;
-				const uint32_t rr = (uint32_t)rank_of(sg[k] ^ mask);
-				// (32-bit byte offset against the block's uniform base: one shift instead of a 64-bit address per lane)
-				g[k] = *(const T*)((const char*)yb + (anti ? rr : (uint32_t)ns) * (uint32_t)sizeof(T));
+				rl[k] = base + k * kTjThreads + (int)threadIdx.x;
+				sg[k] = a.pat[it.r0 + min(rl[k], it.len - 1)];
+				acc[k] = VT<T>::zero();
 			}
+			// S+S- among the low positions: the flipped pattern lies in the same segment -- an LDS read; parallel pairs read the zero element
+			for (int e = 0; e < B.nxl; e++) {
+				const uint32_t mask = pairs_s[e].mask;
+				const double v = pairs_s[e].v;
+				T g[kTjRowsPerThread];
 #pragma unroll
-			for (int k = 0; k < kTjRowsPerThread; k++) tj_mac_real<T>(acc[k], v, g[k]);
-		}
-		// hops: the electron at one end of the bit range moves to the other end, the electrons between shift by one
-		for (int h = 0; h < B.nh; h++) {
-			const TjHop hp = hops_s[h];
-			const int lo = hp.lo, m = hp.m;
-			const uint32_t wm = (2u << m) - 1u; // m + 1 bits
-			const T* const ys = yv + (int64_t)hp.dst * a.pitch;
-			T g[kTjRowsPerThread];
-			uint32_t par[kTjRowsPerThread];
-#pragma unroll
-			for (int k = 0; k < kTjRowsPerThread; k++) {
-				const uint32_t seg = (sg[k] >> lo) & wm;
-				uint32_t b, nseg, ups;
-				if (hp.dir == 0) { // wave-uniform
-					b = seg & 1u;
-					nseg = (seg >> 1) | (b << m);
-					ups = (uint32_t)__popc(seg >> 1);
-				} else {
-					b = (seg >> m) & 1u;
-					nseg = ((seg << 1) & wm) | b;
-					ups = (uint32_t)__popc(seg & (wm >> 1));
+				for (int k = 0; k < kTjRowsPerThread; k++) {
+					const bool anti = __popc(sg[k] & mask) == 1;
+					const int rr = rank_of(sg[k] ^ mask) - it.r0;
+					g[k] = win[anti ? rr : it.len];
 				}
-				// an up electron passes the up electrons between, a down electron the down electrons (m - ups of them)
-				par[k] = (b ? ups : (uint32_t)m - ups) & 1u;
-				const uint32_t s2 = (sg[k] & ~(wm << lo)) | (nseg << lo);
-				g[k] = *(const T*)((const char*)ys + (uint32_t)min(rank_of(s2), ns - 1) * (uint32_t)sizeof(T));
+#pragma unroll
+				for (int k = 0; k < kTjRowsPerThread; k++) tj_mac_real<T>(acc[k], v, g[k]);
+			}
+			// the other bonds: from the block's row in memory (32-bit byte offset against the block's uniform base)
+			for (int e = B.nxl; e < B.nx; e++) {
+				const uint32_t mask = pairs_s[e].mask;
+				const double v = pairs_s[e].v;
+				T g[kTjRowsPerThread];
+#pragma unroll
+				for (int k = 0; k < kTjRowsPerThread; k++) {
+					const bool anti = __popc(sg[k] & mask) == 1;
+					const uint32_t rr = (uint32_t)rank_of(sg[k] ^ mask);
+					g[k] = *(const T*)((const char*)yb + (anti ? rr : (uint32_t)ns) * (uint32_t)sizeof(T));
+				}
+#pragma unroll
+				for (int k = 0; k < kTjRowsPerThread; k++) tj_mac_real<T>(acc[k], v, g[k]);
+			}
+			// hops: the electron at one end of the bit range moves to the other end, the electrons between shift by one
+			for (int h = 0; h < B.nh; h++) {
+				const TjHop hp = hops_s[h];
+				const int lo = hp.lo, m = hp.m;
+				const uint32_t wm = (2u << m) - 1u; // m + 1 bits
+				const T* const ys = yv + (int64_t)hp.dst * a.pitch;
+				T g[kTjRowsPerThread];
+				uint32_t par[kTjRowsPerThread];
+#pragma unroll
+				for (int k = 0; k < kTjRowsPerThread; k++) {
+					const uint32_t seg = (sg[k] >> lo) & wm;
+					uint32_t b, nseg, ups;
+					if (hp.dir == 0) { // wave-uniform
+						b = seg & 1u;
+						nseg = (seg >> 1) | (b << m);
+						ups = (uint32_t)__popc(seg >> 1);
+					} else {
+						b = (seg >> m) & 1u;
+						nseg = ((seg << 1) & wm) | b;
+						ups = (uint32_t)__popc(seg & (wm >> 1));
+					}
+					// an up electron passes the up electrons between, a down electron the down electrons (m - ups of them)
+					par[k] = (b ? ups : (uint32_t)m - ups) & 1u;
+					const uint32_t s2 = (sg[k] & ~(wm << lo)) | (nseg << lo);
+					g[k] = *(const T*)((const char*)ys + (uint32_t)min(rank_of(s2), ns - 1) * (uint32_t)sizeof(T));
+				}
+#pragma unroll
+				for (int k = 0; k < kTjRowsPerThread; k++) {
+					const double vr = par[k] ? -hp.vr : hp.vr;
+					if constexpr (CH) {
+						const double vi = par[k] ? -hp.vi : hp.vi;
+						VT<T>::mac(acc[k], T { vr, vi }, g[k]);
+					} else
+						tj_mac_real<T>(acc[k], vr, g[k]);
+				}
 			}
 #pragma unroll
 			for (int k = 0; k < kTjRowsPerThread; k++) {
-				const double vr = par[k] ? -hp.vr : hp.vr;
-				if constexpr (CH) {
-					const double vi = par[k] ? -hp.vi : hp.vi;
-					VT<T>::mac(acc[k], T { vr, vi }, g[k]);
-				} else
-					tj_mac_real<T>(acc[k], vr, g[k]);
+				if (rl[k] >= it.len) continue;
+				const int64_t at = rowbase + it.r0 + rl[k];
+				tj_mac_real<T>(acc[k], a.diag[at], win[rl[k]]);
+				const T xn = epi_lin(beta, xv[at], alpha, acc[k]);
+				xv[at] = xn;
+				if (DOT) dot += VT<T>::dot_re(yd[at], xn);
 			}
-		}
-#pragma unroll
-		for (int k = 0; k < kTjRowsPerThread; k++) {
-			if (r[k] >= ns) continue;
-			const int64_t at = rowbase + r[k];
-			const T yo = yv[at];
-			tj_mac_real<T>(acc[k], a.diag[at], yo);
-			const T xn = epi_lin(beta, xv[at], alpha, acc[k]);
-			xv[at] = xn;
-			if (DOT) dot += VT<T>::dot_re(yd[at], xn);
 		}
 	}
 	if (DOT) {
