@@ -740,3 +740,64 @@ def test_eight_ranks_as_threads_config2_uneven_shards():
         assert abs(e0 - g["e0"]) <= 1e-10 * abs(g["e0"]) and abs(len(a) - g["steps"]) <= 1
         assert rel(a[:40], np.array(g["a"][:40])) < 1e-8 and rel(b[:40], np.array(g["b"][:40])) < 1e-8
         assert len(a) <= o["ar"] <= len(a) + 8 and o["xc"] >= 2 * len(a)  # ONE all-reduce and two all-to-alls per step
+
+
+@pytest.mark.parametrize("form", ["segments"])  # ("pieces" passes as well, 44 s: the form this sector takes by itself on one GPU is covered by tests/test_gpu_fullsize.py)
+def test_eight_ranks_as_threads_config5_lattice_6up6down_free_fermions(form, monkeypatch):
+    """BASELINE config 5's lattice at the rank count of its node: the (6,6) sector of the 4x5 cluster -- 1,502,337,600 states, rows of 38760
+    positions (beyond one LDS window) -- matrix-free over 8 ranks (threads of one process, ThreadComm) through the transposition exchange:
+    the in-block kernel for rows in pieces on each rank's 4845 blocks ("pieces": the per-position template this sector takes by itself;
+    "segments": the decomposition by high sites the (7,6) sector takes), the coupling kernel on the transposed slice of 4848 positions x 38760
+    blocks.  U = 0: the exact free-fermion energy; every rank's coefficients bitwise identical."""
+    import threading
+    import torch
+    from helpers import square
+    from lanczosplusplus_amd import LanczosEngine
+    from lanczosplusplus_amd._capi import lib
+    from lanczosplusplus_amd.comm import ThreadComm, ThreadGroup
+    monkeypatch.setenv("LPP_PB_SEG", "1" if form == "segments" else "0")
+    world, L = 8, 20
+    n_up = n_dn = 38760
+    hop = square(4, 5, -1.0, pbc=True)
+    lev = np.sort(np.linalg.eigvalsh(hop))
+    exact = 2 * lev[:6].sum()
+    per = -(-n_dn // world)
+    chunk = lib().lpp_xchg_chunk(n_up, n_dn, world)
+    dev = torch.device("cuda", 0)
+    group = ThreadGroup(world, dev)
+    out = [None] * world
+
+    def run(rank):
+        try:
+            torch.cuda.set_device(dev)
+            comm = ThreadComm(group, rank, per * n_up, 300, False, xchg_chunk=chunk)
+            with comm.stream_context():
+                e = LanczosEngine(max_steps=300, eps=1e-11, save_vectors=0, stream=comm.stream_handle)
+                e.setup_hubbard_onthefly(L, 6, 6, hop, np.zeros(L), comm=comm)
+                lay = e.layout(0)
+                eg, _, st = e.lanczos(1, want_vectors=False)
+                rows = e.rows()
+                e.close()
+            out[rank] = {"kernel": lay["kernel"], "segments": lay["segments"], "pieces": lay["pieces"], "rows": rows, "e": float(eg[0]), "steps": st["steps"],
+                         "sums": [(o, t.numpy().tobytes()) for o, _, t in comm.sums]}
+        except Exception:
+            import traceback
+            out[rank] = {"error": traceback.format_exc()}
+            try:
+                group.barrier.abort()
+            except Exception:
+                pass
+
+    threads = [threading.Thread(target=run, args=(r,), daemon=True) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=800)
+    assert not any(t.is_alive() for t in threads), "a rank is stuck inside a collective"
+    for r in range(world):
+        assert "error" not in out[r], out[r]["error"]
+    assert sum(o["rows"] for o in out) == 38760 * 38760 and out[0]["rows"] == 4845 * 38760
+    for o in out:
+        assert o["kernel"] == 4 and o["pieces"] > 1 and (o["segments"] > 0) == (form == "segments"), o
+        assert o["sums"] == out[0]["sums"] and o["steps"] == out[0]["steps"]
+        assert abs(o["e"] - exact) <= 1e-10 * abs(exact), (o["e"], exact, o["steps"])
