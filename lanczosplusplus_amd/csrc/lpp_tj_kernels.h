@@ -29,8 +29,14 @@ namespace lpp {
 constexpr int kTjMaxPairs = 96; // bonds with both sites occupied, per hole configuration
 constexpr int kTjMaxHops = 64; // (electron, neighbouring hole) moves per hole configuration
 constexpr int kTjThreads = 256;
-constexpr int kTjRowsPerThread = 2; // rows of a thread per round (their gathers are in flight together)
-constexpr int kTjWindow = 1024; // patterns of one work item at most: its run of the vector is staged in LDS
+#ifndef LPP_TJ_ROWS
+#define LPP_TJ_ROWS 2
+#endif
+#ifndef LPP_TJ_WINDOW
+#define LPP_TJ_WINDOW 1024
+#endif
+constexpr int kTjRowsPerThread = LPP_TJ_ROWS; // rows of a thread per round (their gathers are in flight together)
+constexpr int kTjWindow = LPP_TJ_WINDOW; // patterns of one work item at most: its run of the vector is staged in LDS
 constexpr int kTjMaxHalf = 12; // bits of a half pattern (rank tables in LDS: 4096 x (4 + 2) bytes at most)
 
 struct TjPair { // 16 bytes
@@ -196,7 +202,7 @@ template <typename T, bool CH, bool DOT> __global__ __launch_bounds__(kTjThreads
 					// an up electron passes the up electrons between, a down electron the down electrons (m - ups of them)
 					par[k] = (b ? ups : (uint32_t)m - ups) & 1u;
 					const uint32_t s2 = (sg[k] & ~(wm << lo)) | (nseg << lo);
-					g[k] = *(const T*)((const char*)ys + (uint32_t)min(rank_of(s2), ns - 1) * (uint32_t)sizeof(T));
+					g[k] = *(const T*)((const char*)ys + (uint32_t)min(rank_of(s2), ns - 1) * (uint32_t)sizeof(T)); // (non-temporal hop reads: 0.406 instead of 0.356 ms)
 				}
 #pragma unroll
 				for (int k = 0; k < kTjRowsPerThread; k++) {
