@@ -6,7 +6,7 @@
 #   call 2:  bash scripts/profile_set.sh <tag> lines      re-runs ONLY the bench lines (same sources, traffic.json now matches)
 #   here:    bash scripts/stamp_round.sh <tag> lines      copies the lines over the ones of call 1
 R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=$(pwd)
-T=${1:-r04}; MODE=${2:-counters}
+T=${1:-r05}; MODE=${2:-counters}
 cd $R; mkdir -p gpurun_out
 cfg() { # name, bench args, env
   case $1 in
