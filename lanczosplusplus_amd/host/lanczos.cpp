@@ -126,17 +126,23 @@ static long binomial(long n, long k)
 
 // one process per GPU: this rank's rows are assembled on its GPU, the Lanczos loop runs on all ranks in lock step
 // (every rank takes bitwise-identical decisions), rank 0 prints the reference's "Energy=" line
-static int mainPartitioned(LppHost::InputReadable& io, int precision, bool onthefly)
+static double realPart(double v) { return v; }
+static double imagPart(double) { return 0.0; }
+static double realPart(const std::complex<double>& v) { return v.real(); }
+static double imagPart(const std::complex<double>& v) { return v.imag(); }
+
+template <typename ComplexOrRealType> static int mainPartitioned(LppHost::InputReadable& io, int precision, bool onthefly)
 {
-	typedef LppHost::Geometry<double> GeometryType;
+	typedef LppHost::Geometry<ComplexOrRealType> GeometryType;
+	const bool isComplex = sizeof(ComplexOrRealType) == 2 * sizeof(double); // SolverOptions=useComplex (lanczos.cpp:194-226): complex vectors, hoppings with phases
 	const int rank = envInt("RANK", 0), world = envInt("WORLD_SIZE", 1), local = envInt("LOCAL_RANK", rank);
 	GeometryType geometry(io);
-	ModelSelector<double> modelSelector(io, geometry);
-	const ModelBase<double>& model = modelSelector();
-	const HubbardOneOrbital<double>* hub = dynamic_cast<const HubbardOneOrbital<double>*>(&model);
+	ModelSelector<ComplexOrRealType> modelSelector(io, geometry);
+	const ModelBase<ComplexOrRealType>& model = modelSelector();
+	const HubbardOneOrbital<ComplexOrRealType>* hub = dynamic_cast<const HubbardOneOrbital<ComplexOrRealType>*>(&model);
 	if (!hub) throw std::runtime_error("lanczos -P: the partitioned path is built for Model=HubbardOneBand / HubbardOneBandExtended\n");
 	const int n = (int)geometry.numberOfSites();
-	const ModelBase<double>::BasisBaseType::PairIntType parts = model.basis().parts();
+	const typename ModelBase<ComplexOrRealType>::BasisBaseType::PairIntType parts = model.basis().parts();
 	const long n_up = binomial(n, parts.first), n_dn = binomial(n, parts.second);
 	const long per = (n_dn + world - 1) / world;
 	std::string exchange = hub->jCoupling() ? "allgather" : "transpose"; // spin-flip terms (SuperHubbardExtended) need the gathered vector
@@ -151,6 +157,7 @@ static int mainPartitioned(LppHost::InputReadable& io, int precision, bool onthe
 	lpp_config cfg;
 	lpp_config_default(&cfg);
 	cfg.device = local;
+	cfg.dtype = isComplex ? LPP_C128 : LPP_F64;
 	cfg.max_steps = (int32_t)params.steps;
 	cfg.min_steps = (int32_t)params.minSteps;
 	cfg.eps = params.tolerance;
@@ -158,16 +165,20 @@ static int mainPartitioned(LppHost::InputReadable& io, int precision, bool onthe
 	cfg.save_vectors = 0; // energies only: no vector of the full length is ever gathered
 	EngineHandle engine(cfg); // engine-owned stream; the communicator is told which one below
 	lpp_rccl_comm* comm = nullptr;
-	rcclCheck(lpp_rccl_comm_create(&comm, rank, world, id, local, lpp_engine_stream(engine.get()), per * n_up, (int32_t)params.steps, 0, chunk));
+	rcclCheck(lpp_rccl_comm_create(&comm, rank, world, id, local, lpp_engine_stream(engine.get()), per * n_up, (int32_t)params.steps, isComplex ? 1 : 0, chunk));
 	if (rank == 0 && world > 1) (void)unlink(getenv("LPP_RCCL_ID_FILE")); // ncclCommInitRank is a collective: every rank has read the id
 	rcclCheck(lpp_rccl_comm_selftest(comm)); // every callback once, checked on every rank, before any step depends on them
-	std::vector<double> hr((size_t)n * n);
-	for (int k = 0; k < n * n; k++) hr[(size_t)k] = hub->hoppings()[(size_t)k];
+	std::vector<double> hr((size_t)n * n), hi((size_t)n * n);
+	for (int k = 0; k < n * n; k++) {
+		hr[(size_t)k] = realPart(hub->hoppings()[(size_t)k]);
+		hi[(size_t)k] = imagPart(hub->hoppings()[(size_t)k]);
+	}
+	const double* him = isComplex ? hi.data() : nullptr;
 	if (onthefly)
-		lppCheck(lpp_engine_setup_hubbard_onthefly_ext(engine.get(), lpp_rccl_comm_get(comm), n, parts.first, parts.second, hr.data(), nullptr,
+		lppCheck(lpp_engine_setup_hubbard_onthefly_ext(engine.get(), lpp_rccl_comm_get(comm), n, parts.first, parts.second, hr.data(), him,
 		                                               hub->hubbardU.data(), hub->potentialEffective.data(), hub->coulombCoupling()));
 	else
-		lppCheck(lpp_engine_assemble_hubbard_super(engine.get(), lpp_rccl_comm_get(comm), n, parts.first, parts.second, hr.data(), nullptr,
+		lppCheck(lpp_engine_assemble_hubbard_super(engine.get(), lpp_rccl_comm_get(comm), n, parts.first, parts.second, hr.data(), him,
 		                                           hub->hubbardU.data(), hub->potentialEffective.data(), hub->coulombCoupling(), hub->jCoupling()));
 	double e0 = 0;
 	lpp_stats st;
@@ -207,10 +218,7 @@ int main(int argc, char** argv)
 		if (io.has("SolverOptions=")) io.readline(options, "SolverOptions=");
 		const bool onthefly = options.find("InternalProductOnTheFly") != LppHost::String::npos;
 		const bool isComplex = options.find("useComplex") != LppHost::String::npos;
-		if (partitioned) {
-			if (isComplex) throw std::runtime_error("lanczos -P: real Hamiltonians only\n");
-			return mainPartitioned(io, precision, onthefly);
-		}
+		if (partitioned) return isComplex ? mainPartitioned<std::complex<double>>(io, precision, onthefly) : mainPartitioned<double>(io, precision, onthefly);
 		return isComplex ? mainLoop0<std::complex<double>>(io, device, precision, onthefly) : mainLoop0<double>(io, device, precision, onthefly);
 	} catch (std::exception& e) {
 		std::cerr << "lanczos: " << e.what();
