@@ -37,4 +37,4 @@ with open('$O/pmc_summary.csv','w') as g:
             v=pm[k][c]; w.writerow([k,c,len(v),sum(v)/len(v)])
 PY
 rm -rf $O/trace $O/fetch $O/write $O/ea $O/sq $O/sq2
-cat $O/bench.json; head -8 $O/kernel_stats.csv; grep -E "spmv|k_pb" $O/pmc_summary.csv
+cat $O/bench.json; head -8 $O/kernel_stats.csv; grep -E "spmv|k_pb|k_tj" $O/pmc_summary.csv || true
