@@ -304,3 +304,34 @@ def test_xx_chain_L32_without_a_csr_free_fermions():
         assert lay["resident_bytes"] < 1.0e9, lay  # one diagonal code per row + tables (the boundary's permutation is not part of the matrix)
         eg, _, st = e.lanczos(1, want_vectors=False)
     assert abs(eg[0] - exact) <= 1e-10 * abs(exact), (eg[0], exact, st["steps"])
+
+
+def test_tj_four_holes_hole_major_form_against_the_general_layout(monkeypatch):
+    """The t-J form without a stored matrix at a shape its small parity cases do not reach: the 4x5 torus with FOUR holes (8 up, 8 down) --
+    4845 hole configurations x 12870 spin patterns = 62,355,150 states, complex engine.  No CPU oracle follows there in test time; the same
+    device-assembled model in the general layout (a 1.9e9-entry CSR) does: coefficients of the first 30 steps to 1e-9, E0 to 1e-10, same
+    stopping step, and x += H y of one random vector element by element."""
+    from helpers import rel
+    from lanczosplusplus_amd import tridiag_lowest
+    L, nup, ndown, t, J = 20, 8, 8, -1.0, 0.4
+    lat = lambda v: square(5, 4, v, pbc=True)
+    rng = np.random.default_rng(11)
+    n = 4845 * 12870
+    y = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex128)
+    res = {}
+    for form in ("1", "0"):
+        monkeypatch.setenv("LPP_TJ_LAYOUT", form)
+        with LanczosEngine(dtype="c128", max_steps=300, save_vectors=0) as e:
+            e.assemble_tj(L, nup, ndown, lat(t), lat(J), lat(J), lat(-J / 4))
+            assert e.rows() == n
+            lay = e.layout()
+            assert (lay["kernel"] == 5) == (form == "1") and lay["nnz"] > 0
+            x = e.matrixVectorProduct(np.zeros(n, np.complex128), y)
+            a, b, st = e.decomposition()
+        res[form] = (lay["nnz"], x, a, b)
+    (z1, x1, a1, b1), (z0, x0, a0, b0) = res["1"], res["0"]
+    assert z1 == z0  # the entry count of the CSR the hole-major form stands for is the assembled one's
+    assert rel(x1, x0) < 1e-13
+    assert abs(len(a1) - len(a0)) <= 1 and rel(a1[:30], a0[:30]) < 1e-9 and rel(b1[:30], b0[:30]) < 1e-9
+    e1, e0 = tridiag_lowest(a1, b1[:-1], 1)[0], tridiag_lowest(a0, b0[:-1], 1)[0]
+    assert abs(e1 - e0) <= 1e-10 * abs(e0), (e1, e0)
