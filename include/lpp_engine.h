@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define LPP_ABI_VERSION 5 /* 5: LPP_SPMV_HOLE_MAJOR (lpp_layout.kernel of the t-J model); 4: lpp_layout.segments, lpp_pb_seg_plan_stats; 2: lpp_layout.stream_bytes, lpp_pb_pack_template(bank_ways), set_solver / stream / _ext / _spin entry points; 3: lpp_layout.pieces / coupling_parts / diagonal_plain / chained_step / split_panel, lpp_stats.reortho_* */
+#define LPP_ABI_VERSION 5 /* 5: LPP_SPMV_HOLE_MAJOR (lpp_layout.kernel of the t-J model), lpp_engine_set_model_tj / _heisenberg; 4: lpp_layout.segments, lpp_pb_seg_plan_stats; 2: lpp_layout.stream_bytes, lpp_pb_pack_template(bank_ways), set_solver / stream / _ext / _spin entry points; 3: lpp_layout.pieces / coupling_parts / diagonal_plain / chained_step / split_panel, lpp_stats.reortho_* */
 
 typedef int32_t lpp_status;
 enum {
@@ -178,6 +178,19 @@ lpp_status lpp_engine_set_solver(lpp_engine* e, int32_t max_steps, int32_t min_s
  * index = i_up + i_down * N_up (BasisHubbardLanczos.h:59-63).  The engine then stages one block of the source vector
  * in LDS per workgroup.  0 = unknown (default).  Results do not depend on it. */
 lpp_status lpp_engine_set_row_block(lpp_engine* e, int64_t rows_per_block);
+
+/* Optional description of the MODEL behind the next lpp_engine_set_csr / _set_csr_device (ABI 5; like lpp_engine_set_row_block a layout hint: results
+ * never depend on it).  The reference hands its matrix over as a CSR (DefaultSymmetry.h:54-57 -> InternalProductStored.h:116); for two model
+ * families the engine has a form that needs no stored matrix at all -- the one-orbital t-J model (TjMultiOrb.h:100-131; arguments as
+ * lpp_engine_assemble_tj) and the S = 1/2 Heisenberg chain (Heisenberg.h:80-114; arguments as lpp_engine_assemble_heisenberg).  With a description
+ * on record the engine regenerates the matrix from it with its device assembler, compares that with the handed-over CSR BIT FOR BIT, and only
+ * if they are the same holds the model in its structured form (lpp_layout.kernel LPP_SPMV_HOLE_MAJOR / LPP_SPMV_PRODUCT) and drops the CSR;
+ * any difference, a model the form does not apply to, or no room for the comparison keeps the general layout of the CSR as handed over.
+ * The description is used for ONE matrix; nsites == 0 forgets it.  The C++ shim records it from the model object (host/EngineGpu.h). */
+lpp_status lpp_engine_set_model_tj(lpp_engine* e, int32_t nsites, int32_t nup, int32_t ndown, const double* hop_re, const double* hop_im,
+                                   const double* jpm, const double* jzz, const double* w, const double* potentialV, int32_t npot);
+lpp_status lpp_engine_set_model_heisenberg(lpp_engine* e, int32_t nsites, int32_t szPlusConst, const double* jpm, const double* jzz,
+                                           const double* field, int32_t nfield);
 
 /* Upload a host CSR (copied).  rowptr[nrows+1], colind[nnz], values[nnz] of the engine dtype. */
 lpp_status lpp_engine_set_csr(lpp_engine* e, int64_t nrows, const int64_t* rowptr, const int32_t* colind,

@@ -92,6 +92,8 @@ SYMBOLS = {
     "lpp_engine_assemble_heisenberg": (C.c_int32, [_P, C.c_int32, C.c_int32, _P, _P, _P, C.c_int32]),
     "lpp_engine_assemble_heisenberg_spin": (C.c_int32, [_P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, C.c_int32, _P, C.c_int32]),
     "lpp_engine_assemble_tj": (C.c_int32, [_P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P, C.c_int32]),
+    "lpp_engine_set_model_tj": (C.c_int32, [_P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P, C.c_int32]),
+    "lpp_engine_set_model_heisenberg": (C.c_int32, [_P, C.c_int32, C.c_int32, _P, _P, _P, C.c_int32]),
     "lpp_engine_get_csr": (C.c_int32, [_P, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64), _P, _P, _P]),
     "lpp_engine_spmv_acc": (C.c_int32, [_P, _P, _P]),
     "lpp_engine_lanczos": (C.c_int32, [_P, _P, C.c_int32, _P, _P, C.POINTER(Stats)]),

@@ -438,6 +438,51 @@ lpp_status heis_asm_params(lpp_engine* e, int L, int szPlusConst, const double* 
 }
 } // namespace
 
+namespace {
+// A chain (couplings between neighbours, and between the two ends): S+S- moves an up spin and nothing sits between the two sites, so the
+// off-diagonal part is the hopping matrix of the up spins -- one block of the product-basis form, the in-block kernel decomposed by the high
+// sites of the basis word (pb_chain, lpp_pbseg.h).  Amplitudes in the planner's convention: value x (-1)^(up spins between), which for the
+// bond between the two ends is the constant (-1)^(n - 1).
+lpp_status heis_chain_try(lpp_engine* e, const AsmParams& P, int L, int szPlusConst, const double* jpm, bool* as_chain)
+{
+	*as_chain = false;
+	bool chain = L >= 2 && !e->is_complex;
+	std::vector<double> hv((size_t)L * L, 0.0);
+	for (int i = 0; i < L && chain; i++)
+		for (int j = 0; j < L && chain; j++) {
+			if (i == j || jpm[i * L + j] == 0) continue;
+			const int d = i > j ? i - j : j - i;
+			if ((d != 1 && d != L - 1) || std::memcmp(&jpm[i * L + j], &jpm[j * L + i], sizeof(double)) != 0) chain = false;
+			const double v = 0.5 * 1.0 * jpm[i * L + j];
+			hv[(size_t)i * L + j] = (d == L - 1 && d != 1 && ((szPlusConst - 1) & 1)) ? -v : v;
+		}
+	if (!chain || szPlusConst < 1 || szPlusConst >= L) return LPP_OK;
+	return pb_chain(e, P, L, szPlusConst, hv, as_chain);
+}
+// the host copy of the couplings lpp_engine_get_csr re-runs the assembler from
+void chain_remember(lpp_engine* e, int L, int m, const double* jpm, const double* jzz, const double* field, int nfield)
+{
+	PbState& B = e->pb;
+	B.chain_L = L;
+	B.chain_m = m;
+	B.chain_nfield = std::max(nfield, 0);
+	B.chain_jpm.assign(jpm, jpm + (size_t)L * L);
+	B.chain_jzz.assign(jzz, jzz + (size_t)L * L);
+	B.chain_field.clear();
+	if (field && nfield > 0) B.chain_field.assign(field, field + nfield);
+}
+// 1 where two device arrays of `bytes` bytes differ
+__global__ void k_bytes_differ(const unsigned char* __restrict__ a, const unsigned char* __restrict__ b, size_t bytes, int* __restrict__ flag)
+{
+	const size_t n8 = bytes / 8;
+	bool bad = false;
+	for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n8; k += (size_t)gridDim.x * blockDim.x) bad |= ((const uint64_t*)a)[k] != ((const uint64_t*)b)[k];
+	if (blockIdx.x == 0 && threadIdx.x == 0)
+		for (size_t k = n8 * 8; k < bytes; k++) bad |= a[k] != b[k];
+	if (bad) *flag = 1;
+}
+} // namespace
+
 namespace lpp {
 lpp_status assemble_heisenberg_raw(lpp_engine* e, int L, int m, const double* jpm, const double* jzz, const double* field, int nfield, DevCsr& A)
 {
@@ -533,6 +578,68 @@ lpp_status assemble_tj_raw(lpp_engine* e, const TjModel& M, DevCsr& A)
 	lpp_status st = tj_asm_params(e, M, D, P);
 	if (st != LPP_OK) return st;
 	return dispatch<ASM_TJ>(e, P, A, 0, 0, true);
+}
+} // namespace lpp
+
+namespace lpp {
+lpp_status model_layout_from_hint(lpp_engine* e, const DevCsr& A, bool* done)
+{
+	*done = false;
+	const ModelHint& H = e->hint;
+	if (H.kind == 0 || e->has_comm || A.nrows <= 0 || !A.rowptr || !A.col || !A.val) return LPP_OK;
+	const std::vector<uint64_t> comb = comb_table();
+	const bool verbose = getenv("LPP_VERBOSE") != nullptr;
+	hipStream_t st = e->stream;
+	// (1) the description must regenerate the handed-over matrix, bit for bit
+	DevCsr T;
+	struct Drop {
+		DevCsr& t;
+		~Drop() { free_csr(t); }
+	} drop { T };
+	lpp_status rc = LPP_OK;
+	if (H.kind == 1) {
+		const TjModel& M = H.tj;
+		if ((int64_t)binom(comb, M.L, M.ndown) * (int64_t)binom(comb, M.L - M.ndown, M.nup) != A.nrows || (M.has_im && !e->is_complex)) return LPP_OK;
+		if (!tj_applies(e, M)) return LPP_OK; // (no regeneration for a form that would not be taken anyway)
+		rc = assemble_tj_raw(e, M, T);
+	} else if (H.kind == 2) {
+		if ((int64_t)binom(comb, H.L, H.m) != A.nrows || e->is_complex) return LPP_OK;
+		if ((size_t)A.nrows * sizeof(double) < ((size_t)32 << 20) && !getenv("LPP_PRODUCT_LAYOUT")) return LPP_OK; // (pb_chain's own threshold)
+		rc = assemble_heisenberg_raw(e, H.L, H.m, H.jpm.data(), H.jzz.data(), H.field.empty() ? nullptr : H.field.data(), H.nfield, T);
+	} else
+		return LPP_OK;
+	if (rc == LPP_ERR_NOMEM || rc == LPP_ERR_INVALID) return LPP_OK; // no room for the second copy / a description the assembler refuses: the general layout
+	if (rc != LPP_OK) return rc;
+	bool same = T.nrows == A.nrows && T.nnz == A.nnz;
+	if (same) {
+		DevBuf flag;
+		HIP_TRY_MEM(hipMalloc(&flag.p, sizeof(int)));
+		HIP_TRY(hipMemsetAsync(flag.p, 0, sizeof(int), st));
+		k_bytes_differ<<<2048, 256, 0, st>>>((const unsigned char*)T.rowptr, (const unsigned char*)A.rowptr, sizeof(int64_t) * (size_t)(A.nrows + 1), (int*)flag.p);
+		k_bytes_differ<<<2048, 256, 0, st>>>((const unsigned char*)T.col, (const unsigned char*)A.col, sizeof(int32_t) * (size_t)A.nnz, (int*)flag.p);
+		k_bytes_differ<<<2048, 256, 0, st>>>((const unsigned char*)T.val, (const unsigned char*)A.val, e->esz * (size_t)A.nnz, (int*)flag.p);
+		int bad = 0;
+		HIP_TRY(hipMemcpyAsync(&bad, flag.p, sizeof(int), hipMemcpyDeviceToHost, st));
+		HIP_TRY(hipGetLastError());
+		HIP_TRY(hipStreamSynchronize(st));
+		same = bad == 0;
+	}
+	free_csr(T);
+	if (verbose) fprintf(stderr, "lpp: the model description %s the handed-over CSR\n", same ? "regenerates" : "does NOT regenerate");
+	if (!same) return LPP_OK;
+	// (2) the structured form of that model (checked on its own against the assembler's row walk)
+	if (H.kind == 1) {
+		TjDev D;
+		AsmParams P {};
+		if ((rc = tj_asm_params(e, H.tj, D, P)) != LPP_OK) return rc;
+		return tj_build(e, H.tj, P, done);
+	}
+	HeisDev D;
+	AsmParams P {};
+	if ((rc = heis_asm_params(e, H.L, H.m, H.jpm.data(), H.jzz.data(), H.field.empty() ? nullptr : H.field.data(), H.nfield, D, P)) != LPP_OK) return rc;
+	if ((rc = heis_chain_try(e, P, H.L, H.m, H.jpm.data(), done)) != LPP_OK) return rc;
+	if (*done) chain_remember(e, H.L, H.m, H.jpm.data(), H.jzz.data(), H.field.empty() ? nullptr : H.field.data(), H.nfield);
+	return LPP_OK;
 }
 } // namespace lpp
 
@@ -751,35 +858,13 @@ lpp_status lpp_engine_assemble_heisenberg(lpp_engine* e, int32_t L, int32_t szPl
 	e->bind_scalars(e->scal_own);
 	free_csr(e->A_rem);
 	drop_product(e);
-	// A chain (couplings between neighbours, and between the two ends): S+S- moves an up spin and nothing sits between the two sites, so
-	// the off-diagonal part is the hopping matrix of the up spins -- one block of the product-basis form, the in-block kernel decomposed by
-	// the high sites of the basis word (pb_chain, lpp_pbseg.h).  Amplitudes in the planner's convention: value x (-1)^(up spins between),
-	// which for the bond between the two ends is the constant (-1)^(n - 1).  Planned from the couplings alone: no CSR is assembled
-	// (lpp_engine_get_csr re-runs the assembler), so the largest chain is bounded by its vectors, not by 12 bytes per entry.
-	bool chain = L >= 2 && !e->is_complex;
-	std::vector<double> hv((size_t)L * L, 0.0);
-	for (int i = 0; i < L && chain; i++)
-		for (int j = 0; j < L && chain; j++) {
-			if (i == j || jpm[i * L + j] == 0) continue;
-			const int d = i > j ? i - j : j - i;
-			if ((d != 1 && d != L - 1) || std::memcmp(&jpm[i * L + j], &jpm[j * L + i], sizeof(double)) != 0) chain = false;
-			const double v = 0.5 * 1.0 * jpm[i * L + j];
-			hv[(size_t)i * L + j] = (d == L - 1 && d != 1 && ((szPlusConst - 1) & 1)) ? -v : v;
-		}
+	// A chain (couplings between neighbours, and between the two ends): one block of the product-basis form, planned from the couplings alone
+	// (heis_chain_try): no CSR is assembled (lpp_engine_get_csr re-runs the assembler), so the largest chain is bounded by its vectors
 	bool as_chain = false;
-	if (chain && szPlusConst >= 1 && szPlusConst < L) {
-		st = pb_chain(e, P, L, szPlusConst, hv, &as_chain);
-		if (st != LPP_OK) return st;
-	}
+	if ((st = heis_chain_try(e, P, L, szPlusConst, jpm, &as_chain)) != LPP_OK) return st;
 	if (as_chain) {
 		free_csr(e->A_loc);
-		PbState& B = e->pb;
-		B.chain_L = L;
-		B.chain_m = szPlusConst;
-		B.chain_nfield = std::max(nfield, 0);
-		B.chain_jpm.assign(jpm, jpm + (size_t)L * L);
-		B.chain_jzz.assign(jzz, jzz + (size_t)L * L);
-		if (field && nfield > 0) B.chain_field.assign(field, field + nfield);
+		chain_remember(e, L, szPlusConst, jpm, jzz, field, nfield);
 	} else {
 		st = dispatch<ASM_HEISENBERG>(e, P, e->A_loc);
 		if (st != LPP_OK) return st;

@@ -1061,6 +1061,18 @@ static lpp_status try_product_layout(lpp_engine* e, DevCsr& A, bool* as_product)
 {
 	*as_product = false;
 	if (A.nrows == 0 || A.nnz == 0) return LPP_OK;
+	if (e->hint.kind) { // the caller described the model behind this matrix (lpp_engine_set_model_*): its structured form, if the description is this CSR
+		StageTimer tm("structured form from the model description");
+		bool done = false;
+		lpp_status st = model_layout_from_hint(e, A, &done);
+		e->hint = ModelHint(); // one matrix per description
+		if (st != LPP_OK) return st;
+		if (done) {
+			*as_product = true;
+			free_csr(A);
+			return LPP_OK;
+		}
+	}
 	int64_t hb = A.hint_block;
 	if (hb == 0 && !(getenv("LPP_DETECT_BLOCK") && atoi(getenv("LPP_DETECT_BLOCK")) == 0) && (size_t)A.nrows * e->esz < ((size_t)1 << 32)) {
 		StageTimer tm("basis block detection");
@@ -1118,6 +1130,50 @@ lpp_status lpp_engine_set_row_block(lpp_engine* e, int64_t rows_per_block)
 {
 	if (!e || rows_per_block < 0) return fail(LPP_ERR_INVALID, "lpp_engine_set_row_block: bad argument");
 	e->row_block_hint = rows_per_block;
+	return LPP_OK;
+}
+
+lpp_status lpp_engine_set_model_tj(lpp_engine* e, int32_t L, int32_t nup, int32_t ndown, const double* hop_re, const double* hop_im, const double* jpm,
+                                   const double* jzz, const double* w, const double* potentialV, int32_t npot)
+{
+	if (!e) return fail(LPP_ERR_INVALID, "lpp_engine_set_model_tj: null engine");
+	e->hint = ModelHint();
+	if (L == 0) return LPP_OK; // forget the description
+	if (!hop_re || !jpm || !jzz || !w || L < 1 || L > 31 || nup < 0 || ndown < 0 || nup + ndown > L || (potentialV && npot > 0 && npot < 2 * L))
+		return fail(LPP_ERR_INVALID, "lpp_engine_set_model_tj: bad argument");
+	TjModel& M = e->hint.tj;
+	M.L = L;
+	M.nup = nup;
+	M.ndown = ndown;
+	M.npot = npot;
+	const size_t LL = (size_t)L * L;
+	M.hop_re.assign(hop_re, hop_re + LL);
+	if (hop_im) M.hop_im.assign(hop_im, hop_im + LL);
+	M.jpm.assign(jpm, jpm + LL);
+	M.jzz.assign(jzz, jzz + LL);
+	M.w.assign(w, w + LL);
+	M.has_pv = potentialV && npot > 0;
+	if (M.has_pv) M.pv.assign(potentialV, potentialV + 2 * (size_t)L);
+	if (hop_im)
+		for (size_t k = 0; k < LL; k++) M.has_im |= (hop_im[k] != 0);
+	e->hint.kind = 1;
+	return LPP_OK;
+}
+
+lpp_status lpp_engine_set_model_heisenberg(lpp_engine* e, int32_t L, int32_t szPlusConst, const double* jpm, const double* jzz, const double* field, int32_t nfield)
+{
+	if (!e) return fail(LPP_ERR_INVALID, "lpp_engine_set_model_heisenberg: null engine");
+	e->hint = ModelHint();
+	if (L == 0) return LPP_OK;
+	if (!jpm || !jzz || L < 1 || L > 62 || szPlusConst < 0 || szPlusConst > L || (nfield > 0 && !field)) return fail(LPP_ERR_INVALID, "lpp_engine_set_model_heisenberg: bad argument");
+	ModelHint& H = e->hint;
+	H.L = L;
+	H.m = szPlusConst;
+	H.nfield = std::max(nfield, 0);
+	H.jpm.assign(jpm, jpm + (size_t)L * L);
+	H.jzz.assign(jzz, jzz + (size_t)L * L);
+	if (nfield > 0) H.field.assign(field, field + nfield);
+	H.kind = 2;
 	return LPP_OK;
 }
 

@@ -222,6 +222,14 @@ struct TjState {
 	int32_t* perm = nullptr; // nblk * ns: stored (block, pattern) -> index in the reference's basis
 };
 
+// what lpp_engine_set_model_* said about the matrix the NEXT lpp_engine_set_csr hands over (kind 0: nothing)
+struct ModelHint {
+	int kind = 0; // 1: one-orbital t-J (tj), 2: S = 1/2 Heisenberg (L, m, jpm, jzz, field)
+	TjModel tj;
+	int L = 0, m = 0, nfield = 0;
+	std::vector<double> jpm, jzz, field;
+};
+
 } // namespace lpp
 
 struct lpp_engine {
@@ -240,6 +248,7 @@ struct lpp_engine {
 	lpp::KronState kron;
 	lpp::PbState pb;
 	lpp::TjState tj;
+	lpp::ModelHint hint;
 	// pitched vector layout (product-basis matrices): block b of `pitch_rows` valid elements starts at element b*pitch; 0 = contiguous
 	int64_t pitch = 0, pitch_rows = 0, pitch_blocks = 0;
 	// transposition exchange (multi-GPU Hubbard): A_loc = diagonal + up-hops on the rank's slice, A_rem = down-hops
@@ -354,12 +363,17 @@ int64_t pb_pitch_for(int64_t n_up);
 // t-J without a stored matrix (lpp_tj.hip).  tj_build: P = the assembler's parameters of the same model (device pointers valid during the
 // call); *done == false: the layout does not apply, the caller assembles the CSR
 void free_tj(lpp_engine* e);
+bool tj_applies(const lpp_engine* e, const TjModel& M);
 lpp_status tj_build(lpp_engine* e, const TjModel& M, const AsmParams& P, bool* done);
 int tj_launch(lpp_engine* e, const void* src, void* x, const void* ydot, double* partial, const EpiScale& sc);
 lpp_status tj_vec_from_host(lpp_engine* e, double* dev, const void* host);
 lpp_status tj_vec_to_host(lpp_engine* e, void* host, const double* dev);
 void tj_fill_random(lpp_engine* e, double* dev, uint64_t seed);
 lpp_status assemble_tj_raw(lpp_engine* e, const TjModel& M, DevCsr& A); // the plain CSR in the reference's order (lpp_assemble.hip)
+// A CSR handed over together with a description of its model (lpp_engine_set_model_*; lpp_assemble.hip): the device assembler regenerates the
+// matrix from the description, and only if that is the handed-over CSR bit for bit is the model taken in its structured form (the t-J model
+// without a stored matrix, a spin chain as one block of the segmented form).  *done == false: the caller keeps the CSR's general layout.
+lpp_status model_layout_from_hint(lpp_engine* e, const DevCsr& A, bool* done);
 // host <-> device vector copies that know the pitched layout
 lpp_status vec_from_host(lpp_engine* e, double* dev, const void* host);
 lpp_status vec_to_host(lpp_engine* e, void* host, const double* dev);

@@ -238,25 +238,35 @@ void tj_fill_random(lpp_engine* e, double* dev, uint64_t seed)
 // The layout from the model's parameters alone: nothing of the matrix is ever stored.  Before it is used, ONE product of a random
 // vector goes through it and through the device assembler's row walk (k_asm_apply: the term list of lpp_engine_assemble_tj, every
 // entry re-derived per row in the reference's order); the largest difference must be below 1e-12 of the largest element.
+// whether the hole-major form would be taken for this model at all (switches, sizes): the part of tj_build that needs no device work
+bool tj_applies(const lpp_engine* e, const TjModel& M)
+{
+	bool forced = false;
+	if (const char* s = getenv("LPP_TJ_LAYOUT")) {
+		if (atoi(s) == 0) return false;
+		forced = true;
+	}
+	if (e->cfg.spmv_kernel != LPP_SPMV_AUTO || getenv("LPP_SPMV_KERNEL")) return false;
+	for (const char* k : { "LPP_SHARED_OFFSETS", "LPP_LOCAL16", "LPP_DIAG_CODES", "LPP_BLOCK_TEMPLATE", "LPP_WINDOW_ROWS", "LPP_COMPRESS_VALUES", "LPP_KEEP_PLAIN_CSR" })
+		if (getenv(k)) return false; // switches of the general layout: measure that one
+	if (e->cfg.compress_values == 0) return false;
+	const int L = M.L, nup = M.nup, ndown = M.ndown, Lo = nup + ndown, nholes = L - Lo;
+	if (Lo < 2 || Lo > 2 * kTjMaxHalf || nup < 1 || ndown < 1 || L > 31 || nholes < 0) return false;
+	const uint64_t ns64 = binom_h(Lo, nup), nblk64 = binom_h(L, nholes);
+	if (ns64 * nblk64 >= ((uint64_t)1 << 31) || ns64 < 64 || nblk64 > (1u << 20)) return false;
+	// from 32 MB per vector on (as the product-basis layout of the Hubbard matrices); below that the general layout's launch is shorter
+	if (!forced && ns64 * nblk64 * e->esz < ((uint64_t)32 << 20)) return false;
+	if (M.has_im && !e->is_complex) return false;
+	return true;
+}
+
 lpp_status tj_build(lpp_engine* e, const TjModel& M, const AsmParams& P, bool* done)
 {
 	*done = false;
 	const bool verbose = getenv("LPP_VERBOSE") != nullptr;
-	bool forced = false;
-	if (const char* s = getenv("LPP_TJ_LAYOUT")) {
-		if (atoi(s) == 0) return LPP_OK;
-		forced = true;
-	}
-	if (e->cfg.spmv_kernel != LPP_SPMV_AUTO || getenv("LPP_SPMV_KERNEL")) return LPP_OK;
-	for (const char* k : { "LPP_SHARED_OFFSETS", "LPP_LOCAL16", "LPP_DIAG_CODES", "LPP_BLOCK_TEMPLATE", "LPP_WINDOW_ROWS", "LPP_COMPRESS_VALUES", "LPP_KEEP_PLAIN_CSR" })
-		if (getenv(k)) return LPP_OK; // switches of the general layout: measure that one
-	if (e->cfg.compress_values == 0) return LPP_OK;
+	if (!tj_applies(e, M)) return LPP_OK;
 	const int L = M.L, nup = M.nup, ndown = M.ndown, Lo = nup + ndown, nholes = L - Lo;
-	if (Lo < 2 || Lo > 2 * kTjMaxHalf || nup < 1 || ndown < 1 || L > 31) return LPP_OK;
 	const uint64_t ns64 = binom_h(Lo, nup), nblk64 = binom_h(L, nholes);
-	if (ns64 * nblk64 >= ((uint64_t)1 << 31) || ns64 < 64 || nblk64 > (1u << 20)) return LPP_OK;
-	// from 32 MB per vector on (as the product-basis layout of the Hubbard matrices); below that the general layout's launch is shorter
-	if (!forced && ns64 * nblk64 * e->esz < ((uint64_t)32 << 20)) return LPP_OK;
 	const int ns = (int)ns64, nblk = (int)nblk64;
 	const int lb = Lo / 2, hb = Lo - lb;
 	hipStream_t st = e->stream;

@@ -87,6 +87,19 @@ class LanczosEngine:
         """Layout hint for the next set_csr: rows_per_block = N_up of the Hubbard product basis (0 = unknown)."""
         check(self._lib.lpp_engine_set_row_block(self._h, int(rows_per_block)))
 
+    def set_model_tj(self, L, nup, ndown, hop, jpm, jzz, w, potentialV=None):
+        """describe the model behind the NEXT set_csr (lpp_engine_set_model_tj): a layout hint, verified against the CSR bit for bit"""
+        hop = np.asarray(hop).reshape(L, L)
+        hr = _mat(hop.real, L)
+        hi = _mat(hop.imag, L) if np.iscomplexobj(hop) else None
+        pv = None if potentialV is None else np.ascontiguousarray(potentialV, np.float64)
+        check(self._lib.lpp_engine_set_model_tj(self._h, L, nup, ndown, _vp(hr), _vp(hi), _vp(_mat(jpm, L)), _vp(_mat(jzz, L)), _vp(_mat(w, L)),
+                                                _vp(pv), 0 if pv is None else len(pv)))
+
+    def set_model_heisenberg(self, L, szPlusConst, jpm, jzz, field=None):
+        f = None if field is None else np.ascontiguousarray(field, np.float64)
+        check(self._lib.lpp_engine_set_model_heisenberg(self._h, L, szPlusConst, _vp(_mat(jpm, L)), _vp(_mat(jzz, L)), _vp(f), 0 if f is None else len(f)))
+
     def set_csr(self, rowptr, colind, values):
         rowptr = np.ascontiguousarray(rowptr, np.int64)
         colind = np.ascontiguousarray(colind, np.int32)

@@ -129,22 +129,22 @@ public:
 		return cfg;
 	}
 	// the reference's two constructors (InternalProductStored.h:104-117) with the default solver configuration
-	InternalProductStored(const ModelType& model, SpecialSymmetryType& rs) : rs_(rs), engine_(defaultConfig()), basis_(model.basis()), rows_(0), sector_(0)
+	InternalProductStored(const ModelType& model, SpecialSymmetryType& rs) : rs_(rs), engine_(defaultConfig()), basis_(model.basis()), model_(&model), rows_(0), sector_(0)
 	{
 		rs_.init(model, model.basis());
 		upload();
 	}
-	InternalProductStored(const ModelType& model, const BasisType& basis, SpecialSymmetryType& rs) : rs_(rs), engine_(defaultConfig()), basis_(basis), rows_(0), sector_(0)
+	InternalProductStored(const ModelType& model, const BasisType& basis, SpecialSymmetryType& rs) : rs_(rs), engine_(defaultConfig()), basis_(basis), model_(&basis == &model.basis() ? &model : nullptr), rows_(0), sector_(0)
 	{
 		rs_.init(model, basis);
 		upload();
 	}
-	InternalProductStored(const ModelType& model, SpecialSymmetryType& rs, const lpp_config& cfg) : rs_(rs), engine_(cfg), basis_(model.basis()), rows_(0), sector_(0)
+	InternalProductStored(const ModelType& model, SpecialSymmetryType& rs, const lpp_config& cfg) : rs_(rs), engine_(cfg), basis_(model.basis()), model_(&model), rows_(0), sector_(0)
 	{
 		rs_.init(model, model.basis());
 		upload();
 	}
-	InternalProductStored(const ModelType& model, const BasisType& basis, SpecialSymmetryType& rs, const lpp_config& cfg) : rs_(rs), engine_(cfg), basis_(basis), rows_(0), sector_(0)
+	InternalProductStored(const ModelType& model, const BasisType& basis, SpecialSymmetryType& rs, const lpp_config& cfg) : rs_(rs), engine_(cfg), basis_(basis), model_(&basis == &model.basis() ? &model : nullptr), rows_(0), sector_(0)
 	{
 		rs_.init(model, basis);
 		upload();
@@ -178,12 +178,45 @@ private:
 		const BasisHubbardLanczos* hb = dynamic_cast<const BasisHubbardLanczos*>(&basis_);
 		const bool whole = rs_.sectors() == 1 && hb && (SizeType)hb->size() == rows_;
 		lppCheck(lpp_engine_set_row_block(engine_.get(), whole ? (int64_t)hb->sizeUp() : 0));
+		describeModel(rs_.sectors() == 1 && model_ && (SizeType)model_->size() == rows_);
 		lppCheck(lpp_engine_set_csr(engine_.get(), (int64_t)m.rows(), m.rowptr().data(), m.colind().data(), m.values().data()));
 		rs_.releaseHostMatrix(); // the device copy is the resident one (matrices small enough for fullDiag stay)
+	}
+	// The matrix is handed over as the CSR the model assembled (DefaultSymmetry.h:54-57).  For the two families the engine can hold without a
+	// stored matrix -- the one-orbital t-J model, the S = 1/2 Heisenberg chain -- the shim also says WHICH model it is (couplings, sector): the
+	// engine regenerates the matrix from that, compares it with the CSR bit for bit and only then takes the structured form (a layout hint:
+	// results never depend on it; include/lpp_engine.h, lpp_engine_set_model_*).  Whole-space matrices only.
+	static double partRe(double v) { return v; }
+	static double partIm(double) { return 0.0; }
+	static double partRe(const std::complex<double>& v) { return v.real(); }
+	static double partIm(const std::complex<double>& v) { return v.imag(); }
+	void describeModel(bool whole)
+	{
+		lppCheck(lpp_engine_set_model_tj(engine_.get(), 0, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0)); // forget an earlier one
+		if (!whole) return;
+		const int n = (int)model_->geometry().numberOfSites();
+		const typename BasisType::PairIntType parts = basis_.parts();
+		if (const TjMultiOrb<ComplexOrRealType>* tj = dynamic_cast<const TjMultiOrb<ComplexOrRealType>*>(model_)) {
+			std::vector<double> hr((size_t)n * n), hi((size_t)n * n);
+			bool cplx = false;
+			for (size_t k = 0; k < hr.size(); k++) {
+				hr[k] = partRe(tj->hoppings()[k]);
+				hi[k] = partIm(tj->hoppings()[k]);
+				cplx |= hi[k] != 0;
+			}
+			const std::vector<RealType>& pv = tj->potentialV;
+			lppCheck(lpp_engine_set_model_tj(engine_.get(), n, (int32_t)parts.first, (int32_t)parts.second, hr.data(), cplx ? hi.data() : nullptr, tj->jpm().data(),
+			                                 tj->jzz().data(), tj->w().data(), pv.size() >= (size_t)2 * n ? pv.data() : nullptr, pv.size() >= (size_t)2 * n ? (int32_t)pv.size() : 0));
+		} else if (const Heisenberg<ComplexOrRealType>* hs = dynamic_cast<const Heisenberg<ComplexOrRealType>*>(model_)) {
+			if (hs->twiceTheSpin() != 1 || !hs->anisotropy.empty() || sizeof(ComplexOrRealType) != sizeof(double)) return;
+			lppCheck(lpp_engine_set_model_heisenberg(engine_.get(), n, (int32_t)parts.second, hs->jpm().data(), hs->jzz().data(),
+			                                         hs->magneticField.empty() ? nullptr : hs->magneticField.data(), (int32_t)hs->magneticField.size()));
+		}
 	}
 	SpecialSymmetryType& rs_;
 	EngineHandle engine_;
 	const BasisType& basis_;
+	const ModelType* model_; // null when the basis is not the model's own (observables on N +- 1 sectors)
 	SizeType rows_, sector_;
 };
 

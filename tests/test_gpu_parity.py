@@ -1378,3 +1378,71 @@ def test_tj_hole_major_form(case, monkeypatch):
         e.assemble_tj(L, nup, ndown, hop, jpm, jzz, w, pv)
         assert e.layout()["kernel"] in (1, 2, 3)
         assert rel(e.matrixVectorProduct(x0.copy(), y), xg) < SPMV_TOL
+
+
+@pytest.mark.parametrize("case", ["chain_c128", "torus_f64"])
+def test_tj_csr_handed_over_with_its_model_description(case, monkeypatch):
+    """The reference's hand-over (lpp_engine_set_csr of the host-assembled matrix) with lpp_engine_set_model_tj in front of it: the engine
+    regenerates the matrix from the description, compares it with the CSR bit for bit and takes the hole-major form -- same layout, products
+    and energies as lpp_engine_assemble_tj, and lpp_engine_get_csr returns the uploaded bits.  One changed value in the CSR, or a description
+    that is not this matrix, keeps the general layout of the CSR as handed over (and computes with THAT matrix)."""
+    L, nup, ndown, hop, jpm, jzz, w, pv, dtype = TJ_CASES[case]()
+    cplx = dtype == "c128"
+    monkeypatch.setenv("LPP_TJ_LAYOUT", "1")
+    A = oracle.tj_csr(L, nup, ndown, hop, jpm, jzz, w, pv, force_complex=cplx)
+    x0, y = oracle.fill_random(A.nrows, 7, cplx), oracle.fill_random(A.nrows, 8, cplx)
+    xo = oracle.spmv_acc(A, x0.copy(), y)
+    eo, _, so = oracle.lanczos_solve(A, oracle.fill_random(A.nrows, 1234, cplx), nstates=1, want_vectors=False)
+    with LanczosEngine(dtype=dtype) as e:
+        e.set_model_tj(L, nup, ndown, hop, jpm, jzz, w, pv)
+        e.set_csr(A.rowptr, A.colind, A.values)
+        lay = e.layout()
+        assert lay["kernel"] == 5 and lay["nnz"] == A.nnz, lay
+        rp, ci, va = e.get_csr()
+        assert np.array_equal(rp, A.rowptr) and np.array_equal(ci, A.colind) and np.array_equal(_bits(va), _bits(A.values))
+        assert rel(e.matrixVectorProduct(x0.copy(), y), xo) < SPMV_TOL
+        eg, _, st = e.lanczos(1, want_vectors=False)
+        assert abs(eg[0] - eo[0]) <= E_TOL * abs(eo[0]) and st["steps"] == so
+        # the description is used for ONE matrix: the next plain upload is a plain upload
+        e.set_csr(A.rowptr, A.colind, A.values)
+        assert e.layout()["kernel"] in (1, 2, 3)
+        # a CSR that is not the described model's: one value changed
+        vals = A.values.copy()
+        k = int(A.rowptr[A.nrows // 2]) + 1
+        vals[k] = vals[k] * 1.5 + 0.25
+        B = oracle.Csr(A.rowptr, A.colind, vals)
+        e.set_model_tj(L, nup, ndown, hop, jpm, jzz, w, pv)
+        e.set_csr(B.rowptr, B.colind, B.values)
+        assert e.layout()["kernel"] in (1, 2, 3)
+        assert rel(e.matrixVectorProduct(x0.copy(), y), oracle.spmv_acc(B, x0.copy(), y)) < SPMV_TOL
+        # a description of another model (J doubled) with the right CSR: the CSR wins
+        e.set_model_tj(L, nup, ndown, hop, 2 * np.asarray(jpm), jzz, w, pv)
+        e.set_csr(A.rowptr, A.colind, A.values)
+        assert e.layout()["kernel"] in (1, 2, 3)
+        assert rel(e.matrixVectorProduct(x0.copy(), y), xo) < SPMV_TOL
+
+
+def test_heisenberg_chain_csr_handed_over_with_its_model_description(monkeypatch):
+    """The same for a spin chain: lpp_engine_set_model_heisenberg + lpp_engine_set_csr -> one block of the segmented form (no CSR kept)."""
+    monkeypatch.setenv("LPP_PRODUCT_LAYOUT", "1")
+    monkeypatch.setenv("LPP_PB_PIECE_ROWS", "256")
+    L, m = 16, 8
+    jpm, jzz, h = chain(L, 1.0, True), chain(L, 0.7, True), np.linspace(-0.3, 0.4, L)
+    A = oracle.heis_csr(L, 1, m, jpm, jzz, h)
+    x0, y = oracle.fill_random(A.nrows, 7), oracle.fill_random(A.nrows, 8)
+    xo = oracle.spmv_acc(A, x0.copy(), y)
+    eo, _, so = oracle.lanczos_solve(A, oracle.fill_random(A.nrows, 1234), nstates=1, want_vectors=False)
+    with LanczosEngine() as e:
+        e.set_model_heisenberg(L, m, jpm, jzz, h)
+        e.set_csr(A.rowptr, A.colind, A.values)
+        lay = e.layout()
+        assert lay["kernel"] == 4 and lay["segments"] == 64 and lay["nnz"] == A.nnz, lay
+        rp, ci, va = e.get_csr()
+        assert np.array_equal(rp, A.rowptr) and np.array_equal(ci, A.colind) and np.array_equal(_bits(va), _bits(A.values))
+        assert rel(e.matrixVectorProduct(x0.copy(), y), xo) < SPMV_TOL
+        eg, _, st = e.lanczos(1, want_vectors=False)
+        assert abs(eg[0] - eo[0]) <= E_TOL * abs(eo[0]) and st["steps"] == so
+        e.set_model_heisenberg(L, m, jpm, 1.25 * jzz, h)  # not this matrix: the CSR as handed over
+        e.set_csr(A.rowptr, A.colind, A.values)
+        assert e.layout()["kernel"] != 4
+        assert rel(e.matrixVectorProduct(x0.copy(), y), xo) < SPMV_TOL

@@ -178,3 +178,27 @@ def test_partitioned_driver_over_rccl_at_world_size_one(name):
     e0 = np.linalg.eigvalsh(A.to_scipy().toarray())[0]
     assert abs(e - e0) <= 1e-10 * abs(e0)
     assert "ranks=1" in res.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,env,marker", [
+    ("tj_chain_L12_complex.inp", {"LPP_TJ_LAYOUT": "1"}, "t-J hole-major form"),
+    ("heisenberg_chain_L16.inp", {"LPP_PRODUCT_LAYOUT": "1", "LPP_PB_PIECE_ROWS": "256"}, "chain layout against the assembler's row walk"),
+])
+def test_driver_describes_the_model_and_the_engine_takes_its_structured_form(name, env, marker):
+    """The reference's hand-over is a CSR (DefaultSymmetry.h:54-57 -> InternalProductStored.h:116).  Round 5: the shim also tells the engine which
+    model that CSR belongs to (lpp_engine_set_model_*); the engine regenerates the matrix from the description, finds it identical to the
+    handed-over one bit for bit, and holds the model without a stored matrix (t-J: hole-major form; spin chain: one block of the segmented
+    form).  Same `lanczos -f` command line, same energy line; the forms are forced onto these small inputs, LPP_VERBOSE says which one ran."""
+    exe = os.path.join(HOST, "lanczos")
+    res = subprocess.run([exe, "-f", os.path.join(GOLD, name), "-p", "12"], capture_output=True, text=True, timeout=300, env=dict(os.environ, LPP_VERBOSE="1", **env))
+    assert res.returncode == 0, res.stderr
+    assert "the model description regenerates the handed-over CSR" in res.stderr and marker in res.stderr, res.stderr[-3000:]
+    e = float(re.search(r"^Energy=(\S+)$", res.stdout, re.M).group(1))
+    A = _oracle_csr(os.path.join(GOLD, name))
+    eo, _, _ = oracle.lanczos_solve(A, oracle.fill_random(A.nrows, 1234, A.is_complex), want_vectors=False)
+    assert abs(e - eo[0]) <= 1e-10 * abs(eo[0])
+    # without the switch that forces the form onto a small input the same command takes the general layout: same line
+    res0 = subprocess.run([exe, "-f", os.path.join(GOLD, name), "-p", "12"], capture_output=True, text=True, timeout=300, env=dict(os.environ, LPP_VERBOSE="1"))
+    assert res0.returncode == 0 and marker not in res0.stderr
+    assert abs(float(re.search(r"^Energy=(\S+)$", res0.stdout, re.M).group(1)) - e) <= 1e-10 * abs(e)
