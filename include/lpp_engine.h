@@ -350,6 +350,15 @@ lpp_status lpp_pb_pack_template(int64_t rows, int64_t pitch, const int64_t* rowp
  * perm (rows int32, may be NULL): stored position -> basis index. */
 lpp_status lpp_pb_seg_plan_stats(int64_t rows, const int64_t* rowptr, const int32_t* colind, const double* values, int32_t wcap, int64_t* out, int32_t* perm);
 
+/* The t-J model's hole-major form, host part (ABI 5; exposed for the CPU test-suite): plans the form from (sites, sector, hoppings, J+-) -- hole
+ * configurations, spin patterns and their ranking, work items, every configuration's bonds and moves (csrc/lpp_tj.h) -- and, given a CSR of the
+ * model in the reference's basis order (BasisTjMultiOrbLanczos.h:29-42), expands the plan again exactly as the kernel walks it and compares it
+ * with the CSR's off-diagonal entries, columns and value bits (the diagonal comes from the device assembler, not from the plan).
+ * out[0] = 1 if the plan applies (and reproduces every row when a CSR is given; rowptr NULL: statistics only), out[1..9] = hole configurations,
+ * spin patterns, low positions of a segment, work items, bonds, moves, bonds among the low positions, most bonds / moves of one configuration. */
+lpp_status lpp_tj_plan_stats(int32_t nsites, int32_t nup, int32_t ndown, const double* hop_re, const double* hop_im, const double* jpm, int64_t nrows,
+                             const int64_t* rowptr, const int32_t* colind, const void* values, int32_t is_complex, int64_t* out);
+
 #ifdef __cplusplus
 }
 #endif

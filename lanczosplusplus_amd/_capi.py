@@ -112,6 +112,7 @@ SYMBOLS = {
     "lpp_pb_pack_template": (C.c_int32, [C.c_int64, C.c_int64, _P, _P, _P, C.POINTER(C.c_int32), _P, C.POINTER(C.c_int32),
                                          C.POINTER(C.c_int64), _P, _P, _P, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int32]),
     "lpp_pb_seg_plan_stats": (C.c_int32, [C.c_int64, _P, _P, _P, C.c_int32, _P, _P]),
+    "lpp_tj_plan_stats": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, C.c_int64, _P, _P, _P, C.c_int32, _P]),
 }
 
 _lib = None

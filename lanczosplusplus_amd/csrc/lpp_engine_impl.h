@@ -10,6 +10,7 @@
 #include "lpp_kernels.h"
 #include "lpp_pb_kernels.h"
 #include "lpp_pbig_kernels.h"
+#include "lpp_tj.h"
 
 #define HIP_TRY(expr)                                                                                                  \
 	do {                                                                                                               \
@@ -200,11 +201,6 @@ struct PbState {
 };
 
 // one-orbital t-J Hamiltonian without a stored matrix, hole-major order (lpp_tj_kernels.h)
-struct TjModel { // host copy of what lpp_engine_assemble_tj was given: lpp_engine_get_csr re-runs the device assembler from it
-	int L = 0, nup = 0, ndown = 0, npot = 0;
-	bool has_im = false, has_pv = false;
-	std::vector<double> hop_re, hop_im, jpm, jzz, w, pv;
-};
 struct TjState {
 	bool active = false;
 	TjModel model;

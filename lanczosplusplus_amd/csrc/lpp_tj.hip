@@ -268,108 +268,29 @@ lpp_status tj_build(lpp_engine* e, const TjModel& M, const AsmParams& P, bool* d
 	const int L = M.L, nup = M.nup, ndown = M.ndown, Lo = nup + ndown, nholes = L - Lo;
 	const uint64_t ns64 = binom_h(Lo, nup), nblk64 = binom_h(L, nholes);
 	const int ns = (int)ns64, nblk = (int)nblk64;
-	const int lb = Lo / 2, hb = Lo - lb;
 	hipStream_t st = e->stream;
-	// ---- spin patterns and their ranking -----------------------------------------------------------------------------------------
-	const std::vector<uint32_t> pat = words_of(Lo, nup);
-	if ((int)pat.size() != ns) return fail(LPP_ERR_INVALID, "tj_build: pattern count");
-	std::vector<int32_t> hi_base((size_t)1 << hb, 0);
-	std::vector<uint16_t> lo_rank((size_t)1 << lb, 0);
+	// the plan (host, no device work: lpp_tj_host.cpp): spin patterns and their ranking, work items, every hole configuration's bonds and moves
+	TjPlan PL;
 	{
-		int64_t run = 0;
-		for (uint32_t h = 0; h < (1u << hb); h++) {
-			hi_base[h] = (int32_t)std::min<int64_t>(run, ns - 1);
-			run += (int64_t)binom_h(lb, nup - __builtin_popcount(h));
-		}
-		std::vector<int> seen((size_t)lb + 1, 0);
-		for (uint32_t l = 0; l < (1u << lb); l++) lo_rank[l] = (uint16_t)seen[(size_t)__builtin_popcount(l)]++;
-	}
-	// ---- work items: runs of whole segments (patterns sharing the bits above the low kbits), at most kTjWindow patterns ----------------
-	int kbits = 1;
-	for (int k = 1; k <= Lo; k++) {
-		uint64_t longest = 0;
-		for (int m = std::max(0, nup - (Lo - k)); m <= std::min(k, nup); m++) longest = std::max(longest, binom_h(k, m));
-		if (longest <= (uint64_t)kTjWindow) kbits = k;
-	}
-	std::vector<TjItem> items;
-	{
-		int64_t r0 = 0;
-		TjItem cur { 0, 0 };
-		for (uint32_t t = 0; t < (1u << (Lo - kbits)); t++) {
-			const int len = (int)binom_h(kbits, nup - __builtin_popcount(t));
-			if (len == 0) continue;
-			if (cur.len > 0 && cur.len + len > kTjWindow) {
-				items.push_back(cur);
-				cur = TjItem { (int32_t)r0, 0 };
-			}
-			if (cur.len == 0) cur.r0 = (int32_t)r0;
-			cur.len += len;
-			r0 += len;
-		}
-		if (cur.len > 0) items.push_back(cur);
-		if (r0 != ns) return fail(LPP_ERR_INVALID, "tj_build: segments do not add up");
-	}
-	// ---- hole configurations: bonds among the occupied sites, moves of an electron onto a neighbouring hole ------------------------
-	const std::vector<uint32_t> holes = words_of(L, nholes);
-	if ((int)holes.size() != nblk) return fail(LPP_ERR_INVALID, "tj_build: block count");
-	auto block_of = [&](uint32_t hm) -> int { return (int)(std::lower_bound(holes.begin(), holes.end(), hm) - holes.begin()); };
-	std::vector<TjBlock> blocks((size_t)nblk);
-	std::vector<TjPair> pairs;
-	std::vector<TjHop> hops;
-	bool cplx_hops = false;
-	for (int b = 0; b < nblk; b++) {
-		const uint32_t hm = holes[(size_t)b];
-		int pos[32];
-		int np = 0;
-		for (int i = 0; i < L; i++) pos[i] = ((hm >> i) & 1u) ? -1 : np++;
-		TjBlock B {};
-		B.x_first = (int32_t)pairs.size();
-		B.h_first = (int32_t)hops.size();
-		for (int i = 0; i < L; i++)
-			for (int j = i + 1; j < L; j++) { // the reference visits j >= i only (TjMultiOrb.h:666, 725)
-				const double jv = M.jpm[(size_t)i * L + j];
-				if (jv != 0 && pos[i] >= 0 && pos[j] >= 0) {
-					TjPair pr;
-					pr.mask = (1u << pos[i]) | (1u << pos[j]);
-					pr.pad = 0;
-					const double h = jv * 0.5; // :736
-					pr.v = ((pos[j] - pos[i]) & 1) ? -h : h; // signSplusSminus (:772-783): the electrons on the sites [i, j) of the bra
-					pairs.push_back(pr);
-				}
-				const double hr = M.hop_re[(size_t)i * L + j], hi = M.has_im ? M.hop_im[(size_t)i * L + j] : 0.0;
-				if (hr == 0 && hi == 0) continue;
-				if ((pos[i] >= 0) == (pos[j] >= 0)) continue; // one electron, one hole (:673, :683: the guards against double occupancy)
-				int between = 0;
-				for (int c = i + 1; c < j; c++) between += pos[c] >= 0 ? 1 : 0;
-				TjHop hp;
-				hp.vr = hr;
-				hp.vi = hi;
-				hp.m = (uint8_t)between;
-				hp.pad = 0;
-				if (pos[i] >= 0) { // the electron at i moves up to the hole at j
-					hp.dir = 0;
-					hp.lo = (uint8_t)pos[i];
-					hp.dst = block_of((hm & ~(1u << j)) | (1u << i));
-				} else { // the electron at j moves down to the hole at i
-					hp.dir = 1;
-					hp.lo = (uint8_t)(pos[j] - between);
-					hp.dst = block_of((hm & ~(1u << i)) | (1u << j));
-				}
-				if (hi != 0) cplx_hops = true;
-				hops.push_back(hp);
-			}
-		const int nxb = (int)pairs.size() - B.x_first, nhb = (int)hops.size() - B.h_first;
-		if (nxb > kTjMaxPairs || nhb > kTjMaxHops) {
-			if (verbose) fprintf(stderr, "lpp: t-J hole-major form does not apply: %d bonds / %d moves in one hole configuration\n", nxb, nhb);
+		bool planned = false;
+		std::string why;
+		tj_plan(M, PL, &planned, &why);
+		if (!planned) {
+			if (verbose) fprintf(stderr, "lpp: t-J hole-major form does not apply: %s\n", why.c_str());
 			return LPP_OK;
 		}
-		// bonds among the low kbits positions first: their flips stay inside a segment (LDS reads of the item's window)
-		const auto low_end = std::stable_partition(pairs.begin() + B.x_first, pairs.end(), [&](const TjPair& q) { return q.mask < (1u << kbits); });
-		B.nx = (int16_t)nxb;
-		B.nxl = (int16_t)(low_end - (pairs.begin() + B.x_first));
-		B.nh = (int16_t)nhb;
-		blocks[(size_t)b] = B;
 	}
+	if (PL.ns != ns || PL.nblk != nblk) return fail(LPP_ERR_INVALID, "tj_build: plan of another size");
+	const int lb = PL.lb, hb = PL.hb, kbits = PL.kbits;
+	const std::vector<uint32_t>& pat = PL.pat;
+	const std::vector<uint32_t>& holes = PL.holes;
+	const std::vector<int32_t>& hi_base = PL.hi_base;
+	const std::vector<uint16_t>& lo_rank = PL.lo_rank;
+	const std::vector<TjItem>& items = PL.items;
+	const std::vector<TjBlock>& blocks = PL.blocks;
+	const std::vector<TjPair>& pairs = PL.pairs;
+	const std::vector<TjHop>& hops = PL.hops;
+	const bool cplx_hops = PL.cplx_hops;
 	if (cplx_hops && !e->is_complex) return LPP_OK;
 	// processing order of the blocks: ascending hole words (neighbouring configurations share most of their hop sources)
 	std::vector<int32_t> order((size_t)nblk);

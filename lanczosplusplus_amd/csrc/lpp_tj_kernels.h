@@ -23,40 +23,9 @@
 // TjState::perm); lpp_engine_get_csr re-runs the device assembler in the reference's order.
 #pragma once
 #include "lpp_kernels.h"
+#include "lpp_tj.h"
 
 namespace lpp {
-
-constexpr int kTjMaxPairs = 96; // bonds with both sites occupied, per hole configuration
-constexpr int kTjMaxHops = 64; // (electron, neighbouring hole) moves per hole configuration
-constexpr int kTjThreads = 256;
-#ifndef LPP_TJ_ROWS
-#define LPP_TJ_ROWS 2
-#endif
-#ifndef LPP_TJ_WINDOW
-#define LPP_TJ_WINDOW 1024
-#endif
-constexpr int kTjRowsPerThread = LPP_TJ_ROWS; // rows of a thread per round (their gathers are in flight together)
-constexpr int kTjWindow = LPP_TJ_WINDOW; // patterns of one work item at most: its run of the vector is staged in LDS
-constexpr int kTjMaxHalf = 12; // bits of a half pattern (rank tables in LDS: 4096 x (4 + 2) bytes at most)
-
-struct TjPair { // 16 bytes
-	uint32_t mask; // bit p | bit q (compressed positions)
-	uint32_t pad;
-	double v; // 0.5 J(i,j) (-1)^(q - p)
-};
-struct TjHop { // 24 bytes
-	int32_t dst; // block of the bra
-	uint8_t lo, m, dir, pad; // bits [lo, lo + m] of sigma rotate: dir 0 the electron sits at lo and moves to lo + m, dir 1 it sits at lo + m and moves to lo
-	double vr, vi;
-};
-struct TjBlock { // 16 bytes
-	int32_t x_first, h_first;
-	int16_t nx, nxl; // bonds; of these the first nxl have both positions among the low kbits of the pattern
-	int16_t nh, pad;
-};
-struct TjItem { // a run of whole segments (patterns sharing the bits above the low kbits): a flip among the low bits stays inside
-	int32_t r0, len;
-};
 
 struct TjArgs {
 	const uint32_t* pat; // [ns] spin patterns, ascending

@@ -322,3 +322,63 @@ def test_segmented_in_block_form_reproduces_the_hopping_matrix():
     assert o[0] == 1 and (o[1], o[2]) == (12, 6)
     H = oracle.heis_csr(12, 1, 6, square(2, 6, 1.0, False), square(2, 6, 1.0, False))
     assert plan(H, 256)[0][0] == 0
+
+
+def test_tj_hole_major_plan_reproduces_the_oracle_matrix():
+    """lpp_tj_plan_stats (host part of k_tj_apply, csrc/lpp_tj.h, lpp_tj_host.cpp): the one-orbital t-J model planned in its hole-major form --
+    hole configurations x spin patterns of the occupied sites, per configuration the bonds whose S+S- flips an antiparallel pair (value
+    0.5 J (-1)^(q-p), TjMultiOrb.h:697-783) and the moves of an electron onto a neighbouring hole (a rotation of the pattern's bits between the
+    two sites, sign of the same-species electrons between, :649-695).  The library expands the plan again exactly as the kernel walks it and
+    compares it with the oracle's restatement of TjMultiOrb::setupHamiltonian in the REFERENCE's basis order (sorted (down << L) | up words):
+    every off-diagonal entry, column and value bits.  A CSR of another model is refused."""
+    import ctypes as C
+    import oracle
+    from helpers import chain, square
+    from math import comb
+    Lib = _capi.lib()
+
+    def vp(a):
+        return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+    def plan(L, nup, ndown, hop, jpm, A):
+        hop = np.asarray(hop)
+        hr = np.ascontiguousarray(hop.real, np.float64)
+        hi = np.ascontiguousarray(hop.imag, np.float64) if np.iscomplexobj(hop) else None
+        jp = np.ascontiguousarray(jpm, np.float64)
+        out = (C.c_int64 * 10)()
+        if A is None:
+            _capi.check(Lib.lpp_tj_plan_stats(L, nup, ndown, vp(hr), vp(hi), vp(jp), 0, None, None, None, 0, out))
+        else:
+            _capi.check(Lib.lpp_tj_plan_stats(L, nup, ndown, vp(hr), vp(hi), vp(jp), A.nrows, vp(A.rowptr), vp(A.colind), vp(A.values), int(A.is_complex), out))
+        return list(out)
+
+    torus_j = square(3, 4, 0.4, pbc=True) * (1 + 0.25 * np.triu(np.ones((12, 12)), 3) + 0.25 * np.tril(np.ones((12, 12)), -3))
+    cases = [  # (L, nup, ndown, hop, jpm, jzz, w, potentialV, complex engine)
+        (12, 5, 5, chain(12, -1.0), chain(12, 0.4), chain(12, 0.4), chain(12, -0.1), None, True),  # two holes, open chain
+        (12, 5, 4, square(3, 4, -1.0, pbc=True), torus_j, square(3, 4, 0.3, pbc=True), square(3, 4, -0.1, pbc=True), np.linspace(-0.2, 0.3, 24), False),  # torus, three holes, unequal bonds
+        (10, 5, 4, chain(10, -1.0, True) * np.exp(0.3j), chain(10, 0.5, True), chain(10, 0.5, True), chain(10, -0.125, True), None, True),  # complex hoppings, one hole
+        (9, 3, 4, square(3, 3, -1.0, pbc=True), square(3, 3, 0.4, pbc=True), square(3, 3, 0.3, pbc=True), square(3, 3, -0.1, pbc=True), None, False),  # odd lattice, two holes
+        (12, 6, 6, chain(12, -1.0, True), chain(12, 0.4, True), chain(12, 0.4, True), chain(12, -0.1, True), None, False),  # no holes: one block
+        (12, 4, 4, square(3, 4, -1.0, pbc=True), square(3, 4, 0.4, pbc=True), square(3, 4, 0.4, pbc=True), square(3, 4, -0.1, pbc=True), None, True),  # four holes
+    ]
+    for L, nup, ndown, hop, jpm, jzz, w, pv, cplx in cases:
+        A = oracle.tj_csr(L, nup, ndown, hop, jpm, jzz, w, pv, force_complex=cplx)
+        o = plan(L, nup, ndown, hop, jpm, A)
+        nholes = L - nup - ndown
+        assert o[0] == 1, (L, nup, ndown, o)
+        assert (o[1], o[2]) == (comb(L, nholes), comb(nup + ndown, nup)) and o[1] * o[2] == A.nrows
+        assert o[3] == min(nup + ndown, 12) or o[3] < nup + ndown  # low positions of a segment: as many as fit a window of 1024 patterns
+        assert o[7] <= o[5] and o[8] <= 96 and o[9] <= 64
+        # off-diagonal entries of the CSR = flips of the antiparallel settings of every bond + one entry per move and pattern
+        assert A.nnz - A.nrows == o[5] * 2 * comb(nup + ndown - 2, nup - 1) + o[6] * o[2]
+    # BASELINE config 4 (4x5 torus, 9 up 9 down): 190 configurations x 48620 patterns in 61 items, segments of the low 12 positions; statistics only
+    o = plan(20, 9, 9, square(5, 4, -1.0, pbc=True), square(5, 4, 0.4, pbc=True), None)
+    assert o[:7] == [1, 190, 48620, 12, 61, 6120, 1440] and (o[8], o[9]) == (33, 8), o
+    # not this model: another J, a changed entry
+    L, nup, ndown, hop, jpm, jzz, w, pv, cplx = cases[0]
+    A = oracle.tj_csr(L, nup, ndown, hop, jpm, jzz, w, pv, force_complex=cplx)
+    assert plan(L, nup, ndown, hop, 2 * jpm, A)[0] == 0
+    vals = A.values.copy()
+    k = int(A.rowptr[100]) + (0 if A.colind[A.rowptr[100]] != 100 else 1)
+    vals[k] = -vals[k]
+    assert plan(L, nup, ndown, hop, jpm, oracle.Csr(A.rowptr, A.colind, vals))[0] == 0
