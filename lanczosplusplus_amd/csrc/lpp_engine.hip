@@ -485,10 +485,26 @@ template <typename T> static lpp_status build_sliced_t(lpp_engine* e, DevCsr& A,
 	} else {
 		HIP_TRY_MEM(hipMalloc(&A.sval, sizeof(T) * (size_t)(nz + 64)));
 		HIP_TRY(hipMemsetAsync((T*)A.sval + nz, 0, sizeof(T) * 64, e->stream));
+		// plain values, window kernel, no shared-offset split: the entries that leave a row's block go into the row's first slots, so that
+		// every 512-byte run of the source vector is gathered by one load (k_slice_fill); needs rows sorted by column
+		bool outs = for_window && !l16 && rp == A.rowptr && g.nblocks >= 2 && nz > 0 && !(getenv("LPP_OUTS_FIRST") && atoi(getenv("LPP_OUTS_FIRST")) == 0);
+		if (outs && !A.known_sorted) {
+			int* unsorted = nullptr;
+			HIP_TRY_MEM(hipMalloc(&unsorted, sizeof(int)));
+			(void)hipMemsetAsync(unsorted, 0, sizeof(int), e->stream);
+			k_rows_sorted<<<(int)((A.nrows + 255) / 256), 256, 0, e->stream>>>(A.nrows, A.rowptr, A.col, unsorted);
+			int bad = 1;
+			hipError_t e1 = hipMemcpyAsync(&bad, unsorted, sizeof(int), hipMemcpyDeviceToHost, e->stream);
+			hipError_t e2 = hipStreamSynchronize(e->stream);
+			(void)hipFree(unsorted);
+			if (e1 != hipSuccess || e2 != hipSuccess) return fail(LPP_ERR_HIP, "row order check failed");
+			outs = bad == 0;
+		}
+		A.outs_first = outs;
 		if (l16)
 			k_slice_fill<T, false, true><<<nb2, kBlock, 0, e->stream>>>(g, rp, cc, vv, A.scol, (T*)A.sval);
 		else
-			k_slice_fill<T, false><<<nb2, kBlock, 0, e->stream>>>(g, rp, cc, vv, A.scol, (T*)A.sval);
+			k_slice_fill<T, false><<<nb2, kBlock, 0, e->stream>>>(g, rp, cc, vv, A.scol, (T*)A.sval, 0, outs ? 1 : 0);
 	}
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipStreamSynchronize(e->stream));
@@ -947,7 +963,7 @@ template <typename T> static lpp_status rebuild_csr_t(lpp_engine* e, const DevCs
 	if (A.local16)
 		k_slice_fill<T, true, true><<<nb2, kBlock, 0, e->stream>>>(A.geom, rp, A.scol, (const T*)A.sval, (int32_t*)tcol.p, plain_vals, A.tmpl ? 1 : 0);
 	else
-		k_slice_fill<T, true><<<nb2, kBlock, 0, e->stream>>>(A.geom, rp, A.scol, (const T*)A.sval, (int32_t*)tcol.p, plain_vals);
+		k_slice_fill<T, true><<<nb2, kBlock, 0, e->stream>>>(A.geom, rp, A.scol, (const T*)A.sval, (int32_t*)tcol.p, plain_vals, 0, A.outs_first ? 1 : 0);
 	if (A.coded) k_slice_decode<T><<<nb2, kBlock, 0, e->stream>>>(A.geom, rp, A.codes, A.code_ptr, A.dict, (T*)tval.p, A.tmpl == 2 ? 1 : 0);
 	if (A.rrowptr) {
 		DevScratch fcol, fval;

@@ -32,11 +32,18 @@ static __global__ void k_slice_meta(SliceGeom g, const int64_t* __restrict__ row
 // one wave per slice: scatter CSR entries into slot-major compact order (INVERSE: back to CSR order)
 // L16: the sliced side holds 16-bit window-local columns (column - first row of the row block)
 // tmpl (INVERSE only): the sliced column stream holds block 0 only (block-periodic structure)
+// outs_first (plain format, window kernel, rows sorted by column; round 5): a row's entries that LEAVE its row block are stored in its
+// first slots -- those below the block, then those above it --, the entries inside the block behind them.  In a product basis all rows of a
+// block leave it the same way (the same down-hops), but in column order the entries above the block sit behind a row's in-block entries,
+// whose number differs from row to row: a slot of the slice then gathers pieces of several 512-byte runs, each run is asked for by up to 7
+// slots ~1 us apart, and the matrix stream renews an XCD's L2 every ~6 us -- 37.7 GB of fabric reads for 22.6 GB of gathered elements at
+// BASELINE config 2 (timing-only build without the gathers: 75.3 instead of 113.0 GB).  With the leaving entries first every run is asked
+// for by ONE load.  Same 12 bytes per entry; the CSR order is restored from the column values (below / inside / above the block).
 template <typename T, bool INVERSE, bool L16 = false>
 __global__ __launch_bounds__(kBlock) void k_slice_fill(SliceGeom g, const int64_t* __restrict__ rowptr,
                                                         const int32_t* __restrict__ col_in,
                                                         const T* __restrict__ val_in, int32_t* __restrict__ col_out,
-                                                        T* __restrict__ val_out, int tmpl = 0)
+                                                        T* __restrict__ val_out, int tmpl = 0, int outs_first = 0)
 {
 	const int lane = threadIdx.x & 63;
 	const int64_t wave0 = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
@@ -58,21 +65,48 @@ __global__ __launch_bounds__(kBlock) void k_slice_fill(SliceGeom g, const int64_
 		int maxlen = len;
 #pragma unroll
 		for (int off = 32; off > 0; off >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, off, 64));
+		// outs_first: entries of this row below / above its row block (rows sorted by column: the CSR order is below, inside, above)
+		int nlo = 0, nhi = 0;
+		if (outs_first && !L16) { // wave-uniform
+			const int64_t w0 = (s / g.spb) * g.B, w1 = w0 + g.B;
+			if (!INVERSE) {
+				for (int k = 0; k < len; k++) {
+					const int64_t c = col_in[p0 + k];
+					nlo += c < w0 ? 1 : 0;
+					nhi += c >= w1 ? 1 : 0;
+				}
+			} else {
+				int64_t b2 = base;
+				for (int k = 0; k < maxlen; k++) {
+					const bool on = len > k;
+					const unsigned long long m = __ballot(on);
+					if (on) {
+						const int64_t c = col_in[b2 + __popcll(m & ((1ull << lane) - 1ull))];
+						nlo += c < w0 ? 1 : 0;
+						nhi += c >= w1 ? 1 : 0;
+					}
+					b2 += __popcll(m);
+				}
+			}
+		}
+		const int nin = len - nlo - nhi;
 		for (int k = 0; k < maxlen; k++) {
 			const bool on = len > k;
 			const unsigned long long m = __ballot(on);
 			const int pos = __popcll(m & ((1ull << lane) - 1ull));
 			if (on) {
 				const int32_t r0 = L16 ? (int32_t)((s / g.spb) * g.B) : 0;
+				// slot k of the row holds CSR entry ek (stored order with outs_first: below the block, above it, inside it)
+				const int ek = (!outs_first || L16 || k < nlo) ? k : (k < nlo + nhi ? nlo + nin + (k - nlo) : nlo + (k - nlo - nhi));
 				if (INVERSE) {
-					col_out[p0 + k] = L16 ? (int32_t)((const uint16_t*)col_in)[base + cshift + pos] + r0 : col_in[base + cshift + pos];
-					if (val_out) val_out[p0 + k] = val_in[base + pos];
+					col_out[p0 + ek] = L16 ? (int32_t)((const uint16_t*)col_in)[base + cshift + pos] + r0 : col_in[base + cshift + pos];
+					if (val_out) val_out[p0 + ek] = val_in[base + pos];
 				} else {
 					if (L16)
-						((uint16_t*)col_out)[base + pos] = (uint16_t)(col_in[p0 + k] - r0);
+						((uint16_t*)col_out)[base + pos] = (uint16_t)(col_in[p0 + ek] - r0);
 					else
-						col_out[base + pos] = col_in[p0 + k];
-					if (val_out) val_out[base + pos] = val_in[p0 + k];
+						col_out[base + pos] = col_in[p0 + ek];
+					if (val_out) val_out[base + pos] = val_in[p0 + ek];
 				}
 			}
 			base += __popcll(m);

@@ -259,6 +259,9 @@ __device__ __forceinline__ T sliced_accumulate(const SlicedArgs<T>& a, int len, 
 		const unsigned long long m_ = __ballot(on_);                                                                  \
 		const uint32_t p_ = run + (on_ ? lane_prefix(m_) : 0u);                                                       \
 		C[u] = LOCAL16 ? (int32_t)ld_off32(colp16, p_) : (nt_ ? ld_off32_nt(colp, p_) : ld_off32(colp, p_));          \
+		/* lanes past their row's end read the window's first element instead of whatever column the stream holds there: the slots   */ \
+		/* behind a slice's longest row (up to U - 1 per slice) gathered a line of the source vector each, 2.3 GB per product at config 2 */ \
+		if (WINDOW && !LOCAL16) C[u] = on_ ? C[u] : r0;                                                                 \
 		if (!CODED) {                                                                                                 \
 			const T t_ = nt_ ? ld_off32_nt(valp, p_) : ld_off32(valp, p_);                                            \
 			V[u] = on_ ? t_ : VT<T>::zero();                                                                          \
@@ -429,7 +432,7 @@ __device__ __forceinline__ double sliced_one(const SlicedArgs<T>& a, int64_t row
 	// long before the epilogue needs them
 	const T xold = a.x[xrow];
 	T yv = VT<T>::zero();
-	if (DOT) yv = a.ydot[xrow];
+	if (DOT) yv = a.ydot[xrow]; // (taking it from the LDS window when ydot is the source vector measured slower: 18.1-18.9 against 16.9-18.4 ms on the plain-format leg)
 	uint32_t dc = 0; // code(s) of the diagonal value, when it travels apart from the per-row entries
 	if (CODED && a.dcode) dc = sizeof(T) == 16 ? (uint32_t)((const uint16_t*)a.dcode)[row] : (uint32_t)a.dcode[row];
 	DiaPre<T> pre;
