@@ -115,6 +115,7 @@ template <typename T> static int spmv_launch_t(lpp_engine* e, const DevCsr& A, c
 		a.tw_off = A.tw_off;
 		a.tw_len = A.tw_len;
 		a.rowmap = nullptr;
+		a.pad = A.pad;
 		const bool dot = partial != nullptr;
 		const bool u8 = (e->k2_variant & 4) != 0;
 		const int sel = (dot ? 4 : 0) | (A.coded ? 2 : 0) | (u8 ? 1 : 0);
@@ -501,10 +502,29 @@ template <typename T> static lpp_status build_sliced_t(lpp_engine* e, DevCsr& A,
 			outs = bad == 0;
 		}
 		A.outs_first = outs;
+		// ... and the vectors pitched to 128-byte lines per row block (whole matrix on one GPU, real, blocks not line-aligned by themselves, from
+		// 256 MB per vector on): the runs gathered from other blocks then start on a line -- 4 lines per run instead of 4.9 at config 2
+		// (N_up = 12870 = 6 mod 16).  LPP_PITCH_ROWS=0/1: never / wherever it applies.
+		int pad = 0;
+		{
+			const int64_t line = 128 / (int64_t)sizeof(T);
+			bool want = (size_t)A.nrows * sizeof(T) >= ((size_t)256 << 20);
+			if (const char* sp = getenv("LPP_PITCH_ROWS")) want = atoi(sp) != 0;
+			const int64_t pitched = (g.B + line - 1) / line * line;
+			if (outs && want && &A == &e->A_loc && !e->has_comm && !e->is_complex && A.src_elems == 0 && g.nrows == g.nblocks * g.B && g.B % line != 0
+			    && pitched * g.nblocks < ((int64_t)1 << 31) && (size_t)(pitched * g.nblocks) * sizeof(T) < ((size_t)1 << 32))
+				pad = (int)(pitched - g.B);
+		}
+		A.pad = pad;
+		if (pad) {
+			e->pitch = g.B + pad;
+			e->pitch_rows = g.B;
+			e->pitch_blocks = g.nblocks;
+		}
 		if (l16)
 			k_slice_fill<T, false, true><<<nb2, kBlock, 0, e->stream>>>(g, rp, cc, vv, A.scol, (T*)A.sval);
 		else
-			k_slice_fill<T, false><<<nb2, kBlock, 0, e->stream>>>(g, rp, cc, vv, A.scol, (T*)A.sval, 0, outs ? 1 : 0);
+			k_slice_fill<T, false><<<nb2, kBlock, 0, e->stream>>>(g, rp, cc, vv, A.scol, (T*)A.sval, 0, outs ? 1 : 0, pad);
 	}
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipStreamSynchronize(e->stream));
@@ -963,7 +983,7 @@ template <typename T> static lpp_status rebuild_csr_t(lpp_engine* e, const DevCs
 	if (A.local16)
 		k_slice_fill<T, true, true><<<nb2, kBlock, 0, e->stream>>>(A.geom, rp, A.scol, (const T*)A.sval, (int32_t*)tcol.p, plain_vals, A.tmpl ? 1 : 0);
 	else
-		k_slice_fill<T, true><<<nb2, kBlock, 0, e->stream>>>(A.geom, rp, A.scol, (const T*)A.sval, (int32_t*)tcol.p, plain_vals, 0, A.outs_first ? 1 : 0);
+		k_slice_fill<T, true><<<nb2, kBlock, 0, e->stream>>>(A.geom, rp, A.scol, (const T*)A.sval, (int32_t*)tcol.p, plain_vals, 0, A.outs_first ? 1 : 0, A.pad);
 	if (A.coded) k_slice_decode<T><<<nb2, kBlock, 0, e->stream>>>(A.geom, rp, A.codes, A.code_ptr, A.dict, (T*)tval.p, A.tmpl == 2 ? 1 : 0);
 	if (A.rrowptr) {
 		DevScratch fcol, fval;

@@ -46,6 +46,7 @@ struct DevCsr {
 	int64_t code_words = 0; // 32-bit words in `codes`
 	bool local16 = false; // scol holds 16-bit window-local columns (window kernel, every per-row entry inside its block)
 	bool outs_first = false; // plain format, window kernel: a row's entries that leave its row block are stored in its first slots (k_slice_fill)
+	int pad = 0; // ... and the vectors are pitched: row block b starts at element b * (geom.B + pad), the stored columns are pitched positions
 	int64_t hint_block = 0; // natural row block of the basis (N_up), 0 = unknown
 	int64_t src_elems = 0; // length of the vector the columns index (0 = nrows)
 	SliceGeom geom {};

@@ -43,8 +43,9 @@ template <typename T, bool INVERSE, bool L16 = false>
 __global__ __launch_bounds__(kBlock) void k_slice_fill(SliceGeom g, const int64_t* __restrict__ rowptr,
                                                         const int32_t* __restrict__ col_in,
                                                         const T* __restrict__ val_in, int32_t* __restrict__ col_out,
-                                                        T* __restrict__ val_out, int tmpl = 0, int outs_first = 0)
+                                                        T* __restrict__ val_out, int tmpl = 0, int outs_first = 0, int pad = 0)
 {
+	// pad (with outs_first only): the sliced side holds PITCHED columns -- column c of row block c / B sits at c + (c / B) * pad
 	const int lane = threadIdx.x & 63;
 	const int64_t wave0 = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
 	const int64_t nwaves = (int64_t)gridDim.x * (kBlock / 64);
@@ -68,7 +69,7 @@ __global__ __launch_bounds__(kBlock) void k_slice_fill(SliceGeom g, const int64_
 		// outs_first: entries of this row below / above its row block (rows sorted by column: the CSR order is below, inside, above)
 		int nlo = 0, nhi = 0;
 		if (outs_first && !L16) { // wave-uniform
-			const int64_t w0 = (s / g.spb) * g.B, w1 = w0 + g.B;
+			const int64_t w0 = (s / g.spb) * (g.B + (INVERSE ? pad : 0)), w1 = w0 + g.B; // (the sliced side's columns are pitched)
 			if (!INVERSE) {
 				for (int k = 0; k < len; k++) {
 					const int64_t c = col_in[p0 + k];
@@ -99,13 +100,15 @@ __global__ __launch_bounds__(kBlock) void k_slice_fill(SliceGeom g, const int64_
 				// slot k of the row holds CSR entry ek (stored order with outs_first: below the block, above it, inside it)
 				const int ek = (!outs_first || L16 || k < nlo) ? k : (k < nlo + nhi ? nlo + nin + (k - nlo) : nlo + (k - nlo - nhi));
 				if (INVERSE) {
-					col_out[p0 + ek] = L16 ? (int32_t)((const uint16_t*)col_in)[base + cshift + pos] + r0 : col_in[base + cshift + pos];
+					int32_t c = L16 ? (int32_t)((const uint16_t*)col_in)[base + cshift + pos] + r0 : col_in[base + cshift + pos];
+					if (pad && !L16) c -= (int32_t)(c / (g.B + pad)) * pad;
+					col_out[p0 + ek] = c;
 					if (val_out) val_out[p0 + ek] = val_in[base + pos];
 				} else {
 					if (L16)
 						((uint16_t*)col_out)[base + pos] = (uint16_t)(col_in[p0 + ek] - r0);
 					else
-						col_out[base + pos] = col_in[p0 + ek];
+						col_out[base + pos] = pad ? col_in[p0 + ek] + (int32_t)(col_in[p0 + ek] / g.B) * pad : col_in[p0 + ek];
 					if (val_out) val_out[base + pos] = val_in[p0 + ek];
 				}
 			}

@@ -162,6 +162,10 @@ template <typename T> struct SlicedArgs {
 	// rows of this matrix are a reordering of the vector's rows (split-panel layout, k_split_count): x and ydot of row r live at
 	// rowmap[r].  null: identity.  Only with plain per-row entries (no shared offsets, no diagonal codes).
 	const int32_t* rowmap;
+	// plain-format window layout with PITCHED vectors (round 5): row block b of the vectors starts at element b * (g.B + pad), so that the
+	// 512-byte runs the slices gather from other blocks start on 128-byte lines; the stored columns are pitched positions.  0: contiguous
+	// (only with plain per-row entries: no shared offsets, no diagonal codes, no template)
+	int32_t pad;
 };
 
 constexpr int32_t kDiaNone = INT32_MIN;
@@ -421,12 +425,13 @@ __device__ __forceinline__ T tmpl_accumulate(const SlicedArgs<T>& a, int j, cons
 template <typename T, bool DOT, bool WINDOW, bool CODED, int U, bool LOCAL16 = false>
 __device__ __forceinline__ double sliced_one(const SlicedArgs<T>& a, int64_t row0, int nvalid, int len, int64_t base, int64_t cbase,
                                              const T* lds, int32_t r0, uint32_t wlen, const double* dict, double alpha, double beta,
-                                             const DiaMeta<T>& dm)
+                                             const DiaMeta<T>& dm, int64_t rowshift = 0)
 {
 	if (nvalid == 0) return 0.0; // wave-uniform
 	const int lane = threadIdx.x & 63;
 	const bool valid = lane < nvalid;
-	const int64_t row = row0 + (valid ? lane : 0);
+	// rowshift (pitched vectors, SlicedArgs::pad): `row` counts positions of the vectors from here on; the slice's metadata was read by the caller
+	const int64_t row = row0 + rowshift + (valid ? lane : 0);
 	const int64_t xrow = a.rowmap ? (int64_t)a.rowmap[row] : row; // where this row's x and y live
 	// the row's old x and y are requested first: they are the oldest loads in flight and have landed
 	// long before the epilogue needs them
@@ -585,8 +590,9 @@ __global__ __launch_bounds__(kWinThreads) void k_spmv_window(SlicedArgs<T> a)
 	}
 	double dot = 0.0;
 	for (int64_t blk = b_begin; blk < b_end; blk += b_stride) {
-		const int64_t r0 = blk * a.g.B;
-		const int64_t wl = min(a.g.B, a.g.nrows - r0);
+		const int64_t rshift = blk * (int64_t)a.pad; // pitched vectors: this block's rows sit rshift positions further on
+		const int64_t r0 = blk * a.g.B + rshift;
+		const int64_t wl = min(a.g.B, a.g.nrows - blk * a.g.B);
 		__syncthreads(); // everyone is done reading the previous window
 		if (threadIdx.x == 0) next_slice = 0;
 		// stage the window: 8 independent loads per thread in flight (a load-wait-store loop exposed
@@ -619,7 +625,7 @@ __global__ __launch_bounds__(kWinThreads) void k_spmv_window(SlicedArgs<T> a)
 				slice_meta<T, CODED>(a, blk * a.g.spb + jn, row0n, nvalidn, lenn, basen, cbasen);
 				dia_meta<T>(a, blk * a.g.spb + jn, dmn);
 			}
-			dot += sliced_one<T, DOT, true, CODED, U, LOCAL16>(a, row0, nvalid, len, base, cbase, lds, (int32_t)r0, (uint32_t)wl, dict_s, alpha, beta, dm);
+			dot += sliced_one<T, DOT, true, CODED, U, LOCAL16>(a, row0, nvalid, len, base, cbase, lds, (int32_t)r0, (uint32_t)wl, dict_s, alpha, beta, dm, rshift);
 			row0 = row0n;
 			base = basen;
 			cbase = cbasen;

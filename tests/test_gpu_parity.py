@@ -1446,3 +1446,42 @@ def test_heisenberg_chain_csr_handed_over_with_its_model_description(monkeypatch
         e.set_csr(A.rowptr, A.colind, A.values)
         assert e.layout()["kernel"] != 4
         assert rel(e.matrixVectorProduct(x0.copy(), y), xo) < SPMV_TOL
+
+
+@pytest.mark.parametrize("source", ["assembled", "uploaded"])
+@pytest.mark.parametrize("pitched", [0, 1])
+def test_plain_format_window_layout_outs_first_and_pitched(source, pitched, monkeypatch):
+    """A matrix in the plain 12-byte format (no value dictionary, no shared offsets: what the `generic_csr` leg of bench.py measures) in the
+    window kernel's layout of round 5: a row's entries that leave its row block sit in its first slots (one load per 512-byte run of the
+    source vector), and -- pitched = 1, taken by itself from 256 MB per vector on -- the vectors are pitched to 128-byte lines per row block
+    (N_up = 924 = 12 mod 16 here), the stored columns being pitched positions.  Both are invisible at the boundary: lpp_engine_get_csr returns
+    the CSR bit for bit, vectors cross in the basis order; products, energies, coefficients and Ritz vectors against the oracle."""
+    L, nup, ndown = 12, 6, 5
+    hop, U, V = chain(L, -1.0, True), np.where(np.arange(L) % 3 == 0, 2.0, 4.0), np.tile([0.25, -0.5, 0.0], 8)
+    for k, v in (("LPP_COMPRESS_VALUES", "0"), ("LPP_SHARED_OFFSETS", "0"), ("LPP_PRODUCT_LAYOUT", "0"), ("LPP_LOCAL16", "0"), ("LPP_PITCH_ROWS", str(pitched))):
+        monkeypatch.setenv(k, v)
+    A = oracle.hubbard_csr(L, nup, ndown, hop, U, V)
+    x0, y = oracle.fill_random(A.nrows, 7), oracle.fill_random(A.nrows, 8)
+    xo = oracle.spmv_acc(A, x0.copy(), y)
+    init = oracle.fill_random(A.nrows, 4321)
+    eo, zo, so = oracle.lanczos_solve(A, oracle.fill_random(A.nrows, 1234), nstates=1)
+    steps_o, ao, bo, _, _ = oracle.lanczos_decomposition(A, init)
+    for save in (-1, 0):
+        with LanczosEngine(compress_values=0, save_vectors=save) as e:
+            if source == "assembled":
+                e.assemble_hubbard(L, nup, ndown, hop, U, V)
+            else:
+                e.set_row_block(comb(L, nup))
+                e.set_csr(A.rowptr, A.colind, A.values)
+            lay = e.layout()
+            assert lay["kernel"] == 3 and lay["coded"] == 0 and lay["shared_stride"] == 0, lay
+            rp, ci, va = e.get_csr()
+            assert np.array_equal(rp, A.rowptr) and np.array_equal(ci, A.colind) and np.array_equal(_bits(va), _bits(A.values))
+            xg = e.matrixVectorProduct(x0.copy(), y)
+            assert rel(xg, xo) < SPMV_TOL
+            eg, zg, st = e.lanczos(1, want_vectors=True)
+            assert abs(eg[0] - eo[0]) <= E_TOL * abs(eo[0]) and st["steps"] == so
+            r = oracle.spmv_acc(A, np.zeros_like(zg[0]), zg[0]) - eg[0] * zg[0]
+            assert np.linalg.norm(r) < 1e-5 and abs(np.linalg.norm(zg[0]) - 1) < 1e-8
+            ag, bg, _ = e.decomposition(init)
+            assert len(ag) == steps_o and rel(ag, ao) < 1e-8 and rel(bg, bo) < 1e-8
