@@ -511,7 +511,7 @@ template <typename T> static lpp_status build_sliced_t(lpp_engine* e, DevCsr& A,
 			bool want = (size_t)A.nrows * sizeof(T) >= ((size_t)256 << 20);
 			if (const char* sp = getenv("LPP_PITCH_ROWS")) want = atoi(sp) != 0;
 			const int64_t pitched = (g.B + line - 1) / line * line;
-			if (outs && want && &A == &e->A_loc && !e->has_comm && !e->is_complex && A.src_elems == 0 && g.nrows == g.nblocks * g.B && g.B % line != 0
+			if (outs && want && &A == &e->A_loc && !A.out_part && !e->has_comm && !e->is_complex && A.src_elems == 0 && g.nrows == g.nblocks * g.B && g.B % line != 0
 			    && pitched * g.nblocks < ((int64_t)1 << 31) && (size_t)(pitched * g.nblocks) * sizeof(T) < ((size_t)1 << 32))
 				pad = (int)(pitched - g.B);
 		}
