@@ -131,6 +131,52 @@ static double imagPart(double) { return 0.0; }
 static double realPart(const std::complex<double>& v) { return v.real(); }
 static double imagPart(const std::complex<double>& v) { return v.imag(); }
 
+// Models without a device assembler for row partitions (Heisenberg, TjMultiOrb, ...): every rank lets the model assemble its CSR on the host
+// (DefaultSymmetry.h:54-57), keeps rows [rank * per, (rank + 1) * per) and hands them over with lpp_engine_set_csr_partition; the Lanczos
+// vector travels by all-gather (the north_star's form).
+template <typename ComplexOrRealType>
+static int partitionedFromHostCsr(const ModelBase<ComplexOrRealType>& model, const ParametersForSolver<double>& params, int precision, bool isComplex)
+{
+	const int rank = envInt("RANK", 0), world = envInt("WORLD_SIZE", 1), local = envInt("LOCAL_RANK", rank);
+	typename ModelBase<ComplexOrRealType>::SparseMatrixType h;
+	model.setupHamiltonian(h);
+	const int64_t rows = (int64_t)h.rows(), per = (rows + world - 1) / world;
+	std::vector<int64_t> starts((size_t)world + 1);
+	for (int k = 0; k <= world; k++) starts[(size_t)k] = std::min<int64_t>((int64_t)k * per, rows);
+	const int64_t r0 = starts[(size_t)rank], r1 = starts[(size_t)rank + 1], p0 = h.rowptr()[(size_t)r0];
+	std::vector<int64_t> rp((size_t)(r1 - r0) + 1);
+	for (int64_t r = r0; r <= r1; r++) rp[(size_t)(r - r0)] = h.rowptr()[(size_t)r] - p0;
+	char id[LPP_RCCL_ID_BYTES];
+	shareUniqueId(id, rank, world);
+	lpp_config cfg;
+	lpp_config_default(&cfg);
+	cfg.device = local;
+	cfg.dtype = isComplex ? LPP_C128 : LPP_F64;
+	cfg.max_steps = (int32_t)params.steps;
+	cfg.min_steps = (int32_t)params.minSteps;
+	cfg.eps = params.tolerance;
+	cfg.reortho = params.options.find("reortho") != LppHost::String::npos;
+	cfg.save_vectors = 0;
+	EngineHandle engine(cfg);
+	lpp_rccl_comm* comm = nullptr;
+	rcclCheck(lpp_rccl_comm_create(&comm, rank, world, id, local, lpp_engine_stream(engine.get()), per, (int32_t)params.steps, isComplex ? 1 : 0, 0));
+	if (rank == 0 && world > 1) (void)unlink(getenv("LPP_RCCL_ID_FILE"));
+	rcclCheck(lpp_rccl_comm_selftest(comm));
+	lppCheck(lpp_engine_set_csr_partition(engine.get(), lpp_rccl_comm_get(comm), rows, starts.data(), rp.data(), h.colind().data() + p0, h.values().data() + p0));
+	double e0 = 0;
+	lpp_stats st;
+	lppCheck(lpp_engine_lanczos(engine.get(), nullptr, 1, &e0, nullptr, &st));
+	if (rank == 0) {
+		std::cout.precision(precision);
+		model.print(std::cout);
+		std::cout << "Energy=" << e0 << "\n";
+		std::cerr << "#LanczosSteps=" << st.steps << " rows=" << rows << " ranks=" << world << " exchange=" << (world > 1 ? "allgather" : "none") << " (host CSR, row partition)\n";
+	}
+	lppCheck(lpp_engine_sync(engine.get()));
+	rcclCheck(lpp_rccl_comm_destroy(comm));
+	return 0;
+}
+
 template <typename ComplexOrRealType> static int mainPartitioned(LppHost::InputReadable& io, int precision, bool onthefly)
 {
 	typedef LppHost::Geometry<ComplexOrRealType> GeometryType;
@@ -140,7 +186,11 @@ template <typename ComplexOrRealType> static int mainPartitioned(LppHost::InputR
 	ModelSelector<ComplexOrRealType> modelSelector(io, geometry);
 	const ModelBase<ComplexOrRealType>& model = modelSelector();
 	const HubbardOneOrbital<ComplexOrRealType>* hub = dynamic_cast<const HubbardOneOrbital<ComplexOrRealType>*>(&model);
-	if (!hub) throw std::runtime_error("lanczos -P: the partitioned path is built for Model=HubbardOneBand / HubbardOneBandExtended\n");
+	if (!hub) {
+		if (onthefly) throw std::runtime_error("lanczos -P: SolverOptions=InternalProductOnTheFly is the Hubbard family's path\n");
+		ParametersForSolver<double> paramsGeneric(io, "Lanczos");
+		return partitionedFromHostCsr<ComplexOrRealType>(model, paramsGeneric, precision, isComplex);
+	}
 	const int n = (int)geometry.numberOfSites();
 	const typename ModelBase<ComplexOrRealType>::BasisBaseType::PairIntType parts = model.basis().parts();
 	const long n_up = binomial(n, parts.first), n_dn = binomial(n, parts.second);

@@ -164,11 +164,14 @@ def test_reference_constructors_honour_the_solver_parameters(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["hubbard_ladder_2x4.inp", "hubbard_extended_2x4_onthefly.inp", "hubbard_ladder_2x4_complex.inp"])
+@pytest.mark.parametrize("name", ["hubbard_ladder_2x4.inp", "hubbard_extended_2x4_onthefly.inp", "hubbard_ladder_2x4_complex.inp", "heisenberg_chain_L12.inp",
+                                  "tj_chain_L8_complex.inp"])
 def test_partitioned_driver_over_rccl_at_world_size_one(name):
-    """lanczos -P: one process per GPU through liblpp_comm_rccl.so (no Python in the loop).  A one-GPU box hosts one rank: the
-    communicator is created (ncclCommInitRank), the rank's rows are assembled on the device, the energy line is the oracle's.
-    The third input says SolverOptions=useComplex (lanczos.cpp:194-226): complex vectors and a c128 communicator (round 5)."""
+    """lanczos -P: one process per GPU through liblpp_comm_rccl.so (no Python in the loop).  A one-GPU box hosts one rank (RCCL refuses two
+    ranks on one device: scripts/experiments/r05_rccl_same_gpu.py): the communicator is created (ncclCommInitRank), the rank's rows are
+    assembled on the device, the energy line is the oracle's.  The third input says SolverOptions=useComplex (lanczos.cpp:194-226): complex
+    vectors and a c128 communicator (round 5).  The last two are not of the Hubbard family: the model assembles its CSR on the host
+    (DefaultSymmetry.h:54-57) and the rank's rows go through lpp_engine_set_csr_partition (Heisenberg real, t-J complex)."""
     exe = os.path.join(HOST, "lanczos")
     env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
     res = subprocess.run([exe, "-f", os.path.join(GOLD, name), "-p", "12", "-P"], capture_output=True, text=True, timeout=300, env=env)
