@@ -105,6 +105,9 @@ lpp_status pb_build(lpp_engine* e, int64_t n_up, int64_t n_blk, const int64_t* t
 	// pieces of <= 8128 positions: two blocks' windows share a workgroup (k_pb_up_big2) and the second one stays within the 64 KB an
 	// LDS instruction's offset reaches; LPP_PB_BIG2=0: one block per workgroup, two 512-thread workgroups per CU (k_pb_up_big, <= 8768)
 	const bool big2 = !(getenv("LPP_PB_BIG2") && atoi(getenv("LPP_PB_BIG2")) == 0);
+	// round 5: four value groups (complex hoppings realified) two blocks at a time too -- half the template words per output row: 4.74 against
+	// 5.48 ms (k_pb_up_big<.., 4, 3>) at 1.47e8 complex states; LPP_PB_BIG2_FOUR=0: the one-block kernel
+	const bool big2_four = !(getenv("LPP_PB_BIG2_FOUR") && atoi(getenv("LPP_PB_BIG2_FOUR")) == 0);
 	// one window needs the row, its diagonal codes and the template's list heads in LDS (pb_up_lds_bytes; two value groups assumed here):
 	// rows of 17,400-19,500 positions pass a test of the row alone and then failed pb_build -- the 3x6 lattice's 6-electron species (18,564)
 	if ((size_t)(pitch + kPbZeroSlots) * sizeof(double) > (size_t)156 * 1024 || pb_up_lds_bytes(pitch, (int)((n_up + 63) / 64), 2) > (size_t)160 * 1024 - 64)
@@ -326,7 +329,7 @@ lpp_status pb_build(lpp_engine* e, int64_t n_up, int64_t n_blk, const int64_t* t
 		if (const char* s = getenv("LPP_PB_PRE0")) B.pre0 = pairs ? std::max(2, std::min(atoi(s), 6)) & ~1 : std::max(3, std::min(atoi(s), 5));
 	}
 	B.big = W > 0;
-	B.big2 = B.big && big2 && (T.G == 1 || T.G == 2) && pb_big2_lds_bytes((int)W) <= (size_t)160 * 1024 - 64 && (W + kPbZeroSlots) * 8 < 65536;
+	B.big2 = B.big && big2 && (T.G == 1 || T.G == 2 || (T.G == 4 && big2_four)) && pb_big2_lds_bytes((int)W) <= (size_t)160 * 1024 - 64 && (W + kPbZeroSlots) * 8 < 65536;
 	B.W = (int)W;
 	B.npieces = seg ? B.seg_nitems : W > 0 ? (int)((n_up + W - 1) / W) : 1;
 	if (B.big && !seg) {
@@ -663,11 +666,13 @@ static int launch_up_big(lpp_engine* e, const double* y, double* u, const uint8_
 	} while (0)
 		if (partial) {
 			if (B.G == 1) LPP_PB_BIG2(true, 1, 4);
+			else if (B.G == 4) LPP_PB_BIG2(true, 4, 2); // two chunks of each of the four groups ahead (three spill: 5.00 against 4.74 ms at 1.47e8 complex states)
 			else if (B.pre0 == 3) LPP_PB_BIG2(true, 2, 3);
 			else if (B.pre0 == 5) LPP_PB_BIG2(true, 2, 5);
 			else LPP_PB_BIG2(true, 2, 4);
 		} else {
 			if (B.G == 1) LPP_PB_BIG2(false, 1, 4);
+			else if (B.G == 4) LPP_PB_BIG2(false, 4, 2);
 			else if (B.pre0 == 3) LPP_PB_BIG2(false, 2, 3);
 			else if (B.pre0 == 5) LPP_PB_BIG2(false, 2, 5);
 			else LPP_PB_BIG2(false, 2, 4);

@@ -320,10 +320,11 @@ template <int GG> struct Big2Words {
 };
 
 // PRE0: look-ahead chunks of value group 0 (group 1: 2 kBigPre - PRE0), as in k_pb_up; the words of a chunk are requested only if the
-// list holds it (at the (7,6) sector of the 4x5 lattice the lists are 2 and 3-4 chunks long: 64 bytes per row were requested for 45)
+// list holds it (at the (7,6) sector of the 4x5 lattice the lists are 2 and 3-4 chunks long: 64 bytes per row were requested for 45).
+// Four value groups (complex hoppings realified, as in k_pb_up_big<.., 4, 3>): PRE0 chunks of EVERY group.
 template <bool DOT, int GT, int PRE0 = kBigPre> __global__ __launch_bounds__(kPbBig2Threads) void k_pb_up_big2(PbUpBigArgs a)
 {
-	static_assert(GT == 1 || GT == 2, "unrolled value groups only");
+	static_assert(GT == 1 || GT == 2 || GT == 4, "unrolled value groups only");
 	extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
 	double* win = (double*)lds_raw; // window of block 0 at LDS address 0, of block 1 at (W + 32) * 8
 	const int WS = a.W + kPbZeroSlots; // window stride in elements
@@ -439,7 +440,7 @@ template <bool DOT, int GT, int PRE0 = kBigPre> __global__ __launch_bounds__(kPb
 #pragma unroll
 			for (int g = 0; g < GG; g++) {
 				const uint2* wp = tw2 + (size_t)h.off[g] * 64 + lane;
-				const int depth = GG == 2 ? (g == 0 ? PRE0 : 2 * kBigPre - PRE0) : kBigPre;
+				const int depth = GG == 2 ? (g == 0 ? PRE0 : 2 * kBigPre - PRE0) : GG == 4 ? PRE0 : kBigPre;
 				const int nc = __builtin_amdgcn_readfirstlane(h.nc[g]); // scalar branches
 #pragma unroll
 				for (int c = 0; c < kPbPreMax; c++)
@@ -465,7 +466,7 @@ template <bool DOT, int GT, int PRE0 = kBigPre> __global__ __launch_bounds__(kPb
 #pragma unroll
 			for (int g = 0; g < GG; g++) {
 				const int nc = __builtin_amdgcn_readfirstlane(h.nc[g]);
-				const int depth = GG == 2 ? (g == 0 ? PRE0 : 2 * kBigPre - PRE0) : kBigPre;
+				const int depth = GG == 2 ? (g == 0 ? PRE0 : 2 * kBigPre - PRE0) : GG == 4 ? PRE0 : kBigPre;
 				double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
 #pragma unroll
 				for (int c = 0; c < kPbPreMax; c += 2) { // pairs of chunks

@@ -12,7 +12,7 @@ for tag in ${LIBS:-base}; do
   python3 - "$R"/gpurun_out/prof_dp/*/*kernel_stats.csv <<'PY'
 import csv, sys
 for r in csv.DictReader(open(sys.argv[1])):
-    if r["Name"].startswith("void lpp::k_pb_down") or r["Name"].startswith("void lpp::k_pb_up"):
+    if "k_pb_" in r["Name"] and "diag" not in r["Name"]:
         print("   %-60s %4s calls  %8.1f us" % (r["Name"][:60], r["Calls"], float(r["AverageNs"]) / 1e3))
 PY
 done

@@ -971,15 +971,19 @@ def test_product_basis_layout_with_complex_hoppings(case, monkeypatch):
         assert rel(e.matrixVectorProduct(x0.copy(), y), xo) < SPMV_TOL
 
 
-@pytest.mark.parametrize("case,form", [("peierls_ring", "pieces"), ("kane_mele_like", "pieces"), ("disorder", "pieces"), ("peierls_ring", "pieces_wide")])
+@pytest.mark.parametrize("case,form", [("peierls_ring", "pieces"), ("kane_mele_like", "pieces"), ("disorder", "pieces"), ("peierls_ring", "pieces_wide"),
+                                       ("peierls_ring", "pieces_one_block")])
 def test_complex_hoppings_beyond_one_lds_window(case, form, monkeypatch):
     """Complex hoppings with rows that do not fit one LDS window (4x4 lattice at 7/8 up electrons: 12870 complex positions): the realified
-    in-block matrix is cut into pieces like any real one (k_pb_up_big, 4-8 value groups), the couplings stay complex (k_pb_down<CPLX>, with
-    64-bit addresses for vectors beyond 4 GiB).  Small case, pieces of 256 positions forced; same checks as the one-window test."""
+    in-block matrix is cut into pieces like any real one (four value groups: two blocks per workgroup since round 5, k_pb_up_big2<.., 4, 2>;
+    `pieces_one_block`: k_pb_up_big<.., 4, 3>), the couplings stay complex (k_pb_down<CPLX>, with 64-bit addresses for vectors beyond 4 GiB).
+    Small case, pieces of 256 positions forced; same checks as the one-window test."""
     monkeypatch.setenv("LPP_PRODUCT_LAYOUT", "1")
     monkeypatch.setenv("LPP_PB_PIECE_ROWS", "256")
     if form == "pieces_wide":
         monkeypatch.setenv("LPP_PB_WIDE", "1")
+    if form == "pieces_one_block":
+        monkeypatch.setenv("LPP_PB_BIG2_FOUR", "0")
     L, nup, ndown = 12, 6, 5
     ring = chain(L, -1.0, True).astype(complex)
     up = np.triu(np.ones((L, L)), 1) > 0
