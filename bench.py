@@ -105,6 +105,8 @@ WORKLOADS = {
     # BASELINE config 5's lattice: 4x5, the (6,6) sector = 1.5e9 states (SURVEY 8(e) option 1); matrix-free engine only on one GPU
     "hubbard_4x5_6up6down_pbc_U4": ("hubbard", dict(L=20, nup=6, ndown=6, hop=lambda: square_lattice(4, 5, -1.0), U=4.0)),
     "hubbard_4x5_7up6down_pbc_U4": ("hubbard", dict(L=20, nup=7, ndown=6, hop=lambda: square_lattice(4, 5, -1.0), U=4.0)),  # 3.0e9 states
+    # 6.0e9 states, 48 GB per vector, 77520 blocks of 77520 positions: more blocks than one LDS image of the coupling lists holds
+    "hubbard_4x5_7up7down_pbc_U4": ("hubbard", dict(L=20, nup=7, ndown=7, hop=lambda: square_lattice(4, 5, -1.0), U=4.0)),
     "hubbard_4x5_8up7down_pbc_U4": ("hubbard", dict(L=20, nup=8, ndown=7, hop=lambda: square_lattice(4, 5, -1.0), U=4.0)),  # 9.8e9 states, 78 GB per vector
     "hubbard_chain_L12_half_filling_U4": ("hubbard", dict(L=12, nup=6, ndown=6, hop=lambda: chain(12, -1.0), U=4.0)),
     "hubbard_chain_L14_half_filling_U4": ("hubbard", dict(L=14, nup=7, ndown=7, hop=lambda: chain(14, -1.0), U=4.0)),

@@ -117,7 +117,9 @@ typedef struct lpp_layout {
 	int32_t segments; /* product-basis layout, rows beyond one LDS window (ABI 4): > 0 = the in-block matrix is held decomposed by the high sites of
 	                     the species' basis word into that many segments (k_pb_up_seg; positions stored segment by segment, longest first -- internal
 	                     as above); 0 = one per-position template for the whole row */
-	int32_t reserved2;
+	int32_t coupling_rounds; /* product-basis layout (was `reserved2`, always 0, until round 5): pieces of a workgroup's block range the coupling
+	                            kernel walks inside every panel, one LDS image of coupling lists each (1: one image per launch; > 1: sectors of
+	                            65536 blocks and more); 0: not a product-basis layout */
 } lpp_layout;
 
 /* Communicator for the 1-D row-partitioned multi-GPU path.  The engine never

@@ -49,7 +49,7 @@ class Layout(C.Structure):
                 ("nnz", C.c_int64), ("per_row_entries", C.c_int64), ("shared_entries", C.c_int64),
                 ("rows_per_block", C.c_int64), ("resident_bytes", C.c_int64), ("stream_bytes", C.c_int64),
                 ("pieces", C.c_int32), ("coupling_parts", C.c_int32), ("diagonal_plain", C.c_int32), ("chained_step", C.c_int32),
-                ("split_panel", C.c_int32), ("rows_by_list_length", C.c_int32), ("segments", C.c_int32), ("reserved2", C.c_int32)]
+                ("split_panel", C.c_int32), ("rows_by_list_length", C.c_int32), ("segments", C.c_int32), ("coupling_rounds", C.c_int32)]
 
     def as_dict(self):
         return {name: getattr(self, name) for name, _ in self._fields_}

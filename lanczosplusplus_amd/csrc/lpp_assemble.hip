@@ -256,7 +256,7 @@ lpp_status assemble_hubbard_pb(lpp_engine* e, AsmParams P, int nup, int ndown, i
 	const int64_t pitch = pb_pitch_for(cplx ? 2 * n_up : n_up); // in doubles
 	// rows beyond one LDS window and vectors beyond 4 GiB take the pieces / parts kernels (lpp_pbig_kernels.h); what the layout
 	// cannot hold at all (more than 65535 blocks, coupling lists beyond LDS) comes back from pb_build as "does not apply"
-	if (n_dn > 65535 || n_up >= ((int64_t)1 << 24)) return LPP_OK;
+	if (n_dn >= ((int64_t)1 << 24) || n_up >= ((int64_t)1 << 24)) return LPP_OK;
 	{
 		// two work vectors + the two parts of a product + one code per row must fit beside everything else
 		const int64_t nloc = (nblk_loc >= 0 ? nblk_loc : n_dn) * pitch;

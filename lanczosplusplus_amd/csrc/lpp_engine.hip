@@ -1541,6 +1541,7 @@ lpp_status lpp_engine_get_layout(lpp_engine* e, int32_t which, lpp_layout* out)
 		L.chained_step = pb_chain_ok(e) ? 1 : 0;
 		L.rows_by_list_length = e->pb.perm && !B.seg ? 1 : 0;
 		L.segments = B.seg ? B.seg_nsegs : 0;
+		L.coupling_rounds = B.c_nnz > 0 && !B.parts ? B.down_rounds : 1;
 		L.diagonal_plain = B.dval ? 1 : 0;
 		const size_t small = sizeof(uint32_t) * (size_t)B.f_words + sizeof(uint32_t) * (size_t)B.tw_words + (sizeof(int32_t) + sizeof(uint16_t)) * (size_t)B.spb * (size_t)B.G
 		    + (size_t)B.seg_bytes + (size_t)B.t_entries * 12 + (B.chain_model ? 0 : sizeof(int64_t) * (size_t)(B.n_up + 1)) + (size_t)B.c_nnz * 5 + sizeof(int64_t) * 2 * (size_t)(B.n_blk + 1) + 256 * sizeof(double);

@@ -133,6 +133,8 @@ struct PbState {
 	uint8_t* c_code = nullptr;
 	int64_t c_nnz = 0;
 	int rowcap = 0, ids_per_wg = 0, down_grid = 0;
+	int down_rounds = 1, ids_per_round = 0; // k_pb_down: pieces of a workgroup's block range per panel (one LDS image each)
+	void* down_image = nullptr; // rounds > 1: the images, prepared once (k_pb_down_image)
 	size_t down_lds = 0;
 	int32_t* order = nullptr; // blocks of every workgroup's range by decreasing list length
 	int* pace = nullptr;

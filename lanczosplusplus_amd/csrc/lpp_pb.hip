@@ -22,7 +22,7 @@ void free_pb(lpp_engine* e)
 {
 	PbState& B = e->pb;
 	for (void* p : { (void*)B.tw, (void*)B.tw_off, (void*)B.tw_len, (void*)B.t_ptr, (void*)B.t_col, (void*)B.t_val, (void*)B.c_ptr, (void*)B.c_col,
-	                 (void*)B.c_code, (void*)B.order, (void*)B.pace, (void*)B.z, (void*)B.u, (void*)B.xy, (void*)B.dict, (void*)B.dcode, (void*)B.blockbase,
+	                 (void*)B.c_code, (void*)B.order, (void*)B.down_image, (void*)B.pace, (void*)B.z, (void*)B.u, (void*)B.xy, (void*)B.dict, (void*)B.dcode, (void*)B.blockbase,
 	                 (void*)B.fw, (void*)B.f_off, (void*)B.f_len, (void*)B.c_pstart, (void*)B.dval, (void*)B.perm, (void*)B.inv, (void*)B.cdict,
 	                 B.seg_items, B.seg_segs, B.seg_cross, B.seg_hh, B.seg_slices, (void*)B.seg_tw, (void*)B.seg_xw })
 		if (p) (void)hipFree(p);
@@ -127,7 +127,7 @@ lpp_status pb_build(lpp_engine* e, int64_t n_up, int64_t n_blk, const int64_t* t
 	// (the misses of an over-full L2 are Infinity-Cache hits), 2 parts 51.4, 3 parts 56.7, 4 parts 63.4, 6 parts 84.3 -- the part
 	// phases cost more (a wait per part, lists padded per part) than the L2 hits return.  So parts are kept for panels beyond
 	// 6 MB only; up to there the whole-panel kernel runs, with 64-bit addresses where the vector needs them (k_pb_down<WIDE>).
-	int nparts = (size_t)nblk_padded * 128 <= (size_t)6 << 20 ? 1 : 2;
+	int nparts = (size_t)nblk_padded * 128 <= (size_t)6 << 20 || n_blk > 65535 ? 1 : 2; // (the parts form keeps 16-bit places and all of a workgroup's sums in registers: below 65536 blocks)
 	if (const char* s = getenv("LPP_PB_PARTS")) nparts = std::max(1, std::min(atoi(s), kPbMaxParts));
 	const bool parts = nparts > 1 || getenv("LPP_PB_PARTS") != nullptr;
 	const bool wide = vec_bytes >= ((size_t)1 << 32) || getenv("LPP_PB_WIDE") != nullptr;
@@ -427,8 +427,27 @@ lpp_status pb_build(lpp_engine* e, int64_t n_up, int64_t n_blk, const int64_t* t
 	B.rowcap = (int)std::max<int64_t>(4, (longest_list + 3) & ~(int64_t)3);
 	B.ids_per_wg = (int)((n_blk + slots - 1) / slots);
 	B.down_grid = grid;
-	B.down_lds = pb_down_lds_bytes(B.ids_per_wg, B.rowcap);
-	if (n_blk > 65535) return fail(LPP_ERR_INVALID, "pb_build: more than 65535 blocks");
+	// the LDS image of a workgroup's coupling lists (150 KB at most): when its blocks' lists do not fit, the workgroup walks its range in
+	// rounds of ids_per_round blocks inside every panel (k_pb_down, whole-panel form only); LPP_PB_DOWN_ROUNDS=n forces n rounds (tests)
+	B.down_rounds = 1;
+	B.ids_per_round = B.ids_per_wg;
+	if (!parts) { // (the parts form has an image of its own)
+		const int unit = B.ids_per_wg >= 512 ? 64 : 8; // whole sorting windows of `order` (small ranges: whole tasks)
+		auto per_round = [&](int r) { return r == 1 ? B.ids_per_wg : (int)((((int64_t)B.ids_per_wg + r - 1) / r + unit - 1) / unit * unit); };
+		// Pieces of ~320 blocks also run FASTER than one long range where a workgroup owns 800 blocks and more (measured on the 4x5 lattice,
+		// scripts/experiments/README.md "Round 5": 38760 blocks, 1212 per workgroup: 33.2 ms in one round, 28.5 in four; 77520 blocks, 2423 per
+		// workgroup: 82.6 ms in the two rounds LDS asks for, 76.8 in eight), and slower below (config 2, 403 per workgroup: 1.30 / 1.50 / 1.69 ms
+		// in 1 / 2 / 3 rounds).  Only the forms that cannot take the chained step (it keeps one image per launch): wide vectors or rows in pieces
+		int r = 1;
+		if (const char* s = getenv("LPP_PB_DOWN_ROUNDS")) r = std::max(1, std::min(atoi(s), 64));
+		else if (B.ids_per_wg >= 800 && (wide || W > 0)) r = std::min(64, (B.ids_per_wg + 160) / 320);
+		while (r < 64 && pb_down_lds_bytes(per_round(r), B.rowcap) > (size_t)150 * 1024) r++;
+		while (r > 1 && (int64_t)per_round(r) * (r - 1) >= B.ids_per_wg) r--; // (a last round without blocks: one round less covers the range)
+		B.down_rounds = r;
+		B.ids_per_round = per_round(r);
+	}
+	B.down_lds = pb_down_lds_bytes(B.ids_per_round, B.rowcap);
+	if (n_blk >= ((int64_t)1 << 24)) return fail(LPP_ERR_INVALID, "pb_build: more than 2^24 - 1 blocks");
 	B.parts = parts;
 	B.wide = wide;
 	if (parts) {
@@ -501,6 +520,23 @@ lpp_status pb_build(lpp_engine* e, int64_t n_up, int64_t n_blk, const int64_t* t
 			}
 		}
 		if ((rc = to_device(&B.order, order, st)) != LPP_OK) return rc;
+	}
+	if (B.down_rounds > 1 && !(getenv("LPP_PB_DOWN_IMAGE") && atoi(getenv("LPP_PB_DOWN_IMAGE")) == 0)) {
+		// the LDS images of all (workgroup, round) pairs, made once: a round then starts with a copy instead of a walk through the lists
+		// ((7,6) sector of the 4x5 lattice forced into two rounds: coupling kernel 33.2 ms in one round, 43.0 ms rebuilding)
+		const size_t bytes = pb_down_lds_bytes(B.ids_per_round, B.rowcap) * (size_t)slots * (size_t)B.down_rounds;
+		HIP_TRY_MEM(hipMalloc(&B.down_image, bytes));
+		PbDownArgs d = {};
+		d.n_blk = n_blk;
+		d.ids_per_wg = B.ids_per_wg;
+		d.rounds = B.down_rounds;
+		d.ids_per_round = B.ids_per_round;
+		d.rowcap = B.rowcap;
+		d.c_ptr = B.c_ptr;
+		d.c_col = B.c_col;
+		d.c_code = B.c_code;
+		d.order = B.order;
+		k_pb_down_image<<<slots * B.down_rounds, 256, 0, st>>>(d, (uint4*)B.down_image);
 	}
 	if (!(getenv("LPP_PB_PACE") && atoi(getenv("LPP_PB_PACE")) == 0))
 		HIP_TRY_MEM(hipMalloc(&B.pace, sizeof(int) * 8 * (parts ? (size_t)B.pace_stride : (size_t)(std::max(pitch, pitch_dn) / 16))));
@@ -765,6 +801,9 @@ int pb_launch(lpp_engine* e, const void* y, void* x, double* partial, const EpiS
 		d.n_blk = B.n_blk;
 		d.npanels = (int)(B.pitch / 16);
 		d.ids_per_wg = B.ids_per_wg;
+	d.rounds = B.down_rounds;
+	d.ids_per_round = B.ids_per_round;
+	d.image = (const uint4*)B.down_image;
 		d.rowcap = B.rowcap;
 		d.c_ptr = B.c_ptr;
 		d.c_col = B.c_col;
@@ -894,6 +933,9 @@ void pb_tx_down(lpp_engine* e, const void* gath, void* send2, const EpiScale& sc
 	d.n_blk = B.n_blk;
 	d.npanels = (int)(B.pitch_dn / 16);
 	d.ids_per_wg = B.ids_per_wg;
+	d.rounds = B.down_rounds;
+	d.ids_per_round = B.ids_per_round;
+	d.image = (const uint4*)B.down_image;
 	d.rowcap = B.rowcap;
 	d.c_ptr = B.c_ptr;
 	d.c_col = B.c_col;
@@ -933,7 +975,7 @@ bool pb_chain_ok(const lpp_engine* e)
 {
 	const PbState& B = e->pb;
 	if (getenv("LPP_PB_CHAIN") && atoi(getenv("LPP_PB_CHAIN")) == 0) return false;
-	return B.active && !B.tx && !B.big && !B.parts && !B.wide && !B.dval && B.c_nnz > 0 && B.G >= 1 && B.G <= kPbMaxGroups; // more than two value groups (complex hoppings realified, t-t' models): the any-number-of-groups path of k_pb_up
+	return B.active && !B.tx && !B.big && !B.parts && !B.wide && !B.dval && B.down_rounds == 1 && B.c_nnz > 0 && B.G >= 1 && B.G <= kPbMaxGroups; // more than two value groups (complex hoppings realified, t-t' models): the any-number-of-groups path of k_pb_up
 }
 
 template <int GT, int PRE0 = kPbPre> static void launch_up_chain(const PbUpArgs& u, int nb, size_t lds, hipStream_t st)
@@ -983,6 +1025,9 @@ int pb_launch_chain(lpp_engine* e, void* w, void* y, double* partial, const EpiS
 	d.n_blk = B.n_blk;
 	d.npanels = (int)(B.pitch / 16);
 	d.ids_per_wg = B.ids_per_wg;
+	d.rounds = B.down_rounds;
+	d.ids_per_round = B.ids_per_round;
+	d.image = (const uint4*)B.down_image;
 	d.rowcap = B.rowcap;
 	d.c_ptr = B.c_ptr;
 	d.c_col = B.c_col;

@@ -397,7 +397,7 @@ template <bool DOT, int GT, bool CHAIN = false, int PRE0 = kPbPre> __global__ __
 // The kernel only READS y (L2 hits after the first touch of a line) and WRITES z (non-temporal): no HBM load sits in the
 // in-order return queue in front of the gathers (an x read-modify-write here cost an HBM round trip per task).
 // ---------------------------------------------------------------------------------------------
-// LDS image of k_pb_down: one 32-bit word per place of a block's coupling list (source block | value code << 16), rows of
+// LDS image of k_pb_down: one 32-bit word per place of a block's coupling list (source block | value code << 24), rows of
 // `stride` words.  A lane reads the 4 places of a chunk with ONE 16-byte LDS read (the 8 blocks of a task sit `stride` words
 // apart: stride / 4 odd puts their 16-byte segments on different bank groups); separate 2-byte index and 1-byte code arrays
 // cost 8 LDS instructions per chunk instead, and the LDS pipeline was what the kernel's instruction skeleton waited for
@@ -405,10 +405,40 @@ template <bool DOT, int GT, bool CHAIN = false, int PRE0 = kPbPre> __global__ __
 __host__ __device__ inline int pb_down_stride(int rowcap) { return ((rowcap >> 2) & 1) ? rowcap : rowcap + 4; }
 __host__ __device__ inline size_t pb_down_lds_bytes(int ids_per_wg, int rowcap) { return (((size_t)ids_per_wg * 8 + 15) & ~(size_t)15) + (size_t)ids_per_wg * (size_t)pb_down_stride(rowcap) * 4 + 16; }
 
+// The image of `nown` blocks order[b0 ...]: row[il] = block * rowmul, len[il] = its list length, place[il * stride + k] = source block | code << 24.
+// Places beyond a list carry code 0 (+0.0) and the address the task's first block (the longest list) reads at this place, so the filling
+// lanes of a gather ask for a line that is requested anyway; no per-lane conditions in the gather loop.
+__device__ inline void pb_down_fill_image(uint32_t* row, int32_t* len, uint32_t* place, int stride, int rowcap, const int32_t* order, const int64_t* c_ptr,
+                                          const int32_t* c_col, const uint8_t* c_code, int64_t b0, int nown, uint32_t rowmul, int tid, int nthreads)
+{
+	constexpr int BPT = 8; // blocks of a wave task
+	for (int il = tid; il < nown; il += nthreads) {
+		const int64_t b = order[b0 + il];
+		row[il] = (uint32_t)b * rowmul;
+		len[il] = (int32_t)(c_ptr[b + 1] - c_ptr[b]);
+	}
+	for (int i = tid; i < nown * rowcap; i += nthreads) {
+		const int il = i / rowcap, k = i - il * rowcap;
+		const int64_t b = order[b0 + il];
+		const int64_t p0 = c_ptr[b];
+		const bool in = k < (int)(c_ptr[b + 1] - p0);
+		const int64_t bl = order[b0 + (il & ~(BPT - 1))];
+		const int64_t pl = c_ptr[bl];
+		const int32_t fill = k < (int)(c_ptr[bl + 1] - pl) ? c_col[pl + k] : (int32_t)bl;
+		place[il * stride + k] = ((uint32_t)(in ? c_col[p0 + k] : fill) & 0xffffffu) | ((uint32_t)(in ? c_code[p0 + k] : (uint8_t)0) << 24);
+	}
+}
+
 struct PbDownArgs {
 	int64_t pitch, n_blk;
 	int npanels; // pitch / 16
 	int ids_per_wg; // blocks owned by one workgroup
+	// More blocks per workgroup than one LDS image of their lists holds (round 5: sectors of 65536 blocks and more -- 77520 at the 4x5
+	// lattice's (7,7) sector, 2423 per workgroup): the workgroup walks its range in `rounds` pieces of `ids_per_round` blocks (a multiple
+	// of 64, the sorting window of `order`) inside every panel and rebuilds the image for each -- the lists come from L2, 4 % of what the
+	// piece gathers.  rounds == 1: the image is built once per launch (ids_per_round == ids_per_wg)
+	int rounds, ids_per_round;
+	const uint4* image; // rounds > 1: the images of all (workgroup, round) pairs, made once (k_pb_down_image; rows as block numbers); null: rebuilt from the lists
 	int rowcap; // longest coupling list rounded up to a multiple of 4
 	const int64_t* c_ptr; // couplings: CSR over blocks, off-diagonal, ascending
 	const int32_t* c_col;
@@ -444,9 +474,9 @@ template <int THREADS, bool RMW = false, bool WIDE = false, bool CPLX = false, b
 	// LDS image of this workgroup's coupling lists in `order` (block numbers and value codes, 3 bytes per place: a workgroup of
 	// k_pb_up must fit next to this one)
 	const int stride = pb_down_stride(a.rowcap);
-	uint32_t* row_s = (uint32_t*)lds_raw; // [ids_per_wg] byte offset of the block itself
-	int32_t* len_s = (int32_t*)(row_s + a.ids_per_wg); // [ids_per_wg] list length
-	uint32_t* place_s = (uint32_t*)(lds_raw + (((size_t)a.ids_per_wg * 8 + 15) & ~(size_t)15)); // [ids_per_wg][stride] source block (n_blk < 65536: the lists must fit LDS anyway) | code << 16
+	uint32_t* row_s = (uint32_t*)lds_raw; // [ids_per_round] byte offset of the block itself
+	int32_t* len_s = (int32_t*)(row_s + a.ids_per_round); // [ids_per_round] list length
+	uint32_t* place_s = (uint32_t*)(lds_raw + (((size_t)a.ids_per_round * 8 + 15) & ~(size_t)15)); // [ids_per_round][stride] source block (< 2^24) | code << 24
 	__shared__ double smem_d[THREADS / 64];
 	__shared__ int task_s[3]; // PF: next task of the panels k, k + 1, k + 2 (mod 3)
 	if (PF && threadIdx.x < 3) task_s[threadIdx.x] = 0;
@@ -463,28 +493,34 @@ template <int THREADS, bool RMW = false, bool WIDE = false, bool CPLX = false, b
 	const int grp = nx == 8 ? (int)(blockIdx.x & 7) : 0;
 	const int slot = nx == 8 ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
 	const int nslots = (int)(gridDim.x / nx);
-	const int64_t b0 = (int64_t)slot * a.ids_per_wg;
-	const int nown = (int)max((int64_t)0, min((int64_t)a.ids_per_wg, a.n_blk - b0));
 	const uint32_t rowbytes = WIDE ? (uint32_t)((a.pitch * 8) >> LSH) : (uint32_t)(a.pitch * 8); // WIDE: panel lines per row
-	for (int il = threadIdx.x; il < nown; il += THREADS) {
-		const int64_t b = a.order[b0 + il];
-		row_s[il] = (uint32_t)b * rowbytes;
-		len_s[il] = (int32_t)(a.c_ptr[b + 1] - a.c_ptr[b]);
-	}
-	for (int i = threadIdx.x; i < nown * a.rowcap; i += THREADS) {
-		const int il = i / a.rowcap, k = i - il * a.rowcap;
-		const int64_t b = a.order[b0 + il];
-		const int64_t p0 = a.c_ptr[b];
-		const bool in = k < (int)(a.c_ptr[b + 1] - p0);
-		// places beyond the list carry code 0 (+0.0) and the address the task's first block (the longest list) reads at this
-		// place, so the filling lanes of a gather ask for a line that is requested anyway; no per-lane conditions in the loop
-		const int64_t bl = a.order[b0 + (il & ~(BPT - 1))];
-		const int64_t pl = a.c_ptr[bl];
-		const int32_t fill = k < (int)(a.c_ptr[bl + 1] - pl) ? a.c_col[pl + k] : (int32_t)bl;
-		place_s[il * stride + k] = (uint32_t)(uint16_t)(in ? a.c_col[p0 + k] : fill) | ((uint32_t)(in ? a.c_code[p0 + k] : (uint8_t)0) << 16);
-	}
+	const int64_t b0w = (int64_t)slot * a.ids_per_wg; // this workgroup's range of `order`
+	const int nown_w = (int)max((int64_t)0, min((int64_t)a.ids_per_wg, a.n_blk - b0w));
+	const int rounds = PF ? 1 : a.rounds;
+	int64_t b0 = b0w;
+	int nown = rounds == 1 ? nown_w : 0;
+	auto build_image = [&](int r) __attribute__((always_inline)) {
+		b0 = b0w + (int64_t)r * a.ids_per_round;
+		nown = rounds == 1 ? nown_w : max(0, min(a.ids_per_round, nown_w - r * a.ids_per_round));
+		if (rounds > 1 && a.image) { // a copy of the prepared image: 16-byte pieces, the rows' block numbers become offsets on the way
+			const int n4 = (int)(pb_down_lds_bytes(a.ids_per_round, a.rowcap) >> 4);
+			const uint4* const src = a.image + ((size_t)slot * rounds + r) * (size_t)n4;
+			for (int i = threadIdx.x; i < n4; i += THREADS) {
+				uint4 v = src[i];
+				if (4 * i < a.ids_per_round) { // (ids_per_round is a multiple of 8: a piece holds rows only or none)
+					v.x *= rowbytes;
+					v.y *= rowbytes;
+					v.z *= rowbytes;
+					v.w *= rowbytes;
+				}
+				((uint4*)lds_raw)[i] = v;
+			}
+			return;
+		}
+		pb_down_fill_image(row_s, len_s, place_s, stride, a.rowcap, a.order, a.c_ptr, a.c_col, a.c_code, b0, nown, rowbytes, (int)threadIdx.x, THREADS);
+	};
+	if (rounds == 1) build_image(0);
 	__syncthreads();
-	const int ngroups = (nown + BPT - 1) / BPT;
 	const char* ysrc = (const char*)a.y;
 	for (int p = grp; p < a.npanels; p += nx) {
 		if (a.pace && p >= grp + 2 * nx) {
@@ -527,6 +563,13 @@ template <int THREADS, bool RMW = false, bool WIDE = false, bool CPLX = false, b
 			if (lane == 0) g = atomicAdd(&task_s[pk % 3], 1);
 			return __builtin_amdgcn_readfirstlane(g);
 		};
+		for (int r = 0; r < rounds; r++) {
+		if (rounds > 1) { // (wave-uniform) this piece of the workgroup's range: its image replaces the previous piece's
+			__syncthreads();
+			build_image(r);
+			__syncthreads();
+		}
+		const int ngroups = (nown + BPT - 1) / BPT;
 		for (int g = next_task(-1); g < ngroups; g = next_task(g)) {
 			const int il = min(g * BPT + sub, nown - 1);
 			const bool valid = g * BPT + sub < nown;
@@ -543,7 +586,7 @@ template <int THREADS, bool RMW = false, bool WIDE = false, bool CPLX = false, b
 				const uint32_t w4[4] = { pw.x, pw.y, pw.z, pw.w };
 #pragma unroll
 				for (int q = 0; q < 4; q++) {
-					gbuf[q] = *(const double2*)(ysrc + at((w4[q] & 0xffffu) * rowbytes));
+					gbuf[q] = *(const double2*)(ysrc + at((w4[q] & 0xffffffu) * rowbytes));
 				}
 			};
 			auto consume = [&](const double2* gbuf, const uint4& pw) __attribute__((always_inline)) {
@@ -551,11 +594,11 @@ template <int THREADS, bool RMW = false, bool WIDE = false, bool CPLX = false, b
 #pragma unroll
 				for (int q = 0; q < 4; q++) {
 					if (CPLX) {
-						const double2 v = ((const double2*)dict_s)[w4[q] >> 16];
+						const double2 v = ((const double2*)dict_s)[w4[q] >> 24];
 						acc.x = fma(v.x, gbuf[q].x, fma(-v.y, gbuf[q].y, acc.x));
 						acc.y = fma(v.x, gbuf[q].y, fma(v.y, gbuf[q].x, acc.y));
 					} else {
-						const double v = dict_s[w4[q] >> 16];
+						const double v = dict_s[w4[q] >> 24];
 						acc.x = fma(v, gbuf[q].x, acc.x);
 						acc.y = fma(v, gbuf[q].y, acc.y);
 					}
@@ -594,6 +637,7 @@ template <int THREADS, bool RMW = false, bool WIDE = false, bool CPLX = false, b
 				}
 			}
 		}
+		}
 		if (PF && wave == THREADS / 64 - 1 && nown > 0) { // (the touched lines are used by nobody here: this only keeps the loads)
 			uint32_t x = 0;
 #pragma unroll
@@ -613,6 +657,21 @@ template <int THREADS, bool RMW = false, bool WIDE = false, bool CPLX = false, b
 			if (threadIdx.x == 0) a.partial[2 * blockIdx.x + 1] = q;
 		}
 	}
+}
+
+// rounds > 1: the images of all (workgroup, round) pairs in the layout k_pb_down keeps in LDS, rows as block numbers.  grid = slots * rounds
+static __global__ __launch_bounds__(256) void k_pb_down_image(PbDownArgs a, uint4* out)
+{
+	const int slot = (int)blockIdx.x / a.rounds, r = (int)blockIdx.x - slot * a.rounds;
+	const int64_t b0w = (int64_t)slot * a.ids_per_wg;
+	const int nown_w = (int)max((int64_t)0, min((int64_t)a.ids_per_wg, a.n_blk - b0w));
+	const int nown = max(0, min(a.ids_per_round, nown_w - r * a.ids_per_round));
+	const size_t bytes = pb_down_lds_bytes(a.ids_per_round, a.rowcap);
+	unsigned char* const img = (unsigned char*)out + (size_t)blockIdx.x * bytes;
+	uint32_t* const row = (uint32_t*)img;
+	int32_t* const len = (int32_t*)(row + a.ids_per_round);
+	uint32_t* const place = (uint32_t*)(img + (((size_t)a.ids_per_round * 8 + 15) & ~(size_t)15));
+	pb_down_fill_image(row, len, place, pb_down_stride(a.rowcap), a.rowcap, a.order, a.c_ptr, a.c_col, a.c_code, b0w + (int64_t)r * a.ids_per_round, nown, 1u, (int)threadIdx.x, 256);
 }
 
 // leaving the chained form: the pending pass  y = y - g x  (g = *g_a / *g_b2), with the partials of Re<y_new|x> that the

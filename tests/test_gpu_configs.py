@@ -126,6 +126,25 @@ def test_config5_7up6down_sector_matrix_free_free_fermions():
         assert e.rows() == 77520 * 38760 == 3004675200
         lay = e.layout()  # rows of 77520 positions: the in-block matrix decomposed by the 5 high sites (one slab of the lattice), 32 segments in 14 items
         assert lay["kernel"] == 4 and (lay["segments"], lay["pieces"]) == (32, 14), lay
+        assert lay["coupling_rounds"] == 4  # 1212 blocks per workgroup of the coupling kernel, walked in four pieces per panel (round 5)
+        eg, _, st = e.lanczos(1, want_vectors=False)
+    assert abs(eg[0] - exact) <= E_TOL * abs(exact), (eg[0], exact, st["steps"])
+
+
+def test_7up7down_sector_more_blocks_than_one_lds_image_free_fermions():
+    """6,009,350,400 states of BASELINE config 5's lattice: 77520 blocks of 77520 positions, 48 GB per vector.  A workgroup of the coupling
+    kernel owns 2423 blocks, more than one LDS image of their coupling lists holds and more than 16-bit places number: until round 5 such
+    sectors fell back to the fused block-order kernel (337 ms per step); now the product-basis form walks every workgroup's range in rounds
+    (k_pb_down, PbDownArgs::rounds; 186 ms per step).  Exact free-fermion energy."""
+    L = 20
+    hop = square(4, 5, -1.0, pbc=True)
+    lev = np.sort(np.linalg.eigvalsh(hop))
+    exact = 2 * lev[:7].sum()
+    with LanczosEngine(max_steps=300, eps=1e-11, save_vectors=0) as e:
+        e.setup_hubbard_onthefly(L, 7, 7, hop, np.zeros(L))
+        assert e.rows() == 77520 * 77520 == 6009350400
+        lay = e.layout()
+        assert lay["kernel"] == 4 and (lay["segments"], lay["pieces"]) == (32, 14) and lay["coupling_parts"] == 1 and lay["coupling_rounds"] == 8, lay
         eg, _, st = e.lanczos(1, want_vectors=False)
     assert abs(eg[0] - exact) <= E_TOL * abs(exact), (eg[0], exact, st["steps"])
 

@@ -768,7 +768,7 @@ def _pb_oracle(case):
     return _PB_ORACLE[case]
 
 
-@pytest.mark.parametrize("form", ["window", "natural", "segments", "pieces", "wide"])
+@pytest.mark.parametrize("form", ["window", "natural", "segments", "pieces", "wide", "wide_rounds"])
 @pytest.mark.parametrize("case", sorted(PB_CASES))
 def test_product_basis_layout(case, form, monkeypatch):
     """Device assembly of Hubbard straight into the product-basis layout (T, C, diagonal codes; lpp_pb_kernels.h): the CSR it
@@ -780,7 +780,8 @@ def test_product_basis_layout(case, form, monkeypatch):
     whole-panel coupling kernel with 64-bit addresses (what BASELINE config 5's sectors take on one GPU); "segments": what those
     sectors take since round 4 -- the in-block matrix decomposed by the high sites of the species' basis word (lpp_pbseg.h, k_pb_up_seg:
     segments of <= 256 positions here), read off T and verified against it; a species with more than two hopping magnitudes
-    (two_hoppings) keeps the per-position template."""
+    (two_hoppings) keeps the per-position template; "wide_rounds" (round 5): "wide" with every workgroup of the coupling kernel walking its
+    block range in two pieces per panel, one LDS image of coupling lists each (what sectors of 65536 blocks and more take)."""
     L, nup, ndown, hop, U, V = PB_CASES[case]()
     monkeypatch.setenv("LPP_PRODUCT_LAYOUT", "1")  # these matrices are below the size from which the layout is chosen by itself
     if form in ("pieces", "segments"):
@@ -789,7 +790,9 @@ def test_product_basis_layout(case, form, monkeypatch):
         monkeypatch.setenv("LPP_PB_SEG", "1" if form == "segments" else "0")  # "pieces": the per-position template (k_pb_up_big2)
     if form == "natural":
         monkeypatch.setenv("LPP_PB_PERM", "0")  # positions of a block in the basis order ("window": stored in the order of their list lengths)
-    if form == "wide":
+    if form == "wide_rounds":
+        monkeypatch.setenv("LPP_PB_DOWN_ROUNDS", "2")
+    if form in ("wide", "wide_rounds"):
         monkeypatch.setenv("LPP_PB_PIECE_ROWS", "320")
         monkeypatch.setenv("LPP_PB_WIDE", "1")
         monkeypatch.setenv("LPP_PB_BIG2", "0")  # one block per workgroup (k_pb_up_big); "pieces" runs two per workgroup (k_pb_up_big2)
@@ -800,7 +803,8 @@ def test_product_basis_layout(case, form, monkeypatch):
         assert lay["kernel"] == 4 and lay["nnz"] == A.nnz and lay["resident_bytes"] < (0.12 if case == "disorder" else 0.05) * 12 * A.nnz
         assert (lay["diagonal_plain"], lay["diagonal_codes"], lay["chained_step"]) == ((1, 0, 0) if case == "disorder" else (0, 1, 1 if form in ("window", "natural") else 0))  # the chained step: any number of hopping values (two_hoppings: the any-number-of-groups path)
         seg = form == "segments" and case != "two_hoppings"  # C(12, 6) = 924 or C(12, 5) = 792 positions: 2 high sites, 4 segments of 210 / 252
-        assert (lay["pieces"], lay["coupling_parts"]) == {"window": (1, 1), "pieces": (4, 3), "segments": (4, 3), "natural": (1, 1), "wide": (3, 1)}[form]
+        assert (lay["pieces"], lay["coupling_parts"]) == {"window": (1, 1), "pieces": (4, 3), "segments": (4, 3), "natural": (1, 1), "wide": (3, 1), "wide_rounds": (3, 1)}[form]
+        assert lay["coupling_rounds"] == (2 if form == "wide_rounds" else 1)
         assert lay["segments"] == (4 if seg else 0)
         assert lay["rows_by_list_length"] == (1 if form == "window" else 0)  # one-window form only; internal: every check below is in the basis order
         st = e.stats()
