@@ -617,7 +617,7 @@ def main():
             lay = None
         if lay is not None and (args.engine == "stored" or lay["kernel"] == 4):
             layout = {"kernel": {1: "rowgroup", 2: "sliced", 3: "window", 4: "product", 5: "hole_major"}.get(lay["kernel"]), "value_codes": bool(lay["coded"]),
-                      "pieces": lay["pieces"], "segments": lay.get("segments", 0), "one_block": bool(lay["kernel"] == 4 and lay["rows_per_block"] >= st0["nrows"]), "coupling_parts": lay["coupling_parts"], "chained_step": bool(lay["chained_step"]), "rows_by_list_length": bool(lay.get("rows_by_list_length", 0)),
+                      "pieces": lay["pieces"], "segments": lay.get("segments", 0), "one_block": bool(lay["kernel"] == 4 and lay["rows_per_block"] >= st0["nrows"]), "coupling_parts": lay["coupling_parts"], "coupling_rounds": lay.get("coupling_rounds", 1), "chained_step": bool(lay["chained_step"]), "rows_by_list_length": bool(lay.get("rows_by_list_length", 0)),
                       "local16_columns": bool(lay["local16"]), "block_template": lay["block_template"], "diagonal_codes": bool(lay["diagonal_codes"]), "per_row_entries": lay["per_row_entries"],
                       "shared_offset_entries": lay["shared_entries"], "resident_GB": round(lay["resident_bytes"] / 1e9, 2)}
             min_bytes = float(lay["stream_bytes"]) + 3.0 * st0["nrows"] * esz
