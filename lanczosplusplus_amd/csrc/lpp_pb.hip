@@ -437,10 +437,12 @@ lpp_status pb_build(lpp_engine* e, int64_t n_up, int64_t n_blk, const int64_t* t
 		// Pieces of ~320 blocks also run FASTER than one long range where a workgroup owns 800 blocks and more (measured on the 4x5 lattice,
 		// scripts/experiments/README.md "Round 5": 38760 blocks, 1212 per workgroup: 33.2 ms in one round, 28.5 in four; 77520 blocks, 2423 per
 		// workgroup: 82.6 ms in the two rounds LDS asks for, 76.8 in eight), and slower below (config 2, 403 per workgroup: 1.30 / 1.50 / 1.69 ms
-		// in 1 / 2 / 3 rounds).  Only the forms that cannot take the chained step (it keeps one image per launch): wide vectors or rows in pieces
+		// in 1 / 2 / 3 rounds) -- and slower on the same 38760 blocks when the vector is 12 instead of 24 GB (the (6,6) sector: 12.1 ms in one round,
+		// 13.5 in four): what the rounds cure grows with the span of addresses a panel touches (one line every 620 KB over 24 GB at the (7,6)
+		// sector, whose coupling kernel takes 36 % longer per element than the (6,6) sector's in one round, 17 % in four).  So: vectors from 16 GB on
 		int r = 1;
 		if (const char* s = getenv("LPP_PB_DOWN_ROUNDS")) r = std::max(1, std::min(atoi(s), 64));
-		else if (B.ids_per_wg >= 800 && (wide || W > 0)) r = std::min(64, (B.ids_per_wg + 160) / 320);
+		else if (B.ids_per_wg >= 800 && vec_bytes >= ((size_t)16 << 30)) r = std::min(64, (B.ids_per_wg + 160) / 320);
 		while (r < 64 && pb_down_lds_bytes(per_round(r), B.rowcap) > (size_t)150 * 1024) r++;
 		while (r > 1 && (int64_t)per_round(r) * (r - 1) >= B.ids_per_wg) r--; // (a last round without blocks: one round less covers the range)
 		B.down_rounds = r;
