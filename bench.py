@@ -30,6 +30,9 @@ LAYOUT_ENV = ("LPP_PB_CHAIN", "LPP_PB_SEG", "LPP_SPLIT_PANEL", "LPP_ONTHEFLY_KRO
               "LPP_WINDOW_ROWS", "LPP_K2_VARIANT", "LPP_KRON_NO_WINDOW", "LPP_KRON_NO_PACK", "LPP_TEMPLATE_PACK", "LPP_PRODUCT_LAYOUT")
 
 
+ENV_SWITCHES_AT_START = {k: os.environ[k] for k in sorted(os.environ) if k.startswith("LPP_") and k not in ("LPP_RCCL_ID_FILE", "LPP_RCCL_NONCE")}
+
+
 def csrc_hash():
     """sha256 over the engine sources: profiles/traffic.json is stamped with it by scripts/traffic_stamp.py, so a
     PMC byte count is only ever quoted for the code it was measured on."""
@@ -669,6 +672,9 @@ def main():
                        "attempts": tried, "coefficients_vs_cpu_oracle": coeff_check,
                        "per_rank_memory_GB": round(per_rank_bytes(eng, comm, st0, esz, args.engine) / 1e9, 2),
                        "device_memory_after_setup_GB": (round(mem_used[0], 2) if mem_used[0] is not None else None),
+                       # the engine reads layout switches from the environment (DESIGN.md §6, table of switches): a line says which ones were
+                       # set when it was made (none in the default run; LPP_VERBOSE / LPP_ENGINE_LIB are not layout switches but are listed too)
+                       "env_switches": ENV_SWITCHES_AT_START,
                        "layout": layout},
             "roofline": roofline,
             "e0_after_steps": e0,
