@@ -515,6 +515,7 @@ def _worker_pb_tx(rank, world, port, q):
                 e = lp.LanczosEngine(max_steps=300, stream=comm.stream_handle)
                 e.assemble_hubbard(L, nup, ndown, hop, U, comm=comm, ninj=ninj)
                 out[tag + "_kernel"] = e.layout(0)["kernel"]
+                out[tag + "_rounds"] = e.layout(0)["coupling_rounds"]
                 out[tag + "_rows"] = e.rows()
                 ar0 = comm.calls["allreduce"]
                 eg, _, st = e.lanczos(1, want_vectors=False)  # scale-free recurrence, one all-reduce per step
@@ -548,8 +549,12 @@ def _worker_pb_tx(rank, world, port, q):
         q.put((rank, {"error": traceback.format_exc()}))
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_product_basis_kernels_on_the_transposition_exchange(world):
+@pytest.mark.parametrize("world,rounds", [(2, 1), (4, 1), (2, 2)])
+def test_product_basis_kernels_on_the_transposition_exchange(world, rounds, monkeypatch):
+    """(2, 2): the coupling kernel on the transposed slice walks every workgroup's block range in two rounds per panel (round 5: what slices of
+    65536 blocks and more need -- BASELINE config 5 as literally written has 184756 -- forced onto the small case here)."""
+    if rounds > 1:
+        monkeypatch.setenv("LPP_PB_DOWN_ROUNDS", str(rounds))  # the ranks are child processes: they inherit it
     res = _run_ranks(_worker_pb_tx, world, timeout=400)
     for r in range(world):
         assert "error" not in res[r], res[r].get("error")
@@ -561,6 +566,7 @@ def test_product_basis_kernels_on_the_transposition_exchange(world):
         for r in range(world):
             o = res[r]
             assert o[tag + "_kernel"] == 4, "the product-basis layout was not taken"
+            assert o[tag + "_rounds"] == rounds
             assert abs(o[tag + "_e"] - eo) <= 1e-10 * abs(eo) and o[tag + "_steps"] == so
             assert abs(o[tag + "_e2"] - eo) <= 1e-10 * abs(eo)
             assert o[tag + "_steps"] <= o[tag + "_ar"] <= o[tag + "_steps"] + 8
