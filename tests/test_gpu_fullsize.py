@@ -335,3 +335,32 @@ def test_tj_four_holes_hole_major_form_against_the_general_layout(monkeypatch):
     assert abs(len(a1) - len(a0)) <= 1 and rel(a1[:30], a0[:30]) < 1e-9 and rel(b1[:30], b0[:30]) < 1e-9
     e1, e0 = tridiag_lowest(a1, b1[:-1], 1)[0], tridiag_lowest(a0, b0[:-1], 1)[0]
     assert abs(e1 - e0) <= 1e-10 * abs(e0), (e1, e0)
+
+
+@pytest.mark.parametrize("nup,ndown", [(10, 3), (3, 10)])
+def test_config5_as_written_species_shapes(nup, ndown, monkeypatch):
+    """BASELINE config 5 as literally written (4x5, 10 up 10 down: 184756 x 184756 = 3.4e10 states, 273 GB per vector) does not fit one GPU;
+    the shapes its two kernels see do, on sectors of 2.1e8 states: (10,3) -- rows of 184756 positions, the in-block kernel in the segmented
+    form; (3,10) -- 184756 blocks, the coupling kernel with 24-bit block numbers walking every workgroup's 5774 blocks in 7 rounds per panel
+    (round 5; the product layout is forced onto rows of 1140 positions).  Exact free-fermion energy, and with U = 4 the same energy and
+    stopping step as the fused block-order kernel that such sectors took before."""
+    if ndown == 10:
+        monkeypatch.setenv("LPP_PRODUCT_LAYOUT", "1")
+    L = 20
+    hop = square(4, 5, -1.0, pbc=True)
+    lev = np.sort(np.linalg.eigvalsh(hop))
+    exact = lev[:nup].sum() + lev[:ndown].sum()
+    got = {}
+    for U, kron in ((0.0, "0"), (4.0, "0"), (4.0, "1")):
+        monkeypatch.setenv("LPP_ONTHEFLY_KRON", kron)
+        with LanczosEngine(max_steps=400, eps=1e-11, save_vectors=0) as e:
+            e.setup_hubbard_onthefly(L, nup, ndown, hop, np.full(L, U))
+            assert e.rows() == 184756 * 1140
+            if kron == "0":
+                lay = e.layout()
+                assert lay["kernel"] == 4 and lay["coupling_parts"] == 1, lay
+                assert (lay["segments"], lay["pieces"], lay["coupling_rounds"]) == ((32, 31, 1) if nup == 10 else (0, 1, 7)), lay
+            eg, _, st = e.lanczos(1, want_vectors=False)
+            got[(U, kron)] = (eg[0], st["steps"])
+    assert abs(got[(0.0, "0")][0] - exact) <= 1e-10 * abs(exact)
+    assert abs(got[(4.0, "0")][0] - got[(4.0, "1")][0]) <= 1e-10 * abs(got[(4.0, "1")][0]) and got[(4.0, "0")][1] == got[(4.0, "1")][1]
