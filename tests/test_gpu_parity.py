@@ -792,6 +792,8 @@ def test_product_basis_layout(case, form, monkeypatch):
         monkeypatch.setenv("LPP_PB_PERM", "0")  # positions of a block in the basis order ("window": stored in the order of their list lengths)
     if form == "wide_rounds":
         monkeypatch.setenv("LPP_PB_DOWN_ROUNDS", "2")
+        if case in ("chain_L12", "disorder"):
+            monkeypatch.setenv("LPP_PB_DOWN_IMAGE", "0")  # the round's image rebuilt from the coupling lists instead of copied from the prepared buffer
     if form in ("wide", "wide_rounds"):
         monkeypatch.setenv("LPP_PB_PIECE_ROWS", "320")
         monkeypatch.setenv("LPP_PB_WIDE", "1")
