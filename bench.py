@@ -104,6 +104,8 @@ WORKLOADS = {
     # 2.36e9 states: 14x more than fits one GPU as a stored CSR (would be ~1 TB); matrix-free engine only
     "hubbard_3x6_half_filling_pbc_U4": ("hubbard", dict(L=18, nup=9, ndown=9, hop=lambda: square_lattice(3, 6, -1.0), U=4.0)),
     # 3.4e8 states, ~1.2e10 non-zeros (144 GB as a plain CSR): the largest 3x6 sector whose one-species space fits the LDS window
+    # 1.34e8 states in 43758 blocks of 3060 positions: the chained step with a coupling panel (5.6 MB) beyond one XCD's L2
+    "hubbard_3x6_4up8down_pbc_U4": ("hubbard", dict(L=18, nup=4, ndown=8, hop=lambda: square_lattice(3, 6, -1.0), U=4.0)),
     "hubbard_3x6_6up6down_pbc_U4": ("hubbard", dict(L=18, nup=6, ndown=6, hop=lambda: square_lattice(3, 6, -1.0), U=4.0)),
     # BASELINE config 5's lattice: 4x5, the (6,6) sector = 1.5e9 states (SURVEY 8(e) option 1); matrix-free engine only on one GPU
     "hubbard_4x5_6up6down_pbc_U4": ("hubbard", dict(L=20, nup=6, ndown=6, hop=lambda: square_lattice(4, 5, -1.0), U=4.0)),

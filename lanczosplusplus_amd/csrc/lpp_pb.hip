@@ -1044,12 +1044,17 @@ int pb_launch_chain(lpp_engine* e, void* w, void* y, double* partial, const EpiS
 	d.pace = B.pace;
 	d.order = B.order;
 	d.u_has_beta = 1; // the in-block kernel has put beta r_{j-1} into u
-	if (d.pace) (void)hipMemsetAsync(d.pace, 0, sizeof(int) * 8 * (size_t)d.npanels, st);
 	d.cdict = (const double2*)B.cdict;
 	// the last wave touches the u lines ahead of the tasks and the tasks are handed out by a counter (k_pb_down<..., PF>): config 2 3.03 -> 2.88 ms
 	// per step; LPP_PB_DOWN_PF=0: every wave its fixed share of the tasks, no touching
 	static const bool pf = !(getenv("LPP_PB_DOWN_PF") && atoi(getenv("LPP_PB_DOWN_PF")) == 0);
 	d.pf_lead = 2;
+	// ... and with the tasks handed out by a counter and a barrier per panel the workgroups of a group stay together by themselves: the bounded pacing
+	// (one atomic, one poll and one more barrier per panel, a memset per launch) only costs here -- config 2 1.51 -> 1.41 ms, the 4x4 lattice's (7,7) sector
+	// 1.19 -> 1.08, complex hoppings at (6,6) 1.25 -> 1.09 ms; the plain kernel needs it (3x6 lattice, (6,6): 2.7 ms with, 6.1 without).  LPP_PB_CHAIN_PACE=1: keep it
+	static const bool chain_pace = getenv("LPP_PB_CHAIN_PACE") && atoi(getenv("LPP_PB_CHAIN_PACE")) != 0;
+	if (pf && !chain_pace) d.pace = nullptr;
+	if (d.pace) (void)hipMemsetAsync(d.pace, 0, sizeof(int) * 8 * (size_t)d.npanels, st);
 #define LPP_PB_DOWN_RMW(CPLX_, PF_)                                                                                    \
 	do {                                                                                                              \
 		(void)hipFuncSetAttribute((const void*)k_pb_down<1024, true, false, CPLX_, PF_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B.down_lds); \
