@@ -740,6 +740,43 @@ static int launch_up_big(lpp_engine* e, const double* y, double* u, const uint8_
 	return partial ? nb : 0;
 }
 
+// The plain coupling kernel with the tasks of a step handed out by the LDS counter and NO pacing between the workgroups of a group (k_pb_down<.., PF>
+// with pace == null: the barrier per step keeps a workgroup together, the counter keeps its waves on neighbouring tasks): faster where a panel of all blocks
+// fits an XCD's L2 with room to spare -- complex couplings at 11440 blocks 2.27 -> 2.08 ms, the 3x6 lattice's (6,6) sector (18564 blocks) 2.72 -> 2.56 ms -- and
+// slower where it does not (38760 blocks, 4.96 MB: 28.4 -> 35.8 ms; with pacing on top of the counter 28.5): up to 3 MB per panel.  LPP_PB_DOWN_TASKS=0 / 1
+static bool pb_down_tasks(const PbState& B, int64_t n_blk)
+{
+	if (const char* s = getenv("LPP_PB_DOWN_TASKS")) return atoi(s) != 0;
+	(void)B;
+	return (size_t)n_blk * 128 <= (size_t)3 << 20;
+}
+
+static void pb_launch_down_plain(const PbState& B, PbDownArgs& d, hipStream_t st)
+{
+	const bool tasks = pb_down_tasks(B, d.n_blk);
+	if (tasks) d.pace = nullptr;
+	if (d.pace) (void)hipMemsetAsync(d.pace, 0, sizeof(int) * 8 * (size_t)d.npanels, st);
+#define LPP_PB_DOWN_PLAIN(WIDE_, CPLX_, PF_)                                                                           \
+	do {                                                                                                              \
+		(void)hipFuncSetAttribute((const void*)k_pb_down<1024, false, WIDE_, CPLX_, PF_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B.down_lds); \
+		k_pb_down<1024, false, WIDE_, CPLX_, PF_><<<B.down_grid, 1024, B.down_lds, st>>>(d);                            \
+	} while (0)
+	if (B.cplx && B.wide) {
+		if (tasks) LPP_PB_DOWN_PLAIN(true, true, true);
+		else LPP_PB_DOWN_PLAIN(true, true, false);
+	} else if (B.cplx) {
+		if (tasks) LPP_PB_DOWN_PLAIN(false, true, true);
+		else LPP_PB_DOWN_PLAIN(false, true, false);
+	} else if (B.wide) {
+		if (tasks) LPP_PB_DOWN_PLAIN(true, false, true);
+		else LPP_PB_DOWN_PLAIN(true, false, false);
+	} else {
+		if (tasks) LPP_PB_DOWN_PLAIN(false, false, true);
+		else LPP_PB_DOWN_PLAIN(false, false, false);
+	}
+#undef LPP_PB_DOWN_PLAIN
+}
+
 // block couplings over parts of the source range: z = alpha C y on rows of `pitch` positions; returns the number of partials written
 static int launch_down_parts(lpp_engine* e, const double* y, double* z, int64_t pitch, double* partial, const EpiScale& sc, hipStream_t st)
 {
@@ -820,21 +857,8 @@ int pb_launch(lpp_engine* e, const void* y, void* x, double* partial, const EpiS
 		d.pace = B.pace;
 		d.order = B.order;
 		d.u_has_beta = 0;
-		if (d.pace) (void)hipMemsetAsync(d.pace, 0, sizeof(int) * 8 * (size_t)d.npanels, sd);
 		d.cdict = (const double2*)B.cdict;
-		if (B.cplx && B.wide) {
-			(void)hipFuncSetAttribute((const void*)k_pb_down<1024, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B.down_lds);
-			k_pb_down<1024, false, true, true><<<B.down_grid, 1024, B.down_lds, sd>>>(d);
-		} else if (B.cplx) {
-			(void)hipFuncSetAttribute((const void*)k_pb_down<1024, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B.down_lds);
-			k_pb_down<1024, false, false, true><<<B.down_grid, 1024, B.down_lds, sd>>>(d);
-		} else if (B.wide) {
-			(void)hipFuncSetAttribute((const void*)k_pb_down<1024, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B.down_lds);
-			k_pb_down<1024, false, true><<<B.down_grid, 1024, B.down_lds, sd>>>(d);
-		} else {
-			(void)hipFuncSetAttribute((const void*)k_pb_down<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B.down_lds);
-			k_pb_down<1024><<<B.down_grid, 1024, B.down_lds, sd>>>(d);
-		}
+		pb_launch_down_plain(B, d, sd);
 		if (partial) np += B.down_grid;
 	}
 	if (B.big) {
@@ -952,14 +976,7 @@ void pb_tx_down(lpp_engine* e, const void* gath, void* send2, const EpiScale& sc
 	d.pace = B.pace;
 	d.order = B.order;
 	d.u_has_beta = 0;
-	if (d.pace) (void)hipMemsetAsync(d.pace, 0, sizeof(int) * 8 * (size_t)d.npanels, e->stream);
-	if (B.wide) {
-		(void)hipFuncSetAttribute((const void*)k_pb_down<1024, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B.down_lds);
-		k_pb_down<1024, false, true><<<B.down_grid, 1024, B.down_lds, e->stream>>>(d);
-		return;
-	}
-	(void)hipFuncSetAttribute((const void*)k_pb_down<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B.down_lds);
-	k_pb_down<1024><<<B.down_grid, 1024, B.down_lds, e->stream>>>(d);
+	pb_launch_down_plain(B, d, e->stream);
 }
 
 int pb_tx_unpack_combine(lpp_engine* e, void* x, const void* y, const void* recv2, const EpiScale& sc, int64_t chunk, double* partial, const double* shift)
@@ -1053,7 +1070,7 @@ int pb_launch_chain(lpp_engine* e, void* w, void* y, double* partial, const EpiS
 	// (one atomic, one poll and one more barrier per panel, a memset per launch) only costs here -- config 2 1.51 -> 1.41 ms, the 4x4 lattice's (7,7) sector
 	// 1.19 -> 1.08, complex hoppings at (6,6) 1.25 -> 1.09 ms; the plain kernel needs it (3x6 lattice, (6,6): 2.7 ms with, 6.1 without).  LPP_PB_CHAIN_PACE=1: keep it
 	static const bool chain_pace = getenv("LPP_PB_CHAIN_PACE") && atoi(getenv("LPP_PB_CHAIN_PACE")) != 0;
-	if (pf && !chain_pace) d.pace = nullptr;
+	if (pf && !chain_pace && (size_t)B.n_blk * 128 <= (size_t)3 << 20) d.pace = nullptr; // (a panel beyond an XCD's L2 keeps it: see pb_down_tasks)
 	if (d.pace) (void)hipMemsetAsync(d.pace, 0, sizeof(int) * 8 * (size_t)d.npanels, st);
 #define LPP_PB_DOWN_RMW(CPLX_, PF_)                                                                                    \
 	do {                                                                                                              \

@@ -496,7 +496,7 @@ template <int THREADS, bool RMW = false, bool WIDE = false, bool CPLX = false, b
 	const uint32_t rowbytes = WIDE ? (uint32_t)((a.pitch * 8) >> LSH) : (uint32_t)(a.pitch * 8); // WIDE: panel lines per row
 	const int64_t b0w = (int64_t)slot * a.ids_per_wg; // this workgroup's range of `order`
 	const int nown_w = (int)max((int64_t)0, min((int64_t)a.ids_per_wg, a.n_blk - b0w));
-	const int rounds = PF ? 1 : a.rounds;
+	const int rounds = a.rounds;
 	int64_t b0 = b0w;
 	int nown = rounds == 1 ? nown_w : 0;
 	auto build_image = [&](int r) __attribute__((always_inline)) {
@@ -545,8 +545,7 @@ template <int THREADS, bool RMW = false, bool WIDE = false, bool CPLX = false, b
 		const int pk = (p - grp) / nx; // the group's k-th panel
 		constexpr int NP = 8;
 		uint32_t pft[PF ? NP : 1];
-		if (PF) {
-			if (threadIdx.x == 0) task_s[(pk + 2) % 3] = 0;
+		if (PF && RMW) { // (the chained form: one round per panel, the image of the whole range is in place)
 			if (wave == THREADS / 64 - 1 && nown > 0) { // (a workgroup without blocks -- more slots than ranges -- has no line to touch: row_s[-1] is not its word)
 				const bool nextp = p + nx < a.npanels;
 #pragma unroll
@@ -557,12 +556,6 @@ template <int THREADS, bool RMW = false, bool WIDE = false, bool CPLX = false, b
 				}
 			}
 		}
-		auto next_task = [&](int prev) __attribute__((always_inline)) -> int {
-			if (!PF) return prev < 0 ? wave : prev + THREADS / 64;
-			int g = 0;
-			if (lane == 0) g = atomicAdd(&task_s[pk % 3], 1);
-			return __builtin_amdgcn_readfirstlane(g);
-		};
 		for (int r = 0; r < rounds; r++) {
 		if (rounds > 1) { // (wave-uniform) this piece of the workgroup's range: its image replaces the previous piece's
 			__syncthreads();
@@ -570,6 +563,16 @@ template <int THREADS, bool RMW = false, bool WIDE = false, bool CPLX = false, b
 			__syncthreads();
 		}
 		const int ngroups = (nown + BPT - 1) / BPT;
+		// PF: the tasks of a step (panel, round) are handed out by an LDS counter -- three counters in rotation: the one of step q + 2 is zeroed during
+		// step q, i.e. behind the barrier that ended step q - 1, which used it last
+		const int q = pk * rounds + r;
+		if (PF && threadIdx.x == 0) task_s[(q + 2) % 3] = 0;
+		auto next_task = [&](int prev) __attribute__((always_inline)) -> int {
+			if (!PF) return prev < 0 ? wave : prev + THREADS / 64;
+			int g = 0;
+			if (lane == 0) g = atomicAdd(&task_s[q % 3], 1);
+			return __builtin_amdgcn_readfirstlane(g);
+		};
 		for (int g = next_task(-1); g < ngroups; g = next_task(g)) {
 			const int il = min(g * BPT + sub, nown - 1);
 			const bool valid = g * BPT + sub < nown;
@@ -638,7 +641,7 @@ template <int THREADS, bool RMW = false, bool WIDE = false, bool CPLX = false, b
 			}
 		}
 		}
-		if (PF && wave == THREADS / 64 - 1 && nown > 0) { // (the touched lines are used by nobody here: this only keeps the loads)
+		if (PF && RMW && wave == THREADS / 64 - 1 && nown > 0) { // (the touched lines are used by nobody here: this only keeps the loads)
 			uint32_t x = 0;
 #pragma unroll
 			for (int k = 0; k < NP; k++) x ^= pft[k];
